@@ -1,0 +1,152 @@
+"""
+Mask-YOLO base configuration class (hyper-parameter surface of the hot path).
+
+Mirrors the attribute names and default values of the reference's
+``myolo/config.py:15-257`` so that a user's ``Config`` subclass keeps working
+unchanged.  Two deliberate differences:
+
+* ``finalize()`` recomputes the fields the reference derives at *class
+  definition* time (``TRAIN_ROIS_PER_IMAGE`` config.py:166, ``CLASS_WEIGHTS``
+  config.py:39, ``GRID_H/W`` config.py:31) so that subclass overrides of
+  ``N_BOX`` / ``NUM_CLASSES`` / ``IMAGE_SHAPE`` propagate.  The reference reads
+  the *base class* from free functions (model.py:25); this build threads ONE
+  finalized config object everywhere.
+* ``ALPHA`` (MobileNet width multiplier) is a field; the reference hard-wires
+  1.0 (model.py:55,249).
+"""
+import numpy as np
+
+
+class Config(object):
+    """Base configuration class.  Sub-class and override, as in the reference."""
+
+    # ---- YOLO head (config.py:22-39) -------------------------------------
+    NUM_CLASSES = 1 + 1          # background + classes
+    LABELS = ['background', 'food']
+    ANCHORS = [1.27, 1.31, 1.95, 1.85, 2.40, 2.72, 3.20, 3.32, 5.06, 5.05]
+    N_BOX = 5
+    GRID_H, GRID_W = 7, 7
+    TRUE_BOX_BUFFER = 10
+    BATCH_SIZE = 1
+    OBJECT_SCALE = 5.0
+    COORD_SCALE = 1.0
+    CLASS_SCALE = 1.0
+    NO_OBJECT_SCALE = 1.0
+    WARM_UP_BATCHES = 0
+    CLASS_WEIGHTS = np.ones(NUM_CLASSES, dtype='float32')
+
+    NAME = None
+    GPU_COUNT = 0
+    IMAGES_PER_GPU = 0
+    STEPS_PER_EPOCH = 1000
+    VALIDATION_STEPS = 5
+
+    # ---- backbone (config.py:61-92) ---------------------------------------
+    BACKBONE = "mobilenet"
+    ALPHA = 1.0                  # new: MobileNet width multiplier
+    BACKBONE_STRIDES = [8]
+    TOP_FEATURE_MAP_DEPTH = 256
+    SECOND_PHASE_YOLO_DEPTH = 512
+
+    # ---- masks / ROIs (config.py:120-180) ---------------------------------
+    USE_MINI_MASK = False
+    MINI_MASK_SHAPE = (56, 56)
+    IMAGE_RESIZE_MODE = "square"
+    IMAGE_MIN_DIM = 224
+    IMAGE_MAX_DIM = 224
+    IMAGE_MIN_SCALE = 0
+    IMAGE_CHANNEL_COUNT = 3
+    TRAIN_ROIS_PER_IMAGE = GRID_H * GRID_W * N_BOX
+    POOL_SIZE = 7
+    MASK_POOL_SIZE = 14
+    MASK_SHAPE = [28, 28]
+    MAX_GT_INSTANCES = 10
+
+    # ---- optimiser (config.py:200-212) ------------------------------------
+    LEARNING_RATE = 0.001
+    LEARNING_MOMENTUM = 0.9
+    WEIGHT_DECAY = 0.0001
+    LOSS_WEIGHTS = {
+        "yolo_sum_loss": 1.,
+        "myolo_mask_loss": 1.,
+    }
+    TRAIN_BN = False
+    GRADIENT_CLIP_NORM = 5.0
+
+    IMAGE_SHAPE = [224, 224, 3]
+
+    # ---- reference quirks kept switchable ------------
+    # model.py:385-387 feeds [x1,y1,x2,y2] boxes to crop_and_resize, which reads
+    # them as [y1,x1,y2,x2].  "xyxy_as_yxyx" reproduces that; "yxyx" corrects it.
+    ROI_BOX_ORDER = "xyxy_as_yxyx"
+
+    def __init__(self):
+        self.finalize()
+
+    def finalize(self):
+        """Recompute derived fields from the (possibly overridden) primaries."""
+        h, w = self.IMAGE_SHAPE[0], self.IMAGE_SHAPE[1]
+        if w % 32 != 0 or h % 32 != 0:
+            # same message as model.py:793
+            raise Exception("Image size must be dividable by 32 to adapt with YOLO framework. "
+                            "For example, use 224, 256, 288, 320, 356, ... etc. ")
+        self.GRID_H, self.GRID_W = h // 32, w // 32
+        assert self.GRID_H == self.GRID_W, "decode divides x and y by GRID_W (model.py:1454,1459)"
+        assert len(self.ANCHORS) == 2 * self.N_BOX, \
+            "len(ANCHORS) must be 2*N_BOX (got %d anchors values, N_BOX=%d)" % (len(self.ANCHORS), self.N_BOX)
+        assert self.TRUE_BOX_BUFFER == self.MAX_GT_INSTANCES, \
+            "BatchGenerator sizes gt arrays by both (myolo_utils.py:742-745)"
+        self.TRAIN_ROIS_PER_IMAGE = self.GRID_H * self.GRID_W * self.N_BOX
+        cw = np.asarray(self.CLASS_WEIGHTS, dtype='float32')
+        if cw.shape[0] != self.NUM_CLASSES:
+            cw = np.ones(self.NUM_CLASSES, dtype='float32')
+        self.CLASS_WEIGHTS = cw
+        self.IMAGE_MIN_DIM = self.IMAGE_MAX_DIM = h
+        self.SECOND_PHASE_YOLO_DEPTH = int(512 * self.ALPHA)
+        return self
+
+    def display(self):
+        """Display Configuration values (config.py:251-257)."""
+        print("\nConfigurations:")
+        for a in dir(self):
+            if not a.startswith("__") and not callable(getattr(self, a)):
+                print("{:30} {}".format(a, getattr(self, a)))
+        print("\n")
+
+
+class ShapesConfig(Config):
+    """The Shapes toy-dataset configuration (example/shapes/dataset_shapes.py:14-50),
+    made self-consistent: 3 anchors -> N_BOX=3 (the checked-in class inherits N_BOX=5)."""
+    NAME = "shapes"
+    LABELS = ['background', 'square', 'circle', 'triangle']
+    GPU_COUNT = 0
+    IMAGES_PER_GPU = 8
+    BATCH_SIZE = 16
+    NUM_CLASSES = 1 + 3
+    ANCHORS = [1.27273, 1.277385, 2.47446, 2.56253, 4.03843, 4.07434]
+    N_BOX = 3
+    USE_MINI_MASK = False
+
+
+class ShapesHeadConfig(ShapesConfig):
+    """Shapes inputs with the repository-HEAD head: N_BOX=5 and config.py:28 anchors (R=245)."""
+    ANCHORS = [1.27, 1.31, 1.95, 1.85, 2.40, 2.72, 3.20, 3.32, 5.06, 5.05]
+    N_BOX = 5
+
+
+class RiceConfig(Config):
+    """416x416 rice-shaped inference config (BASELINE.json configs[3];
+    anchors from example/rice/anchors_5.txt, class list rice_dataset.py:60-76)."""
+    NAME = "rice"
+    LABELS = ['background', 'rice']
+    NUM_CLASSES = 1 + 1
+    ANCHORS = [2.09, 2.48, 2.59, 3.01, 3.60, 3.64, 5.25, 4.56, 6.21, 6.25]
+    N_BOX = 5
+    IMAGE_SHAPE = [416, 416, 3]
+
+
+def make_config(base=ShapesConfig, **overrides):
+    """Build a finalized config instance with attribute overrides, e.g.
+    make_config(ShapesConfig, IMAGE_SHAPE=[128,128,3], ALPHA=0.5, BATCH_SIZE=4)."""
+    cls = type(base.__name__ + "_custom", (base,), dict(overrides))
+    return cls()

@@ -1,0 +1,266 @@
+"""
+Host-side data layer of the Mask-YOLO hot path (numpy): target encoding and the small
+post-processing helpers.  Same names / argument meaning as the reference's
+``myolo/myolo_utils.py`` for the rows SURVEY.md section 8 marks in scope:
+
+  BatchGenerator.__getitem__  myolo_utils.py:727-860   (a19)
+  extract_bboxes              myolo_utils.py:247-271   (a20)
+  load_image_gt               myolo_utils.py:274-366   (no resize/augment: out of scope)
+  BoundBox/bbox_iou           myolo_utils.py:161-244
+  decode_one_yolo_output/NMB/unmold_mask  :36-113,883-912  ("next" rows, section 8(f))
+
+Differences: image size comes from config.IMAGE_SHAPE instead of the
+hard-coded 224 (myolo_utils.py:737,744); no cv2 drawing branch (norm=False path).
+"""
+import numpy as np
+
+
+class BoundBox:
+    def __init__(self, xmin, ymin, xmax, ymax, c=None, classes=None):
+        self.xmin, self.ymin, self.xmax, self.ymax = xmin, ymin, xmax, ymax
+        self.c = c
+        self.classes = classes
+        self.label = -1
+        self.score = -1
+
+    def get_label(self):
+        if self.label == -1:
+            self.label = np.argmax(self.classes)
+        return self.label
+
+    def get_score(self):
+        if self.score == -1:
+            self.score = self.classes[self.get_label()]
+        return self.score
+
+
+def _interval_overlap(interval_a, interval_b):
+    x1, x2 = interval_a
+    x3, x4 = interval_b
+    if x3 < x1:
+        if x4 < x1:
+            return 0
+        return min(x2, x4) - x1
+    if x2 < x3:
+        return 0
+    return min(x2, x4) - x3
+
+
+def bbox_iou(box1, box2):
+    iw = _interval_overlap([box1.xmin, box1.xmax], [box2.xmin, box2.xmax])
+    ih = _interval_overlap([box1.ymin, box1.ymax], [box2.ymin, box2.ymax])
+    inter = iw * ih
+    w1, h1 = box1.xmax - box1.xmin, box1.ymax - box1.ymin
+    w2, h2 = box2.xmax - box2.xmin, box2.ymax - box2.ymin
+    return float(inter) / (w1 * h1 + w2 * h2 - inter)
+
+
+def bbox_iou_2(box1, box2, image_shape):
+    w, h = image_shape[0], image_shape[1]
+    a = BoundBox(box1[0] * w, box1[1] * h, box1[2] * w, box1[3] * h)
+    b = BoundBox(box2[0] * w, box2[1] * h, box2[2] * w, box2[3] * h)
+    return bbox_iou(a, b)
+
+
+def extract_bboxes(mask):
+    """mask [H,W,N] -> [N,(x1,y1,x2,y2)] int32; x2,y2 exclusive (myolo_utils.py:247-271)."""
+    n = mask.shape[-1]
+    boxes = np.zeros([n, 4], dtype=np.int32)
+    cols = np.any(mask, axis=0)            # [W,N]
+    rows = np.any(mask, axis=1)            # [H,N]
+    for i in range(n):
+        hz = np.where(cols[:, i])[0]
+        if hz.shape[0]:
+            vt = np.where(rows[:, i])[0]
+            boxes[i] = (hz[0], vt[0], hz[-1] + 1, vt[-1] + 1)
+    return boxes
+
+
+def load_image_gt(dataset, config, image_id, augment=False, augmentation=None, use_mini_mask=False):
+    """-> image, class_ids, bbox [n,(x1,y1,x2,y2)], mask [H,W,n] (myolo_utils.py:274-366).
+    Resizing / augmentation are image-file I/O paths outside the hot path: images must already
+    have config.IMAGE_SHAPE."""
+    image = dataset.load_image(image_id)
+    mask, class_ids = dataset.load_mask(image_id)
+    if list(image.shape) != list(config.IMAGE_SHAPE):
+        raise NotImplementedError("image resize is outside the hot path; supply %s images" % (config.IMAGE_SHAPE,))
+    if augment or augmentation is not None or use_mini_mask:
+        raise NotImplementedError("augmentation / mini-masks are outside the hot path")
+    keep = np.sum(mask, axis=(0, 1)) > 0
+    mask = mask[:, :, keep]
+    class_ids = class_ids[keep]
+    bbox = extract_bboxes(mask)
+    return image, class_ids, bbox, mask
+
+
+class BatchGenerator(object):
+    """Target encoding + batching (myolo_utils.py:689-860).  __getitem__ returns
+    ([images f32, true_boxes f64, y_true f64, gt_class_ids i32, gt_boxes i32, gt_masks bool], [])
+    in 'training' mode, the first three in 'yolo' mode."""
+
+    def __init__(self, all_info, config, mode, shuffle=True, jitter=False, norm=False, rng=None):
+        assert mode in ['yolo', 'training']
+        self.config = config
+        self.mode = mode
+        self.all_info = all_info
+        self.shuffle = shuffle
+        self.jitter = jitter
+        self.norm = norm
+        a = np.asarray(config.ANCHORS, dtype=np.float64).reshape(-1, 2)
+        self.anchor_w, self.anchor_h = a[:, 0], a[:, 1]
+        if shuffle:
+            (rng or np.random).shuffle(self.all_info)
+
+    def __len__(self):
+        return int(np.ceil(float(len(self.all_info)) / self.config.BATCH_SIZE))
+
+    def num_classes(self):
+        return self.config.NUM_CLASSES
+
+    def size(self):
+        return len(self.all_info)
+
+    def _best_anchor(self, w, h):
+        """argmax IoU of origin-anchored boxes, first maximum wins (myolo_utils.py:795-809)."""
+        iw = np.minimum(w, self.anchor_w)
+        ih = np.minimum(h, self.anchor_h)
+        inter = iw * ih
+        iou = inter / (w * h + self.anchor_w * self.anchor_h - inter)
+        return int(np.argmax(iou))
+
+    def __getitem__(self, idx):
+        cfg = self.config
+        l_bound = idx * cfg.BATCH_SIZE
+        r_bound = (idx + 1) * cfg.BATCH_SIZE
+        if r_bound > len(self.all_info):
+            r_bound = len(self.all_info)
+            l_bound = max(0, r_bound - cfg.BATCH_SIZE)
+        n = r_bound - l_bound
+        H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+        T = cfg.TRUE_BOX_BUFFER
+        images = np.zeros((n, H, W, 3), dtype=np.float32)
+        y_true = np.zeros((n, cfg.GRID_H, cfg.GRID_W, cfg.N_BOX, 4 + 1 + cfg.NUM_CLASSES))
+        true_boxes = np.zeros((n, 1, 1, 1, T, 4))
+        gt_ids = np.zeros((n, T), dtype=np.int32)
+        gt_boxes_b = np.zeros((n, T, 4), dtype=np.int32)
+        gt_masks_b = np.zeros((n, H, W, cfg.MAX_GT_INSTANCES), dtype=bool)
+        cell_w = float(W) / cfg.GRID_W
+        cell_h = float(H) / cfg.GRID_H
+        for k, inst in enumerate(self.all_info[l_bound:r_bound]):
+            image, class_ids, boxes, masks = inst[0], inst[1], inst[2], inst[3]
+            if boxes.shape[0] > T:
+                ids = np.random.choice(np.arange(boxes.shape[0]), T, replace=False)
+                class_ids, boxes, masks = class_ids[ids], boxes[ids], masks[:, :, ids]
+            tbi = 0
+            for i in range(boxes.shape[0]):
+                xmin, ymin, xmax, ymax = (boxes[i][0], boxes[i][1], boxes[i][2], boxes[i][3])
+                cx = .5 * (xmin + xmax) / cell_w
+                cy = .5 * (ymin + ymax) / cell_h
+                gx, gy = int(np.floor(cx)), int(np.floor(cy))
+                if gx < cfg.GRID_W and gy < cfg.GRID_H:
+                    bw = (xmax - xmin) / cell_w
+                    bh = (ymax - ymin) / cell_h
+                    box = [cx, cy, bw, bh]
+                    a = self._best_anchor(bw, bh)
+                    y_true[k, gy, gx, a, 0:4] = box
+                    y_true[k, gy, gx, a, 4] = 1.
+                    y_true[k, gy, gx, a, 5 + class_ids[i]] = 1
+                    true_boxes[k, 0, 0, 0, tbi] = box
+                    tbi = (tbi + 1) % T
+            images[k] = image / 255. if self.norm else image
+            gt_ids[k, :class_ids.shape[0]] = class_ids
+            gt_boxes_b[k, :boxes.shape[0]] = boxes
+            gt_masks_b[k, :, :, :masks.shape[-1]] = masks
+        if self.mode == 'yolo':
+            return [images, true_boxes, y_true], []
+        return [images, true_boxes, y_true, gt_ids, gt_boxes_b, gt_masks_b], []
+
+
+# ---------------------------------------------------------------------------
+# "next" rows: inference post-processing on the host
+# ---------------------------------------------------------------------------
+def _sigmoid(x):
+    return 1. / (1. + np.exp(-x))
+
+
+def _softmax(x, axis=-1, t=-100.):
+    x = x - np.max(x)
+    if np.min(x) < t:
+        x = x / np.min(x) * t
+    e_x = np.exp(x)
+    return e_x / e_x.sum(axis, keepdims=True)
+
+
+def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_threshold=0.3):
+    """myolo_utils.py:36-85: per-class greedy NMS on the decoded YOLO grid."""
+    netout = np.array(netout, dtype=np.float64)
+    grid_h, grid_w, nb_box = netout.shape[:3]
+    boxes = []
+    netout[..., 4] = _sigmoid(netout[..., 4])
+    netout[..., 5:] = netout[..., 4][..., np.newaxis] * _softmax(netout[..., 5:])
+    netout[..., 5:] *= netout[..., 5:] > obj_threshold
+    for row in range(grid_h):
+        for col in range(grid_w):
+            for b in range(nb_box):
+                classes = netout[row, col, b, 5:]
+                if np.sum(classes) > 0:
+                    x, y, w, h = netout[row, col, b, :4]
+                    x = (col + _sigmoid(x)) / grid_w
+                    y = (row + _sigmoid(y)) / grid_h
+                    w = anchors[2 * b + 0] * np.exp(w) / grid_w
+                    h = anchors[2 * b + 1] * np.exp(h) / grid_h
+                    boxes.append(BoundBox(x - w / 2, y - h / 2, x + w / 2, y + h / 2, netout[row, col, b, 4], classes))
+    for c in range(nb_class):
+        order = list(reversed(np.argsort([box.classes[c] for box in boxes])))
+        for i in range(len(order)):
+            bi = order[i]
+            if boxes[bi].classes[c] == 0:
+                continue
+            for j in range(i + 1, len(order)):
+                bj = order[j]
+                if bbox_iou(boxes[bi], boxes[bj]) >= nms_threshold:
+                    boxes[bj].classes[c] = 0
+    return [box for box in boxes if box.get_score() > obj_threshold]
+
+
+def NMB(boxes, class_ids, indices, image_shape, nms_threshold=0.3):
+    """myolo_utils.py:88-113: same-class suppression over score-ordered indices."""
+    remove = []
+    for i in range(len(indices)):
+        for j in range(i + 1, len(indices)):
+            if bbox_iou_2(boxes[i], boxes[j], image_shape) >= nms_threshold and class_ids[i] == class_ids[j]:
+                remove.append(j)
+    return np.delete(indices, remove)
+
+
+def _resize_bilinear(mask, out_h, out_w):
+    """Bilinear resize with pixel-centre alignment (stands in for skimage.transform.resize
+    order=1, which is un-vendored; myolo_utils.py:903)."""
+    h, w = mask.shape
+    ys = np.clip((np.arange(out_h) + 0.5) * h / out_h - 0.5, 0, h - 1)
+    xs = np.clip((np.arange(out_w) + 0.5) * w / out_w - 0.5, 0, w - 1)
+    y0 = np.floor(ys).astype(int)
+    x0 = np.floor(xs).astype(int)
+    y1 = np.minimum(y0 + 1, h - 1)
+    x1 = np.minimum(x0 + 1, w - 1)
+    wy = (ys - y0)[:, None]
+    wx = (xs - x0)[None, :]
+    top = mask[y0][:, x0] * (1 - wx) + mask[y0][:, x1] * wx
+    bot = mask[y1][:, x0] * (1 - wx) + mask[y1][:, x1] * wx
+    return top * (1 - wy) + bot * wy
+
+
+def unmold_mask(mask, bbox, image_shape):
+    """myolo_utils.py:883-912: resize a 28x28 mask to its box, threshold 0.5, paste."""
+    threshold = 0.5
+    w, h = image_shape[0], image_shape[1]
+    x1, y1, x2, y2 = bbox
+    x1 = min(max(0, int(x1 * w)), w)
+    x2 = min(max(1, int(x2 * w)), w)
+    y1 = min(max(0, int(y1 * h)), h)
+    y2 = min(max(1, int(y2 * h)), h)
+    m = _resize_bilinear(np.asarray(mask, np.float64), max(1, y2 - y1), max(1, x2 - x1))
+    m = np.where(m >= threshold, 1, 0).astype(bool)
+    full = np.zeros(image_shape[:2], dtype=bool)
+    full[y1:y2, x1:x2] = m[:max(0, y2 - y1), :max(0, x2 - x1)]
+    return full

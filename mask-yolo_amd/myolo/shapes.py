@@ -1,0 +1,158 @@
+"""
+Synthetic Shapes dataset -- the inputs BASELINE.json's metric is quoted on.
+
+Restates example/shapes/dataset_shapes.py:53-180 (ShapesDataset: random_image :158-180,
+random_shape :137-156, draw_shape :121-135, load_mask :102-119) without cv2 / mrcnn:
+the un-vendored ``mrcnn.utils.Dataset`` base and ``mrcnn.utils.non_max_suppression``
+(dataset_shapes.py:6,53,178) are restated inline.  The reference is unseeded; here every
+image is a pure function of (seed, image index) so that all ranks / runs agree.
+"""
+import math
+import random
+
+import numpy as np
+
+
+def _nms(boxes, scores, threshold):
+    """matterport mrcnn.utils.non_max_suppression restated: visit by score descending, drop
+    boxes whose IoU with the kept one exceeds threshold.  boxes [N,(a1,b1,a2,b2)]."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0,), np.int32)
+    b = boxes.astype(np.float32)
+    area = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    ixs = scores.argsort()[::-1]
+    pick = []
+    while len(ixs) > 0:
+        i = ixs[0]
+        pick.append(i)
+        rest = ixs[1:]
+        y1 = np.maximum(b[i, 0], b[rest, 0])
+        y2 = np.minimum(b[i, 2], b[rest, 2])
+        x1 = np.maximum(b[i, 1], b[rest, 1])
+        x2 = np.minimum(b[i, 3], b[rest, 3])
+        inter = np.maximum(x2 - x1, 0) * np.maximum(y2 - y1, 0)
+        iou = inter / (area[i] + area[rest] - inter)
+        ixs = rest[iou <= threshold]
+    return np.array(pick, dtype=np.int32)
+
+
+class ShapesDataset(object):
+    """Squares / circles / triangles on a flat background, generated on the fly."""
+
+    def __init__(self, seed=1234):
+        self.seed = seed
+        self.image_info = []
+        self.class_info = [{"source": "", "id": 0, "name": "BG"}]
+        self.image_ids = []
+        self.class_names = []
+        self.source_class_ids = {}
+
+    # ---- mrcnn.utils.Dataset surface used by load_image_gt (myolo_utils.py:299-300,358-359)
+    def add_class(self, source, class_id, class_name):
+        self.class_info.append({"source": source, "id": class_id, "name": class_name})
+
+    def add_image(self, source, image_id, path, **kwargs):
+        info = {"id": image_id, "source": source, "path": path}
+        info.update(kwargs)
+        self.image_info.append(info)
+
+    def prepare(self):
+        self.num_classes = len(self.class_info)
+        self.class_ids = np.arange(self.num_classes)
+        self.class_names = [c["name"] for c in self.class_info]
+        self.num_images = len(self.image_info)
+        self.image_ids = np.arange(self.num_images)
+        self.source_class_ids = {"shapes": list(range(self.num_classes)), "": [0]}
+
+    # ---- dataset_shapes.py:59-79
+    def load_shapes(self, count, height, width, start_index=0):
+        self.add_class("shapes", 1, "square")
+        self.add_class("shapes", 2, "circle")
+        self.add_class("shapes", 3, "triangle")
+        for i in range(count):
+            rng = random.Random(self.seed + start_index + i)
+            bg_color, shapes = self.random_image(height, width, rng)
+            self.add_image("shapes", image_id=i, path=None, width=width, height=height,
+                           bg_color=bg_color, shapes=shapes)
+
+    def load_image(self, image_id):
+        info = self.image_info[image_id]
+        bg = np.array(info['bg_color']).reshape([1, 1, 3])
+        image = np.ones([info['height'], info['width'], 3], dtype=np.uint8) * bg.astype(np.uint8)
+        for shape, color, dims in info['shapes']:
+            image = self.draw_shape(image, shape, dims, color)
+        return image
+
+    def load_mask(self, image_id):
+        info = self.image_info[image_id]
+        shapes = info['shapes']
+        count = len(shapes)
+        mask = np.zeros([info['height'], info['width'], count], dtype=np.uint8)
+        for i, (shape, _, dims) in enumerate(shapes):
+            mask[:, :, i:i + 1] = self.draw_shape(mask[:, :, i:i + 1].copy(), shape, dims, 1)
+        # occlusions: later shapes hide earlier ones (dataset_shapes.py:112-116)
+        occlusion = np.logical_not(mask[:, :, -1]).astype(np.uint8)
+        for i in range(count - 2, -1, -1):
+            mask[:, :, i] = mask[:, :, i] * occlusion
+            occlusion = np.logical_and(occlusion, np.logical_not(mask[:, :, i]))
+        class_ids = np.array([self.class_names.index(s[0]) for s in shapes])
+        return mask.astype(bool), class_ids.astype(np.int32)
+
+    @staticmethod
+    def draw_shape(image, shape, dims, color):
+        """dataset_shapes.py:121-135 without cv2: square = inclusive [x-s,x+s]; circle =
+        dx^2+dy^2 <= s^2; triangle = int-truncated vertices, edge-function fill."""
+        x, y, s = dims
+        H, W = image.shape[:2]
+        yy, xx = np.mgrid[0:H, 0:W]
+        if shape == 'square':
+            m = (xx >= x - s) & (xx <= x + s) & (yy >= y - s) & (yy <= y + s)
+        elif shape == 'circle':
+            m = (xx - x) ** 2 + (yy - y) ** 2 <= s * s
+        elif shape == 'triangle':
+            k = s / math.sin(math.radians(60))
+            pts = np.array([(x, y - s), (x - k, y + s), (x + k, y + s)]).astype(np.int32)
+            (ax, ay), (bx, by), (cx, cy) = pts
+
+            def edge(px, py, qx, qy):
+                return (xx - px) * (qy - py) - (yy - py) * (qx - px)
+            e0, e1, e2 = edge(ax, ay, bx, by), edge(bx, by, cx, cy), edge(cx, cy, ax, ay)
+            m = ((e0 >= 0) & (e1 >= 0) & (e2 >= 0)) | ((e0 <= 0) & (e1 <= 0) & (e2 <= 0))
+        else:
+            raise ValueError(shape)
+        image = image.copy()
+        image[m] = color
+        return image
+
+    @staticmethod
+    def random_shape(height, width, rng):
+        shape = rng.choice(["square", "circle", "triangle"])
+        color = tuple([rng.randint(0, 255) for _ in range(3)])
+        buffer = 20 if height >= 80 else max(2, height // 5)   # reference: 20 (needs H >= 80)
+        y = rng.randint(buffer, height - buffer - 1)
+        x = rng.randint(buffer, width - buffer - 1)
+        s = rng.randint(buffer, height // 4)
+        return shape, color, (x, y, s)
+
+    def random_image(self, height, width, rng):
+        bg_color = np.array([rng.randint(0, 255) for _ in range(3)])
+        shapes, boxes = [], []
+        N = rng.randint(1, 4)
+        for _ in range(N):
+            shape, color, dims = self.random_shape(height, width, rng)
+            shapes.append((shape, color, dims))
+            x, y, s = dims
+            boxes.append([x - s, y - s, x + s, y + s])
+        keep = _nms(np.array(boxes), np.arange(N), 0.3)
+        shapes = [s for i, s in enumerate(shapes) if i in keep]
+        return bg_color, shapes
+
+
+def make_shapes_samples(count, cfg, seed=1234, start_index=0):
+    """-> list of (image uint8, class_ids, boxes int32 x1y1x2y2, masks bool) like the
+    train_info rows MaskYOLO.train builds (model.py:995-999)."""
+    from .myolo_utils import load_image_gt
+    ds = ShapesDataset(seed)
+    ds.load_shapes(count, cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1], start_index=start_index)
+    ds.prepare()
+    return [list(load_image_gt(ds, cfg, i)) for i in range(count)]
