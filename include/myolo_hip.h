@@ -1,0 +1,168 @@
+/*
+ * myolo_hip.h -- C-ABI of libmyolo_hip.so: the MI355X (gfx950) kernels of the Mask-YOLO
+ * forward/backward hot path.
+ *
+ * The reference (jianing-sun/Mask-YOLO) exposes no FFI: its arithmetic is TensorFlow/Keras
+ * op invocations inside myolo/model.py.  Each entry point below replaces the op invocation
+ * cited next to it (paths relative to the reference root); INTEGRATION.md shows the ctypes
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *   - every tensor is NHWC, contiguous, float32 unless stated; 2-D views are [rows, channels];
+ *   - the CALLER owns every buffer (kernels never allocate); `ws` is caller-provided scratch of
+ *     at least myolo_workspace_bytes(...) bytes;
+ *   - asynchronous on `stream` (a hipStream_t passed as void*), no implicit synchronisation,
+ *     stateless and re-entrant;
+ *   - returns 0 on success, a negative MYOLO_E* code otherwise (myolo_last_error_string()).
+ */
+#ifndef MYOLO_HIP_H
+#define MYOLO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MYOLO_OK            0
+#define MYOLO_EINVAL       -1   /* bad argument (shape / alignment / null pointer)  */
+#define MYOLO_EWORKSPACE   -2   /* workspace too small                               */
+#define MYOLO_ELAUNCH      -3   /* HIP launch error                                  */
+
+#define MYOLO_ACT_NONE   0
+#define MYOLO_ACT_RELU   1
+#define MYOLO_ACT_RELU6  2
+
+int         myolo_version(void);
+const char* myolo_last_error_string(void);
+/* upper bound of scratch any single call below needs for a problem with `rows` rows and
+ * `cols` output channels (weights-gradient split-K partials dominate). */
+size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
+
+/* ---- conv1: ZeroPad(1,1) + Conv2D 3x3 stride 2 valid, Cin=3, no bias -- model.py:45-50 ---- */
+int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y,
+                           int N, int H, int W, int Cout, void* stream);
+int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw,
+                                  int N, int H, int W, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- DepthwiseConv2D 3x3, stride 1 'same' | stride 2 pad-bottom-right 'valid', no bias
+ *      (keras_applications _depthwise_conv_block, model.py:19,68-77,256-268) ---- */
+int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y,
+                        int N, int H, int W, int C, int stride, void* stream);
+int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx,
+                             int N, int H, int W, int C, int stride, void* stream);
+int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw,
+                               int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- pointwise Conv2D 1x1 (conv_pw_N, conv_23 model.py:271) : y[M,Cout] = x[M,Cin] w[Cin,Cout] (+bias) ---- */
+int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
+                        int64_t M, int Cin, int Cout, void* stream);
+int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
+                             int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
+                               int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Conv2D 3x3 'same' + bias (feature_map model.py:848; myolo_mask_conv1-4 model.py:688-709) ---- */
+int myolo_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
+                      int N, int H, int W, int Cin, int Cout, void* stream);
+int myolo_conv3x3_bwd_data(const float* dy, const float* w, float* dx,
+                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_bwd_weight(const float* x, const float* dy, float* dw,
+                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Conv2DTranspose 2x2 stride 2 + bias (+ReLU) (myolo_mask_deconv model.py:711-712);
+ *      kernel layout [2,2,Cout,Cin] ---- */
+int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, float* y,
+                          int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, void* stream);
+int myolo_deconv2x2s2_bwd_data(const float* dy, const float* w, float* dx,
+                               int N, int H, int W, int Cin, int Cout, void* stream);
+int myolo_deconv2x2s2_bwd_weight(const float* x, const float* dy, float* dw,
+                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- per-channel column sums over rows: bias gradients ---- */
+int myolo_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- BatchNormalization(axis=-1, eps=1e-3, momentum=0.99) (model.py:51,690-708) ----
+ * bn_stats: batch mean / biased variance of x[M,C]; writes mean,var and the fused affine
+ *   scale = gamma*rsqrt(var+eps), shift = beta - mean*scale; if moving_* non-null updates them
+ *   Keras-style (momentum 0.99, variance rescaled by M/(M-(1+eps))).
+ * bn_frozen_coeffs: same scale/shift from the moving statistics (inference / training=False).
+ * bn_apply_act: y = act(x*scale + shift).
+ * bn_act_bwd: dy is the gradient wrt act(...) output; recomputes the activation mask from x;
+ *   batch_stats=1 -> training-mode BN backward (needs mean, var); 0 -> frozen affine.
+ *   Writes dx, dgamma, dbeta. */
+int myolo_bn_stats(const float* x, const float* gamma, const float* beta,
+                   float* mean, float* var, float* scale, float* shift,
+                   float* moving_mean, float* moving_var,
+                   int64_t M, int C, void* ws, size_t ws_bytes, void* stream);
+int myolo_bn_frozen_coeffs(const float* gamma, const float* beta, const float* moving_mean,
+                           const float* moving_var, float* scale, float* shift, int C, void* stream);
+int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, float* y,
+                       int64_t M, int C, int act, void* stream);
+int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma,
+                     const float* mean, const float* var, const float* scale, const float* shift,
+                     float* dx, float* dgamma, float* dbeta,
+                     int64_t M, int C, int act, int batch_stats, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- tf.image.crop_and_resize, bilinear, extrapolation 0 (PyramidROIAlign model.py:385-387) ----
+ * boxes [nb,4] = (y1,x1,y2,x2) normalised as crop_and_resize reads them; box_ind [nb] int32. */
+int myolo_crop_and_resize_fwd(const float* image, const float* boxes, const int32_t* box_ind, float* out,
+                              int B, int H, int W, int C, int nb, int crop_h, int crop_w, void* stream);
+int myolo_crop_and_resize_bwd_image(const float* dout, const float* boxes, const int32_t* box_ind, float* dimage,
+                                    int B, int H, int W, int C, int nb, int crop_h, int crop_w, void* stream);
+
+/* ---- DecodeYOLOLayer model.py:1442-1473 / DetectionsLayer model.py:1493-1538 ----
+ * y_pred [B,G,G,A,5+C]; anchors [2A]; proposals [B,G*G*A,4]; detections [B,G*G*A,6]. */
+int myolo_yolo_decode(const float* y_pred, const float* anchors, float* proposals,
+                      int B, int G, int A, int C, void* stream);
+int myolo_yolo_detections(const float* y_pred, const float* anchors, float* detections,
+                          int B, int G, int A, int C, void* stream);
+
+/* ---- yolo_custom_loss model.py:86-242, forward + gradient wrt y_pred in one call ----
+ * y_true [B,G,G,A,5+C] f32; true_boxes [B,T,4] f32 (grid units cx,cy,w,h); class_weights [C];
+ * out_terms[8] = {loss, loss_xy, loss_wh, loss_conf, loss_class, recall, n_coord, n_conf};
+ * grad = d(loss*loss_weight)/d y_pred. */
+int myolo_yolo_loss(const float* y_true, const float* y_pred, const float* true_boxes,
+                    const float* anchors, const float* class_weights,
+                    float object_scale, float no_object_scale, float coord_scale, float class_scale,
+                    float loss_weight, float* out_terms, float* grad,
+                    int B, int G, int A, int C, int T, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- DetectMaskTargetLayer / detect_mask_target_graph model.py:457-661 (+norm_boxes_graph
+ *      :1394-1408, trim_zeros_graph :1411-1420, overlaps_graph :420-454), one block per image ----
+ * proposals [B,R,4] (x1,y1,x2,y2); gt_class_ids [B,T] i32; gt_boxes_px [B,T,4] i32 (x1,y1,x2,y2);
+ * gt_masks [B,H,W,T] uint8 (0/1).  Outputs: rois [B,R,4], target_class_ids [B,R] i32,
+ * target_masks [B,R,mh,mw] f32 in {0,1}, n_pos [B] i32. */
+int myolo_mask_targets(const float* proposals, const int32_t* gt_class_ids, const int32_t* gt_boxes_px,
+                       const uint8_t* gt_masks, float* rois, int32_t* target_class_ids, float* target_masks,
+                       int32_t* n_pos, int B, int R, int T, int H, int W, int mh, int mw, void* stream);
+
+/* ---- final mask conv 1x1 + bias + sigmoid (myolo_mask model.py:713-714), C small ---- */
+int myolo_mask_head_out_fwd(const float* x, const float* w, const float* bias, float* p,
+                            int64_t M, int Cin, int C, void* stream);
+/* backward of the above given dz [M,C] (gradient wrt the pre-sigmoid logits):
+ * dx[M,Cin] = (dz w^T) * (x > 0)   (ReLU of the deconv output folded in), dw[Cin,C], db[C]. */
+int myolo_mask_head_out_bwd(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db,
+                            int64_t M, int Cin, int C, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- myolo_mask_loss_graph model.py:718-754 (K.binary_crossentropy), forward + gradient ----
+ * target_masks [NR,h,w]; ids [NR] i32; pred [NR,h,w,C] post-sigmoid.
+ * loss_out[2] = {loss, n_positive_rois}; dz [NR,h,w,C] = d(loss*loss_weight)/d logits. */
+int myolo_mask_bce(const float* target_masks, const int32_t* target_class_ids, const float* pred,
+                   float loss_weight, float* loss_out, float* dz,
+                   int NR, int h, int w, int C, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Keras Adam (model.py:1071-1075) over a flat parameter buffer ----
+ * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
+                    float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
+
+/* ---- small elementwise helpers ---- */
+int myolo_add_inplace(float* a, const float* b, int64_t n, void* stream);      /* a += b */
+int myolo_fill(float* a, float value, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MYOLO_HIP_H */

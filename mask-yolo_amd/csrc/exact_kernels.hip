@@ -1,0 +1,377 @@
+// Kernels whose outputs feed INTEGER decisions (positive/negative ROI partition, argmax class,
+// no-object mask) and therefore must agree bit-for-bit with the CPU restatement:
+//   yolo_decode / yolo_detections  (DecodeYOLOLayer model.py:1442-1473, DetectionsLayer :1493-1538)
+//   mask_targets                   (detect_mask_target_graph model.py:457-602 + helpers)
+//   yolo_loss fwd+bwd              (yolo_custom_loss model.py:86-242)
+// This translation unit is compiled with -ffp-contract=off: every float expression below is a
+// sequence of individually rounded IEEE-754 binary32 operations in source order, and exp/sigmoid
+// are the explicit polynomial of exact_math.h (same operation sequence as the oracle's det_expf).
+#include "myolo_common.h"
+#include "exact_math.h"
+
+// ---------------------------------------------------------------------------------------
+// decode
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void decode_box(const float* __restrict__ p, const float* __restrict__ anchors, int a, int col,
+                                           int row, float Gf, float* out4)
+{
+    const float x = (myolo_sigmoidf(p[0]) + (float)col) / Gf;
+    const float y = (myolo_sigmoidf(p[1]) + (float)row) / Gf;
+    const float w = (myolo_expf(p[2]) * anchors[2 * a + 0]) / Gf;
+    const float h = (myolo_expf(p[3]) * anchors[2 * a + 1]) / Gf;
+    const float hw = w / 2.0f, hh = h / 2.0f;
+    out4[0] = x - hw;
+    out4[1] = y - hh;
+    out4[2] = x + hw;
+    out4[3] = y + hh;
+}
+
+__global__ void yolo_decode_kernel(const float* __restrict__ yp, const float* __restrict__ anchors, float* __restrict__ out,
+                                   int total, int G, int A, int D, int det)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int a = i % A;
+    const int col = (i / A) % G;
+    const int row = (i / (A * G)) % G;
+    const float* p = yp + (long long)i * D;
+    float b[4];
+    decode_box(p, anchors, a, col, row, (float)G, b);
+    if (!det) {
+        float* o = out + (long long)i * 4;
+        o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+    } else {
+        float* o = out + (long long)i * 6;
+        o[0] = b[0]; o[1] = b[1]; o[2] = b[2]; o[3] = b[3];
+        o[4] = myolo_sigmoidf(p[4]);
+        int best = 0;
+        float bv = p[5];
+        for (int k = 1; k < D - 5; ++k)
+            if (p[5 + k] > bv) { bv = p[5 + k]; best = k; }     // first maximum wins (tf.argmax)
+        o[5] = (float)best;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mask targets: one block per image
+// ---------------------------------------------------------------------------------------
+#define MT_MAXT 64
+#define MT_MAXR 2048
+__global__ __launch_bounds__(256) void mask_targets_kernel(const float* __restrict__ proposals, const int32_t* __restrict__ gt_ids,
+                                                           const int32_t* __restrict__ gt_boxes, const uint8_t* __restrict__ gt_masks,
+                                                           float* __restrict__ rois, int32_t* __restrict__ tcls,
+                                                           float* __restrict__ tmasks, int32_t* __restrict__ npos_out,
+                                                           int R, int T, int H, int W, int mh, int mw)
+{
+    __shared__ float gtb[MT_MAXT][4];
+    __shared__ int keep[MT_MAXT];
+    __shared__ int nkeep_s;
+    __shared__ unsigned char posf[MT_MAXR];
+    __shared__ short arg[MT_MAXR];
+    __shared__ short dest[MT_MAXR];
+    __shared__ short src_of_dest[MT_MAXR];
+    __shared__ int npos_s;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* prop = proposals + (long long)b * R * 4;
+
+    // norm_boxes_graph (model.py:1405-1408): (box - [0,0,1,1]) / ([H,W,H,W] - 1)   (reference splits (H,W) as w,h)
+    if (tid < T) {
+        const int32_t* bp = gt_boxes + ((long long)b * T + tid) * 4;
+        gtb[tid][0] = ((float)bp[0] - 0.0f) / (float)(H - 1);
+        gtb[tid][1] = ((float)bp[1] - 0.0f) / (float)(W - 1);
+        gtb[tid][2] = ((float)bp[2] - 1.0f) / (float)(H - 1);
+        gtb[tid][3] = ((float)bp[3] - 1.0f) / (float)(W - 1);
+    }
+    __syncthreads();
+    if (tid == 0) {   // trim_zeros_graph (model.py:1418): keep rows whose |.| sum is non-zero
+        int n = 0;
+        for (int g = 0; g < T; ++g) {
+            const float s = fabsf(gtb[g][0]) + fabsf(gtb[g][1]) + fabsf(gtb[g][2]) + fabsf(gtb[g][3]);
+            if (s != 0.0f) keep[n++] = g;
+        }
+        nkeep_s = n;
+    }
+    __syncthreads();
+    const int nkeep = nkeep_s;
+    // overlaps_graph (model.py:438-451) + reduce_max / argmax over the kept GT boxes
+    for (int r = tid; r < R; r += blockDim.x) {
+        const float bx1 = prop[r * 4 + 0], by1 = prop[r * 4 + 1], bx2 = prop[r * 4 + 2], by2 = prop[r * 4 + 3];
+        const float a1 = (by2 - by1) * (bx2 - bx1);
+        float best = -INFINITY;
+        int bi = 0;
+        for (int k = 0; k < nkeep; ++k) {
+            const int g = keep[k];
+            const float x1 = fmaxf(bx1, gtb[g][0]), y1 = fmaxf(by1, gtb[g][1]);
+            const float x2 = fminf(bx2, gtb[g][2]), y2 = fminf(by2, gtb[g][3]);
+            const float inter = fmaxf(x2 - x1, 0.0f) * fmaxf(y2 - y1, 0.0f);
+            const float a2 = (gtb[g][3] - gtb[g][1]) * (gtb[g][2] - gtb[g][0]);
+            const float uni = a1 + a2 - inter;
+            const float iou = inter / uni;
+            if (iou > best) { best = iou; bi = k; }
+        }
+        // positive: max IoU >= 0.5 ; negative: < 0.5 ; NaN belongs to neither (2 = dropped)
+        posf[r] = (best >= 0.5f) ? 1 : ((best < 0.5f) ? 0 : 2);
+        arg[r] = (short)bi;
+    }
+    __syncthreads();
+    if (tid == 0) {   // stable partition: positives first, then negatives, index order kept
+        int np = 0, nn = 0;
+        for (int r = 0; r < R; ++r) np += posf[r] == 1;
+        int ip = 0;
+        for (int r = 0; r < R; ++r) {
+            if (posf[r] == 1) dest[r] = (short)(ip++);
+            else if (posf[r] == 0) dest[r] = (short)(np + nn++);
+            else dest[r] = -1;
+        }
+        npos_s = np;
+        npos_out[b] = np;
+        for (int d = 0; d < R; ++d) src_of_dest[d] = -1;
+        for (int r = 0; r < R; ++r)
+            if (dest[r] >= 0) src_of_dest[dest[r]] = (short)r;
+    }
+    __syncthreads();
+    const int npos = npos_s;
+    // rois + class ids
+    for (int d = tid; d < R; d += blockDim.x) {
+        const int r = src_of_dest[d];
+        float* o = rois + ((long long)b * R + d) * 4;
+        if (r >= 0) {
+            o[0] = prop[r * 4 + 0]; o[1] = prop[r * 4 + 1]; o[2] = prop[r * 4 + 2]; o[3] = prop[r * 4 + 3];
+        } else {
+            o[0] = o[1] = o[2] = o[3] = 0.0f;
+        }
+        int cls = 0;
+        if (r >= 0 && d < npos) cls = gt_ids[(long long)b * T + keep[arg[r]]];
+        tcls[(long long)b * R + d] = cls;
+    }
+    // mask targets: crop_and_resize(gt_mask[g], [y1,x1,y2,x2], mh x mw) then tf.round (model.py:558-589)
+    const int msz = mh * mw;
+    float* tm = tmasks + (long long)b * R * msz;
+    for (int i = tid; i < R * msz; i += blockDim.x) {
+        const int d = i / msz;
+        float v = 0.0f;
+        if (d < npos) {
+            const int r = src_of_dest[d];
+            const int g = keep[arg[r]];
+            const int py = (i - d * msz) / mw, px = (i - d * msz) % mw;
+            const float bx1 = prop[r * 4 + 0], by1 = prop[r * 4 + 1], bx2 = prop[r * 4 + 2], by2 = prop[r * 4 + 3];
+            float iny, inx;
+            const float sy = (by2 - by1) * (float)(H - 1) / (float)(mh - 1);
+            iny = by1 * (float)(H - 1) + (float)py * sy;
+            const float sx = (bx2 - bx1) * (float)(W - 1) / (float)(mw - 1);
+            inx = bx1 * (float)(W - 1) + (float)px * sx;
+            const bool ok = !(iny < 0.0f || iny > (float)(H - 1)) && !(inx < 0.0f || inx > (float)(W - 1));
+            if (ok) {
+                const int ty = (int)floorf(iny), byy = (int)ceilf(iny);
+                const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+                const float wy = iny - (float)ty, wx = inx - (float)lx;
+                const uint8_t* mp = gt_masks + (long long)b * H * W * T + g;
+                const float tl = (float)(mp[((long long)ty * W + lx) * T] != 0), tr = (float)(mp[((long long)ty * W + rx) * T] != 0);
+                const float bl = (float)(mp[((long long)byy * W + lx) * T] != 0), br = (float)(mp[((long long)byy * W + rx) * T] != 0);
+                const float top = tl + (tr - tl) * wx;
+                const float bot = bl + (br - bl) * wx;
+                v = rintf(top + (bot - top) * wy);          // round half to even
+            }
+        }
+        tm[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// YOLO loss, forward + gradient.  Single block (B*G*G*A is a few thousand boxes).
+// ---------------------------------------------------------------------------------------
+struct IouOut { float iou, inter, uni, dw, dh; float pminx, pminy, pmaxx, pmaxy, tminx, tminy, tmaxx, tmaxy; };
+
+__device__ __forceinline__ float iou_centre(float px, float py, float pw, float ph, float tx, float ty, float tw, float th, IouOut* o)
+{
+    const float pminx = px - pw / 2.0f, pmaxx = px + pw / 2.0f, pminy = py - ph / 2.0f, pmaxy = py + ph / 2.0f;
+    const float tminx = tx - tw / 2.0f, tmaxx = tx + tw / 2.0f, tminy = ty - th / 2.0f, tmaxy = ty + th / 2.0f;
+    const float dw = fminf(pmaxx, tmaxx) - fmaxf(pminx, tminx);
+    const float dh = fminf(pmaxy, tmaxy) - fmaxf(pminy, tminy);
+    const float iw = fmaxf(dw, 0.0f), ih = fmaxf(dh, 0.0f);
+    const float inter = iw * ih;
+    const float uni = pw * ph + tw * th - inter;
+    const float iou = inter / uni;
+    if (o) {
+        o->iou = iou; o->inter = inter; o->uni = uni; o->dw = dw; o->dh = dh;
+        o->pminx = pminx; o->pminy = pminy; o->pmaxx = pmaxx; o->pmaxy = pmaxy;
+        o->tminx = tminx; o->tminy = tminy; o->tmaxx = tmaxx; o->tmaxy = tmaxy;
+    }
+    return iou;
+}
+
+struct LossArgs {
+    const float* yt; const float* yp; const float* tb; const float* anchors; const float* cw;
+    float obj, noobj, coord, cls, lw;
+    float* out; float* grad;
+    int B, G, A, C, T;
+};
+
+#define LOSS_NACC 9   // sum_xy, sum_wh, sum_conf, sum_cls, n_coord, n_conf, n_cls, nb_true, nb_pred
+__global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a)
+{
+    __shared__ double red[LOSS_NACC][256];
+    __shared__ double tot[LOSS_NACC];
+    const int D = 5 + a.C;
+    const int total = a.B * a.G * a.G * a.A;
+    const int tid = threadIdx.x;
+    double acc[LOSS_NACC];
+    for (int k = 0; k < LOSS_NACC; ++k) acc[k] = 0;
+
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = tid; i < total; i += blockDim.x) {
+            const int an = i % a.A;
+            const int col = (i / a.A) % a.G;
+            const int row = (i / (a.A * a.G)) % a.G;
+            const int b = i / (a.A * a.G * a.G);
+            const float* p = a.yp + (long long)i * D;
+            const float* t = a.yt + (long long)i * D;
+            const float sx = myolo_sigmoidf(p[0]), sy = myolo_sigmoidf(p[1]);
+            const float px = sx + (float)col, py = sy + (float)row;
+            const float pw = myolo_expf(p[2]) * a.anchors[2 * an], ph = myolo_expf(p[3]) * a.anchors[2 * an + 1];
+            const float pc = myolo_sigmoidf(p[4]);
+            const float t4 = t[4];
+            IouOut io;
+            const float iou1 = iou_centre(px, py, pw, ph, t[0], t[1], t[2], t[3], &io);
+            const float tconf = iou1 * t4;
+            int tcls = 0;
+            float tv = t[5];
+            for (int k = 1; k < a.C; ++k)
+                if (t[5 + k] > tv) { tv = t[5 + k]; tcls = k; }
+            float best = -INFINITY;
+            for (int k = 0; k < a.T; ++k) {
+                const float* q = a.tb + ((long long)b * a.T + k) * 4;
+                const float v = iou_centre(px, py, pw, ph, q[0], q[1], q[2], q[3], nullptr);
+                if (v > best) best = v;
+            }
+            const float coord_mask = t4 * a.coord;
+            const float conf_mask = ((best < 0.6f) ? 1.0f : 0.0f) * (1.0f - t4) * a.noobj + t4 * a.obj;
+            const float class_mask = t4 * a.cw[tcls] * a.cls;
+            // softmax CE over class logits
+            float mx = p[5];
+            for (int k = 1; k < a.C; ++k) mx = fmaxf(mx, p[5 + k]);
+            float se = 0.0f;
+            for (int k = 0; k < a.C; ++k) se += expf(p[5 + k] - mx);
+            const float lse = logf(se) + mx;
+            if (pass == 0) {
+                const float ex = t[0] - px, ey = t[1] - py, ew = t[2] - pw, eh = t[3] - ph, ec = tconf - pc;
+                acc[0] += (double)((ex * ex + ey * ey) * coord_mask);
+                acc[1] += (double)((ew * ew + eh * eh) * coord_mask);
+                acc[2] += (double)(ec * ec * conf_mask);
+                acc[3] += (double)((lse - p[5 + tcls]) * class_mask);
+                acc[4] += coord_mask > 0.0f;
+                acc[5] += conf_mask > 0.0f;
+                acc[6] += class_mask > 0.0f;
+                acc[7] += (double)t4;
+                acc[8] += (tconf > 0.5f && pc > 0.3f) ? 1.0 : 0.0;
+            } else {
+                const float ncoord = (float)tot[4] + 1e-6f, nconf = (float)tot[5] + 1e-6f, ncls = (float)tot[6] + 1e-6f;
+                float* g = a.grad + (long long)i * D;
+                float dpx = -(t[0] - px) * coord_mask / ncoord, dpy = -(t[1] - py) * coord_mask / ncoord;
+                float dpw = -(t[2] - pw) * coord_mask / ncoord, dph = -(t[3] - ph) * coord_mask / ncoord;
+                const float dtconf = (tconf - pc) * conf_mask / nconf;
+                const float dpc = -dtconf;
+                const float diou = dtconf * t4;
+                if (diou != 0.0f) {
+                    const float U = io.uni, I = io.inter;
+                    const float dI = diou / U + diou * I / (U * U);
+                    const float dUp = -diou * I / (U * U);
+                    const float iw = fmaxf(io.dw, 0.0f), ih = fmaxf(io.dh, 0.0f);
+                    const float ddw = (io.dw >= 0.0f) ? dI * ih : 0.0f;      // tf.maximum(d, 0.): first arg on ties
+                    const float ddh = (io.dh >= 0.0f) ? dI * iw : 0.0f;
+                    const float dpmaxx = (io.pmaxx <= io.tmaxx) ? ddw : 0.0f, dpmaxy = (io.pmaxy <= io.tmaxy) ? ddh : 0.0f;
+                    const float dpminx = (io.pminx >= io.tminx) ? -ddw : 0.0f, dpminy = (io.pminy >= io.tminy) ? -ddh : 0.0f;
+                    dpx += dpmaxx + dpminx;
+                    dpy += dpmaxy + dpminy;
+                    dpw += (dpmaxx - dpminx) / 2.0f + dUp * ph;
+                    dph += (dpmaxy - dpminy) / 2.0f + dUp * pw;
+                }
+                g[0] = dpx * sx * (1.0f - sx) * a.lw;
+                g[1] = dpy * sy * (1.0f - sy) * a.lw;
+                g[2] = dpw * pw * a.lw;
+                g[3] = dph * ph * a.lw;
+                g[4] = dpc * pc * (1.0f - pc) * a.lw;
+                const float cm = class_mask / ncls;
+                for (int k = 0; k < a.C; ++k) {
+                    const float sm = expf(p[5 + k] - mx) / se;
+                    g[5 + k] = (sm - (k == tcls ? 1.0f : 0.0f)) * cm * a.lw;
+                }
+            }
+        }
+        if (pass == 0) {
+            for (int k = 0; k < LOSS_NACC; ++k) red[k][tid] = acc[k];
+            __syncthreads();
+            for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+                if (tid < o)
+                    for (int k = 0; k < LOSS_NACC; ++k) red[k][tid] += red[k][tid + o];
+                __syncthreads();
+            }
+            if (tid < LOSS_NACC) tot[tid] = red[tid][0];
+            __syncthreads();
+            if (tid == 0) {
+                const float ncoord = (float)tot[4], nconf = (float)tot[5], ncls = (float)tot[6];
+                const float lxy = (float)tot[0] / (ncoord + 1e-6f) / 2.0f;
+                const float lwh = (float)tot[1] / (ncoord + 1e-6f) / 2.0f;
+                const float lcf = (float)tot[2] / (nconf + 1e-6f) / 2.0f;
+                const float lcl = (float)tot[3] / (ncls + 1e-6f);
+                a.out[0] = lxy + lwh + lcf + lcl;
+                a.out[1] = lxy; a.out[2] = lwh; a.out[3] = lcf; a.out[4] = lcl;
+                a.out[5] = (float)tot[8] / ((float)tot[7] + 1e-6f);
+                a.out[6] = ncoord; a.out[7] = nconf;
+            }
+        }
+    }
+}
+
+extern "C" {
+
+int myolo_yolo_decode(const float* y_pred, const float* anchors, float* proposals, int B, int G, int A, int C, void* stream)
+{
+    MYOLO_REQUIRE(y_pred && anchors && proposals && B > 0 && G > 0 && A > 0 && C > 0, "yolo_decode: bad arguments");
+    const int total = B * G * G * A;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, y_pred, anchors,
+                       proposals, total, G, A, 5 + C, 0);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_yolo_detections(const float* y_pred, const float* anchors, float* detections, int B, int G, int A, int C, void* stream)
+{
+    MYOLO_REQUIRE(y_pred && anchors && detections && B > 0 && G > 0 && A > 0 && C > 0, "yolo_detections: bad arguments");
+    const int total = B * G * G * A;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, y_pred, anchors,
+                       detections, total, G, A, 5 + C, 1);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_mask_targets(const float* proposals, const int32_t* gt_class_ids, const int32_t* gt_boxes_px, const uint8_t* gt_masks,
+                       float* rois, int32_t* target_class_ids, float* target_masks, int32_t* n_pos, int B, int R, int T, int H,
+                       int W, int mh, int mw, void* stream)
+{
+    MYOLO_REQUIRE(proposals && gt_class_ids && gt_boxes_px && gt_masks && rois && target_class_ids && target_masks && n_pos,
+                  "mask_targets: null pointer");
+    MYOLO_REQUIRE(B > 0 && R > 0 && R <= MT_MAXR && T > 0 && T <= MT_MAXT && mh > 1 && mw > 1,
+                  "mask_targets: need R<=%d, T<=%d, mask shape > 1", MT_MAXR, MT_MAXT);
+    hipLaunchKernelGGL(mask_targets_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, proposals, gt_class_ids, gt_boxes_px,
+                       gt_masks, rois, target_class_ids, target_masks, n_pos, R, T, H, W, mh, mw);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_yolo_loss(const float* y_true, const float* y_pred, const float* true_boxes, const float* anchors,
+                    const float* class_weights, float object_scale, float no_object_scale, float coord_scale, float class_scale,
+                    float loss_weight, float* out_terms, float* grad, int B, int G, int A, int C, int T, void* ws, size_t ws_bytes,
+                    void* stream)
+{
+    (void)ws; (void)ws_bytes;
+    MYOLO_REQUIRE(y_true && y_pred && true_boxes && anchors && class_weights && out_terms && grad, "yolo_loss: null pointer");
+    MYOLO_REQUIRE(B > 0 && G > 0 && A > 0 && C > 0 && T > 0, "yolo_loss: bad sizes");
+    LossArgs a{y_true, y_pred, true_boxes, anchors, class_weights, object_scale, no_object_scale, coord_scale, class_scale,
+               loss_weight, out_terms, grad, B, G, A, C, T};
+    hipLaunchKernelGGL(yolo_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,600 @@
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) implicit-GEMM kernels for gfx950 -- the MFMA-bound part of
+// the Mask-YOLO hot path: pointwise 1x1 convs, 3x3 'same' convs (feature_map, mask head),
+// 2x2/s2 transposed conv, and their data / weight gradients.
+//
+// Two kernels, each with three A-operand addressing modes (no im2col buffer is ever built):
+//   gemm_nn : C[M,N]  = A(m,k) * B[k,n]        (forward, and dX with pre-transformed weights)
+//   gemm_tn : C[Ka,N] = sum_m A(m,ka) * B[m,n] (weight gradients; split over m, then reduced)
+// A modes : PLAIN  A(m,k)        = A[m*lda + k]
+//           CONV3  k=(tap,c)     = X[pixel(m) + (ty-1,tx-1)][c]   zero outside the image
+//           DECONV k=(ky,kx,c)   = Y[2*pixel(m) + (ky,kx)][c]     (gather from the 2Hx2W grid)
+//
+// Tiling: 128x128 block tile, BK=16, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA
+// 32x32 tiles (64 accumulator VGPRs).  The K order inside a BK chunk is permuted so that MFMA
+// step j takes k=j from lane-half 0 and k=8+j from lane-half 1 (the sum over k is order-free as
+// long as A and B agree).  LDS is double-buffered, one barrier per K step; global loads for
+// step t+1 are issued before the MFMAs of step t and written to LDS after them.
+// A tile is stored k-major ([k][m], row length 130) so fragment reads are conflict-free b32.
+#include "myolo_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define BM 128
+#define BN 128
+#define BK 16
+#define LDAS (BM + 2)
+
+enum { AM_PLAIN = 0, AM_CONV3 = 1, AM_DECONV = 2 };
+enum { EP_PLAIN = 0, EP_DECONV = 1 };
+
+struct GemmArgs {
+    const float* A;
+    const float* B;
+    float* C;
+    const float* bias;
+    long long M;      // rows of the pixel space
+    int N;            // output columns
+    int K;            // NN: reduction length;  TN: number of output rows (Ka)
+    long long lda, ldb, ldc;
+    int H, W;         // pixel grid of the row space (gather modes)
+    int Cc;           // channels per tap of the A operand (gather modes)
+    int Co;           // EP_DECONV: output channels per tap
+    int act;
+    long long m_per_split;   // TN only
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ------------------------------------------------------------------------------------------
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nn(GemmArgs p)
+{
+    __shared__ float As[2][BK][LDAS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + BN - 1) / BN;
+    const long long bid = blockIdx.x;
+    const int tn = (int)(bid % ntn);
+    const long long m0 = (bid / ntn) * BM;
+    const int n0 = tn * BN;
+
+    // ---- per-thread A rows (two rows, one float4 of k each) ----
+    const int ar = tid >> 2, akq = (tid & 3) * 4;
+    long long am[2];
+    bool avalid[2];
+    int ay[2], ax[2];
+    long long abase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long long m = m0 + ar + 64 * i;
+        avalid[i] = m < p.M;
+        if (!avalid[i]) m = 0;
+        am[i] = m;
+        if (AMODE != AM_PLAIN) {
+            const long long hw = (long long)p.H * p.W;
+            const long long n_img = m / hw;
+            const int rem = (int)(m - n_img * hw);
+            ay[i] = rem / p.W;
+            ax[i] = rem - ay[i] * p.W;
+            if (AMODE == AM_DECONV) abase[i] = n_img * 4 * hw + (long long)ay[i] * 4 * p.W + 2 * ax[i];
+        }
+    }
+    // ---- per-thread B elements ----
+    const int bk = tid >> 5, bn4 = (tid & 31) * 4;
+    const bool bvec = (p.N & 3) == 0 && (p.ldb & 3) == 0;
+    const bool avec = (p.K & 3) == 0 && (p.lda & 3) == 0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    float4 ra[2], rb[2];
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        // A
+        if (AMODE == AM_PLAIN) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = k0 + akq;
+                const float* ap = p.A + am[i] * p.lda + k;
+                if (avalid[i] && avec && k + 3 < p.K) {
+                    ra[i] = ld4(ap);
+                } else {
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (avalid[i]) {
+                        if (k + 0 < p.K) v.x = ap[0];
+                        if (k + 1 < p.K) v.y = ap[1];
+                        if (k + 2 < p.K) v.z = ap[2];
+                        if (k + 3 < p.K) v.w = ap[3];
+                    }
+                    ra[i] = v;
+                }
+            }
+        } else if (AMODE == AM_CONV3) {
+            const int tap = k0 / p.Cc, c0 = k0 - tap * p.Cc;
+            const int ty = tap / 3, tx = tap - ty * 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int yy = ay[i] + ty - 1, xx = ax[i] + tx - 1;
+                const bool v = avalid[i] && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+                const long long off = (am[i] + (long long)(ty - 1) * p.W + (tx - 1)) * p.Cc + c0 + akq;
+                ra[i] = v ? ld4(p.A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const int tap = k0 / p.Cc, c0 = k0 - tap * p.Cc;
+            const int ky = tap >> 1, kx = tap & 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const long long off = (abase[i] + (long long)ky * 2 * p.W + kx) * p.Cc + c0 + akq;
+                ra[i] = avalid[i] ? ld4(p.A + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        // B
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = k0 + bk + 8 * i;
+            const int n = n0 + bn4;
+            const float* bp = p.B + (long long)k * p.ldb + n;
+            if (k < p.K && bvec && n + 3 < p.N) {
+                rb[i] = ld4(bp);
+            } else {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < p.K) {
+                    if (n + 0 < p.N) v.x = bp[0];
+                    if (n + 1 < p.N) v.y = bp[1];
+                    if (n + 2 < p.N) v.z = bp[2];
+                    if (n + 3 < p.N) v.w = bp[3];
+                }
+                rb[i] = v;
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            As[buf][akq + 0][ar + 64 * i] = ra[i].x;
+            As[buf][akq + 1][ar + 64 * i] = ra[i].y;
+            As[buf][akq + 2][ar + 64 * i] = ra[i].z;
+            As[buf][akq + 3][ar + 64 * i] = ra[i].w;
+            *reinterpret_cast<float4*>(&Bs[buf][bk + 8 * i][bn4]) = rb[i];
+        }
+    };
+
+    gload(0);
+    sstore(0);
+    __syncthreads();
+
+    const int half = lane >> 5, l31 = lane & 31;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = half * 8 + j;
+            const float a0 = As[cur][kk][wm * 64 + l31];
+            const float a1 = As[cur][kk][wm * 64 + 32 + l31];
+            const float b0 = Bs[cur][kk][wn * 64 + l31];
+            const float b1 = Bs[cur][kk][wn * 64 + 32 + l31];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) sstore(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            long long rowoff;
+            if (EPI == EP_PLAIN) {
+                rowoff = row * p.ldc;
+            } else {
+                const long long hw = (long long)p.H * p.W;
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                rowoff = n_img * 4 * hw + (long long)y * 4 * p.W + 2 * x;   // pixel index on the 2Hx2W grid
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = n0 + wn * 64 + u * 32 + l31;
+                if (col >= p.N) continue;
+                float v = acc[t][u][r];
+                if (EPI == EP_PLAIN) {
+                    if (p.bias) v += p.bias[col];
+                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.C[rowoff + col] = v;
+                } else {
+                    const int tap = col / p.Co, co = col - tap * p.Co;
+                    if (p.bias) v += p.bias[co];
+                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.C[(rowoff + (long long)(tap >> 1) * 2 * p.W + (tap & 1)) * p.Co + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// C_part[split][Ka][N] = sum over this split's rows m of A(m,ka) * B[m,n]
+template <int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_tn(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tn = blockIdx.x % ntn;
+    const int tka = blockIdx.x / ntn;
+    const int ka0 = tka * BM, n0 = tn * BN;
+    const long long ms = (long long)blockIdx.y * p.m_per_split;
+    long long me = ms + p.m_per_split;
+    if (me > p.M) me = p.M;
+
+    const int lr = tid >> 5, c4 = (tid & 31) * 4;
+    const int ka = ka0 + c4;
+    int tap = 0, c0 = ka;
+    if (AMODE != AM_PLAIN) { tap = ka / p.Cc; c0 = ka - tap * p.Cc; }
+    const bool avec = (p.lda & 3) == 0 && (p.K & 3) == 0;
+    const bool bvec = (p.ldb & 3) == 0 && (p.N & 3) == 0;
+    const long long hw = (long long)p.H * p.W;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    auto gload = [&](long long mbase) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long long m = mbase + lr + 8 * i;
+            const bool mv = m < me;
+            // ---- A ----
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mv && ka < p.K) {
+                const float* ap = nullptr;
+                if (AMODE == AM_PLAIN) {
+                    ap = p.A + m * p.lda + ka;
+                } else {
+                    const long long n_img = m / hw;
+                    const int rem = (int)(m - n_img * hw);
+                    const int y = rem / p.W, x = rem - y * p.W;
+                    if (AMODE == AM_CONV3) {
+                        const int ty = tap / 3, tx = tap - ty * 3;
+                        const int yy = y + ty - 1, xx = x + tx - 1;
+                        if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W)
+                            ap = p.A + (m + (long long)(ty - 1) * p.W + (tx - 1)) * p.Cc + c0;
+                    } else {
+                        const int ky = tap >> 1, kx = tap & 1;
+                        ap = p.A + (n_img * 4 * hw + (long long)(2 * y + ky) * 2 * p.W + 2 * x + kx) * p.Cc + c0;
+                    }
+                }
+                if (ap) {
+                    if (avec && ka + 3 < p.K) {
+                        va = ld4(ap);
+                    } else {
+                        va.x = ap[0];
+                        if (ka + 1 < p.K) va.y = ap[1];
+                        if (ka + 2 < p.K) va.z = ap[2];
+                        if (ka + 3 < p.K) va.w = ap[3];
+                    }
+                }
+            }
+            ra[i] = va;
+            // ---- B ----
+            float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int n = n0 + c4;
+            if (mv && n < p.N) {
+                const float* bp = p.B + m * p.ldb + n;
+                if (bvec && n + 3 < p.N) {
+                    vb = ld4(bp);
+                } else {
+                    vb.x = bp[0];
+                    if (n + 1 < p.N) vb.y = bp[1];
+                    if (n + 2 < p.N) vb.z = bp[2];
+                    if (n + 3 < p.N) vb.w = bp[3];
+                }
+            }
+            rb[i] = vb;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(&As[buf][lr + 8 * i][c4]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[buf][lr + 8 * i][c4]) = rb[i];
+        }
+    };
+
+    const long long nsteps = (me > ms) ? (me - ms + BK - 1) / BK : 0;
+    const int half = lane >> 5, l31 = lane & 31;
+    if (nsteps > 0) {
+        gload(ms);
+        sstore(0);
+        __syncthreads();
+        int cur = 0;
+        for (long long st = 0; st < nsteps; ++st) {
+            if (st + 1 < nsteps) gload(ms + (st + 1) * BK);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int kk = half * 8 + j;
+                const float a0 = As[cur][kk][wm * 64 + l31];
+                const float a1 = As[cur][kk][wm * 64 + 32 + l31];
+                const float b0 = Bs[cur][kk][wn * 64 + l31];
+                const float b1 = Bs[cur][kk][wn * 64 + 32 + l31];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (st + 1 < nsteps) sstore(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    float* Cp = p.C + (long long)blockIdx.y * p.K * p.N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ka0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.K) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = n0 + wn * 64 + u * 32 + l31;
+                if (col < p.N) Cp[(long long)row * p.N + col] = acc[t][u][r];
+            }
+        }
+}
+
+__global__ void splitk_reduce(const float* __restrict__ part, float* __restrict__ out, long long n, int splits)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
+        out[i] = s;
+    }
+}
+
+// out[z][c][r] = in[zmap(z)][r][c]; reverse!=0 maps z -> nz-1-z (3x3 tap rotation by 180 degrees)
+__global__ void transpose_batched(const float* __restrict__ in, float* __restrict__ out, int R, int C, int nz, int reverse)
+{
+    __shared__ float tile[32][33];
+    const int z = blockIdx.z;
+    const int zi = reverse ? (nz - 1 - z) : z;
+    const float* ip = in + (long long)zi * R * C;
+    float* op = out + (long long)z * R * C;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int r = r0 + i, c = c0 + threadIdx.x;
+        tile[i][threadIdx.x] = (r < R && c < C) ? ip[(long long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+        const int c = c0 + i, r = r0 + threadIdx.x;
+        if (r < R && c < C) op[(long long)c * R + r] = tile[threadIdx.x][i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int launch_transpose(const float* in, float* out, int R, int C, int nz, int reverse, hipStream_t s)
+{
+    dim3 grid((C + 31) / 32, (R + 31) / 32, nz), block(32, 8);
+    hipLaunchKernelGGL(transpose_batched, grid, block, 0, s, in, out, R, C, nz, reverse);
+    return 0;
+}
+
+template <int AMODE, int EPI>
+static int launch_nn(const GemmArgs& a, hipStream_t s)
+{
+    const long long tiles = cdiv64(a.M, BM) * ((a.N + BN - 1) / BN);
+    if (tiles <= 0) return MYOLO_OK;
+    hipLaunchKernelGGL((gemm_nn<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}
+
+static int choose_splits(long long M, int Ka, int N)
+{
+    const long long tiles = (long long)((Ka + BM - 1) / BM) * ((N + BN - 1) / BN);
+    long long splits = (768 + tiles - 1) / tiles;
+    const long long max_by_rows = cdiv64(M, 8 * BK);     // at least 8 K-steps per split
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    if (splits > 1024) splits = 1024;
+    return (int)splits;
+}
+
+static size_t tn_ws_bytes(long long M, int Ka, int N)
+{
+    const int splits = choose_splits(M, Ka, N);
+    return splits > 1 ? (size_t)splits * Ka * N * sizeof(float) : 0;
+}
+
+template <int AMODE>
+static int launch_tn(GemmArgs a, float* out, void* ws, size_t ws_bytes, hipStream_t s, const char* who)
+{
+    const int splits = choose_splits(a.M, a.K, a.N);
+    const size_t need = splits > 1 ? (size_t)splits * a.K * a.N * sizeof(float) : 0;
+    if (need > ws_bytes || (need && !ws)) {
+        myolo_set_error("%s: workspace too small (%zu needed, %zu given)", who, need, ws_bytes);
+        return MYOLO_EWORKSPACE;
+    }
+    long long mps = cdiv64(a.M, splits);
+    mps = cdiv64(mps, BK) * BK;
+    a.m_per_split = mps;
+    a.C = splits > 1 ? (float*)ws : out;
+    const int tiles = ((a.K + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_tn<AMODE>), dim3(tiles, splits), dim3(256), 0, s, a);
+    if (splits > 1) {
+        const long long n = (long long)a.K * a.N;
+        int blocks = (int)((n + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)ws, out, n, splits);
+    }
+    return MYOLO_OK;
+}
+
+extern "C" {
+
+size_t myolo_workspace_bytes(int64_t rows, int cin, int cout)
+{
+    // largest user: weight-gradient split-K partials of a 3x3 conv (Ka = 9*cin) or deconv (Ka = 4*cout)
+    size_t a = tn_ws_bytes(rows, 9 * cin, cout);
+    size_t b = tn_ws_bytes(rows, 4 * cout, cin);
+    size_t c = (size_t)9 * cin * cout * sizeof(float);          // transformed weights
+    size_t m = a > b ? a : b;
+    return align256(m > c ? m : c) + align256(c) + (size_t)(1 << 20);
+}
+
+int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
+                        int64_t M, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && M > 0 && Cin > 0 && Cout > 0, "pwconv1x1_fwd: bad arguments");
+    GemmArgs a = {};
+    a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = M; a.N = Cout; a.K = Cin;
+    a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = MYOLO_ACT_NONE;
+    launch_nn<AM_PLAIN, EP_PLAIN>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
+                             int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && w && dx && M > 0, "pwconv1x1_bwd_data: bad arguments");
+    MYOLO_NEED_WS((size_t)Cin * Cout * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    launch_transpose(w, (float*)ws, Cin, Cout, 1, 0, s);        // ws = w^T [Cout][Cin]
+    GemmArgs a = {};
+    a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = M; a.N = Cin; a.K = Cout;
+    a.lda = Cout; a.ldb = Cin; a.ldc = Cin;
+    launch_nn<AM_PLAIN, EP_PLAIN>(a, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
+                               int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && dy && dw && M > 0, "pwconv1x1_bwd_weight: bad arguments");
+    GemmArgs a = {};
+    a.A = x; a.B = dy; a.M = M; a.N = Cout; a.K = Cin; a.lda = Cin; a.ldb = Cout;
+    int rc = launch_tn<AM_PLAIN>(a, dw, ws, ws_bytes, (hipStream_t)stream, "pwconv1x1_bwd_weight");
+    if (rc) return rc;
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
+                      int N, int H, int W, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, "conv3x3_fwd: bad arguments");
+    MYOLO_REQUIRE(Cin % BK == 0, "conv3x3_fwd: Cin must be a multiple of %d (got %d)", BK, Cin);
+    GemmArgs a = {};
+    a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin;
+    a.ldb = Cout; a.ldc = Cout; a.H = H; a.W = W; a.Cc = Cin;
+    launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3_bwd_data(const float* dy, const float* w, float* dx,
+                           int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && w && dx && N > 0, "conv3x3_bwd_data: bad arguments");
+    MYOLO_REQUIRE(Cout % BK == 0, "conv3x3_bwd_data: Cout must be a multiple of %d (got %d)", BK, Cout);
+    MYOLO_NEED_WS((size_t)9 * Cin * Cout * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    // ws[tap][co][ci] = w[8-tap][ci][co]  : dx = conv3x3_same(dy, rot180(w)^T)
+    launch_transpose(w, (float*)ws, Cin, Cout, 9, 1, s);
+    GemmArgs a = {};
+    a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 9 * Cout;
+    a.ldb = Cin; a.ldc = Cin; a.H = H; a.W = W; a.Cc = Cout;
+    launch_nn<AM_CONV3, EP_PLAIN>(a, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3_bwd_weight(const float* x, const float* dy, float* dw,
+                             int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && dy && dw && N > 0, "conv3x3_bwd_weight: bad arguments");
+    MYOLO_REQUIRE((Cin & 3) == 0, "conv3x3_bwd_weight: Cin must be a multiple of 4 (got %d)", Cin);
+    GemmArgs a = {};
+    a.A = x; a.B = dy; a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin; a.ldb = Cout;
+    a.H = H; a.W = W; a.Cc = Cin;
+    int rc = launch_tn<AM_CONV3>(a, dw, ws, ws_bytes, (hipStream_t)stream, "conv3x3_bwd_weight");
+    if (rc) return rc;
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, float* y,
+                          int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && N > 0, "deconv2x2s2_fwd: bad arguments");
+    MYOLO_REQUIRE(Cin > 0 && Cout > 0, "deconv2x2s2_fwd: bad channels");
+    MYOLO_NEED_WS((size_t)4 * Cin * Cout * sizeof(float));
+    hipStream_t s = (hipStream_t)stream;
+    launch_transpose(w, (float*)ws, 4 * Cout, Cin, 1, 0, s);     // ws[ci][(ky,kx,co)]
+    GemmArgs a = {};
+    a.A = x; a.B = (const float*)ws; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
+    a.lda = Cin; a.ldb = 4 * Cout; a.H = H; a.W = W; a.Co = Cout; a.act = act;
+    launch_nn<AM_PLAIN, EP_DECONV>(a, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_deconv2x2s2_bwd_data(const float* dy, const float* w, float* dx,
+                               int N, int H, int W, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(dy && w && dx && N > 0, "deconv2x2s2_bwd_data: bad arguments");
+    MYOLO_REQUIRE(Cout % BK == 0, "deconv2x2s2_bwd_data: Cout must be a multiple of %d", BK);
+    GemmArgs a = {};
+    a.A = dy; a.B = w; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 4 * Cout;
+    a.ldb = Cin; a.ldc = Cin; a.H = H; a.W = W; a.Cc = Cout;
+    launch_nn<AM_DECONV, EP_PLAIN>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_deconv2x2s2_bwd_weight(const float* x, const float* dy, float* dw,
+                                 int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && dy && dw && N > 0, "deconv2x2s2_bwd_weight: bad arguments");
+    MYOLO_REQUIRE((Cout & 3) == 0, "deconv2x2s2_bwd_weight: Cout must be a multiple of 4");
+    GemmArgs a = {};
+    a.A = dy; a.B = x; a.M = (long long)N * H * W; a.N = Cin; a.K = 4 * Cout; a.ldb = Cin;
+    a.H = H; a.W = W; a.Cc = Cout;
+    int rc = launch_tn<AM_DECONV>(a, dw, ws, ws_bytes, (hipStream_t)stream, "deconv2x2s2_bwd_weight");
+    if (rc) return rc;
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,1065 @@
+// HBM-bound kernels of the Mask-YOLO hot path for gfx950: conv1 (Cin=3), depthwise 3x3,
+// BatchNorm statistics / apply / backward, ROIAlign (crop_and_resize) gather + scatter-add,
+// the final mask 1x1+sigmoid, mask BCE, Adam, small helpers.
+//
+// Layout rule everywhere: NHWC fp32, one lane owns 4 consecutive channels (16-byte loads/stores),
+// consecutive lanes own consecutive channel quads, so every wave-level access is a run of
+// contiguous 16 B segments.  Column reductions (BN statistics, bias / weight gradients) use
+// one shape: a block owns a slab of rows, each thread accumulates its rows in registers,
+// a shared-memory tree combines the row lanes, per-block partials go to the caller's workspace
+// in double and a second tiny kernel finishes -- deterministic, no atomics.
+#include "myolo_common.h"
+#include <stdarg.h>
+#include <string.h>
+
+// ---------------------------------------------------------------------------------------
+// error string (per-thread)
+// ---------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+extern "C" void myolo_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* myolo_last_error_string(void) { return g_err; }
+extern "C" int myolo_version(void) { return 100; }
+
+__device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c)
+{
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float actf(float v, int act)
+{
+    if (act == MYOLO_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MYOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+__device__ __forceinline__ float actmask(float v, int act)
+{   // 1 where the activation passes gradient
+    if (act == MYOLO_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if (act == MYOLO_ACT_RELU6) return (v > 0.f && v < 6.f) ? 1.f : 0.f;
+    return 1.f;
+}
+
+// ---------------------------------------------------------------------------------------
+// generic column reduction:  out[v][c] = sum_rows OP(row, c)[v]
+// ---------------------------------------------------------------------------------------
+struct ColGeom {
+    int cl;          // channel-quad lanes per block
+    int pl;          // row lanes per block
+    int cgroups;     // ceil((C/4) / cl)
+    int rblocks;     // number of row slabs
+    long long rows_per_block;
+};
+
+static ColGeom col_geom(long long M, int C)
+{
+    ColGeom g;
+    const int q = C / 4;
+    int cl = 1;
+    while (cl * 2 <= q && cl * 2 <= 256) cl *= 2;
+    if (cl > q) cl = q;
+    g.cl = cl;
+    g.pl = 256 / cl;
+    g.cgroups = (q + cl - 1) / cl;
+    long long want = 2048 / g.cgroups;                // target ~2048 blocks in total
+    if (want < 1) want = 1;
+    long long rpb = cdiv64(M, want);
+    const long long min_rows = (long long)g.pl * 8;   // at least 8 rows per thread
+    if (rpb < min_rows) rpb = min_rows;
+    g.rows_per_block = rpb;
+    g.rblocks = (int)cdiv64(M, rpb);
+    return g;
+}
+
+static size_t col_ws_bytes(long long M, int C, int nv)
+{
+    ColGeom g = col_geom(M, C);
+    return (size_t)g.rblocks * nv * C * sizeof(double);
+}
+
+template <class OP>
+__global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int C, ColGeom g, double* __restrict__ part)
+{
+    constexpr int NV = OP::NV;
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x;
+    const int cl_i = tid % g.cl, pl_i = tid / g.cl;
+    const int cq = blockIdx.y * g.cl + cl_i;        // channel quad
+    const bool cok = cq < C / 4 && pl_i < g.pl;
+    const long long r0 = (long long)blockIdx.x * g.rows_per_block;
+    long long r1 = r0 + g.rows_per_block;
+    if (r1 > M) r1 = M;
+    float4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f4zero();
+    if (cok)
+        for (long long r = r0 + pl_i; r < r1; r += g.pl) op(r, cq * 4, acc);
+    // combine row lanes
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        __syncthreads();
+        red[tid] = acc[v];
+        __syncthreads();
+        if (pl_i == 0 && cq < C / 4) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int j = 0; j < g.pl; ++j) {
+                const float4 t = red[j * g.cl + cl_i];
+                s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+            }
+            double* o = part + ((long long)blockIdx.x * NV + v) * C + cq * 4;
+            o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+        }
+    }
+}
+
+// sum partials over row blocks: tot[v*C + c] (double)
+__global__ void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nvc) return;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += part[(long long)b * nvc + i];
+    tot[i] = s;
+}
+
+template <class OP>
+static int run_colreduce(OP op, long long M, int C, double* part, double* tot, hipStream_t s)
+{
+    ColGeom g = col_geom(M, C);
+    hipLaunchKernelGGL((colreduce_kernel<OP>), dim3(g.rblocks, g.cgroups), dim3(256), 0, s, op, M, C, g, part);
+    const int nvc = OP::NV * C;
+    hipLaunchKernelGGL(colreduce_finish, dim3((nvc + 255) / 256), dim3(256), 0, s, part, tot, g.rblocks, nvc);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// colsum (bias gradients)
+// ---------------------------------------------------------------------------------------
+struct OpSum {
+    static constexpr int NV = 1;
+    const float* x;
+    int C;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const float4 v = ld4g(x + r * C + c);
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+    }
+};
+__global__ void d2f_kernel(const double* __restrict__ in, float* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)in[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm
+// ---------------------------------------------------------------------------------------
+struct OpStats {
+    static constexpr int NV = 2;
+    const float* x;
+    int C;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const float4 v = ld4g(x + r * C + c);
+        acc[0].x += v.x; acc[0].y += v.y; acc[0].z += v.z; acc[0].w += v.w;
+        acc[1] = f4fma(v, v, acc[1]);
+    }
+};
+
+__global__ void bn_stats_finish(const double* __restrict__ tot, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* mean, float* var, float* scale,
+                                float* shift, float* mmean, float* mvar, double M, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = tot[c] / M;
+    double vr = tot[C + c] / M - mu * mu;
+    if (vr < 0) vr = 0;
+    const float rstd = (float)(1.0 / sqrt(vr + (double)BN_EPS_F));
+    const float sc = gamma[c] * rstd;
+    mean[c] = (float)mu;
+    var[c] = (float)vr;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mu * sc;
+    if (mmean) {
+        const float vu = (float)vr * ((float)M / ((float)M - (1.0f + BN_EPS_F)));
+        mmean[c] = mmean[c] * BN_MOMENTUM_F + (float)mu * (1.0f - BN_MOMENTUM_F);
+        mvar[c] = mvar[c] * BN_MOMENTUM_F + vu * (1.0f - BN_MOMENTUM_F);
+    }
+}
+
+__global__ void bn_frozen_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
+                                 float* scale, float* shift, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rstd = (float)(1.0 / sqrt((double)mv[c] + (double)BN_EPS_F));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, float* __restrict__ y,
+                                                       long long nquads, int C, int act)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cq = C / 4;
+    for (; i < nquads; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        const float4 v = ld4g(x + i * 4);
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        float4 o;
+        o.x = actf(fmaf(v.x, sc.x, sh.x), act);
+        o.y = actf(fmaf(v.y, sc.y, sh.y), act);
+        o.z = actf(fmaf(v.z, sc.z, sh.z), act);
+        o.w = actf(fmaf(v.w, sc.w, sh.w), act);
+        st4g(y + i * 4, o);
+    }
+}
+
+// backward pass 1: dbeta = sum dz, dgamma = sum dz*xhat, with dz = dy * actmask(x*scale+shift)
+struct OpBnBwd {
+    static constexpr int NV = 2;
+    const float* dy;
+    const float* x;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* var;
+    int C, act;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const float4 g = ld4g(dy + r * C + c), v = ld4g(x + r * C + c);
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c), mu = ld4g(mean + c), vr = ld4g(var + c);
+        float dz, xh;
+        dz = g.x * actmask(fmaf(v.x, sc.x, sh.x), act); xh = (v.x - mu.x) * rsqrtf(vr.x + BN_EPS_F); acc[0].x += dz; acc[1].x = fmaf(dz, xh, acc[1].x);
+        dz = g.y * actmask(fmaf(v.y, sc.y, sh.y), act); xh = (v.y - mu.y) * rsqrtf(vr.y + BN_EPS_F); acc[0].y += dz; acc[1].y = fmaf(dz, xh, acc[1].y);
+        dz = g.z * actmask(fmaf(v.z, sc.z, sh.z), act); xh = (v.z - mu.z) * rsqrtf(vr.z + BN_EPS_F); acc[0].z += dz; acc[1].z = fmaf(dz, xh, acc[1].z);
+        dz = g.w * actmask(fmaf(v.w, sc.w, sh.w), act); xh = (v.w - mu.w) * rsqrtf(vr.w + BN_EPS_F); acc[0].w += dz; acc[1].w = fmaf(dz, xh, acc[1].w);
+    }
+};
+
+// tot = {dbeta[C], dgamma[C]} (double) -> write float grads
+__global__ void bn_bwd_finish(const double* __restrict__ tot, float* dgamma, float* dbeta, int C)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    dbeta[c] = (float)tot[c];
+    dgamma[c] = (float)tot[C + c];
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ mean, const float* __restrict__ var,
+                                                        const double* __restrict__ tot, float* __restrict__ dx,
+                                                        long long nquads, int C, int act, int batch_stats, float invM)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cq = C / 4;
+    for (; i < nquads; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        const float4 g = ld4g(dy + i * 4), v = ld4g(x + i * 4);
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        float gv[4] = {g.x, g.y, g.z, g.w}, xv[4] = {v.x, v.y, v.z, v.w};
+        float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dz = gv[k] * actmask(fmaf(xv[k], scv[k], shv[k]), act);
+            if (batch_stats) {
+                const float xh = (xv[k] - mean[c + k]) * rsqrtf(var[c + k] + BN_EPS_F);
+                const float db = (float)tot[c + k], dg = (float)tot[C + c + k];
+                o[k] = scv[k] * (dz - (db + xh * dg) * invM);
+            } else {
+                o[k] = scv[k] * dz;
+            }
+        }
+        st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// conv1: pad(1,1) + 3x3 stride 2, Cin = 3
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, int N, int H, int W, int Co)
+{
+    extern __shared__ __attribute__((aligned(16))) float ws[];     // [27][Co]
+    for (int i = threadIdx.x; i < 27 * Co; i += blockDim.x) ws[i] = w[i];
+    __syncthreads();
+    const int Ho = H / 2, Wo = W / 2, cq = Co / 4;
+    const long long total = (long long)N * Ho * Wo * cq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        long long pix = i / cq;
+        const int ox = (int)(pix % Wo);
+        pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int n = (int)(pix / Ho);
+        float4 acc = f4zero();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx - 1;
+                if (ix < 0 || ix >= W) continue;
+                const float* xp = x + (((long long)n * H + iy) * W + ix) * 3;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float a = xp[ci];
+                    const float4 wv = *reinterpret_cast<const float4*>(&ws[((ky * 3 + kx) * 3 + ci) * Co + c]);
+                    acc.x = fmaf(a, wv.x, acc.x); acc.y = fmaf(a, wv.y, acc.y);
+                    acc.z = fmaf(a, wv.z, acc.z); acc.w = fmaf(a, wv.w, acc.w);
+                }
+            }
+        }
+        st4g(y + i * 4, acc);
+    }
+}
+
+// dw[k][co] = sum_pixels patch[k] * dy[co]; rows = output pixels, "channels" = Co, 27 accumulators
+struct OpConv1Dw {
+    static constexpr int NV = 27;
+    const float* x;
+    const float* dy;
+    int H, W, Co;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const int Ho = H / 2, Wo = W / 2;
+        const int ox = (int)(r % Wo);
+        long long t = r / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float4 g = ld4g(dy + r * Co + c);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = 2 * oy + ky - 1;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = 2 * ox + kx - 1;
+                const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+                const float* xp = x + (((long long)n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
+#pragma unroll
+                for (int ci = 0; ci < 3; ++ci) {
+                    const float a = ok ? xp[ci] : 0.f;
+                    float4& A = acc[(ky * 3 + kx) * 3 + ci];
+                    A.x = fmaf(a, g.x, A.x); A.y = fmaf(a, g.y, A.y); A.z = fmaf(a, g.z, A.z); A.w = fmaf(a, g.w, A.w);
+                }
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// depthwise 3x3.  Each thread produces TW consecutive outputs along W for one channel quad,
+// holding the (TW-1)*S+3 input columns of each of the 3 rows in registers (each input quad is
+// loaded once per thread instead of up to 9 times).
+// ---------------------------------------------------------------------------------------
+template <int S, int TW>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo)
+{
+    constexpr int NC = (TW - 1) * S + 3;
+    const int pt = (S == 1) ? 1 : 0, plft = (S == 1) ? 1 : 0;
+    const int cq = C / 4;
+    const int wtiles = (Wo + TW - 1) / TW;
+    const long long total = (long long)N * Ho * wtiles * cq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int wt = (int)(t % wtiles);
+        t /= wtiles;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const int ox0 = wt * TW;
+        float4 wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = ld4g(w + k * C + c);
+        float4 acc[TW];
+#pragma unroll
+        for (int j = 0; j < TW; ++j) acc[j] = f4zero();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * S + ky - pt;
+            if (iy < 0 || iy >= H) continue;
+            const float* rowp = x + (((long long)n * H + iy) * W) * C + c;
+            float4 col[NC];
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                const int ix = ox0 * S + k - plft;
+                col[k] = (ix >= 0 && ix < W) ? ld4g(rowp + (long long)ix * C) : f4zero();
+            }
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[j] = f4fma(col[j * S + kx], wv[ky * 3 + kx], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+            if (ox0 + j < Wo) st4g(y + ((((long long)n * Ho + oy) * Wo) + ox0 + j) * C + c, acc[j]);
+    }
+}
+
+// dx[iy,ix] = sum_{ky,kx} dy[(iy+pt-ky)/S, (ix+pl-kx)/S] * w[ky,kx]   (when divisible and in range)
+template <int S>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                          float* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo)
+{
+    const int pt = (S == 1) ? 1 : 0;
+    const int cq = C / 4;
+    const long long total = (long long)N * H * W * cq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int ix = (int)(t % W);
+        t /= W;
+        const int iy = (int)(t % H);
+        const int n = (int)(t / H);
+        float4 acc = f4zero();
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ty = iy + pt - ky;
+            if (ty < 0 || (ty % S) != 0) continue;
+            const int oy = ty / S;
+            if (oy >= Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int tx = ix + pt - kx;
+                if (tx < 0 || (tx % S) != 0) continue;
+                const int ox = tx / S;
+                if (ox >= Wo) continue;
+                acc = f4fma(ld4g(dy + ((((long long)n * Ho + oy) * Wo) + ox) * C + c), ld4g(w + (ky * 3 + kx) * C + c), acc);
+            }
+        }
+        st4g(dx + i * 4, acc);
+    }
+}
+
+// dw[k][c] = sum over output pixels of x[shifted] * dy
+struct OpDwDw {
+    static constexpr int NV = 9;
+    const float* x;
+    const float* dy;
+    int H, W, C, Ho, Wo, S;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const int pt = (S == 1) ? 1 : 0;
+        const int ox = (int)(r % Wo);
+        long long t = r / Wo;
+        const int oy = (int)(t % Ho);
+        const int n = (int)(t / Ho);
+        const float4 g = ld4g(dy + r * C + c);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = oy * S + ky - pt;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = ox * S + kx - pt;
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                    acc[ky * 3 + kx] = f4fma(ld4g(x + (((long long)n * H + iy) * W + ix) * C + c), g, acc[ky * 3 + kx]);
+            }
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
+// crop_and_resize (ROIAlign).  One channel-quad lane per output element quad; the 64 lanes of a
+// wave cover 256 channels of one output pixel, so the four corner reads and the store are each
+// one contiguous 1 KiB wave access.  Same float op order as the TF kernel.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ bool crop_coord(float lo, float hi, int size, int crop, int idx, float& in)
+{
+    if (crop > 1) {
+        const float scale = (hi - lo) * (float)(size - 1) / (float)(crop - 1);
+        in = lo * (float)(size - 1) + (float)idx * scale;
+    } else {
+        in = 0.5f * (lo + hi) * (float)(size - 1);
+    }
+    return !(in < 0.f || in > (float)(size - 1));
+}
+
+__global__ __launch_bounds__(256) void crop_fwd_kernel(const float* __restrict__ img, const float* __restrict__ boxes,
+                                                       const int32_t* __restrict__ bind, float* __restrict__ out,
+                                                       int H, int W, int C, int nb, int ch, int cw)
+{
+    const int cq = C / 4;
+    const long long total = (long long)nb * ch * cw * cq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int px = (int)(t % cw);
+        t /= cw;
+        const int py = (int)(t % ch);
+        const int b = (int)(t / ch);
+        const float4 bx = ld4g(boxes + (long long)b * 4);      // y1,x1,y2,x2
+        float iny, inx;
+        const bool vy = crop_coord(bx.x, bx.z, H, ch, py, iny);
+        const bool vx = crop_coord(bx.y, bx.w, W, cw, px, inx);
+        float4 o = f4zero();
+        if (vy && vx) {
+            const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+            const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+            const float wy = iny - (float)ty, wx = inx - (float)lx;
+            const float* base = img + (long long)bind[b] * H * W * C + c;
+            const float4 tl = ld4g(base + ((long long)ty * W + lx) * C), tr = ld4g(base + ((long long)ty * W + rx) * C);
+            const float4 bl = ld4g(base + ((long long)by * W + lx) * C), br = ld4g(base + ((long long)by * W + rx) * C);
+            float top, bot;
+            top = tl.x + (tr.x - tl.x) * wx; bot = bl.x + (br.x - bl.x) * wx; o.x = top + (bot - top) * wy;
+            top = tl.y + (tr.y - tl.y) * wx; bot = bl.y + (br.y - bl.y) * wx; o.y = top + (bot - top) * wy;
+            top = tl.z + (tr.z - tl.z) * wx; bot = bl.z + (br.z - bl.z) * wx; o.z = top + (bot - top) * wy;
+            top = tl.w + (tr.w - tl.w) * wx; bot = bl.w + (br.w - bl.w) * wx; o.w = top + (bot - top) * wy;
+        }
+        st4g(out + i * 4, o);
+    }
+}
+
+__device__ __forceinline__ void atomic_add4(float* p, float4 v)
+{
+    atomicAdd(p + 0, v.x); atomicAdd(p + 1, v.y); atomicAdd(p + 2, v.z); atomicAdd(p + 3, v.w);
+}
+
+__global__ __launch_bounds__(256) void crop_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                       const int32_t* __restrict__ bind, float* __restrict__ dimg,
+                                                       int H, int W, int C, int nb, int ch, int cw)
+{
+    const int cq = C / 4;
+    const long long total = (long long)nb * ch * cw * cq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int px = (int)(t % cw);
+        t /= cw;
+        const int py = (int)(t % ch);
+        const int b = (int)(t / ch);
+        const float4 bx = ld4g(boxes + (long long)b * 4);
+        float iny, inx;
+        const bool vy = crop_coord(bx.x, bx.z, H, ch, py, iny);
+        const bool vx = crop_coord(bx.y, bx.w, W, cw, px, inx);
+        if (!(vy && vx)) continue;
+        const float4 g = ld4g(dout + i * 4);
+        const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+        const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+        const float wy = iny - (float)ty, wx = inx - (float)lx;
+        float* base = dimg + (long long)bind[b] * H * W * C + c;
+        const float a = (1.f - wy) * (1.f - wx), bq = (1.f - wy) * wx, cc = wy * (1.f - wx), d = wy * wx;
+        atomic_add4(base + ((long long)ty * W + lx) * C, make_float4(g.x * a, g.y * a, g.z * a, g.w * a));
+        atomic_add4(base + ((long long)ty * W + rx) * C, make_float4(g.x * bq, g.y * bq, g.z * bq, g.w * bq));
+        atomic_add4(base + ((long long)by * W + lx) * C, make_float4(g.x * cc, g.y * cc, g.z * cc, g.w * cc));
+        atomic_add4(base + ((long long)by * W + rx) * C, make_float4(g.x * d, g.y * d, g.z * d, g.w * d));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// final mask conv 1x1 (Cin -> C<=8) + bias + sigmoid.  One wave per row: each lane owns
+// channel quads {lane, lane+64, ...}, partial dots are combined with a wave butterfly.
+// ---------------------------------------------------------------------------------------
+#define MASK_MAXC 8
+template <int CC>
+__global__ __launch_bounds__(256) void mask_out_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ p,
+                                                           long long M, int Cin)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int cq = Cin / 4;
+    // weights of this lane's first channel quad stay in registers (covers Cin <= 256 entirely)
+    float wr[4][CC];
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < CC; ++k) wr[e][k] = lane < cq ? w[(lane * 4 + e) * CC + k] : 0.f;
+    const float bl = lane < CC ? bias[lane] : 0.f;
+    for (long long r = wave0; r < M; r += nwaves) {
+        float acc[CC];
+#pragma unroll
+        for (int k = 0; k < CC; ++k) acc[k] = 0.f;
+        if (lane < cq) {
+            const float4 v = ld4g(x + r * Cin + lane * 4);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < CC; ++k) acc[k] = fmaf(xv[e], wr[e][k], acc[k]);
+        }
+        for (int q = lane + 64; q < cq; q += 64) {
+            const float4 v = ld4g(x + r * Cin + q * 4);
+            const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < CC; ++k) acc[k] = fmaf(xv[e], w[(q * 4 + e) * CC + k], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CC; ++k) {
+            float s = acc[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            acc[k] = s;
+        }
+        if (lane < CC) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < CC; ++k) if (lane == k) s = acc[k];
+            s += bl;
+            p[r * CC + lane] = 1.f / (1.f + expf(-s));
+        }
+    }
+}
+
+// backward: dx = (dz w^T) * (x > 0);  dw[ci][k] = sum_m x[m,ci] dz[m,k]
+template <int CC>
+struct OpMaskOutBwd {
+    static constexpr int NV = CC;
+    const float* x;
+    const float* w;     // [Cin][CC]
+    const float* dz;    // [M][CC]
+    float* dx;
+    int Cin;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const float4 v = ld4g(x + r * Cin + c);
+        float g[CC];
+#pragma unroll
+        for (int k = 0; k < CC; ++k) g[k] = dz[r * CC + k];
+        float4 o = f4zero();
+#pragma unroll
+        for (int k = 0; k < CC; ++k) {
+            acc[k].x = fmaf(v.x, g[k], acc[k].x); acc[k].y = fmaf(v.y, g[k], acc[k].y);
+            acc[k].z = fmaf(v.z, g[k], acc[k].z); acc[k].w = fmaf(v.w, g[k], acc[k].w);
+            o.x = fmaf(g[k], w[(c + 0) * CC + k], o.x); o.y = fmaf(g[k], w[(c + 1) * CC + k], o.y);
+            o.z = fmaf(g[k], w[(c + 2) * CC + k], o.z); o.w = fmaf(g[k], w[(c + 3) * CC + k], o.w);
+        }
+        o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f;
+        o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
+        st4g(dx + r * Cin + c, o);
+    }
+};
+// tot[k][ci] (double) -> dw[ci][k]
+__global__ void mask_out_dw_finish(const double* __restrict__ tot, float* dw, int Cin, int CC)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * CC) return;
+    const int ci = i / CC, k = i % CC;
+    dw[i] = (float)tot[k * Cin + ci];
+}
+// db[k] = sum_m dz[m][k]  (single block; M*CC is small relative to everything else)
+__global__ void small_colsum_kernel(const float* __restrict__ dz, float* __restrict__ db, long long M, int CC)
+{
+    __shared__ double red[256];
+    for (int k = 0; k < CC; ++k) {
+        double s = 0;
+        for (long long r = threadIdx.x; r < M; r += blockDim.x) s += dz[r * CC + k];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) db[k] = (float)red[0];
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// mask BCE (K.binary_crossentropy on post-sigmoid p), forward + d/dlogit
+// ---------------------------------------------------------------------------------------
+__global__ void bce_count_kernel(const int32_t* __restrict__ ids, int NR, int* __restrict__ npos)
+{
+    __shared__ int red[256];
+    int s = 0;
+    for (int i = threadIdx.x; i < NR; i += blockDim.x) s += ids[i] > 0;
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *npos = red[0];
+}
+
+__global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ tm, const int32_t* __restrict__ ids,
+                                                  const float* __restrict__ pred, const int* __restrict__ npos_p,
+                                                  float lw, double* __restrict__ part, float* __restrict__ dz,
+                                                  int NR, int hw, int C)
+{
+    __shared__ double red[256];
+    const long long total = (long long)NR * hw;
+    const int npos = *npos_p;
+    const float invn = npos > 0 ? 1.f / ((float)npos * (float)hw) : 0.f;
+    double lsum = 0;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float eps = 1e-7f;
+    for (; i < total; i += stride) {
+        const int roi = (int)(i / hw);
+        const int id = ids[roi];
+        for (int k = 0; k < C; ++k) {
+            float g = 0.f;
+            if (id > 0 && k == id) {
+                const float p = pred[i * C + k], t = tm[i];
+                const float pc = fminf(fmaxf(p, eps), 1.f - eps);
+                const float z = logf(pc / (1.f - pc));
+                const float l = fmaxf(z, 0.f) - z * t + log1pf(expf(-fabsf(z)));
+                lsum += (double)l;
+                const bool inside = (p >= eps) && (p <= 1.f - eps);
+                g = inside ? (pc - t) * invn * lw : 0.f;
+            }
+            dz[i * C + k] = g;
+        }
+    }
+    red[threadIdx.x] = lsum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void bce_finish_kernel(const double* __restrict__ part, int nblk, const int* __restrict__ npos_p, int hw,
+                                  float* __restrict__ out)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += part[b];
+    const int npos = *npos_p;
+    out[0] = npos > 0 ? (float)(s / ((double)npos * hw)) : 0.f;
+    out[1] = (float)npos;
+}
+
+// ---------------------------------------------------------------------------------------
+// Adam, helpers
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr_t, float b1, float b2,
+                                                   float eps, float gs)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float gi = g[i] * gs;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+__global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] += b[i];
+}
+__global__ void fill_kernel(float* __restrict__ a, float v, long long n)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] = v;
+}
+
+static inline int ew_blocks(long long n)
+{
+    long long b = (n + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <int CC>
+static int mask_out_bwd_impl(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int64_t M, int Cin,
+                             void* ws, size_t ws_bytes, hipStream_t s)
+{
+    const size_t pb = col_ws_bytes(M, Cin, CC);
+    MYOLO_NEED_WS(align256(pb) + (size_t)CC * Cin * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    OpMaskOutBwd<CC> op{x, w, dz, dx, Cin};
+    run_colreduce(op, M, Cin, part, tot, s);
+    hipLaunchKernelGGL(mask_out_dw_finish, dim3((Cin * CC + 255) / 256), dim3(256), 0, s, tot, dw, Cin, CC);
+    hipLaunchKernelGGL(small_colsum_kernel, dim3(1), dim3(256), 0, s, dz, db, (long long)M, CC);
+    return MYOLO_OK;
+}
+
+// =======================================================================================
+extern "C" {
+
+int myolo_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && out && M > 0 && C > 0, "colsum: bad arguments");
+    if ((C & 3) != 0) {   // narrow odd-width case (conv_23 bias, C = N_BOX*(5+classes)): one block
+        hipLaunchKernelGGL(small_colsum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, out, (long long)M, C);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
+    const size_t pb = col_ws_bytes(M, C, 1);
+    MYOLO_NEED_WS(align256(pb) + C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpSum op{x, C};
+    run_colreduce(op, M, C, part, tot, s);
+    hipLaunchKernelGGL(d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, out, C);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_stats(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale,
+                   float* shift, float* moving_mean, float* moving_var, int64_t M, int C, void* ws, size_t ws_bytes,
+                   void* stream)
+{
+    MYOLO_REQUIRE(x && gamma && beta && mean && var && scale && shift && M > 0 && (C & 3) == 0, "bn_stats: bad arguments");
+    const size_t pb = col_ws_bytes(M, C, 2);
+    MYOLO_NEED_WS(align256(pb) + 2 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpStats op{x, C};
+    run_colreduce(op, M, C, part, tot, s);
+    hipLaunchKernelGGL(bn_stats_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, gamma, beta, mean, var, scale, shift,
+                       moving_mean, moving_var, (double)M, C);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_frozen_coeffs(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                           float* scale, float* shift, int C, void* stream)
+{
+    MYOLO_REQUIRE(gamma && beta && moving_mean && moving_var && scale && shift && C > 0, "bn_frozen_coeffs: bad arguments");
+    hipLaunchKernelGGL(bn_frozen_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       moving_mean, moving_var, scale, shift, C);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C, int act,
+                       void* stream)
+{
+    MYOLO_REQUIRE(x && scale && shift && y && M > 0 && (C & 3) == 0, "bn_apply_act: bad arguments");
+    const long long nq = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(nq)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, nq, C, act);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* var,
+                     const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                     int act, int batch_stats, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && x && mean && var && scale && shift && dx && dgamma && dbeta && M > 0 && (C & 3) == 0,
+                  "bn_act_bwd: bad arguments");
+    (void)gamma;
+    const size_t pb = col_ws_bytes(M, C, 2);
+    MYOLO_NEED_WS(align256(pb) + 2 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpBnBwd op{dy, x, scale, shift, mean, var, C, act};
+    run_colreduce(op, M, C, part, tot, s);
+    hipLaunchKernelGGL(bn_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, dgamma, dbeta, C);
+    const long long nq = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq,
+                       C, act, batch_stats, 1.0f / (float)M);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y, int N, int H, int W, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0, "conv3x3s2_c3_fwd: bad arguments");
+    const long long total = (long long)N * (H / 2) * (W / 2) * (Cout / 4);
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), (hipStream_t)stream,
+                       x, w, y, N, H, W, Cout);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* ws,
+                                  size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && dy && dw && N > 0 && (Cout & 3) == 0, "conv3x3s2_c3_bwd_weight: bad arguments");
+    const long long M = (long long)N * (H / 2) * (W / 2);
+    const size_t pb = col_ws_bytes(M, Cout, 27);
+    MYOLO_NEED_WS(align256(pb) + 27 * Cout * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpConv1Dw op{x, dy, H, W, Cout};
+    run_colreduce(op, M, Cout, part, tot, s);
+    hipLaunchKernelGGL(d2f_kernel, dim3((27 * Cout + 255) / 256), dim3(256), 0, s, tot, dw, 27 * Cout);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_fwd: bad arguments");
+    MYOLO_REQUIRE(stride == 1 || ((H & 1) == 0 && (W & 1) == 0), "dwconv3x3_fwd: stride 2 needs even H, W");
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = H / stride, Wo = W / stride;
+    if (stride == 1) {
+        const long long total = (long long)N * Ho * ((Wo + 3) / 4) * (C / 4);
+        hipLaunchKernelGGL((dw_fwd_kernel<1, 4>), dim3(ew_blocks(total)), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+    } else {
+        const long long total = (long long)N * Ho * ((Wo + 1) / 2) * (C / 4);
+        hipLaunchKernelGGL((dw_fwd_kernel<2, 2>), dim3(ew_blocks(total)), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+    }
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, void* stream)
+{
+    MYOLO_REQUIRE(dy && w && dx && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_data: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = H / stride, Wo = W / stride;
+    const long long total = (long long)N * H * W * (C / 4);
+    if (stride == 1)
+        hipLaunchKernelGGL((dw_bwd_data_kernel<1>), dim3(ew_blocks(total)), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL((dw_bwd_data_kernel<2>), dim3(ew_blocks(total)), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int stride, void* ws,
+                               size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && dy && dw && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_weight: bad arguments");
+    const int Ho = H / stride, Wo = W / stride;
+    const long long M = (long long)N * Ho * Wo;
+    const size_t pb = col_ws_bytes(M, C, 9);
+    MYOLO_NEED_WS(align256(pb) + 9 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpDwDw op{x, dy, H, W, C, Ho, Wo, stride};
+    run_colreduce(op, M, C, part, tot, s);
+    hipLaunchKernelGGL(d2f_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, s, tot, dw, 9 * C);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_crop_and_resize_fwd(const float* image, const float* boxes, const int32_t* box_ind, float* out, int B, int H, int W,
+                              int C, int nb, int crop_h, int crop_w, void* stream)
+{
+    MYOLO_REQUIRE(image && boxes && box_ind && out && B > 0 && (C & 3) == 0 && nb >= 0, "crop_and_resize_fwd: bad arguments");
+    if (nb == 0) return MYOLO_OK;
+    const long long total = (long long)nb * crop_h * crop_w * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(crop_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image, boxes, box_ind, out,
+                       H, W, C, nb, crop_h, crop_w);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_crop_and_resize_bwd_image(const float* dout, const float* boxes, const int32_t* box_ind, float* dimage, int B,
+                                    int H, int W, int C, int nb, int crop_h, int crop_w, void* stream)
+{
+    MYOLO_REQUIRE(dout && boxes && box_ind && dimage && B > 0 && (C & 3) == 0 && nb >= 0, "crop_and_resize_bwd_image: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(dimage, 0, (size_t)B * H * W * C * sizeof(float), s);
+    if (nb == 0) return MYOLO_OK;
+    const long long total = (long long)nb * crop_h * crop_w * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(crop_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dout, boxes, box_ind, dimage, H, W, C, nb,
+                       crop_h, crop_w);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_mask_head_out_fwd(const float* x, const float* w, const float* bias, float* p, int64_t M, int Cin, int C, void* stream)
+{
+    MYOLO_REQUIRE(x && w && bias && p && M > 0 && (Cin & 3) == 0 && C >= 1 && C <= MASK_MAXC, "mask_head_out_fwd: bad arguments (1<=C<=8)");
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (M + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+#define MO_CASE(K) case K: hipLaunchKernelGGL((mask_out_fwd_kernel<K>), dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, p, M, Cin); break;
+    switch (C) { MO_CASE(1) MO_CASE(2) MO_CASE(3) MO_CASE(4) MO_CASE(5) MO_CASE(6) MO_CASE(7) MO_CASE(8) }
+#undef MO_CASE
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_mask_head_out_bwd(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int64_t M, int Cin,
+                            int C, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && dz && dx && dw && db && M > 0 && (Cin & 3) == 0 && C >= 1 && C <= MASK_MAXC, "mask_head_out_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = MYOLO_EINVAL;
+#define MO_CASE(K) case K: rc = mask_out_bwd_impl<K>(x, w, dz, dx, dw, db, M, Cin, ws, ws_bytes, s); break;
+    switch (C) { MO_CASE(1) MO_CASE(2) MO_CASE(3) MO_CASE(4) MO_CASE(5) MO_CASE(6) MO_CASE(7) MO_CASE(8) }
+#undef MO_CASE
+    if (rc) return rc;
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_mask_bce(const float* target_masks, const int32_t* target_class_ids, const float* pred, float loss_weight,
+                   float* loss_out, float* dz, int NR, int h, int w, int C, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(target_masks && target_class_ids && pred && loss_out && dz && NR > 0 && C > 0, "mask_bce: bad arguments");
+    const int nblk = 1024;
+    MYOLO_NEED_WS(256 + nblk * sizeof(double));
+    int* npos = (int*)ws;
+    double* part = (double*)((char*)ws + 256);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bce_count_kernel, dim3(1), dim3(256), 0, s, target_class_ids, NR, npos);
+    hipLaunchKernelGGL(bce_kernel, dim3(nblk), dim3(256), 0, s, target_masks, target_class_ids, pred, npos, loss_weight, part, dz,
+                       NR, h * w, C);
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, s, part, nblk, npos, h * w, loss_out);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr_t, float beta1, float beta2, float eps,
+                    float grad_scale, void* stream)
+{
+    MYOLO_REQUIRE(p && g && m && v && n > 0, "adam_step: bad arguments");
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr_t, beta1,
+                       beta2, eps, grad_scale);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_add_inplace(float* a, const float* b, int64_t n, void* stream)
+{
+    MYOLO_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
+    hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_fill(float* a, float value, int64_t n, void* stream)
+{
+    MYOLO_REQUIRE(a && n > 0, "fill: bad arguments");
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, value, (long long)n);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+}  // extern "C"

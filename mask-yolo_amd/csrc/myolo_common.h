@@ -1,0 +1,40 @@
+// Internal helpers shared by the kernel translation units of libmyolo_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/myolo_hip.h"
+
+extern "C" void myolo_set_error(const char* fmt, ...);
+
+#define MYOLO_REQUIRE(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) {                                             \
+            myolo_set_error(__VA_ARGS__);                          \
+            return MYOLO_EINVAL;                                   \
+        }                                                          \
+    } while (0)
+
+#define MYOLO_NEED_WS(bytes)                                                         \
+    do {                                                                             \
+        if ((size_t)(bytes) > ws_bytes || (ws == nullptr && (bytes) > 0)) {          \
+            myolo_set_error("%s: workspace too small (%zu needed, %zu given)",       \
+                            __func__, (size_t)(bytes), ws_bytes);                    \
+            return MYOLO_EWORKSPACE;                                                 \
+        }                                                                            \
+    } while (0)
+
+#define MYOLO_CHECK_LAUNCH()                                                         \
+    do {                                                                             \
+        hipError_t e__ = hipGetLastError();                                          \
+        if (e__ != hipSuccess) {                                                     \
+            myolo_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return MYOLO_ELAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+#define BN_EPS_F 1e-3f
+#define BN_MOMENTUM_F 0.99f

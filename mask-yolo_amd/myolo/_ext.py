@@ -1,0 +1,99 @@
+"""ctypes binding of libmyolo_hip.so (the C-ABI declared in include/myolo_hip.h).
+
+PyTorch is used only as the owner of device memory and streams: every function here takes
+torch tensors, checks dtype/contiguity/device, and passes raw device pointers plus the current
+HIP stream to the library.  There is no CPU or torch fallback: if the library is missing, or a
+call returns a negative status, a RuntimeError is raised."""
+import ctypes
+import os
+
+import torch
+
+_LIB = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libmyolo_hip.so")
+
+P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
+
+# name -> argtypes (all return int).  Order/meaning: include/myolo_hip.h
+SIGS = {
+    "myolo_conv3x3s2_c3_fwd": [P, P, P, I, I, I, I, P],
+    "myolo_conv3x3s2_c3_bwd_weight": [P, P, P, I, I, I, I, P, Z, P],
+    "myolo_dwconv3x3_fwd": [P, P, P, I, I, I, I, I, P],
+    "myolo_dwconv3x3_bwd_data": [P, P, P, I, I, I, I, I, P],
+    "myolo_dwconv3x3_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_pwconv1x1_fwd": [P, P, P, P, L, I, I, P],
+    "myolo_pwconv1x1_bwd_data": [P, P, P, L, I, I, P, Z, P],
+    "myolo_pwconv1x1_bwd_weight": [P, P, P, L, I, I, P, Z, P],
+    "myolo_conv3x3_fwd": [P, P, P, P, I, I, I, I, I, P],
+    "myolo_conv3x3_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_conv3x3_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_deconv2x2s2_fwd": [P, P, P, P, I, I, I, I, I, I, P, Z, P],
+    "myolo_deconv2x2s2_bwd_data": [P, P, P, I, I, I, I, I, P],
+    "myolo_deconv2x2s2_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_colsum": [P, P, L, I, P, Z, P],
+    "myolo_bn_stats": [P, P, P, P, P, P, P, P, P, L, I, P, Z, P],
+    "myolo_bn_frozen_coeffs": [P, P, P, P, P, P, I, P],
+    "myolo_bn_apply_act": [P, P, P, P, L, I, I, P],
+    "myolo_bn_act_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, Z, P],
+    "myolo_crop_and_resize_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "myolo_crop_and_resize_bwd_image": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "myolo_yolo_decode": [P, P, P, I, I, I, I, P],
+    "myolo_yolo_detections": [P, P, P, I, I, I, I, P],
+    "myolo_yolo_loss": [P, P, P, P, P, F, F, F, F, F, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_mask_targets": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
+    "myolo_mask_head_out_fwd": [P, P, P, P, L, I, I, P],
+    "myolo_mask_head_out_bwd": [P, P, P, P, P, P, L, I, I, P, Z, P],
+    "myolo_mask_bce": [P, P, P, F, P, P, I, I, I, I, P, Z, P],
+    "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
+    "myolo_add_inplace": [P, P, L, P],
+    "myolo_fill": [P, F, L, P],
+}
+
+
+def load():
+    """dlopen the library and bind every symbol; raises if anything is missing."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libmyolo_hip.so not built (%s): run `python __graft_entry__.py` "
+                           "(hipcc --offload-arch=gfx950); there is no fallback path" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGS.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.myolo_version.restype = ctypes.c_int
+    lib.myolo_last_error_string.restype = ctypes.c_char_p
+    lib.myolo_workspace_bytes.argtypes = [L, I, I]
+    lib.myolo_workspace_bytes.restype = Z
+    _LIB = lib
+    return lib
+
+
+def exported_symbols():
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes"]
+
+
+def ptr(t):
+    """raw device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "C-ABI needs contiguous device tensors"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.myolo_last_error_string().decode()))
+
+
+def workspace_bytes(rows, cin, cout):
+    return int(load().myolo_workspace_bytes(int(rows), int(cin), int(cout)))

@@ -1,0 +1,492 @@
+"""
+Execution engine of the Mask-YOLO hot path on one MI355X.
+
+Holds the network state (one flat fp32 parameter buffer + same-shaped gradient / Adam buffers,
+laid out so that the three gradient buckets of the data-parallel all-reduce are contiguous) and
+runs the training step / inference forward as a fixed sequence of calls into libmyolo_hip.so
+(myolo/_ext.py).  torch is used for device memory and streams only -- there is no torch compute
+and no fallback: every arithmetic op is a HIP kernel behind the C-ABI of include/myolo_hip.h.
+
+Graph followed (reference file:line): MaskYOLO.build model.py:787-941; mobilenet_graph :55-79;
+yolo_branch_graph :249-278; feature_map :848; DecodeYOLOLayer :1442-1473; DetectMaskTargetLayer
+:605-661; build_mask_graph :668-715; yolo_custom_loss :86-242; myolo_mask_loss_graph :718-754;
+compile :1062-1094 (loss sum + Adam).
+"""
+import numpy as np
+import torch
+
+from . import _ext as X
+
+ACT_NONE, ACT_RELU, ACT_RELU6 = 0, 1, 2
+
+BACKBONE_BLOCKS = [(64, 1), (64, 2), (128, 1), (256, 2), (256, 1), (512, 1)]                      # model.py:68-77
+YOLO_BLOCKS = [(512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1), (1024, 2), (1024, 1)]   # model.py:256-268
+MASK_FILTERS = 256                                                                                 # model.py:688-711
+
+
+def layer_table(cfg):
+    """[(layer name, kind, shape, bucket)] -- names are the reference's Keras layer names (the
+    checkpoint schema).  bucket: 0 backbone, 1 yolo head + feature_map, 2 mask head."""
+    a, C = cfg.ALPHA, cfg.NUM_CLASSES
+    t = [("conv1", "conv", (3, 3, 3, int(32 * a)), 0), ("conv1_bn", "bn", int(32 * a), 0)]
+    cin, bid = int(32 * a), 1
+    blocks = [(f, s, 0) for f, s in BACKBONE_BLOCKS] + [(f, s, 1) for f, s in YOLO_BLOCKS]
+    for f, s, bk in blocks:
+        co = int(f * a)
+        t += [("conv_dw_%d" % bid, "dw", (3, 3, cin), bk), ("conv_dw_%d_bn" % bid, "bn", cin, bk),
+              ("conv_pw_%d" % bid, "conv", (1, 1, cin, co), bk), ("conv_pw_%d_bn" % bid, "bn", co, bk)]
+        if bid == len(BACKBONE_BLOCKS):
+            c4 = co
+        cin = co
+        bid += 1
+    t += [("conv_23", "convb", (1, 1, cin, cfg.N_BOX * (5 + C)), 1),
+          ("feature_map", "convb", (3, 3, c4, cfg.TOP_FEATURE_MAP_DEPTH), 1)]
+    cm = cfg.TOP_FEATURE_MAP_DEPTH
+    for i in range(1, 5):
+        t += [("myolo_mask_conv%d" % i, "convb", (3, 3, cm, MASK_FILTERS), 2), ("myolo_mask_bn%d" % i, "bn", MASK_FILTERS, 2)]
+        cm = MASK_FILTERS
+    t += [("myolo_mask_deconv", "deconv", (2, 2, MASK_FILTERS, MASK_FILTERS), 2),
+          ("myolo_mask", "convb", (1, 1, MASK_FILTERS, C), 2)]
+    return t
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def init_state_dict(cfg, seed=0):
+    """Keras default initialisers: glorot_uniform kernels, zero biases, BN gamma=1 beta=0,
+    moving mean 0 / variance 1.  Same draw order on every rank (seeded)."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, kind, shp, _ in layer_table(cfg):
+        if kind in ("conv", "convb"):
+            kh, kw, ci, co = shp
+            sd[name + "/kernel"] = _glorot(rng, shp, kh * kw * ci, kh * kw * co)
+            if kind == "convb":
+                sd[name + "/bias"] = np.zeros(co, np.float32)
+        elif kind == "dw":
+            kh, kw, c = shp
+            sd[name + "/depthwise_kernel"] = _glorot(rng, shp, kh * kw * c, kh * kw)
+        elif kind == "deconv":
+            kh, kw, co, ci = shp
+            sd[name + "/kernel"] = _glorot(rng, shp, kh * kw * co, kh * kw * ci)
+            sd[name + "/bias"] = np.zeros(co, np.float32)
+        else:
+            sd[name + "/gamma"] = np.ones(shp, np.float32)
+            sd[name + "/beta"] = np.zeros(shp, np.float32)
+            sd[name + "/moving_mean"] = np.zeros(shp, np.float32)
+            sd[name + "/moving_variance"] = np.ones(shp, np.float32)
+    return sd
+
+
+class Workspace(object):
+    """One growable scratch buffer shared by every call on the compute stream."""
+
+    def __init__(self, device, nbytes=256 << 20):
+        self.device = device
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def ensure(self, nbytes):
+        if self.buf.numel() < nbytes:
+            torch.cuda.synchronize()
+            self.buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.device)
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    @property
+    def size(self):
+        return self.buf.numel()
+
+
+class Net(object):
+    def __init__(self, cfg, device="cuda:0", seed=0):
+        X.load()
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        self.table = layer_table(cfg)
+        # ---- flat parameter / BN-state layout ----
+        self.pslots, self.sslots = {}, {}
+        self.bucket_ranges = []
+        off, soff = 0, 0
+        for bucket in (0, 1, 2):
+            b0 = off
+            for name, kind, shp, bk in self.table:
+                if bk != bucket:
+                    continue
+                if kind in ("conv", "convb"):
+                    items = [("kernel", shp)] + ([("bias", (shp[3],))] if kind == "convb" else [])
+                elif kind == "dw":
+                    items = [("depthwise_kernel", shp)]
+                elif kind == "deconv":
+                    items = [("kernel", shp), ("bias", (shp[2],))]
+                else:
+                    items = [("gamma", (shp,)), ("beta", (shp,))]
+                    for s in ("moving_mean", "moving_variance"):
+                        self.sslots[name + "/" + s] = (soff, (shp,))
+                        soff += shp
+                for s, sh in items:
+                    n = int(np.prod(sh))
+                    self.pslots[name + "/" + s] = (off, tuple(sh))
+                    off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            self.bucket_ranges.append((b0, off))
+        self.nparam = off
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.flat_p = torch.zeros(off, **f32)
+        self.flat_g = torch.zeros(off, **f32)
+        self.flat_m = torch.zeros(off, **f32)
+        self.flat_v = torch.zeros(off, **f32)
+        self.flat_s = torch.zeros(soff, **f32)
+        self.p = {k: self.flat_p[o:o + int(np.prod(sh))].view(sh) for k, (o, sh) in self.pslots.items()}
+        self.g = {k: self.flat_g[o:o + int(np.prod(sh))].view(sh) for k, (o, sh) in self.pslots.items()}
+        self.s = {k: self.flat_s[o:o + int(np.prod(sh))].view(sh) for k, (o, sh) in self.sslots.items()}
+        self.bnbuf = {}
+        for name, kind, shp, _ in self.table:
+            if kind == "bn":
+                self.bnbuf[name] = torch.zeros(4, shp, **f32)        # mean, var, scale, shift
+        self.ws = Workspace(self.dev)
+        self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
+        self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
+        self.adam_t = 0
+        self.tape = {}
+        self.on_bucket_ready = None       # callable(bucket_index) -- set by myolo/dist.py
+        self.before_optimizer = None      # callable() -- waits for the all-reduce
+        self.grad_scale = 1.0
+        self.load_state_dict(init_state_dict(cfg, seed))
+
+    # ------------------------------------------------------------------ state
+    def trainable_names(self):
+        return list(self.pslots)
+
+    def state_dict(self):
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in self.p.items()}
+        sd.update({k: v.detach().cpu().numpy().copy() for k, v in self.s.items()})
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        for k, v in sd.items():
+            dst = self.p.get(k, self.s.get(k))
+            if dst is None:
+                if strict:
+                    raise KeyError("unexpected tensor %s" % k)
+                continue
+            v = np.asarray(v, np.float32).reshape(dst.shape)
+            dst.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+        if strict:
+            missing = [k for k in list(self.p) + list(self.s) if k not in sd]
+            if missing:
+                raise KeyError("missing tensors: %s" % missing[:5])
+
+    def grads_dict(self):
+        return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items()}
+
+    # ------------------------------------------------------------------ helpers
+    def _new(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def _wsargs(self):
+        return self.ws.ptr, self.ws.size
+
+    # ---- BN + activation --------------------------------------------------
+    def bn_act_fwd(self, name, y, act, batch_stats):
+        """y [M,C] pre-BN conv output.  Returns act(BN(y)); saves what backward needs."""
+        M, C = y.shape
+        buf = self.bnbuf[name]
+        mean, var, scale, shift = buf[0], buf[1], buf[2], buf[3]
+        if batch_stats:
+            X.call("myolo_bn_stats", X.ptr(y), X.ptr(self.p[name + "/gamma"]), X.ptr(self.p[name + "/beta"]),
+                   X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift),
+                   X.ptr(self.s[name + "/moving_mean"]), X.ptr(self.s[name + "/moving_variance"]),
+                   M, C, *self._wsargs(), X.stream())
+        else:
+            X.call("myolo_bn_frozen_coeffs", X.ptr(self.p[name + "/gamma"]), X.ptr(self.p[name + "/beta"]),
+                   X.ptr(self.s[name + "/moving_mean"]), X.ptr(self.s[name + "/moving_variance"]),
+                   X.ptr(scale), X.ptr(shift), C, X.stream())
+        a = self._new(M, C)
+        X.call("myolo_bn_apply_act", X.ptr(y), X.ptr(scale), X.ptr(shift), X.ptr(a), M, C, act, X.stream())
+        self.tape[name] = (y, act, batch_stats)
+        return a
+
+    def bn_act_bwd(self, name, da):
+        y, act, batch_stats = self.tape[name]
+        M, C = y.shape
+        buf = self.bnbuf[name]
+        if batch_stats:
+            mean, var = buf[0], buf[1]
+        else:
+            mean, var = self.s[name + "/moving_mean"], self.s[name + "/moving_variance"]
+        dx = self._new(M, C)
+        X.call("myolo_bn_act_bwd", X.ptr(da), X.ptr(y), X.ptr(self.p[name + "/gamma"]), X.ptr(mean), X.ptr(var),
+               X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dx), X.ptr(self.g[name + "/gamma"]), X.ptr(self.g[name + "/beta"]),
+               M, C, act, 1 if batch_stats else 0, *self._wsargs(), X.stream())
+        return dx
+
+    def colsum(self, x2d, out):
+        M, C = x2d.shape
+        X.call("myolo_colsum", X.ptr(x2d), X.ptr(out), M, C, *self._wsargs(), X.stream())
+
+    # ---- depthwise-separable block ------------------------------------------
+    def dw_block_fwd(self, bid, a, shape, stride, train):
+        """a [N*H*W, C] activation, shape=(N,H,W,C).  Returns (activation, new shape)."""
+        N, H, W, C = shape
+        Ho, Wo = H // stride, W // stride
+        dwn, pwn = "conv_dw_%d" % bid, "conv_pw_%d" % bid
+        y = self._new(N * Ho * Wo, C)
+        X.call("myolo_dwconv3x3_fwd", X.ptr(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(y), N, H, W, C, stride, X.stream())
+        ad = self.bn_act_fwd(dwn + "_bn", y, ACT_RELU6, train)
+        Co = self.p[pwn + "/kernel"].shape[3]
+        y2 = self._new(N * Ho * Wo, Co)
+        X.call("myolo_pwconv1x1_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), None, X.ptr(y2), N * Ho * Wo, C, Co, X.stream())
+        ap = self.bn_act_fwd(pwn + "_bn", y2, ACT_RELU6, train)
+        self.tape["blk%d" % bid] = (a, shape, stride, ad)
+        return ap, (N, Ho, Wo, Co)
+
+    def dw_block_bwd(self, bid, da):
+        a, shape, stride, ad = self.tape["blk%d" % bid]
+        N, H, W, C = shape
+        Ho, Wo = H // stride, W // stride
+        dwn, pwn = "conv_dw_%d" % bid, "conv_pw_%d" % bid
+        Co = self.p[pwn + "/kernel"].shape[3]
+        M = N * Ho * Wo
+        dy2 = self.bn_act_bwd(pwn + "_bn", da)
+        X.call("myolo_pwconv1x1_bwd_weight", X.ptr(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co, *self._wsargs(), X.stream())
+        dad = self._new(M, C)
+        X.call("myolo_pwconv1x1_bwd_data", X.ptr(dy2), X.ptr(self.p[pwn + "/kernel"]), X.ptr(dad), M, C, Co, *self._wsargs(), X.stream())
+        dy = self.bn_act_bwd(dwn + "_bn", dad)
+        X.call("myolo_dwconv3x3_bwd_weight", X.ptr(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride,
+               *self._wsargs(), X.stream())
+        dx = self._new(N * H * W, C)
+        X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(dx), N, H, W, C, stride, X.stream())
+        return dx
+
+    # ---- trunk: backbone, feature_map, YOLO head -----------------------------------
+    def trunk_fwd(self, images, train):
+        cfg = self.cfg
+        N, H, W, _ = images.shape
+        C0 = self.p["conv1/kernel"].shape[3]
+        y = self._new(N * (H // 2) * (W // 2), C0)
+        X.call("myolo_conv3x3s2_c3_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), X.ptr(y), N, H, W, C0, X.stream())
+        a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)
+        shape = (N, H // 2, W // 2, C0)
+        self.tape["images"] = images
+        bid = 1
+        for f, s in BACKBONE_BLOCKS:
+            a, shape = self.dw_block_fwd(bid, a, shape, s, train)
+            bid += 1
+        C4, c4shape = a, shape
+        n, h, w, c = c4shape
+        Cf = cfg.TOP_FEATURE_MAP_DEPTH
+        Fm = self._new(n * h * w, Cf)
+        X.call("myolo_conv3x3_fwd", X.ptr(C4), X.ptr(self.p["feature_map/kernel"]), X.ptr(self.p["feature_map/bias"]), X.ptr(Fm),
+               n, h, w, c, Cf, X.stream())
+        for f, s in YOLO_BLOCKS:
+            a, shape = self.dw_block_fwd(bid, a, shape, s, train)
+            bid += 1
+        n2, h2, w2, c2 = shape
+        D = cfg.N_BOX * (5 + cfg.NUM_CLASSES)
+        yo = self._new(n2 * h2 * w2, D)
+        X.call("myolo_pwconv1x1_fwd", X.ptr(a), X.ptr(self.p["conv_23/kernel"]), X.ptr(self.p["conv_23/bias"]), X.ptr(yo),
+               n2 * h2 * w2, c2, D, X.stream())
+        self.tape["trunk"] = (C4, c4shape, a, shape)
+        return Fm, (n, h, w, Cf), yo
+
+    def trunk_bwd(self, dF, dyolo):
+        C4, c4shape, a14, s14 = self.tape["trunk"]
+        n2, h2, w2, c2 = s14
+        D = dyolo.shape[1]
+        M7 = n2 * h2 * w2
+        X.call("myolo_pwconv1x1_bwd_weight", X.ptr(a14), X.ptr(dyolo), X.ptr(self.g["conv_23/kernel"]), M7, c2, D, *self._wsargs(), X.stream())
+        self.colsum(dyolo, self.g["conv_23/bias"])
+        da = self._new(M7, c2)
+        X.call("myolo_pwconv1x1_bwd_data", X.ptr(dyolo), X.ptr(self.p["conv_23/kernel"]), X.ptr(da), M7, c2, D, *self._wsargs(), X.stream())
+        bid = len(BACKBONE_BLOCKS) + len(YOLO_BLOCKS)
+        for _ in YOLO_BLOCKS:
+            da = self.dw_block_bwd(bid, da)
+            bid -= 1
+        n, h, w, c = c4shape
+        Cf = dF.shape[1]
+        X.call("myolo_conv3x3_bwd_weight", X.ptr(C4), X.ptr(dF), X.ptr(self.g["feature_map/kernel"]), n, h, w, c, Cf, *self._wsargs(), X.stream())
+        self.colsum(dF, self.g["feature_map/bias"])
+        dC4 = self._new(n * h * w, c)
+        X.call("myolo_conv3x3_bwd_data", X.ptr(dF), X.ptr(self.p["feature_map/kernel"]), X.ptr(dC4), n, h, w, c, Cf, *self._wsargs(), X.stream())
+        X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
+        if self.on_bucket_ready:
+            self.on_bucket_ready(1)
+        da = dC4
+        for _ in BACKBONE_BLOCKS:
+            da = self.dw_block_bwd(bid, da)
+            bid -= 1
+        dy = self.bn_act_bwd("conv1_bn", da)
+        images = self.tape["images"]
+        N, H, W, _ = images.shape
+        C0 = self.p["conv1/kernel"].shape[3]
+        X.call("myolo_conv3x3s2_c3_bwd_weight", X.ptr(images), X.ptr(dy), X.ptr(self.g["conv1/kernel"]), N, H, W, C0, *self._wsargs(), X.stream())
+        if self.on_bucket_ready:
+            self.on_bucket_ready(0)
+
+    # ---- mask head -----------------------------------------------------------
+    def mask_head_fwd(self, Fm, fshape, rois, train):
+        """rois [B,R,4] (x1,y1,x2,y2).  Returns pred masks [B*R, mh*mw, C] (post-sigmoid)."""
+        cfg = self.cfg
+        B, R = rois.shape[:2]
+        n, h, w, cf = fshape
+        ps = cfg.MASK_POOL_SIZE
+        if cfg.ROI_BOX_ORDER == "xyxy_as_yxyx":
+            boxes = rois.reshape(B * R, 4)                    # model.py:385-387: read as (y1,x1,y2,x2)
+        else:
+            boxes = rois.reshape(B * R, 4)[:, [1, 0, 3, 2]].contiguous()
+        bind = torch.arange(B, device=self.dev, dtype=torch.int32).repeat_interleave(R).contiguous()
+        NR = B * R
+        x = self._new(NR * ps * ps, cf)
+        X.call("myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x), n, h, w, cf, NR, ps, ps, X.stream())
+        self.tape["roi"] = (boxes, bind, fshape, NR)
+        cin = cf
+        convs = []
+        for i in range(1, 5):
+            cn = "myolo_mask_conv%d" % i
+            y = self._new(NR * ps * ps, MASK_FILTERS)
+            X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(y),
+                   NR, ps, ps, cin, MASK_FILTERS, X.stream())
+            convs.append(x)
+            # bn1 uses batch statistics in training (model.py:690 has no training= argument);
+            # bn2-4 are called with training=False (model.py:696,702,708) -> moving statistics
+            x = self.bn_act_fwd("myolo_mask_bn%d" % i, y, ACT_RELU, train and i == 1)
+            cin = MASK_FILTERS
+        d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
+        X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
+               X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
+        C = cfg.NUM_CLASSES
+        p = self._new(NR * 4 * ps * ps, C)
+        X.call("myolo_mask_head_out_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
+               NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
+        self.tape["mask"] = (convs, x, d)
+        return p
+
+    def mask_head_bwd(self, dz):
+        """dz [NR*mh*mw, C] gradient wrt the pre-sigmoid mask logits.  Returns dF."""
+        cfg = self.cfg
+        convs, a4, d = self.tape["mask"]
+        boxes, bind, fshape, NR = self.tape["roi"]
+        ps = cfg.MASK_POOL_SIZE
+        C = cfg.NUM_CLASSES
+        Md = NR * 4 * ps * ps
+        dd = self._new(Md, MASK_FILTERS)
+        X.call("myolo_mask_head_out_bwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(dz), X.ptr(dd),
+               X.ptr(self.g["myolo_mask/kernel"]), X.ptr(self.g["myolo_mask/bias"]), Md, MASK_FILTERS, C, *self._wsargs(), X.stream())
+        X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NR, ps, ps,
+               MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+        self.colsum(dd, self.g["myolo_mask_deconv/bias"])
+        da = self._new(NR * ps * ps, MASK_FILTERS)
+        X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NR, ps, ps,
+               MASK_FILTERS, MASK_FILTERS, X.stream())
+        del dd
+        for i in range(4, 0, -1):
+            cn = "myolo_mask_conv%d" % i
+            dy = self.bn_act_bwd("myolo_mask_bn%d" % i, da)
+            xin = convs[i - 1]
+            cin = xin.shape[1]
+            X.call("myolo_conv3x3_bwd_weight", X.ptr(xin), X.ptr(dy), X.ptr(self.g[cn + "/kernel"]), NR, ps, ps, cin, MASK_FILTERS,
+                   *self._wsargs(), X.stream())
+            self.colsum(dy, self.g[cn + "/bias"])
+            da = self._new(NR * ps * ps, cin)
+            X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[cn + "/kernel"]), X.ptr(da), NR, ps, ps, cin, MASK_FILTERS,
+                   *self._wsargs(), X.stream())
+        n, h, w, cf = fshape
+        dF = self._new(n * h * w, cf)
+        X.call("myolo_crop_and_resize_bwd_image", X.ptr(da), X.ptr(boxes), X.ptr(bind), X.ptr(dF), n, h, w, cf, NR, ps, ps, X.stream())
+        if self.on_bucket_ready:
+            self.on_bucket_ready(2)
+        return dF
+
+    # ------------------------------------------------------------------ steps
+    def to_device_batch(self, batch):
+        """host batch (the six arrays of model.py:896-897) -> device tensors in C-ABI dtypes."""
+        images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
+        dev = self.dev
+        T = self.cfg.TRUE_BOX_BUFFER
+        return dict(
+            images=torch.as_tensor(np.ascontiguousarray(images, np.float32), device=dev),
+            true_boxes=torch.as_tensor(np.ascontiguousarray(np.asarray(true_boxes, np.float32).reshape(-1, T, 4)), device=dev),
+            y_true=torch.as_tensor(np.ascontiguousarray(y_true, np.float32), device=dev),
+            gt_ids=torch.as_tensor(np.ascontiguousarray(gt_ids, np.int32), device=dev),
+            gt_boxes=torch.as_tensor(np.ascontiguousarray(gt_boxes, np.int32), device=dev),
+            gt_masks=torch.as_tensor(np.ascontiguousarray(gt_masks).view(np.uint8), device=dev))
+
+    def forward_backward(self, db):
+        """One training forward + backward on a device batch.  Gradients land in self.flat_g."""
+        cfg = self.cfg
+        self.tape = {}
+        images = db["images"]
+        B = images.shape[0]
+        G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+        R = G * G * A
+        mh, mw = cfg.MASK_SHAPE
+        Fm, fshape, yo = self.trunk_fwd(images, True)
+        proposals = self._new(B, R, 4)
+        X.call("myolo_yolo_decode", X.ptr(yo), X.ptr(self.anchors), X.ptr(proposals), B, G, A, C, X.stream())
+        rois = self._new(B, R, 4)
+        tcls = self._new(B, R, dtype=torch.int32)
+        tmask = self._new(B, R, mh, mw)
+        npos = self._new(B, dtype=torch.int32)
+        H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+        X.call("myolo_mask_targets", X.ptr(proposals), X.ptr(db["gt_ids"]), X.ptr(db["gt_boxes"]), X.ptr(db["gt_masks"]),
+               X.ptr(rois), X.ptr(tcls), X.ptr(tmask), X.ptr(npos), B, R, T, H, W, mh, mw, X.stream())
+        pred = self.mask_head_fwd(Fm, fshape, rois, True)
+        w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
+        w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
+        yterms = self._new(8)
+        dyolo = self._new(yo.shape[0], yo.shape[1])
+        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+               X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
+               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+        mterms = self._new(2)
+        dz = self._new(pred.shape[0], pred.shape[1])
+        X.call("myolo_mask_bce", X.ptr(tmask), X.ptr(tcls), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), B * R, mh, mw, C,
+               *self._wsargs(), X.stream())
+        dF = self.mask_head_bwd(dz)
+        self.trunk_bwd(dF, dyolo)
+        return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_proposals=proposals, output_rois=rois,
+                    myolo_mask=pred.view(B, R, mh, mw, C), target_class_ids=tcls, target_mask=tmask, n_pos=npos,
+                    yolo_terms=yterms, mask_terms=mterms, feature_map=Fm.view(*fshape), loss_weights=(w1, w2))
+
+    def adam_step(self, lr, b1=0.9, b2=0.999, eps=1e-8):
+        """Keras Adam (model.py:1071-1075) over the whole flat buffer."""
+        if self.before_optimizer:
+            self.before_optimizer()
+        self.adam_t += 1
+        t = self.adam_t
+        lr_t = float(lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t))
+        X.call("myolo_adam_step", X.ptr(self.flat_p), X.ptr(self.flat_g), X.ptr(self.flat_m), X.ptr(self.flat_v),
+               self.nparam, lr_t, b1, b2, eps, float(self.grad_scale), X.stream())
+
+    def train_step(self, db, lr):
+        out = self.forward_backward(db)
+        self.adam_step(lr)
+        return out
+
+    def predict(self, images):
+        """inference graph (model.py:922-936): -> yolo_output, detections [B,R,6], myolo_mask."""
+        cfg = self.cfg
+        self.tape = {}
+        B = images.shape[0]
+        G, A, C = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES
+        R = G * G * A
+        mh, mw = cfg.MASK_SHAPE
+        Fm, fshape, yo = self.trunk_fwd(images, False)
+        det = self._new(B, R, 6)
+        X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
+        rois = det[..., :4].contiguous()
+        pred = self.mask_head_fwd(Fm, fshape, rois, False)
+        self.tape = {}
+        return yo.view(B, G, G, A, 5 + C), det, pred.view(B, R, mh, mw, C)
+
+    def predict_yolo(self, images):
+        """'yolo' mode forward (model.py:906-920)."""
+        self.tape = {}
+        cfg = self.cfg
+        _, _, yo = self.trunk_fwd(images, False)
+        self.tape = {}
+        return yo.view(images.shape[0], cfg.GRID_H, cfg.GRID_W, cfg.N_BOX, 5 + cfg.NUM_CLASSES)

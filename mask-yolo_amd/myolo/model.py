@@ -1,0 +1,259 @@
+"""
+``myolo.model.MaskYOLO`` -- the reference's Python class surface (model.py:761-1391) over the
+MI355X-native engine (myolo/engine.py -> libmyolo_hip.so).
+
+Kept: constructor ``MaskYOLO(mode, config, model_dir=None, yolo_pretrain_dir=None,
+yolo_trainable=True)`` (model.py:767-785), ``build`` (:787), ``train`` (:943-944), ``compile``
+(:1062), ``set_trainable`` (:1120), ``load_weights`` (:1157), ``infer_yolo`` (:1198), ``detect``
+(:1238, returns ``[{bboxes, class_ids, confidence_scores, full_masks}]`` :1316-1321),
+``decode_masks`` (:1330), and a ``keras_model`` attribute offering ``predict`` / ``summary``.
+
+Deliberate differences: one finalized config object everywhere (the
+reference reads the base class from free functions, model.py:25); ``train`` uses every sample of
+the dataset unless ``max_samples`` is given (reference hard-codes 50/6, model.py:995,1002);
+``detect`` keeps the NMB result (reference overrides it with [109,130], model.py:1306) and does not
+mutate ``Config.BATCH_SIZE`` (model.py:1268); checkpoints are ``.npz`` keyed by Keras layer names
+(h5py is not available); weights are cached by (path, mtime) instead of reloaded per call.
+"""
+import datetime
+import os
+import re
+
+import numpy as np
+import torch
+
+from . import myolo_utils as mutils
+from .engine import Net, layer_table
+
+
+class _KerasModelShim(object):
+    """The two ``keras_model`` methods the reference's scripts call
+    (infer_shapes_yolo_model.py:16, train_rice.py:44)."""
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def predict(self, inputs, verbose=0):
+        o = self._o
+        images = inputs[0] if isinstance(inputs, (list, tuple)) else inputs
+        x = torch.as_tensor(np.ascontiguousarray(images, np.float32), device=o.net.dev)
+        if o.mode == 'yolo':
+            return [o.net.predict_yolo(x).cpu().numpy()]
+        if o.mode == 'inference':
+            return [t.cpu().numpy() for t in o.net.predict(x)]
+        raise RuntimeError("predict() on a training-mode model: use train_on_batch()")
+
+    def summary(self):
+        lines = ["%-24s %-8s %s" % (n, k, s) for n, k, s, _ in layer_table(self._o.config)]
+        txt = "\n".join(lines) + "\ntrainable parameters: %d" % self._o.net.nparam
+        print(txt)
+        return txt
+
+
+class MaskYOLO(object):
+    def __init__(self, mode, config, model_dir=None, yolo_pretrain_dir=None, yolo_trainable=True, device="cuda:0", seed=0):
+        assert mode in ['training', 'inference', 'yolo']
+        self.mode = mode
+        self.config = config.finalize() if hasattr(config, "finalize") else config
+        self.model_dir = model_dir
+        self.yolo_pretrain_dir = yolo_pretrain_dir
+        self.yolo_trainable = yolo_trainable
+        self._device, self._seed = device, seed
+        self._weights_cache = None
+        self._lr = None
+        self._trainable_regex = ".*"
+        self.net = self.build(mode=mode, config=self.config)
+        self.keras_model = _KerasModelShim(self)
+        self.epoch = 0
+
+    # ------------------------------------------------------------------ build
+    def build(self, mode, config):
+        assert mode in ['training', 'inference', 'yolo']
+        w, h = config.IMAGE_SHAPE[:2]
+        if w % 32 != 0 or h % 32 != 0:
+            raise Exception("Image size must be dividable by 32 to adapt with YOLO framework. "
+                            "For example, use 224, 256, 288, 320, 356, ... etc. ")
+        assert config.BACKBONE == "mobilenet"          # model.py:62
+        net = Net(config, device=self._device, seed=self._seed)
+        if self.yolo_pretrain_dir is not None:          # model.py:854-868
+            self._load_npz_into(net, self.yolo_pretrain_dir, by_name=True)
+        return net
+
+    # ------------------------------------------------------------------ weights
+    def state_dict(self):
+        return self.net.state_dict()
+
+    def load_state_dict(self, sd, strict=True):
+        self.net.load_state_dict(sd, strict=strict)
+
+    @staticmethod
+    def _load_npz_into(net, filepath, by_name=False, exclude=None):
+        data = np.load(filepath)
+        sd = {}
+        for k in data.files:
+            layer = k.split("/")[0]
+            if exclude and layer in exclude:
+                continue
+            sd[k] = data[k]
+        net.load_state_dict(sd, strict=not (by_name or exclude))
+
+    def load_weights(self, filepath, by_name=False, exclude=None):
+        """model.py:1157-1196 with an .npz container keyed '<keras layer name>/<weight name>'."""
+        if exclude:
+            by_name = True
+        key = (os.path.abspath(filepath), os.path.getmtime(filepath), by_name, tuple(exclude or ()))
+        if self._weights_cache == key:
+            return
+        self._load_npz_into(self.net, filepath, by_name=by_name, exclude=exclude)
+        self._weights_cache = key
+
+    def save_weights(self, filepath):
+        np.savez(filepath, **self.net.state_dict())
+
+    # ------------------------------------------------------------------ training
+    def set_trainable(self, layer_regex, keras_model=None, indent=0, verbose=1):
+        """model.py:1120-1151: layers whose name fully matches the regex are trained; the
+        others keep their weights (their gradient is zeroed before Adam)."""
+        self._trainable_regex = layer_regex
+        mask = torch.zeros_like(self.net.flat_p)
+        for k, (off, shp) in self.net.pslots.items():
+            layer = k.split("/")[0]
+            trainable = bool(re.fullmatch(layer_regex, layer))
+            if self.yolo_pretrain_dir is not None and not self.yolo_trainable and not layer.startswith("myolo_mask") \
+                    and layer != "feature_map":
+                trainable = False                      # model.py:867-868
+            if trainable:
+                mask[off:off + int(np.prod(shp))] = 1.0
+        self._train_mask = None if bool(mask.min() > 0) else mask
+
+    def compile(self, learning_rate, momentum):
+        """model.py:1062-1118: Adam(lr, 0.9, 0.999, 1e-8); loss = sum of the batch-mean losses
+        times LOSS_WEIGHTS.  (momentum is unused by the reference too.)"""
+        self._lr = float(learning_rate)
+
+    def train_on_batch(self, batch, learning_rate=None):
+        """One optimisation step on a host batch (the six arrays of model.py:896-897).
+        Returns the reference's training outputs (model.py:899) + loss scalars as numpy."""
+        lr = self._lr if learning_rate is None else learning_rate
+        if lr is None:
+            lr = self.config.LEARNING_RATE
+        net = self.net
+        db = batch if isinstance(batch, dict) else net.to_device_batch(batch)
+        out = net.forward_backward(db)
+        if getattr(self, "_train_mask", None) is not None:
+            net.flat_g.mul_(self._train_mask)          # torch used as a memory op on a flag vector only
+        net.adam_step(lr)
+        return self._host_outputs(out)
+
+    @staticmethod
+    def _host_outputs(out):
+        yt = out["yolo_terms"].cpu().numpy()
+        mt = out["mask_terms"].cpu().numpy()
+        w1, w2 = out["loss_weights"]
+        res = {k: out[k].cpu().numpy() for k in ("yolo_output", "yolo_proposals", "output_rois", "myolo_mask",
+                                                 "target_class_ids", "target_mask", "n_pos", "feature_map")}
+        res.update(yolo_sum_loss=float(yt[0]), mask_loss=float(mt[0]), loss=float(yt[0] * w1 + mt[0] * w2),
+                   loss_xy=float(yt[1]), loss_wh=float(yt[2]), loss_conf=float(yt[3]), loss_class=float(yt[4]),
+                   recall=float(yt[5]))
+        return res
+
+    def train(self, train_dataset, val_dataset, learning_rate, epochs, layers,
+              augmentation=None, custom_callbacks=None, no_augmentation_sources=None, max_samples=None, verbose=1):
+        """model.py:943-1060.  Returns the list of per-epoch mean training losses."""
+        layer_regex = {"all": ".*"}
+        if layers in layer_regex:
+            layers = layer_regex[layers]
+        cfg = self.config
+
+        def collect(ds):
+            ids = list(ds.image_ids)
+            if max_samples is not None:
+                ids = ids[:max_samples]
+            return [list(mutils.load_image_gt(ds, cfg, i, use_mini_mask=cfg.USE_MINI_MASK)) for i in ids]
+
+        train_info = collect(train_dataset)
+        val_info = collect(val_dataset) if val_dataset is not None else []
+        mode = self.mode if self.mode in ('yolo', 'training') else 'training'
+        train_gen = mutils.BatchGenerator(train_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True)
+        val_gen = mutils.BatchGenerator(val_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True) if val_info else None
+        self.set_trainable(layers)
+        self.compile(learning_rate, cfg.LEARNING_MOMENTUM)
+        history = []
+        for ep in range(epochs):
+            losses = []
+            for i in range(len(train_gen)):
+                inputs, _ = train_gen[i]
+                if len(inputs[0]) != cfg.BATCH_SIZE:
+                    continue
+                out = self.train_on_batch(inputs)
+                losses.append(out["loss"])
+                if verbose:
+                    print("epoch %d step %d/%d loss %.4f (yolo %.4f mask %.4f recall %.3f)" %
+                          (ep + 1, i + 1, len(train_gen), out["loss"], out["yolo_sum_loss"], out["mask_loss"], out["recall"]))
+            history.append(float(np.mean(losses)) if losses else float("nan"))
+            if self.model_dir:
+                os.makedirs(self.model_dir, exist_ok=True)
+                stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
+                self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
+            del val_gen
+            val_gen = None
+        self.epoch = max(self.epoch, epochs)
+        return history
+
+    # ------------------------------------------------------------------ inference
+    def infer_yolo(self, image, weights_dir=None, save_path=None, display=False):
+        """model.py:1198-1236 without the plotting: returns the decoded BoundBox list."""
+        cfg = self.config
+        assert list(image.shape) == list(cfg.IMAGE_SHAPE)
+        assert image.dtype == 'uint8'
+        assert self.mode == 'yolo'
+        if weights_dir is not None:
+            self.load_weights(weights_dir)
+        normed = np.expand_dims(image / 255., axis=0)
+        netout = self.keras_model.predict([normed])[0]
+        return mutils.decode_one_yolo_output(netout[0], anchors=cfg.ANCHORS, nms_threshold=0.3, obj_threshold=0.35,
+                                             nb_class=cfg.NUM_CLASSES)
+
+    def detect(self, image, weights_dir=None, save_path='./img_results/', cs_threshold=0.35, display=False):
+        """model.py:1238-1328.  Returns [ {bboxes, class_ids, confidence_scores, full_masks} ]."""
+        cfg = self.config
+        assert list(image.shape) == list(cfg.IMAGE_SHAPE)
+        assert image.dtype == 'uint8'
+        assert self.mode == 'inference'
+        if weights_dir is not None:
+            self.load_weights(weights_dir)
+        normed = np.expand_dims(image / 255., axis=0)
+        yolo_output, detections, myolo_mask = self.keras_model.predict([normed], verbose=0)
+        boxes, class_ids, scores, full_masks = self.decode_masks(detections, myolo_mask, image.shape)
+        top10 = np.argsort(scores)[::-1][:10]
+        kept = np.array([i for i in top10 if scores[i] >= cs_threshold], dtype=np.int64)
+        nmb = mutils.NMB(boxes[kept], class_ids[kept], kept, cfg.IMAGE_SHAPE, nms_threshold=0.7) if len(kept) else kept
+        nmb = np.asarray(nmb, dtype=np.int64)
+        return [{
+            "bboxes": boxes[nmb],
+            "class_ids": class_ids[nmb],
+            "confidence_scores": scores[nmb],
+            "full_masks": full_masks[:, :, nmb],
+        }]
+
+    def decode_masks(self, detections, myolo_mask, image_shape):
+        """model.py:1330-1391."""
+        assert len(detections) == 1
+        assert len(myolo_mask) == 1
+        assert list(image_shape) == list(self.config.IMAGE_SHAPE)
+        detection, masks_all = detections[0], myolo_mask[0]
+        N = len(detection)
+        boxes = detection[:N, :4]
+        scores = detection[:N, 4]
+        class_ids = detection[:N, 5].astype(np.int32)
+        masks = masks_all[np.arange(N), :, :, class_ids]
+        exclude_ix = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) <= 0)[0]
+        if exclude_ix.shape[0] > 0:
+            boxes = np.delete(boxes, exclude_ix, axis=0)
+            class_ids = np.delete(class_ids, exclude_ix, axis=0)
+            scores = np.delete(scores, exclude_ix, axis=0)
+            masks = np.delete(masks, exclude_ix, axis=0)
+            N = class_ids.shape[0]
+        full_masks = [mutils.unmold_mask(masks[i], boxes[i], image_shape) for i in range(N)]
+        full_masks = np.stack(full_masks, axis=-1) if full_masks else np.empty(tuple(image_shape[:2]) + (0,))
+        return boxes, class_ids, scores, full_masks

@@ -1,0 +1,379 @@
+"""GPU parity tests, op by op: every C-ABI entry point of libmyolo_hip.so against the CPU oracle
+(oracle/np_ops.py) on seeded inputs.  Tolerances: 1e-3 (relative to the tensor's max magnitude)
+for floating-point results -- the north-star's fp32 bound; bit-exact (np.array_equal) for
+integer / index outputs and for the float outputs that feed integer decisions."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ops as O                      # noqa: E402
+from myolo import _ext as X                         # noqa: E402
+from myolo.config import make_config, ShapesConfig  # noqa: E402
+
+DEV = "cuda:0"
+TOL = 1e-3
+
+
+_KEEP = []   # device tensors must outlive the asynchronous kernel that reads them
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def dt(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+    t = t if dtype is None else t.to(dtype)
+    _KEEP.append(t)
+    return t
+
+
+def new(*shape, dtype=torch.float32):
+    return torch.full(shape, float("nan") if dtype == torch.float32 else 0, dtype=dtype, device=DEV)
+
+
+def ws():
+    if not hasattr(ws, "buf"):
+        ws.buf = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    return ws.buf.data_ptr(), ws.buf.numel()
+
+
+def relerr(got, ref):
+    got = got.detach().cpu().numpy() if torch.is_tensor(got) else np.asarray(got)
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), "non-finite output"
+    return float(np.abs(got - ref).max() / max(1.0, np.abs(ref).max()))
+
+
+def check(got, ref, tol=TOL, what=""):
+    e = relerr(got, ref)
+    assert e <= tol, "%s: rel err %.3e > %.1e" % (what, e, tol)
+    return e
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+# ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,Cin,Cout,bias", [(300, 32, 64, False), (1568, 1024, 27, True), (130, 16, 16, True),
+                                             (4096, 64, 128, False), (257, 512, 1024, False)])
+def test_pwconv1x1(M, Cin, Cout, bias):
+    rng = np.random.default_rng(1)
+    x, w = rnd(rng, M, Cin), rnd(rng, Cin, Cout, scale=0.1)
+    b = rnd(rng, Cout) if bias else None
+    dy = rnd(rng, M, Cout)
+    y = new(M, Cout)
+    X.call("myolo_pwconv1x1_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)) if bias else None, X.ptr(y), M, Cin, Cout, X.stream())
+    ref = x.astype(np.float64) @ w + (b if bias else 0)
+    check(y, ref, what="pw fwd")
+    dx, dw = new(M, Cin), new(Cin, Cout)
+    X.call("myolo_pwconv1x1_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), M, Cin, Cout, *ws(), X.stream())
+    X.call("myolo_pwconv1x1_bwd_weight", X.ptr(dt(x)), X.ptr(dt(dy)), X.ptr(dw), M, Cin, Cout, *ws(), X.stream())
+    check(dx, dy.astype(np.float64) @ w.T, what="pw dx")
+    check(dw, x.astype(np.float64).T @ dy, what="pw dw")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 32, 64), (2, 7, 9, 16, 48), (1, 28, 28, 128, 256), (5, 14, 14, 256, 256)])
+def test_conv3x3(N, H, W, Cin, Cout):
+    rng = np.random.default_rng(2)
+    x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout)
+    dy = rnd(rng, N, H, W, Cout)
+    y = new(N, H, W, Cout)
+    X.call("myolo_conv3x3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, X.stream())
+    check(y, O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64), what="conv3 fwd")
+    rdx, rdw, rdb = O.conv2d_bwd(x, w, dy, pads=(1, 1, 1, 1), acc=np.float64)
+    dx, dw = new(N, H, W, Cin), new(3, 3, Cin, Cout)
+    X.call("myolo_conv3x3_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, Cin, Cout, *ws(), X.stream())
+    X.call("myolo_conv3x3_bwd_weight", X.ptr(dt(x)), X.ptr(dt(dy)), X.ptr(dw), N, H, W, Cin, Cout, *ws(), X.stream())
+    check(dx, rdx, what="conv3 dx")
+    check(dw, rdw, what="conv3 dw")
+    db = new(Cout)
+    X.call("myolo_colsum", X.ptr(dt(dy.reshape(-1, Cout))), X.ptr(db), N * H * W, Cout, *ws(), X.stream())
+    check(db, rdb, what="colsum")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 256, 256), (2, 5, 7, 32, 64)])
+def test_deconv2x2s2(N, H, W, Cin, Cout):
+    rng = np.random.default_rng(3)
+    x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 2, 2, Cout, Cin, scale=0.05), rnd(rng, Cout)
+    dy = rnd(rng, N, 2 * H, 2 * W, Cout)
+    y = new(N, 2 * H, 2 * W, Cout)
+    X.call("myolo_deconv2x2s2_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, 1, *ws(), X.stream())
+    ref = O.relu(O.deconv2x2s2(x, w, b))
+    check(y, ref, what="deconv fwd")
+    rdx, rdw, rdb = O.deconv2x2s2_bwd(x, w, dy)
+    dx, dw = new(N, H, W, Cin), new(2, 2, Cout, Cin)
+    X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, Cin, Cout, X.stream())
+    X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(dt(x)), X.ptr(dt(dy)), X.ptr(dw), N, H, W, Cin, Cout, *ws(), X.stream())
+    check(dx, rdx, what="deconv dx")
+    check(dw, rdw, what="deconv dw")
+
+
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 32, 2), (3, 7, 7, 128, 1), (1, 14, 10, 64, 2),
+                                            (2, 9, 13, 16, 1)])
+def test_dwconv3x3(N, H, W, C, stride):
+    rng = np.random.default_rng(4)
+    x, w = rnd(rng, N, H, W, C), rnd(rng, 3, 3, C)
+    ref = O.dwconv3x3(x, w, stride)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    y = new(N, Ho, Wo, C)
+    X.call("myolo_dwconv3x3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(y), N, H, W, C, stride, X.stream())
+    check(y, ref, what="dw fwd")
+    dy = rnd(rng, N, Ho, Wo, C)
+    rdx, rdw = O.dwconv3x3_bwd(x, w, dy, stride)
+    dx, dw = new(N, H, W, C), new(3, 3, C)
+    X.call("myolo_dwconv3x3_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, C, stride, X.stream())
+    X.call("myolo_dwconv3x3_bwd_weight", X.ptr(dt(x)), X.ptr(dt(dy)), X.ptr(dw), N, H, W, C, stride, *ws(), X.stream())
+    check(dx, rdx, what="dw dx")
+    check(dw, rdw, what="dw dw")
+
+
+def test_dw_s2_impulse_pins_pad_side():
+    """4x4 impulse at (3,3): with pad bottom/right (keras_applications>=1.0.5) the stride-2 output
+    at (1,1) sees it through tap (1,1)."""
+    x = np.zeros((1, 4, 4, 4), np.float32)
+    x[0, 3, 3, :] = 1
+    w = np.arange(36, dtype=np.float32).reshape(3, 3, 4)
+    y = new(1, 2, 2, 4)
+    X.call("myolo_dwconv3x3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(y), 1, 4, 4, 4, 2, X.stream())
+    got = y.cpu().numpy()
+    assert np.array_equal(got[0, 1, 1], w[1, 1]) and got[0, 0, 0].sum() == 0
+
+
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32)])
+def test_conv1(N, H, W, Co):
+    rng = np.random.default_rng(5)
+    x, w = rng.random((N, H, W, 3), dtype=np.float32), rnd(rng, 3, 3, 3, Co)
+    y = new(N, H // 2, W // 2, Co)
+    X.call("myolo_conv3x3s2_c3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(y), N, H, W, Co, X.stream())
+    check(y, O.conv2d(x, w, stride=2, pads=(1, 1, 1, 1), acc=np.float64), what="conv1 fwd")
+    dy = rnd(rng, N, H // 2, W // 2, Co)
+    _, rdw, _ = O.conv2d_bwd(x, w, dy, stride=2, pads=(1, 1, 1, 1), acc=np.float64, need_dx=False)
+    dw = new(3, 3, 3, Co)
+    X.call("myolo_conv3x3s2_c3_bwd_weight", X.ptr(dt(x)), X.ptr(dt(dy)), X.ptr(dw), N, H, W, Co, *ws(), X.stream())
+    check(dw, rdw, what="conv1 dw")
+
+
+@pytest.mark.parametrize("M,C,act", [(1000, 32, 2), (37, 256, 1), (50000, 64, 2), (200, 1024, 0)])
+def test_batchnorm(M, C, act):
+    rng = np.random.default_rng(6)
+    x = rnd(rng, M, C, scale=2.0) + rnd(rng, 1, C)
+    g, b = 1 + rnd(rng, C, scale=0.2), rnd(rng, C, scale=0.3)
+    mm, mv = rnd(rng, C, scale=0.1), 1 + np.abs(rnd(rng, C, scale=0.1))
+    dy = rnd(rng, M, C)
+    actf = {0: lambda v: v, 1: O.relu, 2: O.relu6}[act]
+    actb = {0: lambda a, d: d, 1: O.relu_bwd, 2: O.relu6_bwd}[act]
+    # training mode
+    y_ref, cache = O.bn_train(x, g, b)
+    a_ref = actf(y_ref)
+    mean, var, scale, shift = new(C), new(C), new(C), new(C)
+    tmm, tmv = dt(mm), dt(mv)
+    X.call("myolo_bn_stats", X.ptr(dt(x)), X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift),
+           X.ptr(tmm), X.ptr(tmv), M, C, *ws(), X.stream())
+    check(mean, cache[2], 1e-5, "bn mean")
+    check(var, cache[3], 1e-4, "bn var")
+    rmm, rmv = O.bn_moving_update(mm, mv, cache[2], cache[3], M)
+    check(tmm, rmm, 1e-5, "moving mean")
+    check(tmv, rmv, 1e-5, "moving var")
+    a = new(M, C)
+    X.call("myolo_bn_apply_act", X.ptr(dt(x)), X.ptr(scale), X.ptr(shift), X.ptr(a), M, C, act, X.stream())
+    check(a, a_ref, what="bn apply")
+    rdx, rdg, rdb = O.bn_train_bwd(cache, g, actb(a_ref, dy))
+    dx, dg, db = new(M, C), new(C), new(C)
+    X.call("myolo_bn_act_bwd", X.ptr(dt(dy)), X.ptr(dt(x)), X.ptr(dt(g)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift),
+           X.ptr(dx), X.ptr(dg), X.ptr(db), M, C, act, 1, *ws(), X.stream())
+    check(dx, rdx, what="bn dx")
+    check(dg, rdg, what="bn dgamma")
+    check(db, rdb, what="bn dbeta")
+    # frozen mode
+    y_ref, cache = O.bn_infer(x, g, b, mm, mv)
+    a_ref = actf(y_ref)
+    X.call("myolo_bn_frozen_coeffs", X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(dt(mm)), X.ptr(dt(mv)), X.ptr(scale), X.ptr(shift), C, X.stream())
+    X.call("myolo_bn_apply_act", X.ptr(dt(x)), X.ptr(scale), X.ptr(shift), X.ptr(a), M, C, act, X.stream())
+    check(a, a_ref, what="bn frozen apply")
+    rdx, rdg, rdb = O.bn_infer_bwd(cache, g, actb(a_ref, dy))
+    X.call("myolo_bn_act_bwd", X.ptr(dt(dy)), X.ptr(dt(x)), X.ptr(dt(g)), X.ptr(dt(mm)), X.ptr(dt(mv)), X.ptr(scale), X.ptr(shift),
+           X.ptr(dx), X.ptr(dg), X.ptr(db), M, C, act, 0, *ws(), X.stream())
+    check(dx, rdx, what="bn frozen dx")
+    check(dg, rdg, what="bn frozen dgamma")
+    check(db, rdb, what="bn frozen dbeta")
+
+
+def _boxes(rng, nb):
+    c = rng.random((nb, 2)) * 1.2 - 0.1
+    s = rng.random((nb, 2)) * 0.6
+    b = np.concatenate([c - s / 2, c + s / 2], 1).astype(np.float32)
+    b[0] = [0, 0, 0, 0]                      # degenerate box (deprecated/test_mask.py:39)
+    b[1] = [0.2, 0.6, 1.3, 0.9]              # partly outside -> extrapolation rows
+    return b
+
+
+@pytest.mark.parametrize("B,H,W,C,nb,crop", [(2, 28, 28, 256, 40, 14), (3, 7, 9, 16, 11, 5), (1, 16, 16, 64, 6, 1)])
+def test_crop_and_resize(B, H, W, C, nb, crop):
+    rng = np.random.default_rng(7)
+    img = rnd(rng, B, H, W, C)
+    boxes = _boxes(rng, nb)
+    bind = rng.integers(0, B, nb).astype(np.int32)
+    out = new(nb, crop, crop, C)
+    X.call("myolo_crop_and_resize_fwd", X.ptr(dt(img)), X.ptr(dt(boxes)), X.ptr(dt(bind)), X.ptr(out), B, H, W, C, nb, crop, crop, X.stream())
+    check(out, O.crop_and_resize(img, boxes, bind, (crop, crop)), 1e-5, "crop fwd")
+    dout = rnd(rng, nb, crop, crop, C)
+    dimg = new(B, H, W, C)
+    X.call("myolo_crop_and_resize_bwd_image", X.ptr(dt(dout)), X.ptr(dt(boxes)), X.ptr(dt(bind)), X.ptr(dimg), B, H, W, C, nb, crop, crop, X.stream())
+    check(dimg, O.crop_and_resize_bwd_image(dout, boxes, bind, img.shape), 1e-4, "crop bwd")
+
+
+@pytest.mark.parametrize("B,G,A,C", [(4, 7, 3, 4), (2, 13, 5, 2), (3, 4, 3, 4)])
+def test_yolo_decode_bit_exact(B, G, A, C):
+    rng = np.random.default_rng(8)
+    yp = rnd(rng, B, G, G, A, 5 + C, scale=2.0)
+    yp[0, 0, 0, 0, :] = 0                                   # zero-logit KAT row
+    anchors = (rng.random(2 * A) * 4 + 0.5).astype(np.float32)
+    prop, det = new(B, G * G * A, 4), new(B, G * G * A, 6)
+    X.call("myolo_yolo_decode", X.ptr(dt(yp)), X.ptr(dt(anchors)), X.ptr(prop), B, G, A, C, X.stream())
+    X.call("myolo_yolo_detections", X.ptr(dt(yp)), X.ptr(dt(anchors)), X.ptr(det), B, G, A, C, X.stream())
+    assert np.array_equal(prop.cpu().numpy(), O.yolo_decode(yp, anchors, G)), "proposals not bit-exact"
+    ref = O.yolo_detections(yp, anchors, G)
+    got = det.cpu().numpy()
+    assert np.array_equal(got, ref), "detections not bit-exact"
+    assert np.array_equal(got[..., 5].astype(np.int32), np.argmax(yp[..., 5:], -1).reshape(B, -1))
+
+
+def _targets_case(rng, cfg, B):
+    H, W = cfg.IMAGE_SHAPE[:2]
+    T, R = cfg.TRUE_BOX_BUFFER, cfg.TRAIN_ROIS_PER_IMAGE
+    gt_boxes = np.zeros((B, T, 4), np.int32)
+    gt_ids = np.zeros((B, T), np.int32)
+    gt_masks = np.zeros((B, H, W, T), bool)
+    for b in range(B):
+        n = [3, 0, 1, T][b % 4]
+        for k in range(n):
+            x1, y1 = rng.integers(0, W - 30), rng.integers(0, H - 30)
+            w, h = rng.integers(12, 30), rng.integers(12, 30)
+            gt_boxes[b, k] = [x1, y1, x1 + w, y1 + h]
+            gt_ids[b, k] = rng.integers(1, cfg.NUM_CLASSES)
+            yy, xx = np.mgrid[0:H, 0:W]
+            gt_masks[b, :, :, k] = ((xx - (x1 + w / 2)) ** 2 / (w / 2) ** 2 + (yy - (y1 + h / 2)) ** 2 / (h / 2) ** 2) <= 1
+    prop = np.zeros((B, R, 4), np.float32)
+    for b in range(B):
+        for r in range(R):
+            if r % 3 == 0 and gt_boxes[b].any():
+                k = rng.integers(0, max(1, (gt_boxes[b].sum(1) > 0).sum()))
+                g = gt_boxes[b, k].astype(np.float32) / np.array([W, H, W, H], np.float32)
+                prop[b, r] = g + (rng.random(4).astype(np.float32) - 0.5) * 0.08
+            else:
+                c, s = rng.random(2), rng.random(2) * 0.5 + 0.02
+                prop[b, r] = np.concatenate([c - s / 2, c + s / 2])
+    return prop, gt_ids, gt_boxes, gt_masks
+
+
+@pytest.mark.parametrize("size,nbox", [(128, 3), (224, 5)])
+def test_mask_targets_bit_exact(size, nbox):
+    anchors = [1.0, 1.0] * nbox
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[size, size, 3], N_BOX=nbox, ANCHORS=anchors)
+    rng = np.random.default_rng(9)
+    B = 4
+    prop, gt_ids, gt_boxes, gt_masks = _targets_case(rng, cfg, B)
+    R, T = cfg.TRAIN_ROIS_PER_IMAGE, cfg.TRUE_BOX_BUFFER
+    rois, tcls, tmask, npos = new(B, R, 4), new(B, R, dtype=torch.int32), new(B, R, 28, 28), new(B, dtype=torch.int32)
+    X.call("myolo_mask_targets", X.ptr(dt(prop)), X.ptr(dt(gt_ids)), X.ptr(dt(gt_boxes)), X.ptr(dt(gt_masks.view(np.uint8))),
+           X.ptr(rois), X.ptr(tcls), X.ptr(tmask), X.ptr(npos), B, R, T, size, size, 28, 28, X.stream())
+    r_rois, r_cls, r_mask, r_npos = O.mask_targets(prop, gt_ids, gt_boxes, gt_masks, cfg)
+    assert r_npos.sum() > 0, "test case has no positives"
+    assert np.array_equal(npos.cpu().numpy(), r_npos)
+    assert np.array_equal(tcls.cpu().numpy(), r_cls)
+    assert np.array_equal(rois.cpu().numpy(), r_rois)
+    assert np.array_equal(tmask.cpu().numpy(), r_mask)
+
+
+def test_yolo_loss():
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3])
+    rng = np.random.default_rng(10)
+    B, G, A, C, T = 4, cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+    yp = rnd(rng, B, G, G, A, 5 + C)
+    yt = np.zeros_like(yp)
+    tb = np.zeros((B, 1, 1, 1, T, 4), np.float32)
+    for b in range(B):
+        for k in range(b + 1):
+            gy, gx, a = rng.integers(0, G, 2).tolist() + [int(rng.integers(0, A))]
+            box = [gx + rng.random(), gy + rng.random(), 0.5 + 3 * rng.random(), 0.5 + 3 * rng.random()]
+            yt[b, gy, gx, a, :4] = box
+            yt[b, gy, gx, a, 4] = 1
+            yt[b, gy, gx, a, 5 + rng.integers(1, C)] = 1
+            tb[b, 0, 0, 0, k] = box
+            yp[b, gy, gx, a, :4] = [0.1, -0.2, np.log(box[2] / cfg.ANCHORS[2 * a]) + 0.1, np.log(box[3] / cfg.ANCHORS[2 * a + 1])]
+    ref = O.yolo_loss(yt, yp, tb, cfg, want_grad=True)
+    terms, grad = new(8), new(*yp.shape)
+    X.call("myolo_yolo_loss", X.ptr(dt(yt)), X.ptr(dt(yp)), X.ptr(dt(tb.reshape(B, T, 4))), X.ptr(dt(np.asarray(cfg.ANCHORS, np.float32))),
+           X.ptr(dt(cfg.CLASS_WEIGHTS)), cfg.OBJECT_SCALE, cfg.NO_OBJECT_SCALE, cfg.COORD_SCALE, cfg.CLASS_SCALE, 1.0,
+           X.ptr(terms), X.ptr(grad), B, G, A, C, T, *ws(), X.stream())
+    t = terms.cpu().numpy()
+    for i, k in enumerate(["loss", "loss_xy", "loss_wh", "loss_conf", "loss_class", "recall", "n_coord", "n_conf"]):
+        assert abs(t[i] - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (k, t[i], ref[k])
+    check(grad, ref["grad"], 1e-4, "yolo loss grad")
+
+
+def test_mask_head_out_and_bce():
+    rng = np.random.default_rng(11)
+    NR, hw, Cin, C = 6, 28 * 28, 256, 4
+    M = NR * hw
+    x = np.maximum(rnd(rng, M, Cin), 0)
+    w, b = rnd(rng, Cin, C, scale=0.1), rnd(rng, C)
+    p = new(M, C)
+    X.call("myolo_mask_head_out_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(p), M, Cin, C, X.stream())
+    p_ref = O.sigmoid(x.astype(np.float64) @ w + b)
+    check(p, p_ref, 1e-5, "mask out fwd")
+    ids = np.array([2, 0, 1, 0, 3, 0], np.int32)
+    tm = (rng.random((NR, 28, 28)) > 0.5).astype(np.float32)
+    pr = p_ref.reshape(1, NR, 28, 28, C).astype(np.float32)
+    l_ref, dp_ref = O.mask_bce(tm[None], ids[None], pr, want_grad=True)
+    dz_ref = (dp_ref.astype(np.float64) * pr * (1 - pr)).reshape(M, C)
+    lo, dz = new(2), new(M, C)
+    X.call("myolo_mask_bce", X.ptr(dt(tm)), X.ptr(dt(ids)), X.ptr(dt(pr.reshape(M, C))), 1.0, X.ptr(lo), X.ptr(dz), NR, 28, 28, C, *ws(), X.stream())
+    assert abs(lo.cpu().numpy()[0] - float(l_ref)) < 1e-5 and lo.cpu().numpy()[1] == 3
+    assert np.abs(dz.cpu().numpy() - dz_ref).max() <= 1e-3 * np.abs(dz_ref).max()
+    dx, dw, db = new(M, Cin), new(Cin, C), new(C)
+    dzn = dz_ref.astype(np.float32)
+    X.call("myolo_mask_head_out_bwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(dzn)), X.ptr(dx), X.ptr(dw), X.ptr(db), M, Cin, C, *ws(), X.stream())
+    rdx = (dzn.astype(np.float64) @ w.T) * (x > 0)
+    assert np.abs(dx.cpu().numpy() - rdx).max() <= 1e-3 * np.abs(rdx).max()
+    rdw = x.astype(np.float64).T @ dzn
+    assert np.abs(dw.cpu().numpy() - rdw).max() <= 1e-3 * np.abs(rdw).max()
+    assert np.abs(db.cpu().numpy() - dzn.sum(0)).max() <= 1e-3 * np.abs(dzn.sum(0)).max()
+
+
+def test_mask_bce_no_positives_is_zero():
+    NR, C = 3, 4
+    tm, ids = np.zeros((NR, 28, 28), np.float32), np.zeros(NR, np.int32)
+    pr = np.full((NR * 784, C), 0.3, np.float32)
+    lo, dz = new(2), new(NR * 784, C)
+    X.call("myolo_mask_bce", X.ptr(dt(tm)), X.ptr(dt(ids)), X.ptr(dt(pr)), 1.0, X.ptr(lo), X.ptr(dz), NR, 28, 28, C, *ws(), X.stream())
+    assert lo.cpu().numpy()[0] == 0 and float(dz.abs().max()) == 0
+
+
+def test_adam_three_steps():
+    rng = np.random.default_rng(12)
+    n = 10007
+    p0, gs = rnd(rng, n), [rnd(rng, n) for _ in range(3)]
+    p, m, v = dt(p0.copy()), dt(np.zeros(n, np.float32)), dt(np.zeros(n, np.float32))
+    rp, rm, rv = p0.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    for t, g in enumerate(gs, 1):
+        lr_t = float(1e-3 * np.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t))
+        X.call("myolo_adam_step", X.ptr(p), X.ptr(dt(g)), X.ptr(m), X.ptr(v), n, lr_t, 0.9, 0.999, 1e-8, 1.0, X.stream())
+        rp, rm, rv = O.adam_step(rp, g, rm, rv, t)
+    check(p, rp, 1e-6, "adam")
+
+
+def test_bad_arguments_fail_loudly():
+    with pytest.raises(RuntimeError):
+        X.call("myolo_dwconv3x3_fwd", None, None, None, 1, 8, 8, 8, 1, X.stream())
+    with pytest.raises(RuntimeError):       # workspace too small
+        x = dt(np.zeros((64, 64), np.float32))
+        X.call("myolo_pwconv1x1_bwd_data", X.ptr(x), X.ptr(x), X.ptr(x), 64, 64, 64, None, 0, X.stream())
