@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- Mask-YOLO training-step throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A step = one full training step of the hot path on one synthetic Shapes batch per GPU:
+forward (backbone, YOLO head, decode, mask targets, ROIAlign, mask head, both losses), backward of all of
+it, gradient all-reduce (N>1) and the Adam update.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- the dominant kernel (mask-head 3x3 implicit-GEMM, fp32 MFMA), timed live with HIP events
+  cpu_baseline -- the CPU restatement (oracle/torch_ref.py, torch-CPU, all host cores) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "mask-yolo_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+import torch.distributed as dist   # noqa: E402
+
+
+def make_batches(cfg, rank, world, per_gpu, nbatches):
+    """nbatches distinct host batches for this rank; image g of the global stream is seeded by g."""
+    from myolo.shapes import make_shapes_samples
+    from myolo.myolo_utils import BatchGenerator
+    out = []
+    for i in range(nbatches):
+        start = (i * world + rank) * per_gpu
+        samples = make_shapes_samples(per_gpu, cfg, start_index=start)
+        batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
+        out.append(batch)
+    return out
+
+
+def usable_cores():
+    """host cores this process may really use: min(affinity mask, cgroup cpu quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(cfg, sample_images, seed=0, budget_s=25.0):
+    """Time the CPU restatement (torch-CPU fp32 + autograd, oracle/torch_ref.py) on a bounded sample of the
+    same workload.  oneDNN scales poorly past a few dozen threads at this batch size, so the thread count is
+    min(usable cores, 32); that number is what 'cores' reports."""
+    from myolo.config import make_config
+    from myolo.shapes import make_shapes_samples
+    from myolo.myolo_utils import BatchGenerator
+    from oracle import np_model
+    from oracle.torch_ref import TorchRef
+    avail = usable_cores()
+    threads = max(1, min(avail, 32))
+    torch.set_num_threads(threads)
+
+    def build(n):
+        ccfg = make_config(type(cfg).__mro__[1], IMAGE_SHAPE=list(cfg.IMAGE_SHAPE), ALPHA=cfg.ALPHA, BATCH_SIZE=n,
+                           N_BOX=cfg.N_BOX, ANCHORS=list(cfg.ANCHORS))
+        samples = make_shapes_samples(n, ccfg)
+        batch, _ = BatchGenerator(samples, ccfg, 'training', shuffle=False, norm=True)[0]
+        return TorchRef(np_model.init_params(ccfg, seed=seed), ccfg, torch.float32), batch
+
+    ref, batch = build(1)
+    t0 = time.time()
+    ref.train_step(batch)
+    ref.adam({}, 1, 1e-3)
+    t_probe = time.time() - t0                     # 1-image probe (includes first-touch / oneDNN primitive creation)
+    n = int(max(1, min(sample_images, budget_s / max(t_probe, 1e-3))))
+    if n > 1:
+        ref, batch = build(n)
+        ref.train_step(batch)                      # warm-up at the timed batch size
+    state = {}
+    t0 = time.time()
+    ref.train_step(batch)
+    ref.adam(state, 1, 1e-3)
+    t = time.time() - t0
+    return dict(value=n / t, unit="images/sec", cores=threads, kind="port",
+                sample="1 timed training step (fwd+bwd+Adam) of the torch-CPU fp32 restatement (oracle/torch_ref.py) on %d Shapes "
+                       "%dx%d image(s), N_BOX=%d, after a warm-up step; %d threads of %d usable host cores (os.cpu_count()=%d); "
+                       "%.1f s timed, 1-image probe %.1f s"
+                       % (n, cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1], cfg.N_BOX, threads, avail, os.cpu_count() or 0, t, t_probe))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--nbox", type=int, default=3, choices=[3, 5],
+                    help="3 = self-consistent Shapes head (R=147, primary); 5 = repository-HEAD head (R=245)")
+    ap.add_argument("--cpu-images", type=int, default=8, help="images in the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    args = ap.parse_args()
+
+    from myolo import dist as mdist
+    from myolo.config import make_config, ShapesConfig, ShapesHeadConfig
+    from myolo.model import MaskYOLO
+
+    rank, world, local = mdist.init_from_env()
+    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    dev = "cuda:%d" % local
+    base = ShapesConfig if args.nbox == 3 else ShapesHeadConfig
+    cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch)
+    model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
+    net = model.net
+    reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)])
+    reducer.attach(net)
+
+    nb = 2
+    host = make_batches(cfg, rank, world, args.batch, nb)
+    dbs = [net.to_device_batch(b) for b in host]
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        net.train_step(dbs[i % nb], args.lr)
+    barrier()
+    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd"}
+    net.timings = {}
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = net.train_step(dbs[i % nb], args.lr)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss = float(out["yolo_terms"][0]) + float(out["mask_terms"][0])
+    assert np.isfinite(loss), "non-finite loss in the timed region"
+
+    if rank == 0:
+        R = cfg.TRAIN_ROIS_PER_IMAGE
+        ps = cfg.MASK_POOL_SIZE
+        M = args.batch * R * ps * ps
+        conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
+        flop = 2.0 * M * (9 * 256) * 256                      # algorithmic FLOPs of one mask-head 3x3 conv launch
+        achieved = flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        roi_ms, _ = net.kernel_ms("roialign_fwd")
+        roi_bytes = args.batch * R * ps * ps * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
+        res = {
+            "metric": "images/sec fwd+bwd, %dx%d Shapes batch %d, at %d MI355X" % (args.size, args.size, args.batch, world),
+            "value": args.batch * world * args.steps / elapsed,
+            "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
+                                   "(fwd+bwd+Adam%s)" % (args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
+                                                        "+RCCL all-reduce" if world > 1 else ""),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
+            "roofline": {"kernel": "gemm_nn<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M,
+                         "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
+                         "frac": achieved / 157.3, "traffic": None, "launches_timed": conv_n, "avg_launch_ms": conv_ms,
+                         "secondary": {"kernel": "crop_fwd_kernel (ROIAlign fwd)", "bound": "hbm",
+                                       "achieved": roi_bytes / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
+                                       "peak": 8000.0, "unit": "GB/s",
+                                       "frac": (roi_bytes / (roi_ms * 1e-3) / 1e9 / 8000.0) if roi_ms > 0 else 0.0,
+                                       "avg_launch_ms": roi_ms}},
+        }
+        if args.cpu_images > 0 and world == 1:
+            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_images)
+        elif args.cpu_images > 0:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

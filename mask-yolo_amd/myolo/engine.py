@@ -155,6 +155,8 @@ class Net(object):
         self.on_bucket_ready = None       # callable(bucket_index) -- set by myolo/dist.py
         self.before_optimizer = None      # callable() -- waits for the all-reduce
         self.grad_scale = 1.0
+        self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
+        self.timings = {}                 # tag -> [(start_event, end_event), ...]
         self.load_state_dict(init_state_dict(cfg, seed))
 
     # ------------------------------------------------------------------ state
@@ -189,6 +191,23 @@ class Net(object):
 
     def _wsargs(self):
         return self.ws.ptr, self.ws.size
+
+    def _call_timed(self, tag, name, *args):
+        """X.call bracketed by HIP events on the launch stream when `tag` is being measured."""
+        if tag not in self.timed_tags:
+            return X.call(name, *args)
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        X.call(name, *args)
+        e1.record(st)
+        self.timings.setdefault(tag, []).append((e0, e1))
+
+    def kernel_ms(self, tag):
+        """average launch duration (ms) of the timed tag since the last reset (synchronises)."""
+        torch.cuda.synchronize()
+        ev = self.timings.get(tag, [])
+        return sum(a.elapsed_time(b) for a, b in ev) / max(1, len(ev)), len(ev)
 
     # ---- BN + activation --------------------------------------------------
     def bn_act_fwd(self, name, y, act, batch_stats):
@@ -235,7 +254,8 @@ class Net(object):
         Ho, Wo = H // stride, W // stride
         dwn, pwn = "conv_dw_%d" % bid, "conv_pw_%d" % bid
         y = self._new(N * Ho * Wo, C)
-        X.call("myolo_dwconv3x3_fwd", X.ptr(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(y), N, H, W, C, stride, X.stream())
+        self._call_timed("dw%d_fwd" % bid, "myolo_dwconv3x3_fwd", X.ptr(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(y),
+                         N, H, W, C, stride, X.stream())
         ad = self.bn_act_fwd(dwn + "_bn", y, ACT_RELU6, train)
         Co = self.p[pwn + "/kernel"].shape[3]
         y2 = self._new(N * Ho * Wo, Co)
@@ -341,15 +361,16 @@ class Net(object):
         bind = torch.arange(B, device=self.dev, dtype=torch.int32).repeat_interleave(R).contiguous()
         NR = B * R
         x = self._new(NR * ps * ps, cf)
-        X.call("myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x), n, h, w, cf, NR, ps, ps, X.stream())
+        self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
+                         n, h, w, cf, NR, ps, ps, X.stream())
         self.tape["roi"] = (boxes, bind, fshape, NR)
         cin = cf
         convs = []
         for i in range(1, 5):
             cn = "myolo_mask_conv%d" % i
             y = self._new(NR * ps * ps, MASK_FILTERS)
-            X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(y),
-                   NR, ps, ps, cin, MASK_FILTERS, X.stream())
+            self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
+                             X.ptr(self.p[cn + "/bias"]), X.ptr(y), NR, ps, ps, cin, MASK_FILTERS, X.stream())
             convs.append(x)
             # bn1 uses batch statistics in training (model.py:690 has no training= argument);
             # bn2-4 are called with training=False (model.py:696,702,708) -> moving statistics
