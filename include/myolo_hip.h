@@ -105,12 +105,30 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma,
                      float* dx, float* dgamma, float* dbeta,
                      int64_t M, int C, int act, int batch_stats, void* ws, size_t ws_bytes, void* stream);
 
+/* Exact-sparsity helpers for the mask head backward (build_mask_graph model.py:690-708: bn1 is the only
+ * batch-statistics layer, so behind it only ROIs with a positive target carry non-zero gradient):
+ * gather_groups: dst[i] = src[idx[i]] for groups of group_elems floats (one ROI's rows);
+ * bn_act_bwd_rowsparse: training-mode BN+activation backward where the upstream gradient is given only
+ *   for the n_groups row groups idx[] (compact dy [n_groups*group_rows, C]; inv[group] = slot or -1);
+ *   results are identical to bn_act_bwd on the zero-padded dense gradient. */
+int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n, int64_t group_elems, void* stream);
+int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const int32_t* idx, const int32_t* inv,
+                               const float* mean, const float* var, const float* scale, const float* shift,
+                               float* dx, float* dgamma, float* dbeta,
+                               int64_t M, int C, int n_groups, int group_rows, int act,
+                               void* ws, size_t ws_bytes, void* stream);
+
 /* ---- tf.image.crop_and_resize, bilinear, extrapolation 0 (PyramidROIAlign model.py:385-387) ----
  * boxes [nb,4] = (y1,x1,y2,x2) normalised as crop_and_resize reads them; box_ind [nb] int32. */
 int myolo_crop_and_resize_fwd(const float* image, const float* boxes, const int32_t* box_ind, float* out,
                               int B, int H, int W, int C, int nb, int crop_h, int crop_w, void* stream);
 int myolo_crop_and_resize_bwd_image(const float* dout, const float* boxes, const int32_t* box_ind, float* dimage,
                                     int B, int H, int W, int C, int nb, int crop_h, int crop_w, void* stream);
+
+/* Same gradient for the layout build_mask_graph uses (model.py:684-685: boxes [batch, R, 4] flattened,
+ * box b*R+r samples image b): gather formulation, deterministic, no atomics, writes every element. */
+int myolo_roialign_bwd_grouped(const float* dout, const float* boxes, float* dimage,
+                               int B, int H, int W, int C, int R, int crop_h, int crop_w, void* stream);
 
 /* ---- DecodeYOLOLayer model.py:1442-1473 / DetectionsLayer model.py:1493-1538 ----
  * y_pred [B,G,G,A,5+C]; anchors [2A]; proposals [B,G*G*A,4]; detections [B,G*G*A,6]. */

@@ -67,10 +67,10 @@ static ColGeom col_geom(long long M, int C)
     g.cl = cl;
     g.pl = 256 / cl;
     g.cgroups = (q + cl - 1) / cl;
-    long long want = 2048 / g.cgroups;                // target ~2048 blocks in total
+    long long want = 768 / g.cgroups;                 // target ~768 blocks in total (3 per CU)
     if (want < 1) want = 1;
     long long rpb = cdiv64(M, want);
-    const long long min_rows = (long long)g.pl * 8;   // at least 8 rows per thread
+    const long long min_rows = (long long)g.pl * 32;  // at least 32 rows per thread
     if (rpb < min_rows) rpb = min_rows;
     g.rows_per_block = rpb;
     g.rblocks = (int)cdiv64(M, rpb);
@@ -118,14 +118,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int 
     }
 }
 
-// sum partials over row blocks: tot[v*C + c] (double)
-__global__ void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc)
+// sum partials over row blocks: tot[v*C + c] (double).  32 outputs x 8 block-lanes per workgroup.
+__global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nvc) return;
+    __shared__ double red[8][32];
+    const int ol = threadIdx.x & 31, bl = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + ol;
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += part[(long long)b * nvc + i];
-    tot[i] = s;
+    if (i < nvc)
+        for (int b = bl; b < nblk; b += 8) s += part[(long long)b * nvc + i];
+    red[bl][ol] = s;
+    __syncthreads();
+    if (bl == 0 && i < nvc) {
+        double t = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][ol];
+        tot[i] = t;
+    }
 }
 
 template <class OP>
@@ -134,7 +143,7 @@ static int run_colreduce(OP op, long long M, int C, double* part, double* tot, h
     ColGeom g = col_geom(M, C);
     hipLaunchKernelGGL((colreduce_kernel<OP>), dim3(g.rblocks, g.cgroups), dim3(256), 0, s, op, M, C, g, part);
     const int nvc = OP::NV * C;
-    hipLaunchKernelGGL(colreduce_finish, dim3((nvc + 255) / 256), dim3(256), 0, s, part, tot, g.rblocks, nvc);
+    hipLaunchKernelGGL(colreduce_finish, dim3((nvc + 31) / 32), dim3(256), 0, s, part, tot, g.rblocks, nvc);
     return 0;
 }
 
@@ -282,6 +291,80 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
             } else {
                 o[k] = scv[k] * dz;
             }
+        }
+        st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// group gather: dst[i] = src[idx[i]] for groups of `gq` float4 (one group = one ROI's rows)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_groups_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                            float* __restrict__ dst, int n, long long gq)
+{
+    const long long total = (long long)n * gq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long long g = i / gq, o = i - g * gq;
+        st4g(dst + i * 4, ld4g(src + ((long long)idx[g] * gq + o) * 4));
+    }
+}
+
+// Row-sparse training-mode BN backward: the upstream gradient is non-zero only in the row groups
+// listed in idx (compact tensor dyc [n*grows, C]); x is dense [M, C].
+struct OpBnBwdSparse {
+    static constexpr int NV = 2;
+    const float* dyc;
+    const float* x;
+    const int32_t* idx;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* var;
+    int C, act, grows;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {   // r indexes the COMPACT rows
+        const long long g = r / grows;
+        const long long xr = (long long)idx[g] * grows + (r - g * grows);
+        const float4 gv = ld4g(dyc + r * C + c), v = ld4g(x + xr * C + c);
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c), mu = ld4g(mean + c), vr = ld4g(var + c);
+        float dz, xh;
+        dz = gv.x * actmask(fmaf(v.x, sc.x, sh.x), act); xh = (v.x - mu.x) * rsqrtf(vr.x + BN_EPS_F); acc[0].x += dz; acc[1].x = fmaf(dz, xh, acc[1].x);
+        dz = gv.y * actmask(fmaf(v.y, sc.y, sh.y), act); xh = (v.y - mu.y) * rsqrtf(vr.y + BN_EPS_F); acc[0].y += dz; acc[1].y = fmaf(dz, xh, acc[1].y);
+        dz = gv.z * actmask(fmaf(v.z, sc.z, sh.z), act); xh = (v.z - mu.z) * rsqrtf(vr.z + BN_EPS_F); acc[0].z += dz; acc[1].z = fmaf(dz, xh, acc[1].z);
+        dz = gv.w * actmask(fmaf(v.w, sc.w, sh.w), act); xh = (v.w - mu.w) * rsqrtf(vr.w + BN_EPS_F); acc[0].w += dz; acc[1].w = fmaf(dz, xh, acc[1].w);
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_dx_sparse_kernel(const float* __restrict__ dyc, const float* __restrict__ x,
+                                                               const int32_t* __restrict__ inv, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, const float* __restrict__ mean,
+                                                               const float* __restrict__ var, const double* __restrict__ tot,
+                                                               float* __restrict__ dx, long long nquads, int C, int act, int grows,
+                                                               float invM)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cq = C / 4;
+    for (; i < nquads; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        const long long row = i / cq;
+        const long long g = row / grows;
+        const int slot = inv[g];
+        const float4 v = ld4g(x + i * 4);
+        float4 gq = f4zero();
+        if (slot >= 0) gq = ld4g(dyc + ((long long)slot * grows + (row - g * grows)) * C + c);
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        float gv[4] = {gq.x, gq.y, gq.z, gq.w}, xv[4] = {v.x, v.y, v.z, v.w};
+        float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float dz = gv[k] * actmask(fmaf(xv[k], scv[k], shv[k]), act);
+            const float xh = (xv[k] - mean[c + k]) * rsqrtf(var[c + k] + BN_EPS_F);
+            const float db = (float)tot[c + k], dg = (float)tot[C + c + k];
+            o[k] = scv[k] * (dz - (db + xh * dg) * invM);
         }
         st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
@@ -570,6 +653,55 @@ __global__ __launch_bounds__(256) void crop_bwd_kernel(const float* __restrict__
     }
 }
 
+// Gather form of the ROIAlign backward for the layout the mask head uses: boxes grouped by image,
+// R per image (box b*R+r belongs to image b).  One lane per (pixel, channel quad); it walks the R boxes
+// of its image and, for each, the crop samples whose top/bottom (left/right) neighbour is this pixel,
+// summing weight * dout in a fixed order -- no atomics, no memset, bit-reproducible.  With C = 256 a
+// wave is exactly one pixel, so the box walk is wave-uniform.
+__global__ __launch_bounds__(256) void crop_bwd_grouped_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                               float* __restrict__ dimg, int B, int H, int W, int C, int R,
+                                                               int ch, int cw)
+{
+    const int cq = C / 4;
+    const long long total = (long long)B * H * W * cq;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        long long t = i / cq;
+        const int x = (int)(t % W);
+        t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        float4 acc = f4zero();
+        for (int r = 0; r < R; ++r) {
+            const long long bi = (long long)b * R + r;
+            const float4 bx = ld4g(boxes + bi * 4);          // y1,x1,y2,x2
+            for (int py = 0; py < ch; ++py) {
+                float iny;
+                if (!crop_coord(bx.x, bx.z, H, ch, py, iny)) continue;
+                const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+                if (ty != y && by != y) continue;
+                const float ly = iny - (float)ty;
+                const float wyv = (ty == y ? (1.f - ly) : 0.f) + (by == y ? ly : 0.f);
+                for (int px = 0; px < cw; ++px) {
+                    float inx;
+                    if (!crop_coord(bx.y, bx.w, W, cw, px, inx)) continue;
+                    const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+                    if (lx != x && rx != x) continue;
+                    const float lxw = inx - (float)lx;
+                    const float wxv = (lx == x ? (1.f - lxw) : 0.f) + (rx == x ? lxw : 0.f);
+                    const float wgt = wyv * wxv;
+                    const float4 g = ld4g(dout + ((bi * ch + py) * cw + px) * C + c);
+                    acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
+                    acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+                }
+            }
+        }
+        st4g(dimg + i * 4, acc);
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // final mask conv 1x1 (Cin -> C<=8) + bias + sigmoid.  One wave per row: each lane owns
 // channel quads {lane, lane+64, ...}, partial dots are combined with a wave butterfly.
@@ -631,7 +763,7 @@ __global__ __launch_bounds__(256) void mask_out_fwd_kernel(const float* __restri
 // backward: dx = (dz w^T) * (x > 0);  dw[ci][k] = sum_m x[m,ci] dz[m,k]
 template <int CC>
 struct OpMaskOutBwd {
-    static constexpr int NV = CC;
+    static constexpr int NV = CC + 2;   // CC weight-gradient rows + 2 quads of bias gradient (column quad 0 only)
     const float* x;
     const float* w;     // [Cin][CC]
     const float* dz;    // [M][CC]
@@ -640,9 +772,9 @@ struct OpMaskOutBwd {
     __device__ void operator()(long long r, int c, float4* acc) const
     {
         const float4 v = ld4g(x + r * Cin + c);
-        float g[CC];
+        float g[8];
 #pragma unroll
-        for (int k = 0; k < CC; ++k) g[k] = dz[r * CC + k];
+        for (int k = 0; k < 8; ++k) g[k] = k < CC ? dz[r * CC + k] : 0.f;
         float4 o = f4zero();
 #pragma unroll
         for (int k = 0; k < CC; ++k) {
@@ -651,15 +783,20 @@ struct OpMaskOutBwd {
             o.x = fmaf(g[k], w[(c + 0) * CC + k], o.x); o.y = fmaf(g[k], w[(c + 1) * CC + k], o.y);
             o.z = fmaf(g[k], w[(c + 2) * CC + k], o.z); o.w = fmaf(g[k], w[(c + 3) * CC + k], o.w);
         }
+        if (c == 0) {
+            acc[CC].x += g[0]; acc[CC].y += g[1]; acc[CC].z += g[2]; acc[CC].w += g[3];
+            acc[CC + 1].x += g[4]; acc[CC + 1].y += g[5]; acc[CC + 1].z += g[6]; acc[CC + 1].w += g[7];
+        }
         o.x = v.x > 0.f ? o.x : 0.f; o.y = v.y > 0.f ? o.y : 0.f;
         o.z = v.z > 0.f ? o.z : 0.f; o.w = v.w > 0.f ? o.w : 0.f;
         st4g(dx + r * Cin + c, o);
     }
 };
 // tot[k][ci] (double) -> dw[ci][k]
-__global__ void mask_out_dw_finish(const double* __restrict__ tot, float* dw, int Cin, int CC)
+__global__ void mask_out_dw_finish(const double* __restrict__ tot, float* dw, float* db, int Cin, int CC)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < CC) db[i] = (float)tot[(CC + (i >> 2)) * Cin + (i & 3)];
     if (i >= Cin * CC) return;
     const int ci = i / CC, k = i % CC;
     dw[i] = (float)tot[k * Cin + ci];
@@ -792,14 +929,13 @@ template <int CC>
 static int mask_out_bwd_impl(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int64_t M, int Cin,
                              void* ws, size_t ws_bytes, hipStream_t s)
 {
-    const size_t pb = col_ws_bytes(M, Cin, CC);
-    MYOLO_NEED_WS(align256(pb) + (size_t)CC * Cin * sizeof(double));
+    const size_t pb = col_ws_bytes(M, Cin, CC + 2);
+    MYOLO_NEED_WS(align256(pb) + (size_t)(CC + 2) * Cin * sizeof(double));
     double* part = (double*)ws;
     double* tot = (double*)((char*)ws + align256(pb));
     OpMaskOutBwd<CC> op{x, w, dz, dx, Cin};
     run_colreduce(op, M, Cin, part, tot, s);
-    hipLaunchKernelGGL(mask_out_dw_finish, dim3((Cin * CC + 255) / 256), dim3(256), 0, s, tot, dw, Cin, CC);
-    hipLaunchKernelGGL(small_colsum_kernel, dim3(1), dim3(256), 0, s, dz, db, (long long)M, CC);
+    hipLaunchKernelGGL(mask_out_dw_finish, dim3((Cin * CC + 255) / 256), dim3(256), 0, s, tot, dw, db, Cin, CC);
     return MYOLO_OK;
 }
 
@@ -882,6 +1018,38 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq,
                        C, act, batch_stats, 1.0f / (float)M);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n, int64_t group_elems, void* stream)
+{
+    MYOLO_REQUIRE(src && idx && dst && n > 0 && group_elems > 0 && (group_elems & 3) == 0, "gather_groups: bad arguments");
+    const long long total = (long long)n * (group_elems / 4);
+    hipLaunchKernelGGL(gather_groups_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n,
+                       (long long)(group_elems / 4));
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const int32_t* idx, const int32_t* inv, const float* mean,
+                               const float* var, const float* scale, const float* shift, float* dx, float* dgamma, float* dbeta,
+                               int64_t M, int C, int n_groups, int group_rows, int act, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy_compact && x && idx && inv && mean && var && scale && shift && dx && dgamma && dbeta, "bn_act_bwd_rowsparse: null pointer");
+    MYOLO_REQUIRE(M > 0 && (C & 3) == 0 && n_groups > 0 && group_rows > 0 && M % group_rows == 0, "bn_act_bwd_rowsparse: bad sizes");
+    const long long Mc = (long long)n_groups * group_rows;
+    const size_t pb = col_ws_bytes(Mc, C, 2);
+    MYOLO_NEED_WS(align256(pb) + 2 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpBnBwdSparse op{dy_compact, x, idx, scale, shift, mean, var, C, act, group_rows};
+    run_colreduce(op, Mc, C, part, tot, s);
+    hipLaunchKernelGGL(bn_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, dgamma, dbeta, C);
+    const long long nq = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_dx_sparse_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy_compact, x, inv, scale, shift, mean, var, tot,
+                       dx, nq, C, act, group_rows, 1.0f / (float)M);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -988,6 +1156,19 @@ int myolo_crop_and_resize_bwd_image(const float* dout, const float* boxes, const
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(crop_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dout, boxes, box_ind, dimage, H, W, C, nb,
                        crop_h, crop_w);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_roialign_bwd_grouped(const float* dout, const float* boxes, float* dimage, int B, int H, int W, int C, int R,
+                               int crop_h, int crop_w, void* stream)
+{
+    MYOLO_REQUIRE(dout && boxes && dimage && B > 0 && R > 0 && (C & 3) == 0, "roialign_bwd_grouped: bad arguments");
+    const long long total = (long long)B * H * W * (C / 4);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(crop_bwd_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, boxes, dimage, B, H,
+                       W, C, R, crop_h, crop_w);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -38,6 +38,9 @@ SIGS = {
     "myolo_bn_act_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, Z, P],
     "myolo_crop_and_resize_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_crop_and_resize_bwd_image": [P, P, P, P, I, I, I, I, I, I, I, P],
+    "myolo_gather_groups": [P, P, P, I, L, P],
+    "myolo_bn_act_bwd_rowsparse": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, Z, P],
+    "myolo_roialign_bwd_grouped": [P, P, P, I, I, I, I, I, I, I, P],
     "myolo_yolo_decode": [P, P, P, I, I, I, I, P],
     "myolo_yolo_detections": [P, P, P, I, I, I, I, P],
     "myolo_yolo_loss": [P, P, P, P, P, F, F, F, F, F, P, P, I, I, I, I, I, P, Z, P],

@@ -155,6 +155,11 @@ class Net(object):
         self.on_bucket_ready = None       # callable(bucket_index) -- set by myolo/dist.py
         self.before_optimizer = None      # callable() -- waits for the all-reduce
         self.grad_scale = 1.0
+        # exact-sparsity backward of the mask head (see mask_head_bwd_sparse); False = dense reference path
+        self.sparse_mask_bwd = True
+        self._copy_stream = torch.cuda.Stream(device=self.dev)
+        self._npos_ready = torch.cuda.Event()
+        self._npos_pinned = None
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
         self.timings = {}                 # tag -> [(start_event, end_event), ...]
         self.load_state_dict(init_state_dict(cfg, seed))
@@ -229,8 +234,10 @@ class Net(object):
         self.tape[name] = (y, act, batch_stats)
         return a
 
-    def bn_act_bwd(self, name, da):
+    def bn_act_bwd(self, name, da, y_override=None):
         y, act, batch_stats = self.tape[name]
+        if y_override is not None:
+            y = y_override
         M, C = y.shape
         buf = self.bnbuf[name]
         if batch_stats:
@@ -417,7 +424,100 @@ class Net(object):
                    *self._wsargs(), X.stream())
         n, h, w, cf = fshape
         dF = self._new(n * h * w, cf)
-        X.call("myolo_crop_and_resize_bwd_image", X.ptr(da), X.ptr(boxes), X.ptr(bind), X.ptr(dF), n, h, w, cf, NR, ps, ps, X.stream())
+        X.call("myolo_roialign_bwd_grouped", X.ptr(da), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
+        if self.on_bucket_ready:
+            self.on_bucket_ready(2)
+        return dF
+
+    def _gather(self, t, idx, n, group_rows):
+        C = t.shape[1]
+        out = self._new(n * group_rows, C)
+        X.call("myolo_gather_groups", X.ptr(t), X.ptr(idx), X.ptr(out), n, group_rows * C, X.stream())
+        return out
+
+    def _start_npos_copy(self, npos):
+        """async D2H of the per-image positive counts on a side stream (read at the start of backward)."""
+        B = npos.shape[0]
+        if self._npos_pinned is None or self._npos_pinned.shape[0] != B:
+            self._npos_pinned = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ev)
+            self._npos_pinned.copy_(npos, non_blocking=True)
+            self._npos_ready.record(self._copy_stream)
+
+    def mask_head_bwd_sparse(self, dz, B, R):
+        """Same gradients as mask_head_bwd, exploiting a structural zero: bn2-4 are frozen affine maps
+        (model.py:696,702,708) and the mask loss only reads positive ROIs (model.py:739-746), so behind bn1
+        every non-positive ROI's gradient is exactly 0.  conv2-4 / deconv / myolo_mask backward therefore run
+        on the positive ROIs only (compacted); bn1 (batch statistics, model.py:690) and conv1 stay dense,
+        because bn1's backward spreads gradient to every ROI.  Positives are the first n_pos rows of each
+        image (detect_mask_target_graph puts them first, model.py:593)."""
+        cfg = self.cfg
+        convs, a4, d = self.tape["mask"]
+        boxes, bind, fshape, NR = self.tape["roi"]
+        ps = cfg.MASK_POOL_SIZE
+        C = cfg.NUM_CLASSES
+        n, h, w, cf = fshape
+        self._npos_ready.synchronize()
+        npos_h = self._npos_pinned.numpy()
+        pos = np.concatenate([np.arange(b * R, b * R + int(npos_h[b]), dtype=np.int32) for b in range(B)]) if B else np.zeros(0, np.int32)
+        NP = int(pos.shape[0])
+        lo, hi = self.bucket_ranges[2]
+        if NP == 0:                       # no positive ROI: mask loss is the constant 0 (model.py:750-752)
+            self.flat_g[lo:hi].zero_()
+            dF = torch.zeros(n * h * w, cf, dtype=torch.float32, device=self.dev)
+            if self.on_bucket_ready:
+                self.on_bucket_ready(2)
+            return dF
+        inv = np.full(NR, -1, np.int32)
+        inv[pos] = np.arange(NP, dtype=np.int32)
+        idx_d = torch.from_numpy(pos).to(self.dev, non_blocking=True)
+        inv_d = torch.from_numpy(inv).to(self.dev, non_blocking=True)
+        q = ps * ps
+        dz_p = self._gather(dz, idx_d, NP, 4 * q)
+        d_p = self._gather(d, idx_d, NP, 4 * q)
+        Md = NP * 4 * q
+        dd = self._new(Md, MASK_FILTERS)
+        X.call("myolo_mask_head_out_bwd", X.ptr(d_p), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(dz_p), X.ptr(dd),
+               X.ptr(self.g["myolo_mask/kernel"]), X.ptr(self.g["myolo_mask/bias"]), Md, MASK_FILTERS, C, *self._wsargs(), X.stream())
+        a4_p = self._gather(a4, idx_d, NP, q)
+        X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_p), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
+               MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+        self.colsum(dd, self.g["myolo_mask_deconv/bias"])
+        da = self._new(NP * q, MASK_FILTERS)
+        X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NP, ps, ps,
+               MASK_FILTERS, MASK_FILTERS, X.stream())
+        for i in range(4, 1, -1):
+            cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
+            c_p = self._gather(self.tape[bn][0], idx_d, NP, q)
+            dy = self.bn_act_bwd(bn, da, y_override=c_p)
+            xin = self._gather(convs[i - 1], idx_d, NP, q)
+            X.call("myolo_conv3x3_bwd_weight", X.ptr(xin), X.ptr(dy), X.ptr(self.g[cn + "/kernel"]), NP, ps, ps, MASK_FILTERS,
+                   MASK_FILTERS, *self._wsargs(), X.stream())
+            self.colsum(dy, self.g[cn + "/bias"])
+            da = self._new(NP * q, MASK_FILTERS)
+            X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[cn + "/kernel"]), X.ptr(da), NP, ps, ps, MASK_FILTERS,
+                   MASK_FILTERS, *self._wsargs(), X.stream())
+        # bn1: batch statistics -> dense dx from the row-sparse upstream gradient
+        c1, act, _ = self.tape["myolo_mask_bn1"]
+        buf = self.bnbuf["myolo_mask_bn1"]
+        M1 = NR * q
+        dc1 = self._new(M1, MASK_FILTERS)
+        X.call("myolo_bn_act_bwd_rowsparse", X.ptr(da), X.ptr(c1), X.ptr(idx_d), X.ptr(inv_d), X.ptr(buf[0]), X.ptr(buf[1]),
+               X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dc1), X.ptr(self.g["myolo_mask_bn1/gamma"]), X.ptr(self.g["myolo_mask_bn1/beta"]),
+               M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
+        x0 = convs[0]
+        cin = x0.shape[1]
+        X.call("myolo_conv3x3_bwd_weight", X.ptr(x0), X.ptr(dc1), X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
+               MASK_FILTERS, *self._wsargs(), X.stream())
+        self.colsum(dc1, self.g["myolo_mask_conv1/bias"])
+        dp0 = self._new(M1, cin)
+        X.call("myolo_conv3x3_bwd_data", X.ptr(dc1), X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, ps, ps, cin,
+               MASK_FILTERS, *self._wsargs(), X.stream())
+        dF = self._new(n * h * w, cf)
+        X.call("myolo_roialign_bwd_grouped", X.ptr(dp0), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
         if self.on_bucket_ready:
             self.on_bucket_ready(2)
         return dF
@@ -455,6 +555,8 @@ class Net(object):
         H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
         X.call("myolo_mask_targets", X.ptr(proposals), X.ptr(db["gt_ids"]), X.ptr(db["gt_boxes"]), X.ptr(db["gt_masks"]),
                X.ptr(rois), X.ptr(tcls), X.ptr(tmask), X.ptr(npos), B, R, T, H, W, mh, mw, X.stream())
+        if self.sparse_mask_bwd:
+            self._start_npos_copy(npos)
         pred = self.mask_head_fwd(Fm, fshape, rois, True)
         w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
         w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
@@ -467,7 +569,7 @@ class Net(object):
         dz = self._new(pred.shape[0], pred.shape[1])
         X.call("myolo_mask_bce", X.ptr(tmask), X.ptr(tcls), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), B * R, mh, mw, C,
                *self._wsargs(), X.stream())
-        dF = self.mask_head_bwd(dz)
+        dF = self.mask_head_bwd_sparse(dz, B, R) if self.sparse_mask_bwd else self.mask_head_bwd(dz)
         self.trunk_bwd(dF, dyolo)
         return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_proposals=proposals, output_rois=rois,
                     myolo_mask=pred.view(B, R, mh, mw, C), target_class_ids=tcls, target_mask=tmask, n_pos=npos,

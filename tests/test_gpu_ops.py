@@ -230,6 +230,23 @@ def test_crop_and_resize(B, H, W, C, nb, crop):
     check(dimg, O.crop_and_resize_bwd_image(dout, boxes, bind, img.shape), 1e-4, "crop bwd")
 
 
+@pytest.mark.parametrize("B,H,W,C,R,crop", [(2, 28, 28, 256, 20, 14), (3, 7, 9, 16, 5, 5), (2, 12, 12, 64, 7, 14)])
+def test_roialign_bwd_grouped(B, H, W, C, R, crop):
+    """gather formulation == scatter formulation (oracle), incl. degenerate all-zero boxes and boxes
+    outside the image; and it is bit-reproducible."""
+    rng = np.random.default_rng(17)
+    boxes = _boxes(rng, B * R)
+    boxes[R] = [0.3, 0.3, 0.3, 0.3]                                # zero-size box: all samples on one point
+    bind = np.repeat(np.arange(B), R).astype(np.int32)
+    dout = rnd(rng, B * R, crop, crop, C)
+    ref = O.crop_and_resize_bwd_image(dout, boxes, bind, (B, H, W, C))
+    d1, d2 = new(B, H, W, C), new(B, H, W, C)
+    X.call("myolo_roialign_bwd_grouped", X.ptr(dt(dout)), X.ptr(dt(boxes)), X.ptr(d1), B, H, W, C, R, crop, crop, X.stream())
+    X.call("myolo_roialign_bwd_grouped", X.ptr(dt(dout)), X.ptr(dt(boxes)), X.ptr(d2), B, H, W, C, R, crop, crop, X.stream())
+    check(d1, ref, 1e-4, "roialign bwd grouped")
+    assert torch.equal(d1, d2)
+
+
 @pytest.mark.parametrize("B,G,A,C", [(4, 7, 3, 4), (2, 13, 5, 2), (3, 4, 3, 4)])
 def test_yolo_decode_bit_exact(B, G, A, C):
     rng = np.random.default_rng(8)

@@ -171,6 +171,46 @@ def test_mask_head_teacher_forced():
     assert worst < 2e-3, worst
 
 
+def test_sparse_mask_backward_equals_dense():
+    """The positive-ROI-only backward of conv2-4/deconv/myolo_mask is an exact-zero elimination:
+    gradients agree with the dense path to fp32 summation-order noise, on the same device inputs."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    grads = []
+    for sparse in (False, True):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        model.net.sparse_mask_bwd = sparse
+        model.train_on_batch(batch, learning_rate=0.0)
+        grads.append(model.net.grads_dict())
+    worst = 0.0
+    for k in grads[0]:
+        d = grads[0][k]
+        if np.abs(d).max() < 1e-12 or k == "myolo_mask_conv1/bias":
+            continue
+        worst = max(worst, rel(grads[1][k], d))
+    assert worst < 1e-4, worst
+
+
+def test_no_positive_rois_gives_zero_mask_loss_and_grads():
+    """empty-GT batch: every ROI negative, mask loss 0 (model.py:750-752), mask-head gradients 0."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    b2 = [a.copy() for a in batch]
+    b2[3][:] = 0
+    b2[4][:] = 0
+    b2[5][:] = False
+    r2 = np_model.train_step_fwd_bwd(P, b2, cfg)
+    assert r2["n_pos"].sum() == 0 and float(r2["mask_loss"]) == 0.0
+    for sparse in (True, False):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        model.net.sparse_mask_bwd = sparse
+        out = model.train_on_batch(b2, learning_rate=0.0)
+        g = model.net.grads_dict()
+        assert out["mask_loss"] == 0.0 and out["n_pos"].sum() == 0
+        assert all(np.abs(v).max() == 0 for k, v in g.items() if k.startswith("myolo_mask"))
+        assert abs(out["loss"] - float(r2["loss"])) < 1e-3 * max(1.0, abs(float(r2["loss"])))
+
+
 def test_adam_update_and_moving_stats_match_oracle():
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     model = MaskYOLO(mode="training", config=cfg)
