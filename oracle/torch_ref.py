@@ -196,7 +196,7 @@ class TorchRef(object):
         yl, terms = yolo_loss_t(_t(y_true, self.dtype), yolo_out, _t(true_boxes, self.dtype), cfg)
         ml = mask_bce_t(tmask.reshape((-1,) + tmask.shape[2:]), tcls.reshape(-1), pred)
         loss = yl * cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.) + ml * cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.)
-        out = dict(loss=float(loss), yolo_sum_loss=float(yl), mask_loss=float(ml),
+        out = dict(loss=float(loss.detach()), yolo_sum_loss=float(yl.detach()), mask_loss=float(ml.detach()),
                    yolo_output=yo_np, output_rois=rois, target_class_ids=tcls,
                    myolo_mask=pred.detach().permute(0, 2, 3, 1).numpy(),
                    feature_map=Fm.detach().permute(0, 2, 3, 1).numpy())

@@ -1,0 +1,161 @@
+"""CPU tests of the host logic and of the C-ABI boundary (no GPU compute):
+config finalisation, Shapes generator, BatchGenerator vs the oracle's literal loop restatement,
+post-processing helpers, and that libmyolo_hip.so loads and exports every symbol include/myolo_hip.h declares."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import np_ops as O
+from myolo import myolo_utils as mutils
+from myolo.config import Config, ShapesConfig, ShapesHeadConfig, RiceConfig, make_config
+from myolo.shapes import ShapesDataset, make_shapes_samples
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- config (config.py:15-257)
+def test_config_defaults_match_reference():
+    c = Config()
+    assert (c.N_BOX, c.GRID_H, c.GRID_W, c.TRUE_BOX_BUFFER, c.MAX_GT_INSTANCES) == (5, 7, 7, 10, 10)
+    assert (c.OBJECT_SCALE, c.NO_OBJECT_SCALE, c.COORD_SCALE, c.CLASS_SCALE, c.WARM_UP_BATCHES) == (5.0, 1.0, 1.0, 1.0, 0)
+    assert c.ANCHORS == [1.27, 1.31, 1.95, 1.85, 2.40, 2.72, 3.20, 3.32, 5.06, 5.05]
+    assert (c.MASK_POOL_SIZE, c.MASK_SHAPE, c.TOP_FEATURE_MAP_DEPTH, c.LEARNING_RATE) == (14, [28, 28], 256, 0.001)
+    assert c.TRAIN_ROIS_PER_IMAGE == 245 and c.IMAGE_SHAPE == [224, 224, 3]
+
+
+def test_finalize_propagates_overrides():
+    c = ShapesConfig()
+    assert c.N_BOX == 3 and c.TRAIN_ROIS_PER_IMAGE == 147 and len(c.CLASS_WEIGHTS) == 4
+    c2 = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5)
+    assert (c2.GRID_H, c2.GRID_W, c2.TRAIN_ROIS_PER_IMAGE, c2.SECOND_PHASE_YOLO_DEPTH) == (4, 4, 48, 256)
+    assert ShapesHeadConfig().TRAIN_ROIS_PER_IMAGE == 245
+    r = RiceConfig()
+    assert r.GRID_W == 13 and r.TRAIN_ROIS_PER_IMAGE == 845
+    with pytest.raises(Exception):
+        make_config(ShapesConfig, IMAGE_SHAPE=[100, 100, 3])            # model.py:792-794
+    with pytest.raises(AssertionError):
+        make_config(ShapesConfig, N_BOX=5)                              # 3 anchors but N_BOX 5
+
+
+# ---------------------------------------------------------------- Shapes dataset (dataset_shapes.py:53-180)
+def test_shapes_dataset_is_deterministic_and_well_formed():
+    cfg = ShapesConfig()
+    a = make_shapes_samples(3, cfg, start_index=10)
+    b = make_shapes_samples(3, cfg, start_index=10)
+    for (i1, c1, b1, m1), (i2, c2, b2, m2) in zip(a, b):
+        assert np.array_equal(i1, i2) and np.array_equal(b1, b2) and np.array_equal(m1, m2)
+        assert i1.dtype == np.uint8 and i1.shape == (224, 224, 3) and m1.dtype == bool
+        assert 1 <= len(c1) <= 4 and set(c1) <= {1, 2, 3}
+        assert np.array_equal(b1, O.extract_bboxes(m1)) and np.array_equal(b1, mutils.extract_bboxes(m1))
+        assert m1.sum(axis=2).max() <= 1                                 # occlusion handling: masks are disjoint
+    assert not np.array_equal(a[0][0], make_shapes_samples(1, cfg, start_index=11)[0][0])
+
+
+def test_draw_shape_primitives():
+    img = np.zeros((40, 40, 1), np.uint8)
+    sq = ShapesDataset.draw_shape(img, "square", (20, 20, 5), 1)[..., 0]
+    assert sq.sum() == 11 * 11 and sq[15, 15] == 1 and sq[14, 15] == 0
+    ci = ShapesDataset.draw_shape(img, "circle", (20, 20, 5), 1)[..., 0]
+    assert ci[20, 25] == 1 and ci[24, 24] == 0 and ci.sum() == 81
+    tr = ShapesDataset.draw_shape(img, "triangle", (20, 20, 6), 1)[..., 0]
+    assert tr[14, 20] == 1 and tr[26, 14] == 1 and tr[14, 14] == 0
+
+
+# ---------------------------------------------------------------- BatchGenerator (myolo_utils.py:689-860)
+@pytest.mark.parametrize("base,size", [(ShapesConfig, 224), (ShapesHeadConfig, 224), (ShapesConfig, 128)])
+def test_batch_generator_matches_oracle_encoding(base, size):
+    cfg = make_config(base, IMAGE_SHAPE=[size, size, 3], BATCH_SIZE=6)
+    samples = make_shapes_samples(6, cfg, start_index=3)
+    inputs, outputs = mutils.BatchGenerator(samples, cfg, "training", shuffle=False, norm=True)[0]
+    ref = O.encode_batch(samples, cfg)
+    assert outputs == [] and len(inputs) == 6
+    for got, exp in zip(inputs, ref):
+        assert got.dtype == exp.dtype and np.array_equal(got, exp)
+    images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = inputs
+    assert images.dtype == np.float32 and images.max() <= 1.0
+    assert true_boxes.shape == (6, 1, 1, 1, cfg.TRUE_BOX_BUFFER, 4)
+    assert y_true[..., 4].sum() == sum(len(s[1]) for s in samples)      # every box centre lies inside the grid
+    assert np.all(y_true[..., 5:].sum(-1) == y_true[..., 4])            # one-hot class where an object is
+    yolo_inputs, _ = mutils.BatchGenerator(samples, cfg, "yolo", shuffle=False, norm=True)[0]
+    assert len(yolo_inputs) == 3
+
+
+def test_batch_generator_last_partial_batch_and_len():
+    cfg = make_config(ShapesConfig, BATCH_SIZE=4)
+    gen = mutils.BatchGenerator(make_shapes_samples(6, cfg), cfg, "training", shuffle=False, norm=True)
+    assert len(gen) == 2 and gen.size() == 6 and gen.num_classes() == 4
+    assert gen[1][0][0].shape[0] == 4                                    # reference re-uses the tail (myolo_utils.py:731-733)
+
+
+# ---------------------------------------------------------------- post-processing ("next" rows)
+def test_bbox_iou_and_nmb():
+    a, b = mutils.BoundBox(0, 0, 2, 2), mutils.BoundBox(1, 1, 3, 3)
+    assert abs(mutils.bbox_iou(a, b) - 1 / 7) < 1e-12 and mutils.bbox_iou(a, mutils.BoundBox(5, 5, 6, 6)) == 0
+    boxes = np.array([[0, 0, .5, .5], [0.01, 0, .5, .5], [.6, .6, .9, .9]])
+    keep = mutils.NMB(boxes, np.array([1, 1, 1]), np.array([7, 8, 9]), [224, 224, 3], nms_threshold=0.7)
+    assert list(keep) == [7, 9]
+    keep = mutils.NMB(boxes, np.array([1, 2, 1]), np.array([7, 8, 9]), [224, 224, 3], nms_threshold=0.7)
+    assert list(keep) == [7, 8, 9]                                       # different classes are not suppressed
+
+
+def test_decode_one_yolo_output_and_unmold_mask():
+    G, A, C = 7, 3, 4
+    net = np.full((G, G, A, 5 + C), -10.0)
+    net[3, 2, 1, :4] = 0
+    net[3, 2, 1, 4] = 10
+    net[3, 2, 1, 5 + 2] = 10
+    boxes = mutils.decode_one_yolo_output(net, ShapesConfig.ANCHORS, C, obj_threshold=0.35, nms_threshold=0.3)
+    assert len(boxes) == 1 and boxes[0].get_label() == 2
+    assert abs((boxes[0].xmin + boxes[0].xmax) / 2 - 2.5 / 7) < 1e-9
+    m = mutils.unmold_mask(np.ones((28, 28)), [0.25, 0.5, 0.75, 1.0], [224, 224, 3])
+    assert m.shape == (224, 224) and m[112:224, 56:168].all() and m.sum() == 112 * 112
+
+
+# ---------------------------------------------------------------- C-ABI boundary
+def _header_functions():
+    txt = open(os.path.join(ROOT, "include", "myolo_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return re.findall(r"\b(?:int|size_t|const char\*)\s+(myolo_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S)
+
+
+def test_library_exports_every_declared_symbol():
+    from myolo import _ext
+    assert os.path.exists(_ext.LIB_PATH), "run `python __graft_entry__.py` (the driver's build()) first"
+    lib = _ext.load()
+    decl = _header_functions()
+    names = [n for n, _ in decl]
+    assert len(names) >= 35 and len(set(names)) == len(names)
+    for n in names:
+        assert hasattr(lib, n), "symbol %s declared in include/myolo_hip.h is not exported" % n
+    assert set(_ext.exported_symbols()) == set(names), set(_ext.exported_symbols()) ^ set(names)
+    assert lib.myolo_version() >= 100
+    assert isinstance(lib.myolo_last_error_string(), bytes)
+
+
+def test_ctypes_signatures_match_header_arity():
+    from myolo import _ext
+    for name, args in _header_functions():
+        if name in _ext.SIGS:
+            nargs = 0 if args.strip() in ("", "void") else args.count(",") + 1
+            assert nargs == len(_ext.SIGS[name]), (name, nargs, len(_ext.SIGS[name]))
+
+
+def test_workspace_query_and_error_path_without_gpu():
+    from myolo import _ext
+    lib = _ext.load()
+    assert _ext.workspace_bytes(921984, 256, 256) > 9 * 256 * 256 * 4
+    rc = lib.myolo_fill(None, ctypes.c_float(0.0), 0, None)             # argument check happens before any launch
+    assert rc == -1 and b"fill" in lib.myolo_last_error_string()
+
+
+def test_product_never_imports_the_oracle():
+    """the oracle is test infrastructure: nothing under mask-yolo_amd/ may import it."""
+    pkg = os.path.join(ROOT, "mask-yolo_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
