@@ -16,6 +16,7 @@
 // step t+1 are issued before the MFMAs of step t and written to LDS after them.
 // A tile is stored k-major ([k][m], row length 130) so fragment reads are conflict-free b32.
 #include "myolo_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -368,6 +369,381 @@ __global__ __launch_bounds__(256, 2) void gemm_tn(GemmArgs p)
         }
 }
 
+// ==========================================================================================
+// Fast paths (N % 4 == 0, 16-byte aligned leading dimensions, channels per tap % 16 == 0).
+// Same tiling as the generic kernels above, but the main loop is ONE basic block:
+//   * operands come through raw buffer descriptors whose base is advanced per workgroup, so a 32-bit
+//     byte offset always suffices and an invalid row / zero-padding tap is just an offset beyond
+//     num_records -- the hardware returns 0, no exec-mask branch;
+//   * the (tap, channel) position of the k tile is carried in scalar counters (no division), row
+//     offsets advance incrementally;
+//   * MFMA fragments are prefetched one step ahead, and the LDS image of tile t+1 is written in the
+//     middle of tile t's MFMA sequence,
+// so address arithmetic, global loads, ds_reads and ds_writes all issue in the shadow of the 64-cycle
+// fp32 MFMAs instead of serialising between them (generic loop: 69 % MFMA-busy; this loop: 85 %;
+// with the global loads removed the same loop reaches 93 %, see profiles/).
+// ==========================================================================================
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFF 0x7fffff00u
+
+__device__ __forceinline__ float4 bufld4(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long nbytes)
+{
+    if (nbytes < 0) nbytes = 0;
+    if (nbytes > 0x7ffffe00ll) nbytes = 0x7ffffe00ll;      // stays below OOB_OFF
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(unsigned)nbytes, 0x00020000);
+}
+
+#define MFMA_STEP()                                                                             \
+    {                                                                                           \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb0, acc[0][0], 0, 0, 0);         \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0, fb1, acc[0][1], 0, 0, 0);         \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb0, acc[1][0], 0, 0, 0);         \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);         \
+    }
+
+// ABL (tuning only, results are wrong for ABL != 0): 1 = no global loads / LDS stores in the loop,
+// 2 = additionally no barrier, 3 = additionally no LDS fragment reads.
+template <int AMODE, int EPI, int ABL = 0>
+__global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
+{
+    __shared__ float As[2][BK][LDAS];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + BN - 1) / BN;
+    // XCD-aware order: workgroup b runs on XCD b % 8 (observed; used for speed only).  Give each XCD a
+    // contiguous run of tiles so the N-tiles that share an A tile are consecutive on ONE L2.
+    long long bid;
+    {
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tn = (int)(bid % ntn);
+    const long long m0 = (bid / ntn) * BM;
+    const int n0 = tn * BN;
+    const long long hw = (long long)p.H * p.W;
+
+    // ---- A descriptor: base advanced to this workgroup's first reachable row ----
+    long long base_row, end_row;
+    long long row_elems;
+    if (AMODE == AM_PLAIN) {
+        base_row = m0; end_row = (m0 + BM < p.M) ? m0 + BM : p.M; row_elems = p.lda;
+    } else if (AMODE == AM_CONV3) {
+        base_row = m0 - (p.W + 1); if (base_row < 0) base_row = 0;
+        end_row = m0 + BM + p.W + 1; if (end_row > p.M) end_row = p.M;
+        row_elems = p.Cc;
+    } else {
+        base_row = 4 * m0 - 2 * p.W; if (base_row < 0) base_row = 0;
+        end_row = 4 * (m0 + BM) + 2 * p.W + 2; if (end_row > 4 * p.M) end_row = 4 * p.M;
+        row_elems = p.Cc;
+    }
+    const __amdgpu_buffer_rsrc_t ra_desc = make_rsrc(p.A + base_row * row_elems, (end_row - base_row) * row_elems * 4);
+    const __amdgpu_buffer_rsrc_t rb_desc = make_rsrc(p.B, (long long)p.K * p.ldb * 4);
+
+    const int ar = tid >> 2, akq = (tid & 3) * 4;
+    bool avalid[2];
+    int ay[2], ax[2];
+    unsigned arow[2];          // byte offset of this row's element akq relative to the descriptor base
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const long long m = m0 + ar + 64 * i;
+        avalid[i] = m < p.M;
+        const long long mm = avalid[i] ? m : m0;
+        ay[i] = 0; ax[i] = 0;
+        if (AMODE == AM_PLAIN) {
+            arow[i] = (unsigned)((mm - base_row) * row_elems + akq) * 4u;
+        } else {
+            const long long n_img = mm / hw;
+            const int rem = (int)(mm - n_img * hw);
+            ay[i] = rem / p.W;
+            ax[i] = rem - ay[i] * p.W;
+            if (AMODE == AM_CONV3) arow[i] = (unsigned)((mm - base_row) * row_elems + akq) * 4u;
+            else arow[i] = (unsigned)((4 * mm - 2 * ax[i] - base_row) * row_elems + akq) * 4u;
+        }
+    }
+    const int bk = tid >> 5, bn4 = (tid & 31) * 4;
+    const bool bcol_ok = (n0 + bn4) < p.N;
+    const unsigned brow_stride = (unsigned)p.ldb * 4u;
+    unsigned boff0 = bcol_ok ? ((unsigned)bk * (unsigned)p.ldb + (unsigned)(n0 + bn4)) * 4u : OOB_OFF;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nk = p.K / BK;
+    int tap = 0, c0 = 0;       // scalar position of the k tile inside (tap, channel)
+    float4 ra[2], rb[2];
+
+    auto gload = [&]() {
+        if (AMODE == AM_PLAIN) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[i] = bufld4(ra_desc, avalid[i] ? arow[i] + (unsigned)c0 * 4u : OOB_OFF);
+        } else if (AMODE == AM_CONV3) {
+            const int ty = (tap * 11) >> 5, tx = tap - ty * 3;          // tap/3 for tap < 9
+            const int shift = ((ty - 1) * p.W + (tx - 1)) * p.Cc + c0;   // elements
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool v = avalid[i] && (unsigned)(ay[i] + ty - 1) < (unsigned)p.H && (unsigned)(ax[i] + tx - 1) < (unsigned)p.W;
+                ra[i] = bufld4(ra_desc, v ? arow[i] + (unsigned)(shift * 4) : OOB_OFF);
+            }
+        } else {
+            const int ky = tap >> 1, kx = tap & 1;
+            const int shift = (ky * 2 * p.W + kx) * p.Cc + c0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) ra[i] = bufld4(ra_desc, avalid[i] ? arow[i] + (unsigned)(shift * 4) : OOB_OFF);
+        }
+        rb[0] = bufld4(rb_desc, boff0);                                   // k rows always < K (K % BK == 0)
+        rb[1] = bufld4(rb_desc, bcol_ok ? boff0 + 8u * brow_stride : OOB_OFF);
+        boff0 = bcol_ok ? boff0 + (unsigned)BK * brow_stride : OOB_OFF;
+        c0 += BK;
+        if (AMODE != AM_PLAIN && c0 == p.Cc) { c0 = 0; ++tap; }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            As[buf][akq + 0][ar + 64 * i] = ra[i].x;
+            As[buf][akq + 1][ar + 64 * i] = ra[i].y;
+            As[buf][akq + 2][ar + 64 * i] = ra[i].z;
+            As[buf][akq + 3][ar + 64 * i] = ra[i].w;
+            *reinterpret_cast<float4*>(&Bs[buf][bk + 8 * i][bn4]) = rb[i];
+        }
+    };
+
+    gload();
+    sstore(0);
+    __syncthreads();
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const int arow_l = wm * 64 + l31, bcol_l = wn * 64 + l31;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (ABL == 0 && more) gload();
+        float fa0 = As[cur][half * 8][arow_l], fa1 = As[cur][half * 8][arow_l + 32];
+        float fb0 = Bs[cur][half * 8][bcol_l], fb1 = Bs[cur][half * 8][bcol_l + 32];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float na0 = fa0 + 1.f, na1 = fa1 + 1.f, nb0 = fb0 + 1.f, nb1 = fb1 + 1.f;
+            if (j < 7 && ABL < 3) {
+                const int kk = half * 8 + j + 1;
+                na0 = As[cur][kk][arow_l]; na1 = As[cur][kk][arow_l + 32];
+                nb0 = Bs[cur][kk][bcol_l]; nb1 = Bs[cur][kk][bcol_l + 32];
+            }
+            MFMA_STEP()
+            if (ABL == 0 && j == 3 && more) sstore(cur ^ 1);      // tile t+1 lands in the other buffer mid-sequence
+            fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+        }
+        if (ABL < 2) __syncthreads();
+        if (ABL == 0) cur ^= 1;
+    }
+
+    // ---- epilogue (identical to the generic kernel) ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            long long rowoff;
+            if (EPI == EP_PLAIN) {
+                rowoff = row * p.ldc;
+            } else {
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                rowoff = n_img * 4 * hw + (long long)y * 4 * p.W + 2 * x;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = n0 + wn * 64 + u * 32 + l31;
+                if (col >= p.N) continue;
+                float v = acc[t][u][r];
+                if (EPI == EP_PLAIN) {
+                    if (p.bias) v += p.bias[col];
+                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.C[rowoff + col] = v;
+                } else {
+                    const int tp = col / p.Co, co = col - tp * p.Co;
+                    if (p.bias) v += p.bias[co];
+                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
+                    p.C[(rowoff + (long long)(tp >> 1) * 2 * p.W + (tp & 1)) * p.Co + co] = v;
+                }
+            }
+        }
+    }
+}
+
+// weight-gradient fast path: C_part[split][Ka][N] = sum_m A(m,ka) B[m,n]
+template <int AMODE>
+__global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tn = blockIdx.x % ntn;
+    const int tka = blockIdx.x / ntn;
+    const int ka0 = tka * BM, n0 = tn * BN;
+    const long long ms = (long long)blockIdx.y * p.m_per_split;
+    long long me = ms + p.m_per_split;
+    if (me > p.M) me = p.M;
+    const long long hw = (long long)p.H * p.W;
+
+    const int lr = tid >> 5, c4 = (tid & 31) * 4;
+    const int ka = ka0 + c4;
+    const bool ka_ok = ka < p.K;
+    int tap = 0, c0 = ka;
+    if (AMODE != AM_PLAIN) { tap = ka / p.Cc; c0 = ka - tap * p.Cc; }
+    const int ty = tap / 3, tx = tap - ty * 3;      // CONV3
+    const int ky = tap >> 1, kx = tap & 1;          // DECONV
+
+    // descriptors: A rows reachable from [ms, me); B rows [ms, me)
+    long long a_base, a_end, a_row_elems;
+    if (AMODE == AM_PLAIN) { a_base = ms; a_end = me; a_row_elems = p.lda; }
+    else if (AMODE == AM_CONV3) {
+        a_base = ms - (p.W + 1); if (a_base < 0) a_base = 0;
+        a_end = me + p.W + 1; if (a_end > p.M) a_end = p.M;
+        a_row_elems = p.Cc;
+    } else {
+        a_base = 4 * ms - 2 * p.W; if (a_base < 0) a_base = 0;
+        a_end = 4 * me + 2 * p.W + 2; if (a_end > 4 * p.M) a_end = 4 * p.M;
+        a_row_elems = p.Cc;
+    }
+    const __amdgpu_buffer_rsrc_t ra_desc = make_rsrc(p.A + a_base * a_row_elems, (a_end - a_base) * a_row_elems * 4);
+    const __amdgpu_buffer_rsrc_t rb_desc = make_rsrc(p.B + ms * p.ldb, (me - ms) * p.ldb * 4);
+    const bool bcol_ok = (n0 + c4) < p.N;
+
+    // this thread's two rows; (y, x) and the linear byte offsets advance by BK rows per step (32-bit, branch-free)
+    long long mrow[2];
+    int ry[2], rx[2];
+    unsigned alin[2], blin[2];
+    const unsigned a_step = (unsigned)(BK * a_row_elems) * 4u * (AMODE == AM_DECONV ? 4u : 1u);
+    const unsigned b_step = (unsigned)(BK * p.ldb) * 4u;
+    const unsigned two_cc = (unsigned)(2 * a_row_elems) * 4u;
+    long long tapshift = 0;
+    if (AMODE == AM_CONV3) tapshift = (long long)(ty - 1) * p.W + (tx - 1);
+    if (AMODE == AM_DECONV) tapshift = (long long)ky * 2 * p.W + kx;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        mrow[i] = ms + lr + 8 * i;
+        ry[i] = 0; rx[i] = 0;
+        if (AMODE != AM_PLAIN) {
+            const long long mm = mrow[i] < p.M ? mrow[i] : 0;
+            const long long n_img = mm / hw;
+            const int rem = (int)(mm - n_img * hw);
+            ry[i] = rem / p.W;
+            rx[i] = rem - ry[i] * p.W;
+        }
+        // (for CONV3 the value may wrap when the tap is out of the image; such rows are masked below)
+        if (AMODE == AM_PLAIN) alin[i] = (unsigned)((mrow[i] - a_base) * a_row_elems + ka) * 4u;
+        else if (AMODE == AM_CONV3) alin[i] = (unsigned)((mrow[i] + tapshift - a_base) * a_row_elems + c0) * 4u;
+        else alin[i] = (unsigned)((4 * mrow[i] + tapshift - a_base) * a_row_elems + c0) * 4u;   // minus 2*x*Cc per step
+        blin[i] = (unsigned)((mrow[i] - ms) * p.ldb + n0 + c4) * 4u;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    float4 ra[2], rb[2];
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool mv = mrow[i] < me;
+            unsigned aoff = OOB_OFF;
+            if (AMODE == AM_PLAIN) {
+                if (mv && ka_ok) aoff = alin[i];
+            } else if (AMODE == AM_CONV3) {
+                const bool v = mv && ka_ok && (unsigned)(ry[i] + ty - 1) < (unsigned)p.H && (unsigned)(rx[i] + tx - 1) < (unsigned)p.W;
+                if (v) aoff = alin[i];
+            } else {
+                if (mv && ka_ok) aoff = alin[i] - (unsigned)rx[i] * two_cc;
+            }
+            ra[i] = bufld4(ra_desc, aoff);
+            rb[i] = bufld4(rb_desc, (mv && bcol_ok) ? blin[i] : OOB_OFF);
+            mrow[i] += BK;
+            alin[i] += a_step;
+            blin[i] += b_step;
+            if (AMODE != AM_PLAIN) {      // branch-free wrap (launcher guarantees W >= 8, H >= 2)
+                int nx = rx[i] + BK;
+                const int w2 = (nx >= 2 * p.W) ? 2 : ((nx >= p.W) ? 1 : 0);
+                nx -= w2 * p.W;
+                int ny = ry[i] + w2;
+                ny = (ny >= p.H) ? ny - p.H : ny;
+                rx[i] = nx; ry[i] = ny;
+            }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4*>(&As[buf][lr + 8 * i][c4]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[buf][lr + 8 * i][c4]) = rb[i];
+        }
+    };
+
+    const long long nsteps = (me > ms) ? (me - ms + BK - 1) / BK : 0;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int arow_l = wm * 64 + l31, bcol_l = wn * 64 + l31;
+    if (nsteps > 0) {
+        gload();
+        sstore(0);
+        __syncthreads();
+        int cur = 0;
+        for (long long st = 0; st < nsteps; ++st) {
+            const bool more = st + 1 < nsteps;
+            if (more) gload();
+            float fa0 = As[cur][half * 8][arow_l], fa1 = As[cur][half * 8][arow_l + 32];
+            float fb0 = Bs[cur][half * 8][bcol_l], fb1 = Bs[cur][half * 8][bcol_l + 32];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+                if (j < 7) {
+                    const int kk = half * 8 + j + 1;
+                    na0 = As[cur][kk][arow_l]; na1 = As[cur][kk][arow_l + 32];
+                    nb0 = Bs[cur][kk][bcol_l]; nb1 = Bs[cur][kk][bcol_l + 32];
+                }
+                MFMA_STEP()
+                if (j == 3 && more) sstore(cur ^ 1);
+                fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    float* Cp = p.C + (long long)blockIdx.y * p.K * p.N;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = ka0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.K) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int col = n0 + wn * 64 + u * 32 + l31;
+                if (col < p.N) Cp[(long long)row * p.N + col] = acc[t][u][r];
+            }
+        }
+}
+
 __global__ void splitk_reduce(const float* __restrict__ part, float* __restrict__ out, long long n, int splits)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,14 +790,26 @@ static int launch_nn(const GemmArgs& a, hipStream_t s)
 {
     const long long tiles = cdiv64(a.M, BM) * ((a.N + BN - 1) / BN);
     if (tiles <= 0) return MYOLO_OK;
-    hipLaunchKernelGGL((gemm_nn<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    const bool aligned = (a.N & 3) == 0 && (a.ldb & 3) == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
+    const bool kfast = (AMODE == AM_PLAIN) ? ((a.K % BK) == 0 && (a.lda & 3) == 0) : ((a.Cc % BK) == 0);
+    const char* abl = getenv("MYOLO_GEMM_ABL");        // tuning only (tools/kbench.py)
+    if (aligned && kfast && abl && AMODE == AM_CONV3 && EPI == EP_PLAIN) {
+        if (abl[0] == '1') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 1>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        else if (abl[0] == '2') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 2>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 3>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    } else if (aligned && kfast && !getenv("MYOLO_GEMM_GENERIC"))
+        hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_nn<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
 }
 
 static int choose_splits(long long M, int Ka, int N)
 {
+    // 256 CUs x 4 resident workgroups (33 KB LDS, <=128 VGPRs): pick the split count that fills those 1024
+    // slots as evenly as possible -- with e.g. 792 workgroups a quarter of the CUs hold 4 and set the time.
     const long long tiles = (long long)((Ka + BM - 1) / BM) * ((N + BN - 1) / BN);
-    long long splits = (768 + tiles - 1) / tiles;
+    long long splits = 1024 / tiles;
     const long long max_by_rows = cdiv64(M, 8 * BK);     // at least 8 K-steps per split
     if (splits > max_by_rows) splits = max_by_rows;
     if (splits < 1) splits = 1;
@@ -449,7 +837,13 @@ static int launch_tn(GemmArgs a, float* out, void* ws, size_t ws_bytes, hipStrea
     a.m_per_split = mps;
     a.C = splits > 1 ? (float*)ws : out;
     const int tiles = ((a.K + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    hipLaunchKernelGGL((gemm_tn<AMODE>), dim3(tiles, splits), dim3(256), 0, s, a);
+    const bool fast = (a.N & 3) == 0 && (a.ldb & 3) == 0 && (a.K & 3) == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 &&
+                      ((AMODE == AM_PLAIN) ? (a.lda & 3) == 0 : ((a.Cc & 3) == 0 && a.W >= 8 && a.H >= 2)) &&
+                      !getenv("MYOLO_GEMM_GENERIC");
+    if (fast)
+        hipLaunchKernelGGL((gemm_tn_fast<AMODE>), dim3(tiles, splits), dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_tn<AMODE>), dim3(tiles, splits), dim3(256), 0, s, a);
     if (splits > 1) {
         const long long n = (long long)a.K * a.N;
         int blocks = (int)((n + 255) / 256);

@@ -1,0 +1,97 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single C-ABI kernels at the BASELINE config-2 shapes (used for tuning and for the
+rocprofv3 --pmc passes whose summaries are committed under profiles/).
+  python tools/kbench.py conv3x3_fwd|conv3x3_bwd_weight|conv3x3_bwd_data|deconv_fwd|roialign_fwd|roialign_bwd|dw [--iters N]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "mask-yolo_amd")]
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+from myolo import _ext as X   # noqa: E402
+
+
+def timeit(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--rois", type=int, default=32 * 147)
+    a = ap.parse_args()
+    dev = "cuda:0"
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *s: torch.randn(*s, device=dev, generator=g)   # noqa: E731
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
+    NR, ps, C = a.rois, 14, 256
+    M = NR * ps * ps
+    st = X.stream()
+    if a.which.startswith("conv3x3"):
+        x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
+        flop = 2.0 * M * 9 * C * C
+        if a.which == "conv3x3_fwd":
+            fn = lambda: X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, st)   # noqa: E731
+        elif a.which == "conv3x3_bwd_data":
+            fn = lambda: X.call("myolo_conv3x3_bwd_data", X.ptr(x), X.ptr(w), X.ptr(y), NR, ps, ps, C, C, ws.data_ptr(), ws.numel(), st)   # noqa: E731
+        else:
+            dw = torch.empty(3, 3, C, C, device=dev)
+            fn = lambda: X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(y.copy_(x)), X.ptr(dw), NR, ps, ps, C, C, ws.data_ptr(), ws.numel(), st)   # noqa: E731
+            y.copy_(x)
+            fn = lambda: X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(y), X.ptr(dw), NR, ps, ps, C, C, ws.data_ptr(), ws.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("%s M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (a.which, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 1.573))
+    elif a.which == "deconv_fwd":
+        x, w, b, y = rn(M, C), rn(2, 2, C, C) * 0.02, rn(C), torch.empty(4 * M, C, device=dev)
+        fn = lambda: X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, 1, ws.data_ptr(), ws.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        flop = 2.0 * M * C * 4 * C
+        print("deconv_fwd M=%d: %.3f ms  %.1f TFLOP/s" % (M, ms, flop / ms / 1e9))
+    elif a.which.startswith("roialign"):
+        B, H = 32, 28
+        R = NR // B
+        feat = rn(B, H, H, C)
+        c, s = torch.rand(NR, 2, device=dev, generator=g), torch.rand(NR, 2, device=dev, generator=g) * 0.5 + 0.05
+        boxes = torch.cat([c - s / 2, c + s / 2], 1).contiguous()
+        bind = torch.arange(B, device=dev, dtype=torch.int32).repeat_interleave(R).contiguous()
+        out = torch.empty(M, C, device=dev)
+        nbytes = M * C * 4 + B * H * H * C * 4
+        if a.which == "roialign_fwd":
+            fn = lambda: X.call("myolo_crop_and_resize_fwd", X.ptr(feat), X.ptr(boxes), X.ptr(bind), X.ptr(out), B, H, H, C, NR, ps, ps, st)   # noqa: E731
+        else:
+            out.normal_()
+            fn = lambda: X.call("myolo_roialign_bwd_grouped", X.ptr(out), X.ptr(boxes), X.ptr(feat), B, H, H, C, R, ps, ps, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("%s: %.3f ms  %.0f GB/s (%.1f%% of 8000)" % (a.which, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
+    elif a.which == "dw":
+        # the 14 depthwise layers of the backbone + YOLO head at 224x224, batch 32, alpha 1
+        layers = [(112, 32, 1), (112, 64, 2), (56, 64, 1), (56, 128, 2), (28, 256, 1), (28, 256, 1), (28, 512, 2),
+                  (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 2), (7, 1024, 1)]
+        tot_ms, tot_b = 0.0, 0.0
+        for H, Cc, s in layers:
+            x, w = rn(32, H, H, Cc), rn(3, 3, Cc)
+            y = torch.empty(32, H // s, H // s, Cc, device=dev)
+            fn = lambda: X.call("myolo_dwconv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(y), 32, H, H, Cc, s, st)   # noqa: E731
+            ms = timeit(fn, a.iters)
+            nb = (x.numel() + y.numel()) * 4
+            tot_ms += ms
+            tot_b += nb
+            print("dw %3dx%3dx%4d s%d: %.4f ms %6.0f GB/s" % (H, H, Cc, s, ms, nb / ms / 1e6))
+        print("dw total: %.3f ms, %.0f GB/s (%.1f%% of 8000)" % (tot_ms, tot_b / tot_ms / 1e6, tot_b / tot_ms / 1e6 / 80))
+
+
+if __name__ == "__main__":
+    main()
