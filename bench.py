@@ -172,7 +172,7 @@ def main():
                                    "(fwd+bwd+Adam%s)" % (args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
                                                         "+RCCL all-reduce" if world > 1 else ""),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
-            "roofline": {"kernel": "gemm_nn<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M,
+            "roofline": {"kernel": "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M,
                          "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": achieved / 157.3, "traffic": None, "launches_timed": conv_n, "avg_launch_ms": conv_ms,
                          "secondary": {"kernel": "crop_fwd_kernel (ROIAlign fwd)", "bound": "hbm",
