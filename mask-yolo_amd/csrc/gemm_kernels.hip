@@ -33,6 +33,8 @@ struct GemmArgs {
     const float* B;
     float* C;
     const float* bias;
+    const float* scale;   // optional per-column affine applied after the bias (folded frozen BatchNorm)
+    const float* shift;
     long long M;      // rows of the pixel space
     int N;            // output columns
     int K;            // NN: reduction length;  TN: number of output rows (Ka)
@@ -218,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn(GemmArgs p)
                 float v = acc[t][u][r];
                 if (EPI == EP_PLAIN) {
                     if (p.bias) v += p.bias[col];
+                    if (p.scale) v = fmaf(v, p.scale[col], p.shift[col]);
                     if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
                     p.C[rowoff + col] = v;
                 } else {
@@ -549,7 +552,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         if (ABL == 0) cur ^= 1;
     }
 
-    // ---- epilogue (identical to the generic kernel) ----
+    // ---- epilogue: per-column parameters are loaded once, then 64 row-contiguous 128-byte stores per wave ----
+    float cb[2], cs[2], ct[2];
+    int ccol[2], ctap[2];
+    bool cok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = n0 + wn * 64 + u * 32 + l31;
+        cok[u] = col < p.N;
+        const int colc = cok[u] ? col : 0;
+        ctap[u] = 0;
+        ccol[u] = colc;
+        if (EPI == EP_DECONV) { ctap[u] = colc / p.Co; ccol[u] = colc - ctap[u] * p.Co; }
+        cb[u] = p.bias ? p.bias[ccol[u]] : 0.f;
+        cs[u] = p.scale ? p.scale[colc] : 1.f;
+        ct[u] = p.scale ? p.shift[colc] : 0.f;
+    }
+    const bool relu = p.act == MYOLO_ACT_RELU;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -567,19 +586,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
             }
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int col = n0 + wn * 64 + u * 32 + l31;
-                if (col >= p.N) continue;
-                float v = acc[t][u][r];
-                if (EPI == EP_PLAIN) {
-                    if (p.bias) v += p.bias[col];
-                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
-                    p.C[rowoff + col] = v;
-                } else {
-                    const int tp = col / p.Co, co = col - tp * p.Co;
-                    if (p.bias) v += p.bias[co];
-                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
-                    p.C[(rowoff + (long long)(tp >> 1) * 2 * p.W + (tp & 1)) * p.Co + co] = v;
-                }
+                if (!cok[u]) continue;
+                float v = fmaf(acc[t][u][r] + cb[u], cs[u], ct[u]);
+                if (relu) v = fmaxf(v, 0.f);
+                if (EPI == EP_PLAIN) p.C[rowoff + ccol[u]] = v;
+                else p.C[(rowoff + (long long)(ctap[u] >> 1) * 2 * p.W + (ctap[u] & 1)) * p.Co + ccol[u]] = v;
             }
         }
     }
@@ -744,14 +755,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
         }
 }
 
-__global__ void splitk_reduce(const float* __restrict__ part, float* __restrict__ out, long long n, int splits)
+// out = sum over splits of part[split]; n4 = n/4 float4 elements.  Loads of 4 splits are issued together.
+__global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ part, float* __restrict__ out, long long n, int splits)
 {
+    const long long n4 = (n & 3) ? 0 : (n >> 2);      // vector path only when every split slab stays 16-byte aligned
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += part[(long long)k * n + i];
-        out[i] = s;
+    const float4* p4 = reinterpret_cast<const float4*>(part);
+    for (; i < n4; i += stride) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (; k + 4 <= splits; k += 4) {
+            const float4 a = p4[(long long)(k + 0) * n4 + i], b = p4[(long long)(k + 1) * n4 + i];
+            const float4 c = p4[(long long)(k + 2) * n4 + i], d = p4[(long long)(k + 3) * n4 + i];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+            s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+            s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+        }
+        for (; k < splits; ++k) {
+            const float4 a = p4[(long long)k * n4 + i];
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        reinterpret_cast<float4*>(out)[i] = s;
+    }
+    // tail (n % 4 elements)
+    for (long long j = (n4 << 2) + (long long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) {
+        float t = 0.f;
+        for (int k = 0; k < splits; ++k) t += part[(long long)k * n + j];
+        out[j] = t;
     }
 }
 
@@ -845,9 +877,10 @@ static int launch_tn(GemmArgs a, float* out, void* ws, size_t ws_bytes, hipStrea
     else
         hipLaunchKernelGGL((gemm_tn<AMODE>), dim3(tiles, splits), dim3(256), 0, s, a);
     if (splits > 1) {
-        const long long n = (long long)a.K * a.N;
-        int blocks = (int)((n + 255) / 256);
+        const long long n = (long long)a.K * a.N;      // n % 4 == 0 whenever N % 4 == 0; partial slabs are 16-byte aligned then
+        int blocks = (int)((n / 4 + 255) / 256);
         if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)ws, out, n, splits);
     }
     return MYOLO_OK;
@@ -911,6 +944,21 @@ int myolo_conv3x3_fwd(const float* x, const float* w, const float* bias, float* 
     MYOLO_REQUIRE(Cin % BK == 0, "conv3x3_fwd: Cin must be a multiple of %d (got %d)", BK, Cin);
     GemmArgs a = {};
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin;
+    a.ldb = Cout; a.ldc = Cout; a.H = H; a.W = W; a.Cc = Cin;
+    launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3_affine_act_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
+                                 float* y, int N, int H, int W, int Cin, int Cout, int act, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && scale && shift && N > 0 && H > 0 && W > 0, "conv3x3_affine_act_fwd: bad arguments");
+    MYOLO_REQUIRE(Cin % BK == 0, "conv3x3_affine_act_fwd: Cin must be a multiple of %d (got %d)", BK, Cin);
+    MYOLO_REQUIRE(act == MYOLO_ACT_NONE || act == MYOLO_ACT_RELU, "conv3x3_affine_act_fwd: act must be NONE or RELU");
+    GemmArgs a = {};
+    a.A = x; a.B = w; a.C = y; a.bias = bias; a.scale = scale; a.shift = shift; a.act = act;
+    a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin;
     a.ldb = Cout; a.ldc = Cout; a.H = H; a.W = W; a.Cc = Cin;
     launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream);
     MYOLO_CHECK_LAUNCH();

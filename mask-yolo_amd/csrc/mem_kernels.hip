@@ -67,10 +67,10 @@ static ColGeom col_geom(long long M, int C)
     g.cl = cl;
     g.pl = 256 / cl;
     g.cgroups = (q + cl - 1) / cl;
-    long long want = 768 / g.cgroups;                 // target ~768 blocks in total (3 per CU)
+    long long want = 1024 / g.cgroups;                // target ~1024 blocks in total (4 per CU)
     if (want < 1) want = 1;
     long long rpb = cdiv64(M, want);
-    const long long min_rows = (long long)g.pl * 32;  // at least 32 rows per thread
+    const long long min_rows = (long long)g.pl * 4;   // at least 4 rows per thread (small layers: spread wide)
     if (rpb < min_rows) rpb = min_rows;
     g.rows_per_block = rpb;
     g.rblocks = (int)cdiv64(M, rpb);
@@ -674,17 +674,35 @@ __global__ __launch_bounds__(256) void crop_bwd_grouped_kernel(const float* __re
         const int y = (int)(t % H);
         const int b = (int)(t / H);
         float4 acc = f4zero();
+        const float fy = (float)y, fx = (float)x;
         for (int r = 0; r < R; ++r) {
             const long long bi = (long long)b * R + r;
             const float4 bx = ld4g(boxes + bi * 4);          // y1,x1,y2,x2
-            for (int py = 0; py < ch; ++py) {
+            // sample k sits at c0 + k*s (same float expressions as the forward kernel); only samples within
+            // one pixel of (y, x) can touch it.  Conservative index window first, exact test inside.
+            const float sy = (ch > 1) ? (bx.z - bx.x) * (float)(H - 1) / (float)(ch - 1) : 0.f;
+            const float sx = (cw > 1) ? (bx.w - bx.y) * (float)(W - 1) / (float)(cw - 1) : 0.f;
+            const float y0 = (ch > 1) ? bx.x * (float)(H - 1) : 0.5f * (bx.x + bx.z) * (float)(H - 1);
+            const float x0 = (cw > 1) ? bx.y * (float)(W - 1) : 0.5f * (bx.y + bx.w) * (float)(W - 1);
+            int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
+            if (fabsf(sy) > 1e-6f) {
+                const float a = (fy - 1.f - y0) / sy, c = (fy + 1.f - y0) / sy;
+                pya = max(0, (int)floorf(fminf(a, c)) - 1);
+                pyb = min(ch - 1, (int)ceilf(fmaxf(a, c)) + 1);
+            } else if (fabsf(y0 - fy) > 1.5f) continue;
+            if (fabsf(sx) > 1e-6f) {
+                const float a = (fx - 1.f - x0) / sx, c = (fx + 1.f - x0) / sx;
+                pxa = max(0, (int)floorf(fminf(a, c)) - 1);
+                pxb = min(cw - 1, (int)ceilf(fmaxf(a, c)) + 1);
+            } else if (fabsf(x0 - fx) > 1.5f) continue;
+            for (int py = pya; py <= pyb; ++py) {
                 float iny;
                 if (!crop_coord(bx.x, bx.z, H, ch, py, iny)) continue;
                 const int ty = (int)floorf(iny), by = (int)ceilf(iny);
                 if (ty != y && by != y) continue;
                 const float ly = iny - (float)ty;
                 const float wyv = (ty == y ? (1.f - ly) : 0.f) + (by == y ? ly : 0.f);
-                for (int px = 0; px < cw; ++px) {
+                for (int px = pxa; px <= pxb; ++px) {
                     float inx;
                     if (!crop_coord(bx.y, bx.w, W, cw, px, inx)) continue;
                     const int lx = (int)floorf(inx), rx = (int)ceilf(inx);

@@ -373,15 +373,28 @@ class Net(object):
         self.tape["roi"] = (boxes, bind, fshape, NR)
         cin = cf
         convs = []
+        fuse = self.sparse_mask_bwd or not train     # frozen BN + ReLU folded into the conv epilogue
         for i in range(1, 5):
-            cn = "myolo_mask_conv%d" % i
+            cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             y = self._new(NR * ps * ps, MASK_FILTERS)
-            self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
-                             X.ptr(self.p[cn + "/bias"]), X.ptr(y), NR, ps, ps, cin, MASK_FILTERS, X.stream())
             convs.append(x)
             # bn1 uses batch statistics in training (model.py:690 has no training= argument);
             # bn2-4 are called with training=False (model.py:696,702,708) -> moving statistics
-            x = self.bn_act_fwd("myolo_mask_bn%d" % i, y, ACT_RELU, train and i == 1)
+            batch_stats = train and i == 1
+            if fuse and not batch_stats:
+                buf = self.bnbuf[bn]
+                X.call("myolo_bn_frozen_coeffs", X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
+                       X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+                       X.ptr(buf[2]), X.ptr(buf[3]), MASK_FILTERS, X.stream())
+                self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_affine_act_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
+                                 X.ptr(self.p[cn + "/bias"]), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps, cin,
+                                 MASK_FILTERS, ACT_RELU, X.stream())
+                self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
+                x = y
+            else:
+                self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
+                                 X.ptr(self.p[cn + "/bias"]), X.ptr(y), NR, ps, ps, cin, MASK_FILTERS, X.stream())
+                x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
             cin = MASK_FILTERS
         d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
@@ -491,9 +504,16 @@ class Net(object):
                MASK_FILTERS, MASK_FILTERS, X.stream())
         for i in range(4, 1, -1):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
-            c_p = self._gather(self.tape[bn][0], idx_d, NP, q)
-            dy = self.bn_act_bwd(bn, da, y_override=c_p)
             xin = self._gather(convs[i - 1], idx_d, NP, q)
+            if self.tape[bn][0] is None:
+                # the fused forward never wrote the pre-BN tensor: recompute it for the positive ROIs with the
+                # same kernel (same k order per output element -> the same fp32 values)
+                c_p = self._new(NP * q, MASK_FILTERS)
+                X.call("myolo_conv3x3_fwd", X.ptr(xin), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(c_p),
+                       NP, ps, ps, MASK_FILTERS, MASK_FILTERS, X.stream())
+            else:
+                c_p = self._gather(self.tape[bn][0], idx_d, NP, q)
+            dy = self.bn_act_bwd(bn, da, y_override=c_p)
             X.call("myolo_conv3x3_bwd_weight", X.ptr(xin), X.ptr(dy), X.ptr(self.g[cn + "/kernel"]), NP, ps, ps, MASK_FILTERS,
                    MASK_FILTERS, *self._wsargs(), X.stream())
             self.colsum(dy, self.g[cn + "/bias"])

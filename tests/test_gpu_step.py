@@ -134,14 +134,17 @@ def test_train_step_head_config_nbox5():
     assert not bad, bad
 
 
-def test_mask_head_teacher_forced():
+@pytest.mark.parametrize("sparse", [False, True])
+def test_mask_head_teacher_forced(sparse):
     """Mask head forward + BCE + backward with the ORACLE's feature map and ROIs fed to the GPU
-    (no ROI jitter): every mask-head gradient and dF within 2e-3 (max-norm)."""
+    (no ROI jitter): every mask-head gradient and dF within 2e-3 (max-norm), for the dense backward and
+    for the default exact-sparsity backward (fused frozen-BN epilogue, positive ROIs only behind bn1)."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     from myolo import _ext as X
     model = MaskYOLO(mode="training", config=cfg)
     model.load_state_dict(P)
     net = model.net
+    net.sparse_mask_bwd = sparse
     net.tape = {}
     Fm = torch.as_tensor(ref["feature_map"], device=net.dev).contiguous()
     n, h, w, cf = Fm.shape
@@ -155,7 +158,11 @@ def test_mask_head_teacher_forced():
     mterms, dz = net._new(2), net._new(pred.shape[0], C)
     X.call("myolo_mask_bce", X.ptr(tmask), X.ptr(tcls), X.ptr(pred), 1.0, X.ptr(mterms), X.ptr(dz), B * R, 28, 28, C,
            net.ws.ptr, net.ws.size, X.stream())
-    dF = net.mask_head_bwd(dz)
+    if sparse:
+        net._start_npos_copy(torch.as_tensor(ref["n_pos"].astype(np.int32), device=net.dev))
+        dF = net.mask_head_bwd_sparse(dz, B, R)
+    else:
+        dF = net.mask_head_bwd(dz)
     grads = net.grads_dict()
     # oracle: same pieces
     T = ref["tape"]
