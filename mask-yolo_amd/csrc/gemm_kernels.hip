@@ -487,6 +487,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 
     const int nk = p.K / BK;
     int tap = 0, c0 = 0;       // scalar position of the k tile inside (tap, channel)
+    // CONV3 K order: 32-channel group outermost, then the 9 taps, then the two 16-channel halves, so the
+    // 18 k tiles that touch one 128-byte line of X run back to back (the 9 taps re-read the same pixels
+    // shifted by <= W+1 rows): the re-reads hit L2 instead of the fabric.  The sum over K is order-free.
+    const bool grouped = (AMODE == AM_CONV3) && (p.Cc % 32) == 0;
+    int grp = 0, hh = 0;
     float4 ra[2], rb[2];
 
     auto gload = [&]() {
@@ -507,11 +512,24 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[i] = bufld4(ra_desc, avalid[i] ? arow[i] + (unsigned)(shift * 4) : OOB_OFF);
         }
-        rb[0] = bufld4(rb_desc, boff0);                                   // k rows always < K (K % BK == 0)
-        rb[1] = bufld4(rb_desc, bcol_ok ? boff0 + 8u * brow_stride : OOB_OFF);
-        boff0 = bcol_ok ? boff0 + (unsigned)BK * brow_stride : OOB_OFF;
-        c0 += BK;
-        if (AMODE != AM_PLAIN && c0 == p.Cc) { c0 = 0; ++tap; }
+        if (AMODE == AM_CONV3) {      // B row of this k tile = tap*Cc + c0 (+bk)
+            const unsigned krow = (unsigned)(tap * p.Cc + c0 + bk);
+            const unsigned bo = bcol_ok ? (krow * (unsigned)p.ldb + (unsigned)(n0 + bn4)) * 4u : OOB_OFF;
+            rb[0] = bufld4(rb_desc, bo);
+            rb[1] = bufld4(rb_desc, bcol_ok ? bo + 8u * brow_stride : OOB_OFF);
+        } else {
+            rb[0] = bufld4(rb_desc, boff0);                               // k rows always < K (K % BK == 0)
+            rb[1] = bufld4(rb_desc, bcol_ok ? boff0 + 8u * brow_stride : OOB_OFF);
+            boff0 = bcol_ok ? boff0 + (unsigned)BK * brow_stride : OOB_OFF;
+        }
+        if (grouped) {
+            hh ^= 1;
+            if (hh == 0) { ++tap; if (tap == 9) { tap = 0; ++grp; } }
+            c0 = grp * 32 + hh * 16;
+        } else {
+            c0 += BK;
+            if (AMODE != AM_PLAIN && c0 == p.Cc) { c0 = 0; ++tap; }
+        }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
@@ -533,7 +551,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (ABL == 0 && more) gload();
+        if ((ABL == 0 || ABL == 4) && more) gload();
         float fa0 = As[cur][half * 8][arow_l], fa1 = As[cur][half * 8][arow_l + 32];
         float fb0 = Bs[cur][half * 8][bcol_l], fb1 = Bs[cur][half * 8][bcol_l + 32];
 #pragma unroll
@@ -545,11 +563,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
                 nb0 = Bs[cur][kk][bcol_l]; nb1 = Bs[cur][kk][bcol_l + 32];
             }
             MFMA_STEP()
-            if (ABL == 0 && j == 3 && more) sstore(cur ^ 1);      // tile t+1 lands in the other buffer mid-sequence
+            if ((ABL == 0 || ABL == 5) && j == 3 && more) sstore(cur ^ 1);   // tile t+1 lands in the other buffer mid-sequence
             fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
         }
         if (ABL < 2) __syncthreads();
         if (ABL == 0) cur ^= 1;
+        if (ABL == 4) { asm volatile("" :: "v"(ra[0].x), "v"(ra[1].x), "v"(rb[0].x), "v"(rb[1].x)); }
     }
 
     // ---- epilogue: per-column parameters are loaded once, then 64 row-contiguous 128-byte stores per wave ----
@@ -828,7 +847,9 @@ static int launch_nn(const GemmArgs& a, hipStream_t s)
     if (aligned && kfast && abl && AMODE == AM_CONV3 && EPI == EP_PLAIN) {
         if (abl[0] == '1') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 1>), dim3((unsigned)tiles), dim3(256), 0, s, a);
         else if (abl[0] == '2') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 2>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 3>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        else if (abl[0] == '3') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 3>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        else if (abl[0] == '4') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 5>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     } else if (aligned && kfast && !getenv("MYOLO_GEMM_GENERIC"))
         hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     else
