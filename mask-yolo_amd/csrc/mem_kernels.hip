@@ -118,21 +118,27 @@ __global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int 
     }
 }
 
-// sum partials over row blocks: tot[v*C + c] (double).  32 outputs x 8 block-lanes per workgroup.
+// sum partials over row blocks: tot[v*C + c] (double).  8 outputs x 32 block-lanes per workgroup.
 __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc)
 {
-    __shared__ double red[8][32];
-    const int ol = threadIdx.x & 31, bl = threadIdx.x >> 5;
-    const int i = blockIdx.x * 32 + ol;
-    double s = 0;
-    if (i < nvc)
-        for (int b = bl; b < nblk; b += 8) s += part[(long long)b * nvc + i];
-    red[bl][ol] = s;
+    __shared__ double red[32][9];
+    const int ol = threadIdx.x & 7, bl = threadIdx.x >> 3;
+    const int i = blockIdx.x * 8 + ol;
+    double s0 = 0, s1 = 0;
+    if (i < nvc) {
+        int b = bl;
+        for (; b + 32 < nblk; b += 64) {
+            s0 += part[(long long)b * nvc + i];
+            s1 += part[(long long)(b + 32) * nvc + i];
+        }
+        if (b < nblk) s0 += part[(long long)b * nvc + i];
+    }
+    red[bl][ol] = s0 + s1;
     __syncthreads();
     if (bl == 0 && i < nvc) {
         double t = 0;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][ol];
+        for (int k = 0; k < 32; ++k) t += red[k][ol];
         tot[i] = t;
     }
 }
@@ -143,7 +149,7 @@ static int run_colreduce(OP op, long long M, int C, double* part, double* tot, h
     ColGeom g = col_geom(M, C);
     hipLaunchKernelGGL((colreduce_kernel<OP>), dim3(g.rblocks, g.cgroups), dim3(256), 0, s, op, M, C, g, part);
     const int nvc = OP::NV * C;
-    hipLaunchKernelGGL(colreduce_finish, dim3((nvc + 31) / 32), dim3(256), 0, s, part, tot, g.rblocks, nvc);
+    hipLaunchKernelGGL(colreduce_finish, dim3((nvc + 7) / 8), dim3(256), 0, s, part, tot, g.rblocks, nvc);
     return 0;
 }
 
