@@ -28,6 +28,12 @@ extern "C" int myolo_version(void) { return 100; }
 
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+typedef float f32x4n __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4g_nt(float* p, float4 v)
+{   // streaming store: the line is not kept in L2 (the consumer is a later kernel and the tensor is >> L2)
+    f32x4n t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<f32x4n*>(p));
+}
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 __device__ __forceinline__ float4 f4fma(float4 a, float4 b, float4 c)
 {
@@ -350,19 +356,22 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_sparse_kernel(const float* __re
                                                                float* __restrict__ dx, long long nquads, int C, int act, int grows,
                                                                float invM)
 {
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    // grid.x = row group (one ROI): the group's slot lookup is block-uniform and nothing is divided per element
+    (void)nquads;
     const int cq = C / 4;
-    for (; i < nquads; i += stride) {
-        const int c = (int)(i % cq) * 4;
-        const long long row = i / cq;
-        const long long g = row / grows;
-        const int slot = inv[g];
-        const float4 v = ld4g(x + i * 4);
-        float4 gq = f4zero();
-        if (slot >= 0) gq = ld4g(dyc + ((long long)slot * grows + (row - g * grows)) * C + c);
+    const long long g = blockIdx.x;
+    const int slot = inv[g];
+    const unsigned gq = (unsigned)grows * (unsigned)cq;
+    const float* xg = x + g * (long long)grows * C;
+    float* dxg = dx + g * (long long)grows * C;
+    const float* dyg = slot >= 0 ? dyc + (long long)slot * grows * C : nullptr;
+    for (unsigned e = threadIdx.x; e < gq; e += blockDim.x) {
+        const int c = (int)(e % (unsigned)cq) * 4;
+        const float4 v = ld4g(xg + (long long)e * 4);
+        float4 gv4 = f4zero();
+        if (dyg) gv4 = ld4g(dyg + (long long)e * 4);
         const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
-        float gv[4] = {gq.x, gq.y, gq.z, gq.w}, xv[4] = {v.x, v.y, v.z, v.w};
+        float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, xv[4] = {v.x, v.y, v.z, v.w};
         float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
         float o[4];
 #pragma unroll
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_sparse_kernel(const float* __re
             const float db = (float)tot[c + k], dg = (float)tot[C + c + k];
             o[k] = scv[k] * (dz - (db + xh * dg) * invM);
         }
-        st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        st4g(dxg + (long long)e * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -461,47 +470,43 @@ template <int S, int TW>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo)
 {
+    // grid: x = (w-tile, channel quad) pairs, y = output row, z = image: no 64-bit div/mod per thread
     constexpr int NC = (TW - 1) * S + 3;
     const int pt = (S == 1) ? 1 : 0, plft = (S == 1) ? 1 : 0;
     const int cq = C / 4;
     const int wtiles = (Wo + TW - 1) / TW;
-    const long long total = (long long)N * Ho * wtiles * cq;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int c = (int)(i % cq) * 4;
-        long long t = i / cq;
-        const int wt = (int)(t % wtiles);
-        t /= wtiles;
-        const int oy = (int)(t % Ho);
-        const int n = (int)(t / Ho);
-        const int ox0 = wt * TW;
-        float4 wv[9];
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (unsigned)(wtiles * cq)) return;
+    const int wt = e / (unsigned)cq;
+    const int c = (e - wt * cq) * 4;
+    const int oy = blockIdx.y, n = blockIdx.z;
+    const int ox0 = wt * TW;
+    float4 wv[9];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wv[k] = ld4g(w + k * C + c);
-        float4 acc[TW];
+    for (int k = 0; k < 9; ++k) wv[k] = ld4g(w + k * C + c);
+    float4 acc[TW];
 #pragma unroll
-        for (int j = 0; j < TW; ++j) acc[j] = f4zero();
+    for (int j = 0; j < TW; ++j) acc[j] = f4zero();
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * S + ky - pt;
-            if (iy < 0 || iy >= H) continue;
-            const float* rowp = x + (((long long)n * H + iy) * W) * C + c;
-            float4 col[NC];
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * S + ky - pt;
+        if (iy < 0 || iy >= H) continue;
+        const float* rowp = x + (((long long)n * H + iy) * W) * C + c;
+        float4 col[NC];
 #pragma unroll
-            for (int k = 0; k < NC; ++k) {
-                const int ix = ox0 * S + k - plft;
-                col[k] = (ix >= 0 && ix < W) ? ld4g(rowp + (long long)ix * C) : f4zero();
-            }
-#pragma unroll
-            for (int j = 0; j < TW; ++j)
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[j] = f4fma(col[j * S + kx], wv[ky * 3 + kx], acc[j]);
+        for (int k = 0; k < NC; ++k) {
+            const int ix = ox0 * S + k - plft;
+            col[k] = (ix >= 0 && ix < W) ? ld4g(rowp + (long long)ix * C) : f4zero();
         }
 #pragma unroll
         for (int j = 0; j < TW; ++j)
-            if (ox0 + j < Wo) st4g(y + ((((long long)n * Ho + oy) * Wo) + ox0 + j) * C + c, acc[j]);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[j] = f4fma(col[j * S + kx], wv[ky * 3 + kx], acc[j]);
     }
+    float* yrow = y + (((long long)n * Ho + oy) * Wo) * C + c;
+#pragma unroll
+    for (int j = 0; j < TW; ++j)
+        if (ox0 + j < Wo) st4g(yrow + (long long)(ox0 + j) * C, acc[j]);
 }
 
 // dx[iy,ix] = sum_{ky,kx} dy[(iy+pt-ky)/S, (ix+pl-kx)/S] * w[ky,kx]   (when divisible and in range)
@@ -511,34 +516,28 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 {
     const int pt = (S == 1) ? 1 : 0;
     const int cq = C / 4;
-    const long long total = (long long)N * H * W * cq;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int c = (int)(i % cq) * 4;
-        long long t = i / cq;
-        const int ix = (int)(t % W);
-        t /= W;
-        const int iy = (int)(t % H);
-        const int n = (int)(t / H);
-        float4 acc = f4zero();
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (unsigned)(W * cq)) return;
+    const int ix = e / (unsigned)cq;
+    const int c = (e - ix * cq) * 4;
+    const int iy = blockIdx.y, n = blockIdx.z;
+    float4 acc = f4zero();
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int ty = iy + pt - ky;
-            if (ty < 0 || (ty % S) != 0) continue;
-            const int oy = ty / S;
-            if (oy >= Ho) continue;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = iy + pt - ky;
+        if (ty < 0 || (ty % S) != 0) continue;
+        const int oy = ty / S;
+        if (oy >= Ho) continue;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int tx = ix + pt - kx;
-                if (tx < 0 || (tx % S) != 0) continue;
-                const int ox = tx / S;
-                if (ox >= Wo) continue;
-                acc = f4fma(ld4g(dy + ((((long long)n * Ho + oy) * Wo) + ox) * C + c), ld4g(w + (ky * 3 + kx) * C + c), acc);
-            }
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = ix + pt - kx;
+            if (tx < 0 || (tx % S) != 0) continue;
+            const int ox = tx / S;
+            if (ox >= Wo) continue;
+            acc = f4fma(ld4g(dy + ((((long long)n * Ho + oy) * Wo) + ox) * C + c), ld4g(w + (ky * 3 + kx) * C + c), acc);
         }
-        st4g(dx + i * 4, acc);
     }
+    st4g(dx + ((((long long)n * H + iy) * W) + ix) * C + c, acc);
 }
 
 // dw[k][c] = sum over output pixels of x[shifted] * dy
@@ -550,10 +549,11 @@ struct OpDwDw {
     __device__ void operator()(long long r, int c, float4* acc) const
     {
         const int pt = (S == 1) ? 1 : 0;
-        const int ox = (int)(r % Wo);
-        long long t = r / Wo;
-        const int oy = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        const unsigned ru = (unsigned)r;                 // rows < 2^31 (checked by the launcher)
+        const unsigned t = ru / (unsigned)Wo;
+        const int ox = (int)(ru - t * Wo);
+        const int n = (int)(t / (unsigned)Ho);
+        const int oy = (int)(t - (unsigned)n * Ho);
         const float4 g = ld4g(dy + r * C + c);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -588,36 +588,36 @@ __global__ __launch_bounds__(256) void crop_fwd_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ bind, float* __restrict__ out,
                                                        int H, int W, int C, int nb, int ch, int cw)
 {
+    // grid: x = crop row py, y = box.  The y coordinate is block-uniform, the x coordinate is uniform per
+    // group of C/4 lanes; no integer division by runtime 64-bit values.
+    const int b = blockIdx.y, py = blockIdx.x;
     const int cq = C / 4;
-    const long long total = (long long)nb * ch * cw * cq;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const int c = (int)(i % cq) * 4;
-        long long t = i / cq;
-        const int px = (int)(t % cw);
-        t /= cw;
-        const int py = (int)(t % ch);
-        const int b = (int)(t / ch);
-        const float4 bx = ld4g(boxes + (long long)b * 4);      // y1,x1,y2,x2
-        float iny, inx;
-        const bool vy = crop_coord(bx.x, bx.z, H, ch, py, iny);
+    const float4 bx = ld4g(boxes + (long long)b * 4);      // y1,x1,y2,x2
+    float iny;
+    const bool vy = crop_coord(bx.x, bx.z, H, ch, py, iny);
+    const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+    const float wy = iny - (float)ty;
+    const float* base = img + (long long)bind[b] * H * W * C;
+    float* orow = out + ((long long)b * ch + py) * cw * C;
+    const unsigned total = (unsigned)(cw * cq);
+    for (unsigned e = threadIdx.x; e < total; e += blockDim.x) {
+        const int px = e / (unsigned)cq;
+        const int c = (e - px * cq) * 4;
+        float inx;
         const bool vx = crop_coord(bx.y, bx.w, W, cw, px, inx);
         float4 o = f4zero();
         if (vy && vx) {
-            const int ty = (int)floorf(iny), by = (int)ceilf(iny);
             const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
-            const float wy = iny - (float)ty, wx = inx - (float)lx;
-            const float* base = img + (long long)bind[b] * H * W * C + c;
-            const float4 tl = ld4g(base + ((long long)ty * W + lx) * C), tr = ld4g(base + ((long long)ty * W + rx) * C);
-            const float4 bl = ld4g(base + ((long long)by * W + lx) * C), br = ld4g(base + ((long long)by * W + rx) * C);
+            const float wx = inx - (float)lx;
+            const float4 tl = ld4g(base + ((long long)ty * W + lx) * C + c), tr = ld4g(base + ((long long)ty * W + rx) * C + c);
+            const float4 bl = ld4g(base + ((long long)by * W + lx) * C + c), br = ld4g(base + ((long long)by * W + rx) * C + c);
             float top, bot;
             top = tl.x + (tr.x - tl.x) * wx; bot = bl.x + (br.x - bl.x) * wx; o.x = top + (bot - top) * wy;
             top = tl.y + (tr.y - tl.y) * wx; bot = bl.y + (br.y - bl.y) * wx; o.y = top + (bot - top) * wy;
             top = tl.z + (tr.z - tl.z) * wx; bot = bl.z + (br.z - bl.z) * wx; o.z = top + (bot - top) * wy;
             top = tl.w + (tr.w - tl.w) * wx; bot = bl.w + (br.w - bl.w) * wx; o.w = top + (bot - top) * wy;
         }
-        st4g(out + i * 4, o);
+        st4g_nt(orow + (long long)px * C + c, o);
     }
 }
 
@@ -1072,8 +1072,8 @@ int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const in
     run_colreduce(op, Mc, C, part, tot, s);
     hipLaunchKernelGGL(bn_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, dgamma, dbeta, C);
     const long long nq = (long long)M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_dx_sparse_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy_compact, x, inv, scale, shift, mean, var, tot,
-                       dx, nq, C, act, group_rows, 1.0f / (float)M);
+    hipLaunchKernelGGL(bn_bwd_dx_sparse_kernel, dim3((unsigned)(M / group_rows)), dim3(256), 0, s, dy_compact, x, inv, scale, shift, mean,
+                       var, tot, dx, nq, C, act, group_rows, 1.0f / (float)M);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1112,11 +1112,11 @@ int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y, int N, int H, 
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / stride, Wo = W / stride;
     if (stride == 1) {
-        const long long total = (long long)N * Ho * ((Wo + 3) / 4) * (C / 4);
-        hipLaunchKernelGGL((dw_fwd_kernel<1, 4>), dim3(ew_blocks(total)), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        const int per_row = ((Wo + 3) / 4) * (C / 4);
+        hipLaunchKernelGGL((dw_fwd_kernel<1, 4>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
     } else {
-        const long long total = (long long)N * Ho * ((Wo + 1) / 2) * (C / 4);
-        hipLaunchKernelGGL((dw_fwd_kernel<2, 2>), dim3(ew_blocks(total)), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        const int per_row = ((Wo + 1) / 2) * (C / 4);
+        hipLaunchKernelGGL((dw_fwd_kernel<2, 2>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
     }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
@@ -1127,11 +1127,11 @@ int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, 
     MYOLO_REQUIRE(dy && w && dx && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_data: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / stride, Wo = W / stride;
-    const long long total = (long long)N * H * W * (C / 4);
+    const int per_row = W * (C / 4);
     if (stride == 1)
-        hipLaunchKernelGGL((dw_bwd_data_kernel<1>), dim3(ew_blocks(total)), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
+        hipLaunchKernelGGL((dw_bwd_data_kernel<1>), dim3((per_row + 255) / 256, H, N), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
     else
-        hipLaunchKernelGGL((dw_bwd_data_kernel<2>), dim3(ew_blocks(total)), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
+        hipLaunchKernelGGL((dw_bwd_data_kernel<2>), dim3((per_row + 255) / 256, H, N), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1159,10 +1159,8 @@ int myolo_crop_and_resize_fwd(const float* image, const float* boxes, const int3
 {
     MYOLO_REQUIRE(image && boxes && box_ind && out && B > 0 && (C & 3) == 0 && nb >= 0, "crop_and_resize_fwd: bad arguments");
     if (nb == 0) return MYOLO_OK;
-    const long long total = (long long)nb * crop_h * crop_w * (C / 4);
-    long long blocks = (total + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(crop_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, image, boxes, box_ind, out,
+    MYOLO_REQUIRE(nb <= 65535, "crop_and_resize_fwd: at most 65535 boxes per call (got %d)", nb);
+    hipLaunchKernelGGL(crop_fwd_kernel, dim3(crop_h, nb), dim3(256), 0, (hipStream_t)stream, image, boxes, box_ind, out,
                        H, W, C, nb, crop_h, crop_w);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
