@@ -160,6 +160,13 @@ def main():
         achieved = flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
         roi_ms, _ = net.kernel_ms("roialign_fwd")
         roi_bytes = args.batch * R * ps * ps * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
+        traffic = None      # HBM-side bytes per launch of the dominant kernel, from the separate --pmc passes (tools/collect_profiles.sh)
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_conv3x3_fwd.json")))
+            if args.batch * R == 32 * 147:        # the counters were collected at exactly this shape
+                traffic = pj["traffic_bytes_per_launch_corrected"]
+        except Exception:
+            pass
         res = {
             "metric": "images/sec fwd+bwd, %dx%d Shapes batch %d, at %d MI355X" % (args.size, args.size, args.batch, world),
             "value": args.batch * world * args.steps / elapsed,
@@ -174,7 +181,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": {"kernel": "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M,
                          "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": None, "launches_timed": conv_n, "avg_launch_ms": conv_ms,
+                         "frac": achieved / 157.3, "traffic": traffic,
+                         "algorithmic_bytes": 2.0 * M * 256 * 4 + 9 * 256 * 256 * 4, "algorithmic_flop": flop, "launches_timed": conv_n, "avg_launch_ms": conv_ms,
                          "secondary": {"kernel": "crop_fwd_kernel (ROIAlign fwd)", "bound": "hbm",
                                        "achieved": roi_bytes / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
                                        "peak": 8000.0, "unit": "GB/s",

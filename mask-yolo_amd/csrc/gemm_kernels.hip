@@ -43,6 +43,7 @@ struct GemmArgs {
     int Cc;           // channels per tap of the A operand (gather modes)
     int Co;           // EP_DECONV: output channels per tap
     int act;
+    int nt;                  // streaming (non-temporal) stores for outputs much larger than the L2
     long long m_per_split;   // TN only
 };
 
@@ -608,8 +609,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
                 if (!cok[u]) continue;
                 float v = fmaf(acc[t][u][r] + cb[u], cs[u], ct[u]);
                 if (relu) v = fmaxf(v, 0.f);
-                if (EPI == EP_PLAIN) p.C[rowoff + ccol[u]] = v;
-                else p.C[(rowoff + (long long)(ctap[u] >> 1) * 2 * p.W + (ctap[u] & 1)) * p.Co + ccol[u]] = v;
+                float* dst = (EPI == EP_PLAIN) ? p.C + rowoff + ccol[u]
+                                               : p.C + (rowoff + (long long)(ctap[u] >> 1) * 2 * p.W + (ctap[u] & 1)) * p.Co + ccol[u];
+                if (p.nt) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
             }
         }
     }
@@ -843,6 +846,8 @@ static int launch_nn(const GemmArgs& a, hipStream_t s)
     if (tiles <= 0) return MYOLO_OK;
     const bool aligned = (a.N & 3) == 0 && (a.ldb & 3) == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
     const bool kfast = (AMODE == AM_PLAIN) ? ((a.K % BK) == 0 && (a.lda & 3) == 0) : ((a.Cc % BK) == 0);
+    GemmArgs& am = const_cast<GemmArgs&>(a);
+    am.nt = ((long long)a.M * a.N * 4 > (64ll << 20)) && !getenv("MYOLO_NO_NT");
     const char* abl = getenv("MYOLO_GEMM_ABL");        // tuning only (tools/kbench.py)
     if (aligned && kfast && abl && AMODE == AM_CONV3 && EPI == EP_PLAIN) {
         if (abl[0] == '1') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 1>), dim3((unsigned)tiles), dim3(256), 0, s, a);

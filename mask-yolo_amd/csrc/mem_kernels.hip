@@ -230,6 +230,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ shift, float* __restrict__ y,
                                                        long long nquads, int C, int act)
 {
+    const bool nt = nquads > (4ll << 20);      // > 64 MB: stream past the L2
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int cq = C / 4;
@@ -242,7 +243,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
         o.y = actf(fmaf(v.y, sc.y, sh.y), act);
         o.z = actf(fmaf(v.z, sc.z, sh.z), act);
         o.w = actf(fmaf(v.w, sc.w, sh.w), act);
-        st4g(y + i * 4, o);
+        if (nt) st4g_nt(y + i * 4, o); else st4g(y + i * 4, o);
     }
 }
 
@@ -304,7 +305,8 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
                 o[k] = scv[k] * dz;
             }
         }
-        st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        if (nquads > (4ll << 20)) st4g_nt(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        else st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_sparse_kernel(const float* __re
             const float db = (float)tot[c + k], dg = (float)tot[C + c + k];
             o[k] = scv[k] * (dz - (db + xh * dg) * invM);
         }
-        st4g(dxg + (long long)e * 4, make_float4(o[0], o[1], o[2], o[3]));
+        st4g_nt(dxg + (long long)e * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 

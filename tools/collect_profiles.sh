@@ -1,0 +1,54 @@
+#!/bin/bash
+# Regenerates the rocprofv3 evidence under gpurun_out/ (copy the summaries into profiles/ afterwards).
+#   gpurun -- 'bash tools/collect_profiles.sh r1'
+# Counters are collected in their own passes (never combined with sys/hip traces), as MI355X_MICROARCH.md prescribes:
+# FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots).
+TAG=${1:-r1}
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/profiles_$TAG
+mkdir -p $OUT
+# 1. the bench command itself: per-kernel time
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --steps 5 --warmup 2 --cpu-images 0 > $OUT/bench_under_rocprof.log 2>&1
+cp $OUT/bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
+# 2. un-profiled bench line (the number of record)
+python bench.py --steps 10 --warmup 3 2> /dev/null | tail -1 > $OUT/${TAG}_bench.json
+# 3. single-kernel micro-benchmarks
+for k in conv3x3_fwd conv3x3_bwd_data conv3x3_bwd_weight deconv_fwd roialign_fwd roialign_bwd dw; do python tools/kbench.py $k --iters 20 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_kbench.txt
+# 4. PMC passes on the dominant kernel (+ a pure streaming kernel to calibrate FETCH_SIZE / WRITE_SIZE units)
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python tools/kbench.py conv3x3_fwd --iters 3 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/cal_$c -o p -- python tools/kbench.py roialign_fwd --iters 3 > /dev/null 2>&1
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/kbench.py conv3x3_fwd --iters 3 > /dev/null 2>&1
+python - "$OUT" "$TAG" <<'PY'
+import csv, collections, json, sys
+out, tag = sys.argv[1], sys.argv[2]
+def per_launch(d, kname):
+    rows = [r for r in csv.DictReader(open("%s/%s/p_counter_collection.csv" % (out, d))) if kname in r["Kernel_Name"]]
+    acc = collections.defaultdict(float); disp = set()
+    for r in rows:
+        acc[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
+    kt = [r for r in csv.DictReader(open("%s/%s/p_kernel_trace.csv" % (out, d))) if kname in r["Kernel_Name"]]
+    dur = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kt]
+    return {k: v / max(1, len(disp)) for k, v in acc.items()}, sum(dur) / max(1, len(dur)), len(disp)
+res = {"kernel": "gemm_nn_fast<CONV3> M=921984 K=2304 N=256 (mask-head 3x3 conv fwd)"}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v, ns, n = per_launch("pmc_" + c, "gemm_nn_fast")
+    res[c + "_KB_per_launch"] = v.get(c); res["avg_ns_" + c] = ns
+    v, ns, n = per_launch("cal_" + c, "crop_fwd")
+    res["calibration_crop_fwd_" + c + "_KB_per_launch"] = v.get(c)
+res["calibration_crop_fwd_true_bytes"] = {"written": 4704 * 196 * 256 * 4, "read_unique": 32 * 28 * 28 * 256 * 4}
+v, ns, n = per_launch("pmc_sq", "gemm_nn_fast")
+res["sq_per_launch"] = v; res["avg_ns_sq"] = ns
+xcds, simds = 8, 1024
+if "GRBM_GUI_ACTIVE" in v:
+    cyc = v["GRBM_GUI_ACTIVE"] / xcds
+    res["effective_clock_GHz"] = cyc / ns
+    res["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cyc
+json.dump(res, open("%s/%s_pmc_conv3x3_fwd.json" % (out, tag), "w"), indent=1)
+print(json.dumps(res, indent=1))
+PY
+head -12 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-160
+cat $OUT/${TAG}_kbench.txt | grep -v "^dw  \|^dw 1"
+cat $OUT/${TAG}_bench.json | cut -c1-400

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("which")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--rois", type=int, default=32 * 147)
+    ap.add_argument("--cout", type=int, default=256)
     a = ap.parse_args()
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
@@ -41,10 +42,11 @@ def main():
     M = NR * ps * ps
     st = X.stream()
     if a.which.startswith("conv3x3"):
-        x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
-        flop = 2.0 * M * 9 * C * C
+        Co = a.cout
+        x, w, b, y = rn(M, C), rn(3, 3, C, Co) * 0.02, rn(Co), torch.empty(M, Co, device=dev)
+        flop = 2.0 * M * 9 * C * Co
         if a.which == "conv3x3_fwd":
-            fn = lambda: X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, st)   # noqa: E731
+            fn = lambda: X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, Co, st)   # noqa: E731
         elif a.which == "conv3x3_bwd_data":
             fn = lambda: X.call("myolo_conv3x3_bwd_data", X.ptr(x), X.ptr(w), X.ptr(y), NR, ps, ps, C, C, ws.data_ptr(), ws.numel(), st)   # noqa: E731
         else:
@@ -76,6 +78,13 @@ def main():
             fn = lambda: X.call("myolo_roialign_bwd_grouped", X.ptr(out), X.ptr(boxes), X.ptr(feat), B, H, H, C, R, ps, ps, st)   # noqa: E731
         ms = timeit(fn, a.iters)
         print("%s: %.3f ms  %.0f GB/s (%.1f%% of 8000)" % (a.which, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80))
+    elif a.which == "bn_apply":
+        # pure streaming pass over the mask-head activation tensor: reads M*C*4 bytes, writes the same
+        x, y = rn(M, C), torch.empty(M, C, device=dev)
+        sc, sh = rn(C), rn(C)
+        fn = lambda: X.call("myolo_bn_apply_act", X.ptr(x), X.ptr(sc), X.ptr(sh), X.ptr(y), M, C, 1, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("bn_apply M=%d C=%d: %.3f ms  %.0f GB/s (read %d B + write %d B)" % (M, C, ms, 2 * M * C * 4 / ms / 1e6, M * C * 4, M * C * 4))
     elif a.which == "dw":
         # the 14 depthwise layers of the backbone + YOLO head at 224x224, batch 32, alpha 1
         layers = [(112, 32, 1), (112, 64, 2), (56, 64, 1), (56, 128, 2), (28, 256, 1), (28, 256, 1), (28, 512, 2),
