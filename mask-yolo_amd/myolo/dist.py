@@ -48,14 +48,16 @@ class GradReducer(object):
     wait() is called before the optimiser (Net.before_optimizer).  With world_size 1 both are no-ops,
     so the single-GPU path is bit-identical to running without a reducer."""
 
-    def __init__(self, flat_grad, bucket_ranges, group=None):
+    def __init__(self, flat_grad, bucket_ranges, group=None, always=False):
         self.flat = flat_grad
         self.ranges = list(bucket_ranges)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
         self.handles = []
-        if self.cuda and self.world > 1:
+        # always=True issues the collectives even in a 1-rank group (used to test the RCCL/stream path on one GPU)
+        self.active = self.world > 1 or (always and dist.is_initialized())
+        if self.cuda and self.active:
             self.comm_stream = torch.cuda.Stream(device=flat_grad.device)
             self.done = [torch.cuda.Event() for _ in self.ranges]
 
@@ -64,7 +66,7 @@ class GradReducer(object):
         return 1.0 / self.world
 
     def bucket_ready(self, i):
-        if self.world == 1:
+        if not self.active:
             return
         lo, hi = self.ranges[i]
         view = self.flat[lo:hi]
@@ -79,7 +81,7 @@ class GradReducer(object):
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
-        if self.world == 1:
+        if not self.active:
             return
         if self.cuda:
             cur = torch.cuda.current_stream()

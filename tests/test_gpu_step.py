@@ -291,3 +291,37 @@ if __name__ == "__main__":
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     print("oracle n_pos", ref["n_pos"], "loss", ref["loss"])
     compare_step(cfg, P, batch, ref, verbose=True)
+
+
+def test_rccl_reducer_path_single_rank_group():
+    """The data-parallel step on ONE GPU through the real RCCL path: a 1-rank "nccl" process group, the three
+    gradient buckets all-reduced on the side stream as backward completes them, Adam waiting on their events.
+    Must reproduce the no-communication step bit for bit (sum over one rank, grad_scale 1)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from myolo.dist import GradReducer
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+
+    def run(with_comm):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        if with_comm:
+            GradReducer(model.net.flat_g, model.net.bucket_ranges, always=True).attach(model.net)
+        for _ in range(2):
+            out = model.train_on_batch(batch, learning_rate=1e-3)
+        torch.cuda.synchronize()
+        return out["loss"], model.net.flat_p.clone()
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        l1, p1 = run(True)
+    finally:
+        dist.destroy_process_group()
+    l0, p0 = run(False)
+    assert l0 == l1 and torch.equal(p0, p1)
