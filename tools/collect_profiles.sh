@@ -11,6 +11,23 @@ mkdir -p $OUT
 # 1. the bench command itself: per-kernel time
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --steps 5 --warmup 2 --cpu-images 0 > $OUT/bench_under_rocprof.log 2>&1
 cp $OUT/bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
+# per (kernel, grid) averages from the same trace: the stats file pools every launch of a symbol, this one
+# isolates e.g. the four mask-head conv forwards (grid 14406 x 256) that bench.py times live with HIP events
+python - "$OUT/bench/bench_kernel_trace.csv" "$OUT/${TAG}_bench_kernel_by_grid.csv" <<'PY'
+import csv, collections, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+acc = collections.defaultdict(list)
+for r in rows:
+    grid = "x".join(r[k] for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+    wg = "x".join(r[k] for k in ("Workgroup_Size_X", "Workgroup_Size_Y", "Workgroup_Size_Z"))
+    acc[(r["Kernel_Name"], grid, wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+out = sorted(((sum(v), k, v) for k, v in acc.items()), reverse=True)
+with open(sys.argv[2], "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "Grid_Size(threads)", "Workgroup_Size", "Calls", "TotalNs", "AverageNs", "MinNs", "MaxNs"])
+    for tot, k, v in out[:60]:
+        w.writerow([k[0], k[1], k[2], len(v), tot, tot / len(v), min(v), max(v)])
+PY
 # 2. un-profiled bench line (the number of record)
 python bench.py --steps 10 --warmup 3 2> /dev/null | tail -1 > $OUT/${TAG}_bench.json
 # 3. single-kernel micro-benchmarks
@@ -49,6 +66,6 @@ if "GRBM_GUI_ACTIVE" in v:
 json.dump(res, open("%s/%s_pmc_conv3x3_fwd.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
-head -12 $OUT/${TAG}_bench_kernel_stats.csv | cut -c1-160
+head -8 $OUT/${TAG}_bench_kernel_by_grid.csv | cut -c1-170
 cat $OUT/${TAG}_kbench.txt | grep -v "^dw  \|^dw 1"
 cat $OUT/${TAG}_bench.json | cut -c1-400
