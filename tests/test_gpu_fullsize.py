@@ -1,0 +1,173 @@
+"""Parity at BASELINE.json's full sizes (Shapes 224x224, batch 32, alpha 1, R = 147 ROIs/image), where the CPU
+oracle would take minutes per op: size-independent properties checked on the GPU kernels themselves.
+
+  * adjointness: every (forward, data-gradient, weight-gradient) triple satisfies
+        <Y, f(X, W)> = <X, f_bwd_data(Y, W)> = <W, f_bwd_weight(X, Y)>
+    which pins the two backward kernels to the forward one (itself pinned against the oracle at small sizes);
+  * linearity: f(aX1 + X2) = a f(X1) + f(X2);
+  * a sampled sub-block of the full-size result against the oracle;
+  * the exact-sparsity backward equals the dense backward on a full-size step; the loss is finite and reproducible.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ops as O                      # noqa: E402
+from myolo import _ext as X                         # noqa: E402
+
+DEV = "cuda:0"
+B, R, PS, C = 32, 147, 14, 256
+NR = B * R
+M = NR * PS * PS
+
+
+def ws():
+    if not hasattr(ws, "buf"):
+        ws.buf = torch.empty(768 << 20, dtype=torch.uint8, device=DEV)
+    return ws.buf.data_ptr(), ws.buf.numel()
+
+
+def rn(gen, *shape, scale=1.0):
+    return torch.randn(*shape, device=DEV, generator=gen) * scale
+
+
+def dot(a, b):
+    return float((a.double().flatten() * b.double().flatten()).sum())
+
+
+def close(a, b, tol=2e-4):
+    assert abs(a - b) <= tol * max(abs(a), abs(b), 1e-30), (a, b)
+
+
+@pytest.fixture(scope="module")
+def gen():
+    return torch.Generator(device=DEV).manual_seed(1234)
+
+
+def test_mask_conv3x3_adjoint_linear_and_sampled_oracle(gen):
+    x, w, bias = rn(gen, M, C), rn(gen, 3, 3, C, C, scale=0.02), rn(gen, C)
+    dy = rn(gen, M, C)
+    y, dx, dw = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV), torch.empty(3, 3, C, C, device=DEV)
+    zero = torch.zeros(C, device=DEV)
+    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), X.ptr(y), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), NR, PS, PS, C, C, *ws(), X.stream())
+    X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), NR, PS, PS, C, C, *ws(), X.stream())
+    a, b, c = dot(dy, y), dot(x, dx), dot(w, dw)
+    close(a, b)
+    close(a, c)
+    # linearity
+    x2 = rn(gen, M, C)
+    y2, y3 = torch.empty_like(y), torch.empty_like(y)
+    X.call("myolo_conv3x3_fwd", X.ptr(x2), X.ptr(w), X.ptr(zero), X.ptr(y2), NR, PS, PS, C, C, X.stream())
+    x3 = (0.5 * x + x2).contiguous()
+    X.call("myolo_conv3x3_fwd", X.ptr(x3), X.ptr(w), X.ptr(zero), X.ptr(y3), NR, PS, PS, C, C, X.stream())
+    assert float((y3 - (0.5 * y + y2)).abs().max()) <= 1e-3 * float(y3.abs().max())
+    # sampled ROIs (first, one in the middle, last -> exercises the tail tiles) against the oracle, with bias
+    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(bias), X.ptr(y), NR, PS, PS, C, C, X.stream())
+    wn, bn = w.cpu().numpy(), bias.cpu().numpy()
+    for roi in (0, NR // 2 + 3, NR - 1):
+        xs = x.view(NR, PS, PS, C)[roi:roi + 1].cpu().numpy()
+        ref = O.conv2d(xs, wn, pads=(1, 1, 1, 1), bias=bn, acc=np.float64)
+        got = y.view(NR, PS, PS, C)[roi:roi + 1].cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
+
+
+def test_deconv_adjoint_full_size(gen):
+    x, w = rn(gen, M, C), rn(gen, 2, 2, C, C, scale=0.05)
+    dy = rn(gen, 4 * M, C)
+    y, dx, dw = torch.empty(4 * M, C, device=DEV), torch.empty(M, C, device=DEV), torch.empty(2, 2, C, C, device=DEV)
+    zero = torch.zeros(C, device=DEV)
+    X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), X.ptr(y), NR, PS, PS, C, C, 0, *ws(), X.stream())
+    X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), NR, PS, PS, C, C, *ws(), X.stream())
+    a = dot(dy, y)
+    close(a, dot(x, dx))
+    close(a, dot(w, dw))
+
+
+@pytest.mark.parametrize("H,Cin,Cout", [(112, 32, 64), (28, 256, 512), (7, 1024, 1024), (7, 1024, 27)])
+def test_pointwise_adjoint_backbone_shapes(gen, H, Cin, Cout):
+    Mm = B * H * H
+    x, w, dy = rn(gen, Mm, Cin), rn(gen, Cin, Cout, scale=0.05), rn(gen, Mm, Cout)
+    y, dx, dw = torch.empty(Mm, Cout, device=DEV), torch.empty(Mm, Cin, device=DEV), torch.empty(Cin, Cout, device=DEV)
+    X.call("myolo_pwconv1x1_fwd", X.ptr(x), X.ptr(w), None, X.ptr(y), Mm, Cin, Cout, X.stream())
+    X.call("myolo_pwconv1x1_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), Mm, Cin, Cout, *ws(), X.stream())
+    X.call("myolo_pwconv1x1_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), Mm, Cin, Cout, *ws(), X.stream())
+    a = dot(dy, y)
+    close(a, dot(x, dx))
+    close(a, dot(w, dw))
+
+
+@pytest.mark.parametrize("H,Cc,stride", [(112, 32, 1), (112, 64, 2), (28, 512, 2), (14, 512, 1), (7, 1024, 1)])
+def test_depthwise_adjoint_backbone_shapes(gen, H, Cc, stride):
+    Ho = H // stride
+    x, w, dy = rn(gen, B, H, H, Cc), rn(gen, 3, 3, Cc), rn(gen, B, Ho, Ho, Cc)
+    y, dx, dw = torch.empty(B, Ho, Ho, Cc, device=DEV), torch.empty(B, H, H, Cc, device=DEV), torch.empty(3, 3, Cc, device=DEV)
+    X.call("myolo_dwconv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(y), B, H, H, Cc, stride, X.stream())
+    X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), B, H, H, Cc, stride, X.stream())
+    X.call("myolo_dwconv3x3_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), B, H, H, Cc, stride, *ws(), X.stream())
+    a = dot(dy, y)
+    close(a, dot(x, dx))
+    close(a, dot(w, dw))
+
+
+def test_roialign_adjoint_full_size(gen):
+    H = 28
+    feat = rn(gen, B, H, H, C)
+    c = torch.rand(NR, 2, device=DEV, generator=gen) * 1.2 - 0.1
+    s = torch.rand(NR, 2, device=DEV, generator=gen) * 0.7 + 0.02
+    boxes = torch.cat([c - s / 2, c + s / 2], 1).contiguous()
+    boxes[5] = 0.0                                            # zero-padded ROI
+    bind = torch.arange(B, device=DEV, dtype=torch.int32).repeat_interleave(R).contiguous()
+    out, g = torch.empty(M, C, device=DEV), rn(gen, M, C)
+    dimg, dimg2 = torch.empty(B, H, H, C, device=DEV), torch.empty(B, H, H, C, device=DEV)
+    X.call("myolo_crop_and_resize_fwd", X.ptr(feat), X.ptr(boxes), X.ptr(bind), X.ptr(out), B, H, H, C, NR, PS, PS, X.stream())
+    X.call("myolo_roialign_bwd_grouped", X.ptr(g), X.ptr(boxes), X.ptr(dimg), B, H, H, C, R, PS, PS, X.stream())
+    X.call("myolo_crop_and_resize_bwd_image", X.ptr(g), X.ptr(boxes), X.ptr(bind), X.ptr(dimg2), B, H, H, C, NR, PS, PS, X.stream())
+    close(dot(g, out), dot(feat, dimg))
+    assert float((dimg - dimg2).abs().max()) <= 1e-3 * float(dimg.abs().max())       # gather form == scatter form
+    # sampled boxes against the oracle
+    sel = [0, 5, NR // 2, NR - 1]
+    ref = O.crop_and_resize(feat.cpu().numpy(), boxes[sel].cpu().numpy(), bind[sel].cpu().numpy(), (PS, PS))
+    got = out.view(NR, PS, PS, C)[sel].cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-5
+
+
+def test_bn_statistics_full_size_properties(gen):
+    x = rn(gen, M, C) * 3.0 + 1.5
+    g, b = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    mean, var, scale, shift = (torch.empty(C, device=DEV) for _ in range(4))
+    X.call("myolo_bn_stats", X.ptr(x), X.ptr(g), X.ptr(b), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), None, None,
+           M, C, *ws(), X.stream())
+    y = torch.empty_like(x)
+    X.call("myolo_bn_apply_act", X.ptr(x), X.ptr(scale), X.ptr(shift), X.ptr(y), M, C, 0, X.stream())
+    # the normalised tensor has zero mean and variance var/(var+eps) per channel
+    m2 = y.double().mean(0)
+    v2 = y.double().var(0, unbiased=False)
+    assert float(m2.abs().max()) < 1e-4
+    assert float((v2 - (var.double() / (var.double() + 1e-3))).abs().max()) < 1e-4
+
+
+def test_full_size_step_sparse_equals_dense_and_is_reproducible():
+    from myolo.config import make_config, ShapesConfig
+    from myolo.model import MaskYOLO
+    from myolo.shapes import make_shapes_samples
+    from myolo.myolo_utils import BatchGenerator
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], ALPHA=1.0, BATCH_SIZE=32)
+    samples = make_shapes_samples(32, cfg)
+    batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
+    res = []
+    for sparse in (True, False, True):
+        model = MaskYOLO(mode="training", config=cfg, seed=0)
+        model.net.sparse_mask_bwd = sparse
+        out = model.train_on_batch(batch, learning_rate=0.0)
+        res.append((out["loss"], out["n_pos"].copy(), model.net.flat_g.clone()))
+        del model
+        torch.cuda.empty_cache()
+    assert np.isfinite(res[0][0]) and res[0][1].sum() > 0
+    assert res[0][0] == res[2][0] and torch.equal(res[0][2], res[2][2])            # bit-reproducible
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])         # same forward
+    d = (res[0][2] - res[1][2]).double().norm() / res[1][2].double().norm()
+    assert float(d) < 1e-4, float(d)                                               # sparse == dense gradients
