@@ -10,7 +10,8 @@
  * Conventions
  *   - every tensor is NHWC, contiguous, float32 unless stated; 2-D views are [rows, channels];
  *   - the CALLER owns every buffer (kernels never allocate); `ws` is caller-provided scratch of
- *     at least myolo_workspace_bytes(...) bytes;
+ *     at least myolo_workspace_bytes(...) bytes (forward convolutions accept ws = NULL: they then skip
+ *     the split-K path used for small problems);
  *   - asynchronous on `stream` (a hipStream_t passed as void*), no implicit synchronisation,
  *     stateless and re-entrant;
  *   - returns 0 on success, a negative MYOLO_E* code otherwise (myolo_last_error_string()).
@@ -65,12 +66,13 @@ int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
 
 /* ---- Conv2D 3x3 'same' + bias (feature_map model.py:848; myolo_mask_conv1-4 model.py:688-709) ---- */
 int myolo_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
-                      int N, int H, int W, int Cin, int Cout, void* stream);
+                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* same convolution with a per-channel affine (a folded frozen BatchNormalization: scale/shift from
  * myolo_bn_frozen_coeffs) and optional ReLU applied in the epilogue: y = act((conv + bias)*scale + shift)
  * -- TimeDistributed(Conv2D) + BatchNormalization(training=False) + ReLU, model.py:693-709 */
 int myolo_conv3x3_affine_act_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
-                                 float* y, int N, int H, int W, int Cin, int Cout, int act, void* stream);
+                                 float* y, int N, int H, int W, int Cin, int Cout, int act,
+                                 void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_bwd_data(const float* dy, const float* w, float* dx,
                            int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_bwd_weight(const float* x, const float* dy, float* dw,
@@ -81,7 +83,7 @@ int myolo_conv3x3_bwd_weight(const float* x, const float* dy, float* dw,
 int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, float* y,
                           int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, void* stream);
 int myolo_deconv2x2s2_bwd_data(const float* dy, const float* w, float* dx,
-                               int N, int H, int W, int Cin, int Cout, void* stream);
+                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_deconv2x2s2_bwd_weight(const float* x, const float* dy, float* dw,
                                  int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 

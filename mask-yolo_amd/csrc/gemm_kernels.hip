@@ -44,6 +44,8 @@ struct GemmArgs {
     int Co;           // EP_DECONV: output channels per tap
     int act;
     int nt;                  // streaming (non-temporal) stores for outputs much larger than the L2
+    int ksplits;             // NN fast path: >1 = split the K tiles over blockIdx.y, raw partials to `part`
+    float* part;             // [ksplits][M][N] fp32 partial sums (workspace)
     long long m_per_split;   // TN only
 };
 
@@ -476,7 +478,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
     const int bk = tid >> 5, bn4 = (tid & 31) * 4;
     const bool bcol_ok = (n0 + bn4) < p.N;
     const unsigned brow_stride = (unsigned)p.ldb * 4u;
-    unsigned boff0 = bcol_ok ? ((unsigned)bk * (unsigned)p.ldb + (unsigned)(n0 + bn4)) * 4u : OOB_OFF;
+    unsigned boff0 = bcol_ok ? ((unsigned)bk * (unsigned)p.ldb + (unsigned)(n0 + bn4)) * 4u : OOB_OFF;   // advanced to kt_begin below
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -486,13 +488,23 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
-    const int nk = p.K / BK;
+    const int nk_total = p.K / BK;
+    // split-K (under-filled grids): this workgroup owns k tiles [kt_begin, kt_begin + nk)
+    const int ksp = p.ksplits > 1 ? p.ksplits : 1;
+    const int kt_per = (nk_total + ksp - 1) / ksp;
+    const int kt_begin = (int)blockIdx.y * kt_per;
+    const int nk = max(0, min(kt_per, nk_total - kt_begin));
     int tap = 0, c0 = 0;       // scalar position of the k tile inside (tap, channel)
     // CONV3 K order: 32-channel group outermost, then the 9 taps, then the two 16-channel halves, so the
     // 18 k tiles that touch one 128-byte line of X run back to back (the 9 taps re-read the same pixels
     // shifted by <= W+1 rows): the re-reads hit L2 instead of the fabric.  The sum over K is order-free.
     const bool grouped = (AMODE == AM_CONV3) && (p.Cc % 32) == 0;
     int grp = 0, hh = 0;
+    if (kt_begin > 0) {          // position of k tile kt_begin in the loop order used below
+        if (grouped) { grp = kt_begin / 18; const int rem = kt_begin - grp * 18; tap = rem >> 1; hh = rem & 1; c0 = grp * 32 + hh * 16; }
+        else if (AMODE == AM_PLAIN) { c0 = kt_begin * BK; }
+        else { const int per_tap = p.Cc / BK; tap = kt_begin / per_tap; c0 = (kt_begin - tap * per_tap) * BK; }
+    }
     float4 ra[2], rb[2];
 
     auto gload = [&]() {
@@ -543,12 +555,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         }
     };
 
-    gload();
-    sstore(0);
-    __syncthreads();
-
+    if (bcol_ok && AMODE != AM_CONV3) boff0 += (unsigned)kt_begin * (unsigned)BK * brow_stride;
     const int half = lane >> 5, l31 = lane & 31;
     const int arow_l = wm * 64 + l31, bcol_l = wn * 64 + l31;
+    if (nk > 0) {
+        gload();
+        sstore(0);
+    }
+    __syncthreads();
+
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
@@ -572,6 +587,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         if (ABL == 4) { asm volatile("" :: "v"(ra[0].x), "v"(ra[1].x), "v"(rb[0].x), "v"(rb[1].x)); }
     }
 
+    if (p.ksplits > 1) {          // raw partial sums; bias / affine / activation / scatter happen in splitk_epilogue
+        float* Pp = p.part + (long long)blockIdx.y * p.M * p.N;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= p.M) continue;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int col = n0 + wn * 64 + u * 32 + l31;
+                    if (col < p.N) Pp[row * p.N + col] = acc[t][u][r];
+                }
+            }
+        return;
+    }
     // ---- epilogue: per-column parameters are loaded once, then 64 row-contiguous 128-byte stores per wave ----
     float cb[2], cs[2], ct[2];
     int ccol[2], ctap[2];
@@ -809,6 +840,46 @@ __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ p
     }
 }
 
+// split-K epilogue of the NN kernels: out = act((sum_s part[s] + bias) * scale + shift), PLAIN or deconv scatter
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_epilogue(GemmArgs p)
+{
+    const long long total = p.M * (long long)(p.N >> 2);
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int nq = p.N >> 2;
+    const long long slab = p.M * (long long)p.N;
+    const long long hw = (long long)p.H * p.W;
+    for (; i < total; i += stride) {
+        const long long row = i / nq;
+        const int col = (int)(i - row * nq) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < p.ksplits; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(p.part + k * slab + row * p.N + col);
+            s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        }
+        float v[4] = {s.x, s.y, s.z, s.w};
+        int tap = 0, cc = col;
+        if (EPI == EP_DECONV) { tap = col / p.Co; cc = col - tap * p.Co; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (p.bias) v[e] += p.bias[cc + e];
+            if (p.scale) v[e] = fmaf(v[e], p.scale[col + e], p.shift[col + e]);
+            if (p.act == MYOLO_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+        }
+        float* dst;
+        if (EPI == EP_PLAIN) {
+            dst = p.C + row * p.ldc + col;
+        } else {
+            const long long n_img = row / hw;
+            const int rem = (int)(row - n_img * hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+            dst = p.C + (n_img * 4 * hw + (long long)y * 4 * p.W + 2 * x + (long long)(tap >> 1) * 2 * p.W + (tap & 1)) * p.Co + cc;
+        }
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
 // out[z][c][r] = in[zmap(z)][r][c]; reverse!=0 maps z -> nz-1-z (3x3 tap rotation by 180 degrees)
 __global__ void transpose_batched(const float* __restrict__ in, float* __restrict__ out, int R, int C, int nz, int reverse)
 {
@@ -840,7 +911,7 @@ static int launch_transpose(const float* in, float* out, int R, int C, int nz, i
 }
 
 template <int AMODE, int EPI>
-static int launch_nn(const GemmArgs& a, hipStream_t s)
+static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, size_t sk_ws_bytes = 0)
 {
     const long long tiles = cdiv64(a.M, BM) * ((a.N + BN - 1) / BN);
     if (tiles <= 0) return MYOLO_OK;
@@ -855,9 +926,31 @@ static int launch_nn(const GemmArgs& a, hipStream_t s)
         else if (abl[0] == '3') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 3>), dim3((unsigned)tiles), dim3(256), 0, s, a);
         else if (abl[0] == '4') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
         else hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 5>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-    } else if (aligned && kfast && !getenv("MYOLO_GEMM_GENERIC"))
-        hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-    else
+    } else if (aligned && kfast && !getenv("MYOLO_GEMM_GENERIC")) {
+        // under-filled grid (fewer tiles than the 1024 resident-workgroup slots) and a long K loop: split K so the
+        // whole chip works on it; a lone 128x128 tile with K = 2304 takes ~185 us however few tiles there are
+        const int nk = a.K / BK;
+        int splits = 1;
+        if (sk_ws && tiles < 512 && nk >= 16 && (a.N & 3) == 0 && (EPI == EP_PLAIN ? (a.ldc & 3) == 0 : (a.Co & 3) == 0) &&
+            !getenv("MYOLO_NO_SPLITK")) {
+            splits = (int)(1024 / tiles);
+            if (splits > nk / 8) splits = nk / 8;
+            const size_t per = (size_t)a.M * a.N * sizeof(float);
+            if ((size_t)splits * per > sk_ws_bytes) splits = (int)(sk_ws_bytes / per);
+            if (splits < 2) splits = 1;
+        }
+        if (splits > 1) {
+            am.ksplits = splits;
+            am.part = (float*)sk_ws;
+            hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI>), dim3((unsigned)tiles, splits), dim3(256), 0, s, a);
+            const long long total = a.M * (long long)(a.N / 4);
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL((splitk_epilogue<EPI>), dim3(blocks), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+        }
+    } else
         hipLaunchKernelGGL((gemm_nn<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
 }
@@ -946,7 +1039,8 @@ int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
     GemmArgs a = {};
     a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = M; a.N = Cin; a.K = Cout;
     a.lda = Cout; a.ldb = Cin; a.ldc = Cin;
-    launch_nn<AM_PLAIN, EP_PLAIN>(a, s);
+    const size_t wbytes = align256((size_t)Cin * Cout * sizeof(float));
+    launch_nn<AM_PLAIN, EP_PLAIN>(a, s, (char*)ws + wbytes, ws_bytes > wbytes ? ws_bytes - wbytes : 0);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -964,20 +1058,20 @@ int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
 }
 
 int myolo_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,
-                      int N, int H, int W, int Cin, int Cout, void* stream)
+                      int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, "conv3x3_fwd: bad arguments");
     MYOLO_REQUIRE(Cin % BK == 0, "conv3x3_fwd: Cin must be a multiple of %d (got %d)", BK, Cin);
     GemmArgs a = {};
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin;
     a.ldb = Cout; a.ldc = Cout; a.H = H; a.W = W; a.Cc = Cin;
-    launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream);
+    launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
 
 int myolo_conv3x3_affine_act_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift,
-                                 float* y, int N, int H, int W, int Cin, int Cout, int act, void* stream)
+                                 float* y, int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && w && y && scale && shift && N > 0 && H > 0 && W > 0, "conv3x3_affine_act_fwd: bad arguments");
     MYOLO_REQUIRE(Cin % BK == 0, "conv3x3_affine_act_fwd: Cin must be a multiple of %d (got %d)", BK, Cin);
@@ -986,7 +1080,7 @@ int myolo_conv3x3_affine_act_fwd(const float* x, const float* w, const float* bi
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.scale = scale; a.shift = shift; a.act = act;
     a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin;
     a.ldb = Cout; a.ldc = Cout; a.H = H; a.W = W; a.Cc = Cin;
-    launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream);
+    launch_nn<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1003,7 +1097,8 @@ int myolo_conv3x3_bwd_data(const float* dy, const float* w, float* dx,
     GemmArgs a = {};
     a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 9 * Cout;
     a.ldb = Cin; a.ldc = Cin; a.H = H; a.W = W; a.Cc = Cout;
-    launch_nn<AM_CONV3, EP_PLAIN>(a, s);
+    const size_t wbytes = align256((size_t)9 * Cin * Cout * sizeof(float));
+    launch_nn<AM_CONV3, EP_PLAIN>(a, s, (char*)ws + wbytes, ws_bytes > wbytes ? ws_bytes - wbytes : 0);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1039,14 +1134,14 @@ int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, flo
 }
 
 int myolo_deconv2x2s2_bwd_data(const float* dy, const float* w, float* dx,
-                               int N, int H, int W, int Cin, int Cout, void* stream)
+                               int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(dy && w && dx && N > 0, "deconv2x2s2_bwd_data: bad arguments");
     MYOLO_REQUIRE(Cout % BK == 0, "deconv2x2s2_bwd_data: Cout must be a multiple of %d", BK);
     GemmArgs a = {};
     a.A = dy; a.B = w; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 4 * Cout;
     a.ldb = Cin; a.ldc = Cin; a.H = H; a.W = W; a.Cc = Cout;
-    launch_nn<AM_DECONV, EP_PLAIN>(a, (hipStream_t)stream);
+    launch_nn<AM_DECONV, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -25,12 +25,12 @@ SIGS = {
     "myolo_pwconv1x1_fwd": [P, P, P, P, L, I, I, P],
     "myolo_pwconv1x1_bwd_data": [P, P, P, L, I, I, P, Z, P],
     "myolo_pwconv1x1_bwd_weight": [P, P, P, L, I, I, P, Z, P],
-    "myolo_conv3x3_fwd": [P, P, P, P, I, I, I, I, I, P],
-    "myolo_conv3x3_affine_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P],
+    "myolo_conv3x3_fwd": [P, P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_conv3x3_affine_act_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_deconv2x2s2_fwd": [P, P, P, P, I, I, I, I, I, I, P, Z, P],
-    "myolo_deconv2x2s2_bwd_data": [P, P, P, I, I, I, I, I, P],
+    "myolo_deconv2x2s2_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_deconv2x2s2_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_colsum": [P, P, L, I, P, Z, P],
     "myolo_bn_stats": [P, P, P, P, P, P, P, P, P, L, I, P, Z, P],

@@ -308,7 +308,7 @@ class Net(object):
         Cf = cfg.TOP_FEATURE_MAP_DEPTH
         Fm = self._new(n * h * w, Cf)
         X.call("myolo_conv3x3_fwd", X.ptr(C4), X.ptr(self.p["feature_map/kernel"]), X.ptr(self.p["feature_map/bias"]), X.ptr(Fm),
-               n, h, w, c, Cf, X.stream())
+               n, h, w, c, Cf, *self._wsargs(), X.stream())
         for f, s in YOLO_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
@@ -388,12 +388,12 @@ class Net(object):
                        X.ptr(buf[2]), X.ptr(buf[3]), MASK_FILTERS, X.stream())
                 self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_affine_act_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
                                  X.ptr(self.p[cn + "/bias"]), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps, cin,
-                                 MASK_FILTERS, ACT_RELU, X.stream())
+                                 MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
                 self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
                 x = y
             else:
                 self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
-                                 X.ptr(self.p[cn + "/bias"]), X.ptr(y), NR, ps, ps, cin, MASK_FILTERS, X.stream())
+                                 X.ptr(self.p[cn + "/bias"]), X.ptr(y), NR, ps, ps, cin, MASK_FILTERS, *self._wsargs(), X.stream())
                 x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
             cin = MASK_FILTERS
         d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
@@ -422,7 +422,7 @@ class Net(object):
         self.colsum(dd, self.g["myolo_mask_deconv/bias"])
         da = self._new(NR * ps * ps, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NR, ps, ps,
-               MASK_FILTERS, MASK_FILTERS, X.stream())
+               MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
         del dd
         for i in range(4, 0, -1):
             cn = "myolo_mask_conv%d" % i
@@ -501,7 +501,7 @@ class Net(object):
         self.colsum(dd, self.g["myolo_mask_deconv/bias"])
         da = self._new(NP * q, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NP, ps, ps,
-               MASK_FILTERS, MASK_FILTERS, X.stream())
+               MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
         for i in range(4, 1, -1):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             xin = self._gather(convs[i - 1], idx_d, NP, q)
@@ -510,7 +510,7 @@ class Net(object):
                 # same kernel (same k order per output element -> the same fp32 values)
                 c_p = self._new(NP * q, MASK_FILTERS)
                 X.call("myolo_conv3x3_fwd", X.ptr(xin), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(c_p),
-                       NP, ps, ps, MASK_FILTERS, MASK_FILTERS, X.stream())
+                       NP, ps, ps, MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
             else:
                 c_p = self._gather(self.tape[bn][0], idx_d, NP, q)
             dy = self.bn_act_bwd(bn, da, y_override=c_p)

@@ -51,7 +51,7 @@ def test_mask_conv3x3_adjoint_linear_and_sampled_oracle(gen):
     dy = rn(gen, M, C)
     y, dx, dw = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV), torch.empty(3, 3, C, C, device=DEV)
     zero = torch.zeros(C, device=DEV)
-    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), X.ptr(y), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), X.ptr(y), NR, PS, PS, C, C, *ws(), X.stream())
     X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), NR, PS, PS, C, C, *ws(), X.stream())
     X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), NR, PS, PS, C, C, *ws(), X.stream())
     a, b, c = dot(dy, y), dot(x, dx), dot(w, dw)
@@ -60,12 +60,12 @@ def test_mask_conv3x3_adjoint_linear_and_sampled_oracle(gen):
     # linearity
     x2 = rn(gen, M, C)
     y2, y3 = torch.empty_like(y), torch.empty_like(y)
-    X.call("myolo_conv3x3_fwd", X.ptr(x2), X.ptr(w), X.ptr(zero), X.ptr(y2), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_conv3x3_fwd", X.ptr(x2), X.ptr(w), X.ptr(zero), X.ptr(y2), NR, PS, PS, C, C, *ws(), X.stream())
     x3 = (0.5 * x + x2).contiguous()
-    X.call("myolo_conv3x3_fwd", X.ptr(x3), X.ptr(w), X.ptr(zero), X.ptr(y3), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_conv3x3_fwd", X.ptr(x3), X.ptr(w), X.ptr(zero), X.ptr(y3), NR, PS, PS, C, C, *ws(), X.stream())
     assert float((y3 - (0.5 * y + y2)).abs().max()) <= 1e-3 * float(y3.abs().max())
     # sampled ROIs (first, one in the middle, last -> exercises the tail tiles) against the oracle, with bias
-    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(bias), X.ptr(y), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(bias), X.ptr(y), NR, PS, PS, C, C, *ws(), X.stream())
     wn, bn = w.cpu().numpy(), bias.cpu().numpy()
     for roi in (0, NR // 2 + 3, NR - 1):
         xs = x.view(NR, PS, PS, C)[roi:roi + 1].cpu().numpy()
@@ -80,7 +80,7 @@ def test_deconv_adjoint_full_size(gen):
     y, dx, dw = torch.empty(4 * M, C, device=DEV), torch.empty(M, C, device=DEV), torch.empty(2, 2, C, C, device=DEV)
     zero = torch.zeros(C, device=DEV)
     X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), X.ptr(y), NR, PS, PS, C, C, 0, *ws(), X.stream())
-    X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), NR, PS, PS, C, C, X.stream())
+    X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), NR, PS, PS, C, C, *ws(), X.stream())
     X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), NR, PS, PS, C, C, *ws(), X.stream())
     a = dot(dy, y)
     close(a, dot(x, dx))

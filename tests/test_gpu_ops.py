@@ -86,7 +86,7 @@ def test_conv3x3(N, H, W, Cin, Cout):
     x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout)
     dy = rnd(rng, N, H, W, Cout)
     y = new(N, H, W, Cout)
-    X.call("myolo_conv3x3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, X.stream())
+    X.call("myolo_conv3x3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, *ws(), X.stream())
     check(y, O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64), what="conv3 fwd")
     rdx, rdw, rdb = O.conv2d_bwd(x, w, dy, pads=(1, 1, 1, 1), acc=np.float64)
     dx, dw = new(N, H, W, Cin), new(3, 3, Cin, Cout)
@@ -110,7 +110,7 @@ def test_deconv2x2s2(N, H, W, Cin, Cout):
     check(y, ref, what="deconv fwd")
     rdx, rdw, rdb = O.deconv2x2s2_bwd(x, w, dy)
     dx, dw = new(N, H, W, Cin), new(2, 2, Cout, Cin)
-    X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, Cin, Cout, X.stream())
+    X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, Cin, Cout, *ws(), X.stream())
     X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(dt(x)), X.ptr(dt(dy)), X.ptr(dw), N, H, W, Cin, Cout, *ws(), X.stream())
     check(dx, rdx, what="deconv dx")
     check(dw, rdw, what="deconv dw")

@@ -46,7 +46,7 @@ def main():
         x, w, b, y = rn(M, C), rn(3, 3, C, Co) * 0.02, rn(Co), torch.empty(M, Co, device=dev)
         flop = 2.0 * M * 9 * C * Co
         if a.which == "conv3x3_fwd":
-            fn = lambda: X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, Co, st)   # noqa: E731
+            fn = lambda: X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, Co, ws.data_ptr(), ws.numel(), st)   # noqa: E731
         elif a.which == "conv3x3_bwd_data":
             fn = lambda: X.call("myolo_conv3x3_bwd_data", X.ptr(x), X.ptr(w), X.ptr(y), NR, ps, ps, C, C, ws.data_ptr(), ws.numel(), st)   # noqa: E731
         else:
