@@ -415,15 +415,21 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
 
 // ABL (tuning only, results are wrong for ABL != 0): 1 = no global loads / LDS stores in the loop,
 // 2 = additionally no barrier, 3 = additionally no LDS fragment reads.
-template <int AMODE, int EPI, int ABL = 0>
+// WNT = MFMA 32x32 tiles per wave along N: 2 -> 128x128 block tile (4 waves/SIMD), 4 -> 128x256 (2 waves/SIMD,
+// A fetched once for 256 output channels, 25 % fewer loads and LDS reads per MFMA).
+template <int AMODE, int EPI, int ABL = 0, int WNT = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 {
     __shared__ float As[2][BK][LDAS];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+    constexpr int BN_ = 64 * WNT;          // block tile width
+    constexpr int BLANES = BN_ / 4;        // lanes covering one B row with float4
+    constexpr int BROWS = 256 / BLANES;    // B rows loaded per pass
+    constexpr int NB = BK / BROWS;         // passes (float4 per thread)
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN_];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int ntn = (p.N + BN - 1) / BN;
+    const int ntn = (p.N + BN_ - 1) / BN_;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed; used for speed only).  Give each XCD a
     // contiguous run of tiles so the N-tiles that share an A tile are consecutive on ONE L2.
     long long bid;
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
     }
     const int tn = (int)(bid % ntn);
     const long long m0 = (bid / ntn) * BM;
-    const int n0 = tn * BN;
+    const int n0 = tn * BN_;
     const long long hw = (long long)p.H * p.W;
 
     // ---- A descriptor: base advanced to this workgroup's first reachable row ----
@@ -475,16 +481,16 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
             else arow[i] = (unsigned)((4 * mm - 2 * ax[i] - base_row) * row_elems + akq) * 4u;
         }
     }
-    const int bk = tid >> 5, bn4 = (tid & 31) * 4;
+    const int bk = tid / BLANES, bn4 = (tid % BLANES) * 4;
     const bool bcol_ok = (n0 + bn4) < p.N;
     const unsigned brow_stride = (unsigned)p.ldb * 4u;
     unsigned boff0 = bcol_ok ? ((unsigned)bk * (unsigned)p.ldb + (unsigned)(n0 + bn4)) * 4u : OOB_OFF;   // advanced to kt_begin below
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][WNT];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+        for (int u = 0; u < WNT; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         else if (AMODE == AM_PLAIN) { c0 = kt_begin * BK; }
         else { const int per_tap = p.Cc / BK; tap = kt_begin / per_tap; c0 = (kt_begin - tap * per_tap) * BK; }
     }
-    float4 ra[2], rb[2];
+    float4 ra[2], rb[NB];
 
     auto gload = [&]() {
         if (AMODE == AM_PLAIN) {
@@ -528,11 +534,11 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         if (AMODE == AM_CONV3) {      // B row of this k tile = tap*Cc + c0 (+bk)
             const unsigned krow = (unsigned)(tap * p.Cc + c0 + bk);
             const unsigned bo = bcol_ok ? (krow * (unsigned)p.ldb + (unsigned)(n0 + bn4)) * 4u : OOB_OFF;
-            rb[0] = bufld4(rb_desc, bo);
-            rb[1] = bufld4(rb_desc, bcol_ok ? bo + 8u * brow_stride : OOB_OFF);
-        } else {
-            rb[0] = bufld4(rb_desc, boff0);                               // k rows always < K (K % BK == 0)
-            rb[1] = bufld4(rb_desc, bcol_ok ? boff0 + 8u * brow_stride : OOB_OFF);
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = bufld4(rb_desc, bcol_ok ? bo + (unsigned)(i * BROWS) * brow_stride : OOB_OFF);
+        } else {                                                          // k rows always < K (K % BK == 0)
+#pragma unroll
+            for (int i = 0; i < NB; ++i) rb[i] = bufld4(rb_desc, bcol_ok ? boff0 + (unsigned)(i * BROWS) * brow_stride : OOB_OFF);
             boff0 = bcol_ok ? boff0 + (unsigned)BK * brow_stride : OOB_OFF;
         }
         if (grouped) {
@@ -551,13 +557,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
             As[buf][akq + 1][ar + 64 * i] = ra[i].y;
             As[buf][akq + 2][ar + 64 * i] = ra[i].z;
             As[buf][akq + 3][ar + 64 * i] = ra[i].w;
-            *reinterpret_cast<float4*>(&Bs[buf][bk + 8 * i][bn4]) = rb[i];
         }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(&Bs[buf][bk + BROWS * i][bn4]) = rb[i];
     };
 
     if (bcol_ok && AMODE != AM_CONV3) boff0 += (unsigned)kt_begin * (unsigned)BK * brow_stride;
     const int half = lane >> 5, l31 = lane & 31;
-    const int arow_l = wm * 64 + l31, bcol_l = wn * 64 + l31;
+    const int arow_l = wm * 64 + l31, bcol_l = wn * 32 * WNT + l31;
     if (nk > 0) {
         gload();
         sstore(0);
@@ -568,23 +575,35 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if ((ABL == 0 || ABL == 4) && more) gload();
-        float fa0 = As[cur][half * 8][arow_l], fa1 = As[cur][half * 8][arow_l + 32];
-        float fb0 = Bs[cur][half * 8][bcol_l], fb1 = Bs[cur][half * 8][bcol_l + 32];
+        float fa[2], fb[WNT];
+        fa[0] = As[cur][half * 8][arow_l]; fa[1] = As[cur][half * 8][arow_l + 32];
+#pragma unroll
+        for (int u = 0; u < WNT; ++u) fb[u] = Bs[cur][half * 8][bcol_l + 32 * u];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float na0 = fa0 + 1.f, na1 = fa1 + 1.f, nb0 = fb0 + 1.f, nb1 = fb1 + 1.f;
+            float na[2], nb[WNT];
+            na[0] = fa[0] + 1.f; na[1] = fa[1] + 1.f;
+#pragma unroll
+            for (int u = 0; u < WNT; ++u) nb[u] = fb[u] + 1.f;
             if (j < 7 && ABL < 3) {
                 const int kk = half * 8 + j + 1;
-                na0 = As[cur][kk][arow_l]; na1 = As[cur][kk][arow_l + 32];
-                nb0 = Bs[cur][kk][bcol_l]; nb1 = Bs[cur][kk][bcol_l + 32];
+                na[0] = As[cur][kk][arow_l]; na[1] = As[cur][kk][arow_l + 32];
+#pragma unroll
+                for (int u = 0; u < WNT; ++u) nb[u] = Bs[cur][kk][bcol_l + 32 * u];
             }
-            MFMA_STEP()
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < WNT; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[u], acc[t][u], 0, 0, 0);
             if ((ABL == 0 || ABL == 5) && j == 3 && more) sstore(cur ^ 1);   // tile t+1 lands in the other buffer mid-sequence
-            fa0 = na0; fa1 = na1; fb0 = nb0; fb1 = nb1;
+            fa[0] = na[0]; fa[1] = na[1];
+#pragma unroll
+            for (int u = 0; u < WNT; ++u) fb[u] = nb[u];
         }
         if (ABL < 2) __syncthreads();
         if (ABL == 0) cur ^= 1;
-        if (ABL == 4) { asm volatile("" :: "v"(ra[0].x), "v"(ra[1].x), "v"(rb[0].x), "v"(rb[1].x)); }
+        if (ABL == 4) { asm volatile("" :: "v"(ra[0].x), "v"(ra[1].x), "v"(rb[0].x), "v"(rb[NB - 1].x)); }
     }
 
     if (p.ksplits > 1) {          // raw partial sums; bias / affine / activation / scatter happen in splitk_epilogue
@@ -596,20 +615,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
                 const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row >= p.M) continue;
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int col = n0 + wn * 64 + u * 32 + l31;
+                for (int u = 0; u < WNT; ++u) {
+                    const int col = n0 + wn * 32 * WNT + u * 32 + l31;
                     if (col < p.N) Pp[row * p.N + col] = acc[t][u][r];
                 }
             }
         return;
     }
     // ---- epilogue: per-column parameters are loaded once, then 64 row-contiguous 128-byte stores per wave ----
-    float cb[2], cs[2], ct[2];
-    int ccol[2], ctap[2];
-    bool cok[2];
+    float cb[WNT], cs[WNT], ct[WNT];
+    int ccol[WNT], ctap[WNT];
+    bool cok[WNT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int col = n0 + wn * 64 + u * 32 + l31;
+    for (int u = 0; u < WNT; ++u) {
+        const int col = n0 + wn * 32 * WNT + u * 32 + l31;
         cok[u] = col < p.N;
         const int colc = cok[u] ? col : 0;
         ctap[u] = 0;
@@ -636,7 +655,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
                 rowoff = n_img * 4 * hw + (long long)y * 4 * p.W + 2 * x;
             }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < WNT; ++u) {
                 if (!cok[u]) continue;
                 float v = fmaf(acc[t][u][r] + cb[u], cs[u], ct[u]);
                 if (relu) v = fmaxf(v, 0.f);
@@ -938,6 +957,12 @@ static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, si
             const size_t per = (size_t)a.M * a.N * sizeof(float);
             if ((size_t)splits * per > sk_ws_bytes) splits = (int)(sk_ws_bytes / per);
             if (splits < 2) splits = 1;
+        }
+        static const bool w256 = getenv("MYOLO_GEMM_W256") != nullptr;
+        if (w256 && (a.N % 256) == 0 && tiles >= 1024) {
+            const long long tiles256 = cdiv64(a.M, BM) * (a.N / 256);
+            hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI, 0, 4>), dim3((unsigned)tiles256), dim3(256), 0, s, a);
+            return MYOLO_OK;
         }
         if (splits > 1) {
             am.ksplits = splits;

@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from oracle import np_model, np_ops as O                      # noqa: E402
-from myolo.config import make_config, ShapesConfig, ShapesHeadConfig  # noqa: E402
+from myolo.config import make_config, ShapesConfig, ShapesHeadConfig, RiceConfig  # noqa: E402
 from myolo.model import MaskYOLO                               # noqa: E402
 from myolo.shapes import make_shapes_samples                   # noqa: E402
 from myolo.myolo_utils import BatchGenerator                   # noqa: E402
@@ -325,3 +325,33 @@ def test_rccl_reducer_path_single_rank_group():
         dist.destroy_process_group()
     l0, p0 = run(False)
     assert l0 == l1 and torch.equal(p0, p1)
+
+
+def test_inference_rice_416_matches_oracle():
+    """BASELINE.json configs[3] shape in fp32: 416x416, 5 rice anchors (example/rice/anchors_5.txt), 2 classes,
+    G=13, R=845 boxes all through ROIAlign + mask head (model.py:926-931: no score gate).  alpha=1, batch 1."""
+    cfg = make_config(RiceConfig, BATCH_SIZE=1)
+    assert (cfg.GRID_W, cfg.TRAIN_ROIS_PER_IMAGE, cfg.NUM_CLASSES) == (13, 845, 2)
+    P = np_model.init_params(cfg, seed=5, bias_scale=0.05)
+    rng = np.random.default_rng(5)
+    images = rng.random((1, 416, 416, 3), dtype=np.float32)
+    ref = np_model.inference_fwd(P, images, cfg)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    yo, det, mask = model.keras_model.predict([images])
+    assert yo.shape == (1, 13, 13, 5, 7) and det.shape == (1, 845, 6) and mask.shape == (1, 845, 28, 28, 2)
+    assert rel(yo, ref["yolo_output"]) < TOL
+    margin = np.sort(ref["yolo_output"][..., 5:], -1)
+    safe = (margin[..., -1] - margin[..., -2]).reshape(1, -1) > 1e-3          # class argmax decided by > 1e-3
+    assert np.array_equal(det[..., 5][safe], ref["detections"][..., 5][safe])
+    assert rel(det[..., :5], ref["detections"][..., :5]) < TOL
+    # ROI sample rows within fp32 noise of the extrapolation boundary may flip to zero rows on one side
+    # (see decision_margins); compare the masks of ROIs whose sample coordinates are safely inside/outside.
+    fh = ref["feature_map"].shape[1]
+    rb = O.roi_boxes_to_crop_order(ref["detections"][0, :, :4], cfg.ROI_BOX_ORDER)
+    ok = np.ones(845, bool)
+    for lo, hi in ((rb[:, 0], rb[:, 2]), (rb[:, 1], rb[:, 3])):
+        c = O._crop_coords(lo, hi, fh, cfg.MASK_POOL_SIZE)
+        ok &= np.minimum(np.abs(c), np.abs(c - (fh - 1))).min(1) > 2e-2
+    assert ok.sum() > 600
+    assert rel(mask[0][ok], ref["myolo_mask"][0][ok]) < TOL
