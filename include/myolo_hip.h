@@ -163,6 +163,13 @@ int myolo_mask_targets(const float* proposals, const int32_t* gt_class_ids, cons
                        const uint8_t* gt_masks, float* rois, int32_t* target_class_ids, float* target_masks,
                        int32_t* n_pos, int B, int R, int T, int H, int W, int mh, int mw, void* stream);
 
+/* ---- inference post-processing: unmold_mask for all detections of one image (myolo_utils.py:883-912 as
+ *      called from MaskYOLO.decode_masks model.py:1355-1389).  masks [N,mh,mw,C] post-sigmoid, detections [N,6]
+ *      (x1,y1,x2,y2,score,class) normalised; full_masks [H,W,N] uint8 0/1 (class channel picked, order-1 resize to
+ *      the clamped pixel window, threshold 0.5, paste). ---- */
+int myolo_unmold_masks(const float* masks, const float* detections, uint8_t* full_masks,
+                       int N, int mh, int mw, int C, int H, int W, void* stream);
+
 /* ---- final mask conv 1x1 + bias + sigmoid (myolo_mask model.py:713-714), C small ---- */
 int myolo_mask_head_out_fwd(const float* x, const float* w, const float* bias, float* p,
                             int64_t M, int Cin, int C, void* stream);

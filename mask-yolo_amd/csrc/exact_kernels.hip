@@ -323,6 +323,50 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// unmold_mask for every detection of one image (myolo_utils.py:883-912 inside MaskYOLO.decode_masks,
+// model.py:1355-1389): pick the class channel, resize the mh x mw mask to the detection's clamped pixel
+// window (order-1, pixel centres aligned, edge clamp -- float32, this operation order), threshold at 0.5,
+// paste.  out[H][W][N] uint8 (the reference's np.stack(axis=-1) layout); lanes run along N so a wave writes
+// N contiguous bytes per pixel.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void unmold_kernel(const float* __restrict__ masks, const float* __restrict__ det,
+                                                     uint8_t* __restrict__ out, int N, int mh, int mw, int C, int H, int W)
+{
+    const long long total = (long long)H * W * N;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const int n = (int)(i % N);
+        const int pix = (int)(i / N);
+        const int y = pix / W, x = pix - y * W;
+        const float* d = det + (long long)n * 6;
+        // image_shape[0] is used for x and [1] for y (myolo_utils.py:892); square images here
+        int x1 = min(max(0, (int)(d[0] * (float)W)), W), x2 = min(max(1, (int)(d[2] * (float)W)), W);
+        int y1 = min(max(0, (int)(d[1] * (float)H)), H), y2 = min(max(1, (int)(d[3] * (float)H)), H);
+        uint8_t v = 0;
+        if (y >= y1 && y < y2 && x >= x1 && x < x2) {
+            const int oh = max(1, y2 - y1), ow = max(1, x2 - x1);
+            const int cls = (int)d[5];
+            const float sy = (float)mh / (float)oh, sx = (float)mw / (float)ow;
+            float fy = ((float)(y - y1) + 0.5f) * sy - 0.5f;
+            float fx = ((float)(x - x1) + 0.5f) * sx - 0.5f;
+            fy = fminf(fmaxf(fy, 0.0f), (float)(mh - 1));
+            fx = fminf(fmaxf(fx, 0.0f), (float)(mw - 1));
+            const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+            const int yb = min(y0 + 1, mh - 1), xb = min(x0 + 1, mw - 1);
+            const float wy = fy - (float)y0, wx = fx - (float)x0;
+            const float* m = masks + (long long)n * mh * mw * C + cls;
+            const float tl = m[((long long)y0 * mw + x0) * C], tr = m[((long long)y0 * mw + xb) * C];
+            const float bl = m[((long long)yb * mw + x0) * C], br = m[((long long)yb * mw + xb) * C];
+            const float top = tl + (tr - tl) * wx;
+            const float bot = bl + (br - bl) * wx;
+            v = (top + (bot - top) * wy) >= 0.5f ? 1 : 0;
+        }
+        out[i] = v;
+    }
+}
+
 extern "C" {
 
 int myolo_yolo_decode(const float* y_pred, const float* anchors, float* proposals, int B, int G, int A, int C, void* stream)
@@ -341,6 +385,19 @@ int myolo_yolo_detections(const float* y_pred, const float* anchors, float* dete
     const int total = B * G * G * A;
     hipLaunchKernelGGL(yolo_decode_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, y_pred, anchors,
                        detections, total, G, A, 5 + C, 1);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_unmold_masks(const float* masks, const float* detections, uint8_t* full_masks, int N, int mh, int mw, int C, int H,
+                       int W, void* stream)
+{
+    MYOLO_REQUIRE(masks && detections && full_masks && N > 0 && mh > 0 && mw > 0 && C > 0 && H > 0 && W > 0, "unmold_masks: bad arguments");
+    const long long total = (long long)H * W * N;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(unmold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, masks, detections, full_masks, N, mh,
+                       mw, C, H, W);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

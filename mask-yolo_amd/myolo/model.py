@@ -222,9 +222,10 @@ class MaskYOLO(object):
         assert self.mode == 'inference'
         if weights_dir is not None:
             self.load_weights(weights_dir)
-        normed = np.expand_dims(image / 255., axis=0)
-        yolo_output, detections, myolo_mask = self.keras_model.predict([normed], verbose=0)
-        boxes, class_ids, scores, full_masks = self.decode_masks(detections, myolo_mask, image.shape)
+        normed = np.expand_dims(image / 255., axis=0).astype(np.float32)
+        x = torch.as_tensor(np.ascontiguousarray(normed), device=self.net.dev)
+        yolo_output, det_d, mask_d = self.net.predict(x)                   # device tensors
+        boxes, class_ids, scores, full_masks = self._decode_masks_device(det_d[0], mask_d[0], image.shape)
         top10 = np.argsort(scores)[::-1][:10]
         kept = np.array([i for i in top10 if scores[i] >= cs_threshold], dtype=np.int64)
         nmb = mutils.NMB(boxes[kept], class_ids[kept], kept, cfg.IMAGE_SHAPE, nms_threshold=0.7) if len(kept) else kept
@@ -236,11 +237,36 @@ class MaskYOLO(object):
             "full_masks": full_masks[:, :, nmb],
         }]
 
+    def _decode_masks_device(self, det, masks, image_shape):
+        """decode_masks (model.py:1330-1391) with the unmold/paste of every detection on the GPU
+        (myolo_unmold_masks).  det [N,6], masks [N,mh,mw,C] device tensors of one image."""
+        from . import _ext as X
+        det_h = det.cpu().numpy()
+        boxes, scores = det_h[:, :4], det_h[:, 4]
+        class_ids = det_h[:, 5].astype(np.int32)
+        keep = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0)[0]     # model.py:1373-1380
+        if keep.shape[0] != det_h.shape[0]:
+            idx = torch.as_tensor(keep, device=det.device)
+            det, masks = det.index_select(0, idx).contiguous(), masks.index_select(0, idx).contiguous()
+            boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
+        N = int(det.shape[0])
+        H, W = int(image_shape[0]), int(image_shape[1])
+        if N == 0:
+            return boxes, class_ids, scores, np.empty((H, W, 0))
+        mh, mw, C = int(masks.shape[1]), int(masks.shape[2]), int(masks.shape[3])
+        full = torch.empty(H, W, N, dtype=torch.uint8, device=det.device)
+        X.call("myolo_unmold_masks", X.ptr(masks.contiguous()), X.ptr(det.contiguous()), X.ptr(full), N, mh, mw, C, H, W, X.stream())
+        return boxes, class_ids, scores, full.cpu().numpy().astype(bool)
+
     def decode_masks(self, detections, myolo_mask, image_shape):
-        """model.py:1330-1391."""
+        """model.py:1330-1391 (numpy in / numpy out; the unmolding runs on the GPU)."""
         assert len(detections) == 1
         assert len(myolo_mask) == 1
         assert list(image_shape) == list(self.config.IMAGE_SHAPE)
+        if torch.cuda.is_available():
+            dev = self.net.dev
+            return self._decode_masks_device(torch.as_tensor(np.ascontiguousarray(detections[0], np.float32), device=dev),
+                                             torch.as_tensor(np.ascontiguousarray(myolo_mask[0], np.float32), device=dev), image_shape)
         detection, masks_all = detections[0], myolo_mask[0]
         N = len(detection)
         boxes = detection[:N, :4]

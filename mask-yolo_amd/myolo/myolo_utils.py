@@ -234,32 +234,31 @@ def NMB(boxes, class_ids, indices, image_shape, nms_threshold=0.3):
 
 
 def _resize_bilinear(mask, out_h, out_w):
-    """Bilinear resize with pixel-centre alignment (stands in for skimage.transform.resize
-    order=1, which is un-vendored; myolo_utils.py:903)."""
+    """Order-1 resize with pixel-centre alignment and edge clamp, float32 (stands in for the un-vendored
+    skimage.transform.resize, myolo_utils.py:903; same definition as the GPU kernel myolo_unmold_masks)."""
+    f = np.float32
+    mask = np.asarray(mask, f)
     h, w = mask.shape
-    ys = np.clip((np.arange(out_h) + 0.5) * h / out_h - 0.5, 0, h - 1)
-    xs = np.clip((np.arange(out_w) + 0.5) * w / out_w - 0.5, 0, w - 1)
-    y0 = np.floor(ys).astype(int)
-    x0 = np.floor(xs).astype(int)
-    y1 = np.minimum(y0 + 1, h - 1)
-    x1 = np.minimum(x0 + 1, w - 1)
-    wy = (ys - y0)[:, None]
-    wx = (xs - x0)[None, :]
-    top = mask[y0][:, x0] * (1 - wx) + mask[y0][:, x1] * wx
-    bot = mask[y1][:, x0] * (1 - wx) + mask[y1][:, x1] * wx
-    return top * (1 - wy) + bot * wy
+    ys = np.clip((np.arange(out_h, dtype=f) + f(0.5)) * (f(h) / f(out_h)) - f(0.5), f(0), f(h - 1)).astype(f)
+    xs = np.clip((np.arange(out_w, dtype=f) + f(0.5)) * (f(w) / f(out_w)) - f(0.5), f(0), f(w - 1)).astype(f)
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
+    wy, wx = (ys - y0.astype(f))[:, None], (xs - x0.astype(f))[None, :]
+    top = mask[y0][:, x0] + (mask[y0][:, x1] - mask[y0][:, x0]) * wx
+    bot = mask[y1][:, x0] + (mask[y1][:, x1] - mask[y1][:, x0]) * wx
+    return (top + (bot - top) * wy).astype(f)
 
 
 def unmold_mask(mask, bbox, image_shape):
     """myolo_utils.py:883-912: resize a 28x28 mask to its box, threshold 0.5, paste."""
-    threshold = 0.5
+    threshold = np.float32(0.5)
     w, h = image_shape[0], image_shape[1]
-    x1, y1, x2, y2 = bbox
-    x1 = min(max(0, int(x1 * w)), w)
-    x2 = min(max(1, int(x2 * w)), w)
-    y1 = min(max(0, int(y1 * h)), h)
-    y2 = min(max(1, int(y2 * h)), h)
-    m = _resize_bilinear(np.asarray(mask, np.float64), max(1, y2 - y1), max(1, x2 - x1))
+    x1, y1, x2, y2 = [np.float32(v) for v in bbox]
+    x1 = min(max(0, int(x1 * np.float32(w))), w)
+    x2 = min(max(1, int(x2 * np.float32(w))), w)
+    y1 = min(max(0, int(y1 * np.float32(h))), h)
+    y2 = min(max(1, int(y2 * np.float32(h))), h)
+    m = _resize_bilinear(mask, max(1, y2 - y1), max(1, x2 - x1))
     m = np.where(m >= threshold, 1, 0).astype(bool)
     full = np.zeros(image_shape[:2], dtype=bool)
     full[y1:y2, x1:x2] = m[:max(0, y2 - y1), :max(0, x2 - x1)]

@@ -355,3 +355,29 @@ def test_inference_rice_416_matches_oracle():
         ok &= np.minimum(np.abs(c), np.abs(c - (fh - 1))).min(1) > 2e-2
     assert ok.sum() > 600
     assert rel(mask[0][ok], ref["myolo_mask"][0][ok]) < TOL
+
+
+def test_train_api_reduces_loss_and_checkpoint_roundtrip(tmp_path):
+    """MaskYOLO.train (model.py:943-1060) through the public surface on a small Shapes set: the mean epoch loss
+    goes down, a checkpoint is written per epoch (model.py:1026) and loads back bit-exactly; set_trainable freezes
+    what the regex excludes (model.py:1120-1151)."""
+    from myolo.shapes import ShapesDataset
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=8)
+    ds = ShapesDataset(seed=7)
+    ds.load_shapes(32, 128, 128)
+    ds.prepare()
+    model = MaskYOLO(mode="training", config=cfg, model_dir=str(tmp_path), seed=1)
+    hist = model.train(ds, None, learning_rate=1e-3, epochs=4, layers="all", verbose=0)
+    assert len(hist) == 4 and np.isfinite(hist).all() and hist[-1] < 0.7 * hist[0], hist
+    ck = sorted(p for p in tmp_path.iterdir() if p.suffix == ".npz")
+    assert ck, "no checkpoint written"
+    m2 = MaskYOLO(mode="inference", config=cfg)
+    m2.load_weights(str(ck[-1]))
+    a, b = model.state_dict(), m2.state_dict()
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    # freeze everything but the mask head: backbone weights must not move
+    before = model.state_dict()
+    model.train(ds, None, learning_rate=1e-3, epochs=1, layers=r"myolo_mask.*", verbose=0)
+    after = model.state_dict()
+    assert np.array_equal(before["conv_pw_3/kernel"], after["conv_pw_3/kernel"])
+    assert not np.array_equal(before["myolo_mask_conv1/kernel"], after["myolo_mask_conv1/kernel"])
