@@ -130,6 +130,11 @@ class MaskYOLO(object):
         """model.py:1062-1118: Adam(lr, 0.9, 0.999, 1e-8); loss = sum of the batch-mean losses
         times LOSS_WEIGHTS.  (momentum is unused by the reference too.)"""
         self._lr = float(learning_rate)
+        # the reference instantiates a new keras.optimizers.Adam on every compile() (model.py:1071): fresh moments and
+        # step count.  (This is also what keeps frozen layers still: zero gradient AND zero momentum.)
+        self.net.flat_m.zero_()
+        self.net.flat_v.zero_()
+        self.net.adam_t = 0
 
     def train_on_batch(self, batch, learning_rate=None):
         """One optimisation step on a host batch (the six arrays of model.py:896-897).
