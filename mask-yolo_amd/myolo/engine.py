@@ -334,12 +334,18 @@ class Net(object):
             da = self.dw_block_bwd(bid, da)
             bid -= 1
         n, h, w, c = c4shape
-        Cf = dF.shape[1]
-        X.call("myolo_conv3x3_bwd_weight", X.ptr(C4), X.ptr(dF), X.ptr(self.g["feature_map/kernel"]), n, h, w, c, Cf, *self._wsargs(), X.stream())
-        self.colsum(dF, self.g["feature_map/bias"])
-        dC4 = self._new(n * h * w, c)
-        X.call("myolo_conv3x3_bwd_data", X.ptr(dF), X.ptr(self.p["feature_map/kernel"]), X.ptr(dC4), n, h, w, c, Cf, *self._wsargs(), X.stream())
-        X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
+        if dF is None:
+            # 'yolo' mode (model.py:906-920): feature_map and the mask head are not in the graph, their gradients are zero
+            self.g["feature_map/kernel"].zero_()
+            self.g["feature_map/bias"].zero_()
+            dC4 = da
+        else:
+            Cf = dF.shape[1]
+            X.call("myolo_conv3x3_bwd_weight", X.ptr(C4), X.ptr(dF), X.ptr(self.g["feature_map/kernel"]), n, h, w, c, Cf, *self._wsargs(), X.stream())
+            self.colsum(dF, self.g["feature_map/bias"])
+            dC4 = self._new(n * h * w, c)
+            X.call("myolo_conv3x3_bwd_data", X.ptr(dF), X.ptr(self.p["feature_map/kernel"]), X.ptr(dC4), n, h, w, c, Cf, *self._wsargs(), X.stream())
+            X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
         if self.on_bucket_ready:
             self.on_bucket_ready(1)
         da = dC4
@@ -545,9 +551,15 @@ class Net(object):
     # ------------------------------------------------------------------ steps
     def to_device_batch(self, batch):
         """host batch (the six arrays of model.py:896-897) -> device tensors in C-ABI dtypes."""
-        images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
         dev = self.dev
         T = self.cfg.TRUE_BOX_BUFFER
+        if len(batch) == 3:              # 'yolo' mode generator output (myolo_utils.py:849-851)
+            images, true_boxes, y_true = batch
+            return dict(
+                images=torch.as_tensor(np.ascontiguousarray(images, np.float32), device=dev),
+                true_boxes=torch.as_tensor(np.ascontiguousarray(np.asarray(true_boxes, np.float32).reshape(-1, T, 4)), device=dev),
+                y_true=torch.as_tensor(np.ascontiguousarray(y_true, np.float32), device=dev))
+        images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
         return dict(
             images=torch.as_tensor(np.ascontiguousarray(images, np.float32), device=dev),
             true_boxes=torch.as_tensor(np.ascontiguousarray(np.asarray(true_boxes, np.float32).reshape(-1, T, 4)), device=dev),
@@ -594,6 +606,28 @@ class Net(object):
         return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_proposals=proposals, output_rois=rois,
                     myolo_mask=pred.view(B, R, mh, mw, C), target_class_ids=tcls, target_mask=tmask, n_pos=npos,
                     yolo_terms=yterms, mask_terms=mterms, feature_map=Fm.view(*fshape), loss_weights=(w1, w2))
+
+    def forward_backward_yolo(self, db):
+        """'yolo' mode training step (model.py:906-920: outputs [yolo_output, yolo_sum_loss]): backbone + YOLO head
+        + yolo_custom_loss, no feature_map / ROIAlign / mask head.  db needs images, true_boxes, y_true."""
+        cfg = self.cfg
+        self.tape = {}
+        images = db["images"]
+        B = images.shape[0]
+        G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+        Fm, fshape, yo = self.trunk_fwd(images, True)
+        w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
+        yterms = self._new(8)
+        dyolo = self._new(yo.shape[0], yo.shape[1])
+        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+               X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
+               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+        lo, hi = self.bucket_ranges[2]
+        self.flat_g[lo:hi].zero_()
+        if self.on_bucket_ready:
+            self.on_bucket_ready(2)
+        self.trunk_bwd(None, dyolo)
+        return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_terms=yterms, loss_weights=(w1, 0.0))
 
     def adam_step(self, lr, b1=0.9, b2=0.999, eps=1e-8):
         """Keras Adam (model.py:1071-1075) over the whole flat buffer."""

@@ -144,10 +144,16 @@ class MaskYOLO(object):
             lr = self.config.LEARNING_RATE
         net = self.net
         db = batch if isinstance(batch, dict) else net.to_device_batch(batch)
-        out = net.forward_backward(db)
+        yolo_only = self.mode == 'yolo' or "gt_masks" not in db
+        out = net.forward_backward_yolo(db) if yolo_only else net.forward_backward(db)
         if getattr(self, "_train_mask", None) is not None:
             net.flat_g.mul_(self._train_mask)          # torch used as a memory op on a flag vector only
         net.adam_step(lr)
+        if yolo_only:
+            yt = out["yolo_terms"].cpu().numpy()
+            return dict(yolo_output=out["yolo_output"].cpu().numpy(), yolo_sum_loss=float(yt[0]), mask_loss=0.0,
+                        loss=float(yt[0] * out["loss_weights"][0]), loss_xy=float(yt[1]), loss_wh=float(yt[2]),
+                        loss_conf=float(yt[3]), loss_class=float(yt[4]), recall=float(yt[5]))
         return self._host_outputs(out)
 
     @staticmethod

@@ -252,6 +252,18 @@ def train_step_fwd_bwd(P, batch, cfg):
                 feature_map=Fm, C4=C4, grads=G, moving=T.moving, tape=T)
 
 
+def yolo_step_fwd_bwd(P, batch, cfg):
+    """'yolo' mode training step (model.py:906-920, compile :1084-1085): loss = mean(yolo_sum_loss) only."""
+    images, true_boxes, y_true = batch[:3]
+    T = Tape(P, cfg, training=True)
+    C4, Fm, yolo_out = T.trunk(images.astype(O.F32))
+    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=True)
+    w1 = O.F32(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
+    G = {}
+    T.trunk_bwd(np.zeros_like(Fm), yl["grad"] * w1, G)
+    return dict(yolo_output=yolo_out, yolo_sum_loss=yl["loss"], loss=O.F32(yl["loss"] * w1), grads=G)
+
+
 def inference_fwd(P, images, cfg):
     """inference graph model.py:922-936: outputs [yolo_output, detections, myolo_mask]."""
     T = Tape(P, cfg, training=False)

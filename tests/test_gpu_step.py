@@ -381,3 +381,33 @@ def test_train_api_reduces_loss_and_checkpoint_roundtrip(tmp_path):
     after = model.state_dict()
     assert np.array_equal(before["conv_pw_3/kernel"], after["conv_pw_3/kernel"])
     assert not np.array_equal(before["myolo_mask_conv1/kernel"], after["myolo_mask_conv1/kernel"])
+
+
+def test_yolo_mode_training_step_and_two_phase_recipe(tmp_path):
+    """'yolo' mode (model.py:906-920): the YOLO-only step matches the oracle, mask-side gradients
+    are zero; then the two-phase recipe of the examples (train_rice.py:42-43): load the YOLO weights into a
+    mask+yolo model with yolo_trainable=False and check only feature_map / mask head move."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    r = np_model.yolo_step_fwd_bwd(P, batch, cfg)
+    model = MaskYOLO(mode="yolo", config=cfg)
+    model.load_state_dict(P)
+    out = model.train_on_batch(batch[:3], learning_rate=0.0)
+    g = model.net.grads_dict()
+    assert abs(out["loss"] - float(r["loss"])) < 1e-4 * max(1.0, abs(float(r["loss"])))
+    assert rel(out["yolo_output"], r["yolo_output"]) < TOL
+    assert all(np.abs(v).max() == 0 for k, v in g.items() if k.startswith("myolo_mask") or k.startswith("feature_map"))
+    worst = max(float(np.linalg.norm(g[k].astype(np.float64) - v) / max(1e-30, np.linalg.norm(v)))
+                for k, v in r["grads"].items() if not (k.startswith("myolo_mask") or k.startswith("feature_map")))
+    assert worst < 2e-2, worst
+    ck = str(tmp_path / "yolo.npz")
+    model.save_weights(ck)
+    m2 = MaskYOLO(mode="training", config=cfg, yolo_pretrain_dir=ck, yolo_trainable=False)
+    assert np.array_equal(m2.state_dict()["conv_pw_9/kernel"], P["conv_pw_9/kernel"])
+    m2.set_trainable(".*")
+    m2.compile(1e-3, 0.9)
+    before = m2.state_dict()
+    m2.train_on_batch(batch)
+    after = m2.state_dict()
+    assert np.array_equal(before["conv_pw_9/kernel"], after["conv_pw_9/kernel"]) and np.array_equal(before["conv_23/bias"], after["conv_23/bias"])
+    assert not np.array_equal(before["feature_map/kernel"], after["feature_map/kernel"])
+    assert not np.array_equal(before["myolo_mask_conv2/kernel"], after["myolo_mask_conv2/kernel"])
