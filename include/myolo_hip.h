@@ -163,6 +163,18 @@ int myolo_mask_targets(const float* proposals, const int32_t* gt_class_ids, cons
                        const uint8_t* gt_masks, float* rois, int32_t* target_class_ids, float* target_masks,
                        int32_t* n_pos, int B, int R, int T, int H, int W, int mh, int mw, void* stream);
 
+/* ---- Shapes input producer: from per-image shape specifications to the six training inputs
+ *      of model.py:896-897 on the device -- ShapesDataset.load_image / load_mask / draw_shape
+ *      (example/shapes/dataset_shapes.py:80-135), load_image_gt's empty-instance filter + extract_bboxes
+ *      (myolo_utils.py:247-271,346-352) and BatchGenerator.__getitem__'s target encoding (myolo_utils.py:753-844).
+ *      spec [B, spec_stride] int32: bg r,g,b, n_shapes, then 13 ints per shape (type 1/2/3 = class id, r,g,b, x,y,s,
+ *      triangle vertices ax,ay,bx,by,cx,cy).  lut[256] = float32(v / 255.).  anchors double [2A]. ---- */
+int myolo_shapes_batch(const int32_t* spec, int spec_stride, const double* anchors, const float* lut,
+                       float* images, uint8_t* gt_masks, int32_t* gt_boxes, int32_t* gt_class_ids,
+                       float* y_true, float* true_boxes,
+                       int B, int H, int W, int S, int T, int G, int A, int C,
+                       void* ws, size_t ws_bytes, void* stream);
+
 /* ---- inference post-processing: unmold_mask for all detections of one image (myolo_utils.py:883-912 as
  *      called from MaskYOLO.decode_masks model.py:1355-1389).  masks [N,mh,mw,C] post-sigmoid, detections [N,6]
  *      (x1,y1,x2,y2,score,class) normalised; full_masks [H,W,N] uint8 0/1 (class channel picked, order-1 resize to

@@ -367,6 +367,133 @@ __global__ __launch_bounds__(256) void unmold_kernel(const float* __restrict__ m
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// GPU producer of the Shapes input pipeline: rasterise the images and instance masks
+// of a batch from their shape specifications (example/shapes/dataset_shapes.py:80-135: load_image / load_mask /
+// draw_shape incl. the occlusion rule :112-116), drop empty instances and take tight boxes (load_image_gt + extract_bboxes,
+// myolo_utils.py:247-271,346-352), and encode the YOLO targets (BatchGenerator.__getitem__, myolo_utils.py:753-844).
+// spec layout per image (int32): [bg_r, bg_g, bg_b, n_shapes] then SHAPE_INTS per shape:
+//   [type(1 square, 2 circle, 3 triangle), r, g, b, x, y, s, ax, ay, bx, by, cx, cy]  (triangle vertices already int-truncated)
+// ---------------------------------------------------------------------------------------
+#define SHAPE_INTS 13
+#define SPEC_MAXS 8
+
+__device__ __forceinline__ bool shape_covers(const int* sp, int px, int py)
+{
+    const int type = sp[0], x = sp[4], y = sp[5], s = sp[6];
+    if (type == 1) return px >= x - s && px <= x + s && py >= y - s && py <= y + s;
+    if (type == 2) return (px - x) * (px - x) + (py - y) * (py - y) <= s * s;
+    const int ax = sp[7], ay = sp[8], bx = sp[9], by = sp[10], cx = sp[11], cy = sp[12];
+    const int e0 = (px - ax) * (by - ay) - (py - ay) * (bx - ax);
+    const int e1 = (px - bx) * (cy - by) - (py - by) * (cx - bx);
+    const int e2 = (px - cx) * (ay - cy) - (py - cy) * (ax - cx);
+    return (e0 >= 0 && e1 >= 0 && e2 >= 0) || (e0 <= 0 && e1 <= 0 && e2 <= 0);
+}
+
+__global__ void shapes_stats_init_kernel(int* stats, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { stats[i * 5 + 0] = 0; stats[i * 5 + 1] = 0x7fffffff; stats[i * 5 + 2] = -1; stats[i * 5 + 3] = 0x7fffffff; stats[i * 5 + 4] = -1; }
+}
+
+// pass 1: per (image, shape) visible-pixel count and extent.  stats[b][s] = {count, minx, maxx, miny, maxy}
+__global__ __launch_bounds__(256) void shapes_stats_kernel(const int* __restrict__ spec, int spec_stride, int* __restrict__ stats,
+                                                           int H, int W, int S)
+{
+    const int b = blockIdx.y;
+    const int* sp = spec + (long long)b * spec_stride;
+    const int n = sp[3];
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= H * W) return;
+    const int py = pix / W, px = pix - py * W;
+    bool later = false;
+    for (int k = n - 1; k >= 0; --k) {          // walk from the last drawn shape: it occludes the earlier ones
+        const bool in = shape_covers(sp + 4 + k * SHAPE_INTS, px, py);
+        if (in && !later) {
+            int* st = stats + ((long long)b * S + k) * 5;
+            atomicAdd(st + 0, 1);
+            atomicMin(st + 1, px); atomicMax(st + 2, px);
+            atomicMin(st + 3, py); atomicMax(st + 4, py);
+        }
+        later = later || in;
+    }
+}
+
+// pass 2 (one workgroup per image): compaction of non-empty instances, boxes, class ids, YOLO target encoding
+__global__ void shapes_encode_kernel(const int* __restrict__ spec, int spec_stride, const int* __restrict__ stats, int* __restrict__ slotmap,
+                                     int32_t* __restrict__ gt_ids, int32_t* __restrict__ gt_boxes, float* __restrict__ y_true,
+                                     float* __restrict__ true_boxes, const double* __restrict__ anchors, int H, int W, int S, int T,
+                                     int G, int A, int C)
+{
+    const int b = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const int* sp = spec + (long long)b * spec_stride;
+    const int n = sp[3];
+    const double cell_w = (double)W / G, cell_h = (double)H / G;
+    int m = 0, tbi = 0;
+    for (int k = 0; k < S; ++k) slotmap[b * S + k] = -1;
+    for (int k = 0; k < n; ++k) {
+        const int* st = stats + ((long long)b * S + k) * 5;
+        if (st[0] <= 0 || m >= T) continue;                   // np.sum(mask) > 0 filter (myolo_utils.py:346)
+        slotmap[b * S + k] = m;
+        const int x1 = st[1], x2 = st[2] + 1, y1 = st[3], y2 = st[4] + 1;     // extract_bboxes: x2, y2 exclusive
+        const int cls = sp[4 + k * SHAPE_INTS];
+        gt_ids[b * T + m] = cls;
+        int32_t* gb = gt_boxes + ((long long)b * T + m) * 4;
+        gb[0] = x1; gb[1] = y1; gb[2] = x2; gb[3] = y2;
+        const double cx = .5 * (x1 + x2) / cell_w, cy = .5 * (y1 + y2) / cell_h;
+        const int gx = (int)floor(cx), gy = (int)floor(cy);
+        if (gx < G && gy < G) {
+            const double bw = (x2 - x1) / cell_w, bh = (y2 - y1) / cell_h;
+            int best = -1;
+            double max_iou = -1;
+            for (int j = 0; j < A; ++j) {
+                const double aw = anchors[2 * j], ah = anchors[2 * j + 1];
+                const double iw = fmin(bw, aw), ih = fmin(bh, ah);
+                const double inter = iw * ih;
+                const double iou = inter / (bw * bh + aw * ah - inter);
+                if (max_iou < iou) { best = j; max_iou = iou; }
+            }
+            float* yt = y_true + ((((long long)b * G + gy) * G + gx) * A + best) * (5 + C);
+            yt[0] = (float)cx; yt[1] = (float)cy; yt[2] = (float)bw; yt[3] = (float)bh; yt[4] = 1.0f;
+            yt[5 + cls] = 1.0f;
+            float* tb = true_boxes + ((long long)b * T + tbi) * 4;
+            tb[0] = (float)cx; tb[1] = (float)cy; tb[2] = (float)bw; tb[3] = (float)bh;
+            tbi = (tbi + 1) % T;
+        }
+        ++m;
+    }
+}
+
+// pass 3: pixels -- image (uint8 colour / 255 through a host-provided table) and instance masks in compacted order
+__global__ __launch_bounds__(256) void shapes_render_kernel(const int* __restrict__ spec, int spec_stride, const int* __restrict__ slotmap,
+                                                            const float* __restrict__ lut, float* __restrict__ images,
+                                                            uint8_t* __restrict__ masks, int H, int W, int S, int T)
+{
+    const int b = blockIdx.y;
+    const int* sp = spec + (long long)b * spec_stride;
+    const int n = sp[3];
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= H * W) return;
+    const int py = pix / W, px = pix - py * W;
+    int r = sp[0], g = sp[1], bl = sp[2];
+    uint8_t* mp = masks + ((long long)b * H * W + pix) * T;
+    for (int t = 0; t < T; ++t) mp[t] = 0;
+    bool later = false;
+    for (int k = n - 1; k >= 0; --k) {
+        const int* s1 = sp + 4 + k * SHAPE_INTS;
+        const bool in = shape_covers(s1, px, py);
+        if (in && !later) {
+            r = s1[1]; g = s1[2]; bl = s1[3];               // the top-most shape gives the pixel its colour
+            const int slot = slotmap[b * S + k];
+            if (slot >= 0) mp[slot] = 1;
+        }
+        later = later || in;
+    }
+    float* ip = images + ((long long)b * H * W + pix) * 3;
+    ip[0] = lut[r & 255]; ip[1] = lut[g & 255]; ip[2] = lut[bl & 255];
+}
+
 extern "C" {
 
 int myolo_yolo_decode(const float* y_pred, const float* anchors, float* proposals, int B, int G, int A, int C, void* stream)
@@ -385,6 +512,33 @@ int myolo_yolo_detections(const float* y_pred, const float* anchors, float* dete
     const int total = B * G * G * A;
     hipLaunchKernelGGL(yolo_decode_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, y_pred, anchors,
                        detections, total, G, A, 5 + C, 1);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_shapes_batch(const int32_t* spec, int spec_stride, const double* anchors, const float* lut, float* images, uint8_t* gt_masks,
+                       int32_t* gt_boxes, int32_t* gt_class_ids, float* y_true, float* true_boxes, int B, int H, int W, int S, int T,
+                       int G, int A, int C, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(spec && anchors && lut && images && gt_masks && gt_boxes && gt_class_ids && y_true && true_boxes, "shapes_batch: null pointer");
+    MYOLO_REQUIRE(B > 0 && H > 0 && W > 0 && S > 0 && S <= SPEC_MAXS && T > 0 && spec_stride >= 4 + S * SHAPE_INTS, "shapes_batch: bad sizes");
+    const size_t need = (size_t)B * S * 6 * sizeof(int);
+    MYOLO_NEED_WS(need);
+    int* stats = (int*)ws;
+    int* slotmap = stats + (size_t)B * S * 5;
+    hipStream_t s = (hipStream_t)stream;
+    // stats init: count 0, min = INT_MAX, max = -1  (pattern fill through a tiny kernel-free trick: two memsets)
+    (void)hipMemsetAsync(stats, 0, (size_t)B * S * 5 * sizeof(int), s);
+    (void)hipMemsetAsync(gt_boxes, 0, (size_t)B * T * 4 * sizeof(int32_t), s);
+    (void)hipMemsetAsync(gt_class_ids, 0, (size_t)B * T * sizeof(int32_t), s);
+    (void)hipMemsetAsync(y_true, 0, (size_t)B * G * G * A * (5 + C) * sizeof(float), s);
+    (void)hipMemsetAsync(true_boxes, 0, (size_t)B * T * 4 * sizeof(float), s);
+    hipLaunchKernelGGL(shapes_stats_init_kernel, dim3((B * S + 255) / 256), dim3(256), 0, s, stats, B * S);
+    dim3 grid((H * W + 255) / 256, B);
+    hipLaunchKernelGGL(shapes_stats_kernel, grid, dim3(256), 0, s, spec, spec_stride, stats, H, W, S);
+    hipLaunchKernelGGL(shapes_encode_kernel, dim3(B), dim3(64), 0, s, spec, spec_stride, stats, slotmap, gt_class_ids, gt_boxes, y_true,
+                       true_boxes, anchors, H, W, S, T, G, A, C);
+    hipLaunchKernelGGL(shapes_render_kernel, grid, dim3(256), 0, s, spec, spec_stride, slotmap, lut, images, gt_masks, H, W, S, T);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -211,6 +211,24 @@ class MaskYOLO(object):
         self.epoch = max(self.epoch, epochs)
         return history
 
+    def train_shapes_stream(self, steps, learning_rate=None, seed=1234, start_index=0, verbose=0):
+        """Train on the endless synthetic Shapes stream with the inputs produced ON THE DEVICE
+        (myolo.shapes.ShapesProducer): image g of the stream is bit-identical to what
+        ShapesDataset/load_image_gt/BatchGenerator would feed, without the Python rasteriser in the loop."""
+        from .shapes import ShapesProducer
+        cfg = self.config
+        prod = ShapesProducer(cfg, seed=seed, device=self._device)
+        self.set_trainable(".*")
+        self.compile(cfg.LEARNING_RATE if learning_rate is None else learning_rate, cfg.LEARNING_MOMENTUM)
+        losses = []
+        for i in range(steps):
+            lo = start_index + i * cfg.BATCH_SIZE
+            out = self.train_on_batch(prod.batch(list(range(lo, lo + cfg.BATCH_SIZE))))
+            losses.append(out["loss"])
+            if verbose:
+                print("step %d loss %.4f" % (i + 1, out["loss"]))
+        return losses
+
     # ------------------------------------------------------------------ inference
     def infer_yolo(self, image, weights_dir=None, save_path=None, display=False):
         """model.py:1198-1236 without the plotting: returns the decoded BoundBox list."""

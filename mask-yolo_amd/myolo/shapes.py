@@ -156,3 +156,61 @@ def make_shapes_samples(count, cfg, seed=1234, start_index=0):
     ds.load_shapes(count, cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1], start_index=start_index)
     ds.prepare()
     return [list(load_image_gt(ds, cfg, i)) for i in range(count)]
+
+
+class ShapesProducer(object):
+    """GPU producer of Shapes training batches.  The random shape specifications come
+    from the same seeded generator as ShapesDataset (so image g of the stream is identical to the host pipeline's);
+    rasterisation, the empty-instance filter, extract_bboxes and BatchGenerator's target encoding run on the device
+    (libmyolo_hip.so: myolo_shapes_batch) and the result is the device batch dict Net.forward_backward consumes."""
+
+    SHAPE_INTS, MAX_SHAPES = 13, 4
+    _TYPES = {"square": 1, "circle": 2, "triangle": 3}
+
+    def __init__(self, cfg, seed=1234, device="cuda:0"):
+        import torch
+        from . import _ext as X
+        X.load()
+        self.cfg, self.seed = cfg, seed
+        self.dev = torch.device(device)
+        self._ds = ShapesDataset(seed)
+        self.stride = 4 + self.MAX_SHAPES * self.SHAPE_INTS
+        self.lut = torch.tensor((np.arange(256) / 255.).astype(np.float32), device=self.dev)
+        self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float64), device=self.dev)
+        self.ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
+
+    def specs(self, indices):
+        H, W = self.cfg.IMAGE_SHAPE[0], self.cfg.IMAGE_SHAPE[1]
+        out = np.zeros((len(indices), self.stride), np.int32)
+        for k, g in enumerate(indices):
+            bg, shapes = self._ds.random_image(H, W, random.Random(self.seed + int(g)))
+            out[k, 0:3] = bg
+            out[k, 3] = len(shapes)
+            for j, (shape, color, (x, y, s_)) in enumerate(shapes):
+                o = 4 + j * self.SHAPE_INTS
+                out[k, o:o + 7] = (self._TYPES[shape],) + tuple(color) + (x, y, s_)
+                if shape == "triangle":
+                    kk = s_ / math.sin(math.radians(60))
+                    out[k, o + 7:o + 13] = np.array([x, y - s_, x - kk, y + s_, x + kk, y + s_]).astype(np.int32)
+        return out
+
+    def batch(self, indices):
+        """-> dict(images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks) of device tensors."""
+        import torch
+        from . import _ext as X
+        cfg = self.cfg
+        B = len(indices)
+        H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+        G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+        spec = torch.from_numpy(self.specs(indices)).to(self.dev)
+        d = dict(images=torch.empty(B, H, W, 3, device=self.dev),
+                 gt_masks=torch.empty(B, H, W, T, dtype=torch.uint8, device=self.dev),
+                 gt_boxes=torch.empty(B, T, 4, dtype=torch.int32, device=self.dev),
+                 gt_ids=torch.empty(B, T, dtype=torch.int32, device=self.dev),
+                 y_true=torch.empty(B, G, G, A, 5 + C, device=self.dev),
+                 true_boxes=torch.empty(B, T, 4, device=self.dev))
+        X.call("myolo_shapes_batch", X.ptr(spec), self.stride, X.ptr(self.anchors), X.ptr(self.lut), X.ptr(d["images"]),
+               X.ptr(d["gt_masks"]), X.ptr(d["gt_boxes"]), X.ptr(d["gt_ids"]), X.ptr(d["y_true"]), X.ptr(d["true_boxes"]),
+               B, H, W, self.MAX_SHAPES, T, G, A, C, self.ws.data_ptr(), self.ws.numel(), X.stream())
+        self._keep = spec          # the kernels read it asynchronously
+        return d

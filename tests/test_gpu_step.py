@@ -411,3 +411,19 @@ def test_yolo_mode_training_step_and_two_phase_recipe(tmp_path):
     assert np.array_equal(before["conv_pw_9/kernel"], after["conv_pw_9/kernel"]) and np.array_equal(before["conv_23/bias"], after["conv_23/bias"])
     assert not np.array_equal(before["feature_map/kernel"], after["feature_map/kernel"])
     assert not np.array_equal(before["myolo_mask_conv2/kernel"], after["myolo_mask_conv2/kernel"])
+
+
+def test_device_stream_training_equals_host_fed_training():
+    """feeding the step from the GPU producer gives bit-identical losses to feeding it the host pipeline's batches."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=8)
+    m1 = MaskYOLO(mode="training", config=cfg, seed=3)
+    l1 = m1.train_shapes_stream(3, learning_rate=1e-3, start_index=16)
+    m2 = MaskYOLO(mode="training", config=cfg, seed=3)
+    m2.set_trainable(".*")
+    m2.compile(1e-3, 0.9)
+    l2 = []
+    for i in range(3):
+        samples = make_shapes_samples(8, cfg, start_index=16 + 8 * i)
+        batch, _ = BatchGenerator(samples, cfg, "training", shuffle=False, norm=True)[0]
+        l2.append(m2.train_on_batch(batch)["loss"])
+    assert l1 == l2 and np.isfinite(l1).all()

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 
 from oracle import np_post as Q
+from oracle import np_ops as O
 from myolo import myolo_utils as mutils
 from myolo.config import ShapesConfig, RiceConfig, make_config
 
@@ -74,3 +75,27 @@ def test_gpu_unmold_and_detect_post_match_oracle(base, N):
     for k in ("bboxes", "class_ids", "confidence_scores", "full_masks"):
         assert np.array_equal(res[k], ref[k]), k
     assert res["full_masks"].shape[-1] <= 10
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("base,size", [(ShapesConfig, 224), (ShapesConfig, 128)])
+def test_gpu_shapes_producer_matches_host_pipeline(base, size):
+    """the device producer (rasterise + empty-instance filter + extract_bboxes + target encoding)
+    reproduces the host pipeline (ShapesDataset -> load_image_gt -> BatchGenerator) bit for bit, 64 images."""
+    import torch
+    from myolo.shapes import ShapesProducer, make_shapes_samples
+    from myolo.engine import Net
+    cfg = make_config(base, IMAGE_SHAPE=[size, size, 3], BATCH_SIZE=64)
+    start = 40
+    samples = make_shapes_samples(64, cfg, start_index=start)
+    host, _ = mutils.BatchGenerator(samples, cfg, "training", shuffle=False, norm=True)[0]
+    ref = O.encode_batch(samples, cfg)                      # the oracle's literal restatement of the encoding
+    d = ShapesProducer(cfg).batch(list(range(start, start + 64)))
+    torch.cuda.synchronize()
+    images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = host
+    assert np.array_equal(d["images"].cpu().numpy(), images) and np.array_equal(images, ref[0])
+    assert np.array_equal(d["gt_masks"].cpu().numpy().astype(bool), gt_masks)
+    assert np.array_equal(d["gt_boxes"].cpu().numpy(), gt_boxes) and np.array_equal(d["gt_ids"].cpu().numpy(), gt_ids)
+    assert np.array_equal(d["y_true"].cpu().numpy(), ref[2].astype(np.float32))
+    assert np.array_equal(d["true_boxes"].cpu().numpy(), ref[1].astype(np.float32).reshape(64, -1, 4))
+    assert gt_ids.max() == 3 and (gt_ids > 0).sum() > 64
