@@ -202,6 +202,26 @@ int myolo_mask_bce(const float* target_masks, const int32_t* target_class_ids, c
 int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* ---- bf16 inference path of the mask head (BASELINE.json configs[3]: Rice 416x416, bf16, inference-only) ----
+ * Activations are bf16 (uint16_t bit patterns, NHWC), accumulation fp32 on v_mfma_f32_32x32x16_bf16.  All four
+ * BatchNorm layers of build_mask_graph are frozen in inference (model.py:690-708), so they are folded into the
+ * packed weights.  pack_weights: w fp32 [K][N] (w_is_nk=0; HWIO kernel flattened) or [N][K] (w_is_nk=1; the
+ * Conv2DTranspose kernel [2,2,Co,Ci] flattened) -> wt bf16 [N][K]; gamma==NULL packs without folding. */
+int myolo_pack_weights_bf16(const float* w, int K, int N, int w_is_nk, const float* bias, const float* gamma, const float* beta,
+                            const float* mean, const float* var, uint16_t* wt, float* bias_out, void* stream);
+/* tf.image.crop_and_resize (model.py:385-387) with bf16 output; same sampling arithmetic as myolo_crop_and_resize_fwd */
+int myolo_crop_and_resize_bf16_fwd(const float* image, const float* boxes, const int32_t* box_ind, uint16_t* out,
+                                   int B, int H, int W, int C, int nb, int crop_h, int crop_w, void* stream);
+/* myolo_mask_conv1-4 + folded bn + relu (model.py:687-709): x [N,H,W,Cin] bf16, wt [Cout][9*Cin] bf16 */
+int myolo_conv3x3_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, uint16_t* y,
+                           int N, int H, int W, int Cin, int Cout, int act, void* stream);
+/* myolo_mask_deconv (model.py:711-712): wt [4*Cout][Cin] bf16, y [N,2H,2W,Cout] bf16 */
+int myolo_deconv2x2s2_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, uint16_t* y,
+                               int N, int H, int W, int Cin, int Cout, int act, void* stream);
+/* myolo_mask 1x1 + sigmoid (model.py:713-714) from bf16 activations; fp32 weights and probabilities */
+int myolo_mask_head_out_bf16_fwd(const uint16_t* x, const float* w, const float* bias, float* p,
+                                 int64_t M, int Cin, int C, void* stream);
+
 /* ---- small elementwise helpers ---- */
 int myolo_add_inplace(float* a, const float* b, int64_t n, void* stream);      /* a += b */
 int myolo_fill(float* a, float value, int64_t n, void* stream);

@@ -1,0 +1,390 @@
+// bf16-storage / fp32-accumulate inference kernels for the mask head (BASELINE.json configs[3]:
+// "Rice 416x416, 5 anchors, 28x28 mask head, bf16, inference-only").  The mask head is 99 % of the
+// inference FLOPs; on gfx950 v_mfma_f32_32x32x16_bf16 runs at 16x the
+// fp32 MFMA rate, so the ROIAlign output, the four 3x3 convs (BatchNorm folded into the weights -- all
+// BN layers are frozen in inference, model.py:690-708) and the 2x2 transposed conv are kept in bf16.
+//
+//   gemm_bf16<AMODE, EPI>:  C[m, n] = act( sum_k A(m, k) * Wt[n, k] + bias[n] )
+//     A bf16, gathered im2col-free (PLAIN rows or CONV3 taps with hardware zero-fill through a raw buffer
+//     descriptor), Wt bf16 [N][K] (k contiguous: weights are static, so they are stored transposed once),
+//     128x128x64 tiles, 4 waves x (2x2) MFMA 32x32x16, LDS rows padded to 144 B so every ds_read_b128
+//     fragment read (8 bf16 of one row) is bank-conflict-free, double-buffered, one barrier per K tile.
+//     EPI PLAIN stores bf16 [M, N]; EPI DECONV scatters the 2x2/s2 transposed-conv output (bf16).
+#include "myolo_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define TBM 128
+#define TBN 128
+#define TBK 64
+#define LDSROW 72            // bf16 elements per LDS row (64 + 8 pad = 144 bytes)
+#define OOB_OFF 0x7fffff00u
+
+enum { AM_PLAIN = 0, AM_CONV3 = 1 };
+enum { EP_PLAIN = 0, EP_DECONV = 1 };
+
+struct Bf16Args {
+    const uint16_t* A;       // bf16 bits
+    const uint16_t* Wt;      // [N][K]
+    uint16_t* C;             // bf16 out
+    const float* bias;       // [N] (EP_PLAIN) or [Co] (EP_DECONV)
+    long long M;
+    int N, K;
+    int H, W, Cc, Co;
+    int act;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, long long nbytes)
+{
+    if (nbytes < 0) nbytes = 0;
+    if (nbytes > 0x7ffffe00ll) nbytes = 0x7ffffe00ll;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(unsigned)nbytes, 0x00020000);
+}
+__device__ __forceinline__ u32x4 bufld(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    return __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+}
+__device__ __forceinline__ uint16_t f2bf(float f)
+{   // round to nearest even
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16(Bf16Args p)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][TBM][LDSROW];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][TBN][LDSROW];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + TBN - 1) / TBN;
+    long long bid;
+    {   // XCD-aware order (speed only): each XCD gets a contiguous run of tiles
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tn = (int)(bid % ntn);
+    const long long m0 = (bid / ntn) * TBM;
+    const int n0 = tn * TBN;
+    const long long hw = (long long)p.H * p.W;
+
+    // A descriptor with a per-workgroup base (32-bit offsets, out-of-range => zeros)
+    long long base_row, end_row, row_elems;
+    if (AMODE == AM_PLAIN) { base_row = m0; end_row = (m0 + TBM < p.M) ? m0 + TBM : p.M; row_elems = p.K; }
+    else {
+        base_row = m0 - (p.W + 1); if (base_row < 0) base_row = 0;
+        end_row = m0 + TBM + p.W + 1; if (end_row > p.M) end_row = p.M;
+        row_elems = p.Cc;
+    }
+    const __amdgpu_buffer_rsrc_t ra = mk_rsrc(p.A + base_row * row_elems, (end_row - base_row) * row_elems * 2);
+    const __amdgpu_buffer_rsrc_t rb = mk_rsrc(p.Wt, (long long)p.N * p.K * 2);
+
+    // each thread stages half a row (32 bf16 = 64 B = 4 x 16 B) of A and of B per K tile
+    const int lrow = tid >> 1, lhalf = tid & 1;
+    const long long am = m0 + lrow;
+    const bool avalid = am < p.M;
+    int ay = 0, ax = 0;
+    if (AMODE == AM_CONV3) {
+        const long long mm = avalid ? am : m0;
+        const long long n_img = mm / hw;
+        const int rem = (int)(mm - n_img * hw);
+        ay = rem / p.W; ax = rem - ay * p.W;
+    }
+    const unsigned arow = (unsigned)(((avalid ? am : m0) - base_row) * row_elems + lhalf * 32) * 2u;
+    const int bn = n0 + lrow;
+    const bool bvalid = bn < p.N;
+    const unsigned brow = (unsigned)((long long)(bvalid ? bn : 0) * p.K + lhalf * 32) * 2u;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nk = p.K / TBK;
+    int tap = 0, c0 = 0;
+    u32x4 va[4], vb[4];
+    auto gload = [&](int kt) {
+        unsigned aoff;
+        if (AMODE == AM_PLAIN) {
+            aoff = avalid ? arow + (unsigned)(kt * TBK) * 2u : OOB_OFF;
+        } else {
+            const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
+            const bool v = avalid && (unsigned)(ay + ty - 1) < (unsigned)p.H && (unsigned)(ax + tx - 1) < (unsigned)p.W;
+            const int shift = ((ty - 1) * p.W + (tx - 1)) * p.Cc + c0;
+            aoff = v ? arow + (unsigned)(shift * 2) : OOB_OFF;
+            c0 += TBK;
+            if (c0 == p.Cc) { c0 = 0; ++tap; }
+        }
+        const unsigned boff = bvalid ? brow + (unsigned)(kt * TBK) * 2u : OOB_OFF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            va[i] = bufld(ra, aoff == OOB_OFF ? OOB_OFF : aoff + 16u * i);
+            vb[i] = bufld(rb, boff == OOB_OFF ? OOB_OFF : boff + 16u * i);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<u32x4*>(&As[buf][lrow][lhalf * 32 + i * 8]) = va[i];
+            *reinterpret_cast<u32x4*>(&Bs[buf][lrow][lhalf * 32 + i * 8]) = vb[i];
+        }
+    };
+
+    const int half = lane >> 5, l31 = lane & 31;
+    if (nk > 0) { gload(0); sstore(0); }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            const int kc = ks * 16 + half * 8;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(&As[cur][wm * 64 + l31][kc]);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(&As[cur][wm * 64 + 32 + l31][kc]);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + l31][kc]);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(&Bs[cur][wn * 64 + 32 + l31][kc]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (ks == 1 && more) sstore(cur ^ 1);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias + activation, bf16 stores ----
+    float cb[2];
+    int ccol[2], ctap[2];
+    bool cok[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int col = n0 + wn * 64 + u * 32 + l31;
+        cok[u] = col < p.N;
+        const int colc = cok[u] ? col : 0;
+        ctap[u] = 0; ccol[u] = colc;
+        if (EPI == EP_DECONV) { ctap[u] = colc / p.Co; ccol[u] = colc - ctap[u] * p.Co; }
+        cb[u] = p.bias ? p.bias[ccol[u]] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= p.M) continue;
+            long long rowoff;
+            if (EPI == EP_PLAIN) rowoff = row * p.N;
+            else {
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                rowoff = n_img * 4 * hw + (long long)y * 4 * p.W + 2 * x;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (!cok[u]) continue;
+                float v = acc[t][u][r] + cb[u];
+                if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
+                if (EPI == EP_PLAIN) p.C[rowoff + ccol[u]] = f2bf(v);
+                else p.C[(rowoff + (long long)(ctap[u] >> 1) * 2 * p.W + (ctap[u] & 1)) * p.Co + ccol[u]] = f2bf(v);
+            }
+        }
+}
+
+// ROIAlign (crop_and_resize) with fp32 feature map in, bf16 out -- same coordinate arithmetic as crop_fwd_kernel
+__device__ __forceinline__ bool crop_coord_b(float lo, float hi, int size, int crop, int idx, float& in)
+{
+    if (crop > 1) {
+        const float scale = (hi - lo) * (float)(size - 1) / (float)(crop - 1);
+        in = lo * (float)(size - 1) + (float)idx * scale;
+    } else {
+        in = 0.5f * (lo + hi) * (float)(size - 1);
+    }
+    return !(in < 0.f || in > (float)(size - 1));
+}
+
+__global__ __launch_bounds__(256) void crop_fwd_bf16_kernel(const float* __restrict__ img, const float* __restrict__ boxes,
+                                                            const int32_t* __restrict__ bind, uint16_t* __restrict__ out,
+                                                            int H, int W, int C, int ch, int cw)
+{
+    const int b = blockIdx.y, py = blockIdx.x;
+    const int cq = C / 4;
+    const float4 bx = *reinterpret_cast<const float4*>(boxes + (long long)b * 4);
+    float iny;
+    const bool vy = crop_coord_b(bx.x, bx.z, H, ch, py, iny);
+    const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+    const float wy = iny - (float)ty;
+    const float* base = img + (long long)bind[b] * H * W * C;
+    uint16_t* orow = out + ((long long)b * ch + py) * cw * C;
+    const unsigned total = (unsigned)(cw * cq);
+    for (unsigned e = threadIdx.x; e < total; e += blockDim.x) {
+        const int px = e / (unsigned)cq;
+        const int c = (e - px * cq) * 4;
+        float inx;
+        const bool vx = crop_coord_b(bx.y, bx.w, W, cw, px, inx);
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (vy && vx) {
+            const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+            const float wx = inx - (float)lx;
+            const float4 tl = *reinterpret_cast<const float4*>(base + ((long long)ty * W + lx) * C + c);
+            const float4 tr = *reinterpret_cast<const float4*>(base + ((long long)ty * W + rx) * C + c);
+            const float4 bl = *reinterpret_cast<const float4*>(base + ((long long)by * W + lx) * C + c);
+            const float4 br = *reinterpret_cast<const float4*>(base + ((long long)by * W + rx) * C + c);
+            const float tlv[4] = {tl.x, tl.y, tl.z, tl.w}, trv[4] = {tr.x, tr.y, tr.z, tr.w};
+            const float blv[4] = {bl.x, bl.y, bl.z, bl.w}, brv[4] = {br.x, br.y, br.z, br.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float top = tlv[k] + (trv[k] - tlv[k]) * wx, bot = blv[k] + (brv[k] - blv[k]) * wx;
+                o[k] = top + (bot - top) * wy;
+            }
+        }
+        uint2 pk;
+        pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+        pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+        *reinterpret_cast<uint2*>(orow + (long long)px * C + c) = pk;
+    }
+}
+
+// final 1x1 conv + bias + sigmoid, bf16 activations in, fp32 probabilities out (one wave per row)
+template <int CC>
+__global__ __launch_bounds__(256) void mask_out_bf16_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, float* __restrict__ p, long long M, int Cin)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wave0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const long long nwaves = ((long long)gridDim.x * blockDim.x) >> 6;
+    const int cq = Cin / 4;
+    for (long long r = wave0; r < M; r += nwaves) {
+        float acc[CC];
+#pragma unroll
+        for (int k = 0; k < CC; ++k) acc[k] = 0.f;
+        for (int q = lane; q < cq; q += 64) {
+            const uint2 pk = *reinterpret_cast<const uint2*>(x + r * Cin + q * 4);
+            const float xv[4] = {bf2f((uint16_t)(pk.x & 0xffff)), bf2f((uint16_t)(pk.x >> 16)), bf2f((uint16_t)(pk.y & 0xffff)),
+                                 bf2f((uint16_t)(pk.y >> 16))};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int k = 0; k < CC; ++k) acc[k] = fmaf(xv[e], w[(q * 4 + e) * CC + k], acc[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < CC; ++k) {
+            float s = acc[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            acc[k] = s;
+        }
+        if (lane < CC) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < CC; ++k) if (lane == k) s = acc[k];
+            s += bias[lane];
+            p[r * CC + lane] = 1.f / (1.f + expf(-s));
+        }
+    }
+}
+
+
+// weight packing: fp32 [K][N] (HWIO flattened) or [N][K] -> bf16 [N][K], with the frozen BatchNorm that follows
+// the conv folded in:  w'[n,k] = w[k,n] * g[n],  b'[n] = b[n] * g[n] + beta[n] - mean[n] * g[n],  g = gamma / sqrt(var + eps)
+__global__ __launch_bounds__(256) void pack_weights_bf16_kernel(const float* __restrict__ w, int K, int N, int w_is_nk,
+                                                                const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ mean,
+                                                                const float* __restrict__ var, uint16_t* __restrict__ wt,
+                                                                float* __restrict__ bias_out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)N * K) return;
+    const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+    float g = 1.f;
+    if (gamma) g = gamma[n] / sqrtf(var[n] + BN_EPS_F);
+    const float v = w_is_nk ? w[i] : w[(long long)k * N + n];
+    wt[i] = f2bf(v * g);
+    if (k == 0 && bias_out) {
+        const float b = bias ? bias[n] : 0.f;
+        bias_out[n] = gamma ? b * g + (beta[n] - mean[n] * g) : b;
+    }
+}
+
+template <int AMODE, int EPI>
+static void launch_bf16(const Bf16Args& a, hipStream_t s)
+{
+    const long long tiles = cdiv64(a.M, TBM) * ((a.N + TBN - 1) / TBN);
+    if (tiles > 0) hipLaunchKernelGGL((gemm_bf16<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+}
+
+extern "C" {
+
+int myolo_conv3x3_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, uint16_t* y,
+                           int N, int H, int W, int Cin, int Cout, int act, void* stream)
+{
+    MYOLO_REQUIRE(x && wt && y && N > 0 && H > 0 && W > 0, "conv3x3_bf16_fwd: bad arguments");
+    MYOLO_REQUIRE(Cin % TBK == 0, "conv3x3_bf16_fwd: Cin must be a multiple of %d (got %d)", TBK, Cin);
+    Bf16Args a = {};
+    a.A = x; a.Wt = wt; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = Cout; a.K = 9 * Cin;
+    a.H = H; a.W = W; a.Cc = Cin; a.act = act;
+    launch_bf16<AM_CONV3, EP_PLAIN>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_deconv2x2s2_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, uint16_t* y,
+                               int N, int H, int W, int Cin, int Cout, int act, void* stream)
+{
+    MYOLO_REQUIRE(x && wt && y && N > 0 && H > 0 && W > 0, "deconv2x2s2_bf16_fwd: bad arguments");
+    MYOLO_REQUIRE(Cin % TBK == 0, "deconv2x2s2_bf16_fwd: Cin must be a multiple of %d (got %d)", TBK, Cin);
+    Bf16Args a = {};
+    a.A = x; a.Wt = wt; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
+    a.H = H; a.W = W; a.Co = Cout; a.act = act;
+    launch_bf16<AM_PLAIN, EP_DECONV>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_crop_and_resize_bf16_fwd(const float* image, const float* boxes, const int32_t* box_ind, uint16_t* out, int B, int H, int W,
+                                   int C, int nb, int crop_h, int crop_w, void* stream)
+{
+    MYOLO_REQUIRE(image && boxes && box_ind && out && B > 0 && (C & 3) == 0 && nb >= 0 && nb <= 65535, "crop_and_resize_bf16_fwd: bad arguments");
+    if (nb == 0) return MYOLO_OK;
+    hipLaunchKernelGGL(crop_fwd_bf16_kernel, dim3(crop_h, nb), dim3(256), 0, (hipStream_t)stream, image, boxes, box_ind, out, H, W, C,
+                       crop_h, crop_w);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_mask_head_out_bf16_fwd(const uint16_t* x, const float* w, const float* bias, float* p, int64_t M, int Cin, int C, void* stream)
+{
+    MYOLO_REQUIRE(x && w && bias && p && M > 0 && (Cin & 3) == 0 && C >= 1 && C <= 8, "mask_head_out_bf16_fwd: bad arguments (1<=C<=8)");
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (M + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+#define MO_CASE(K) case K: hipLaunchKernelGGL((mask_out_bf16_kernel<K>), dim3((unsigned)blocks), dim3(256), 0, s, x, w, bias, p, M, Cin); break;
+    switch (C) { MO_CASE(1) MO_CASE(2) MO_CASE(3) MO_CASE(4) MO_CASE(5) MO_CASE(6) MO_CASE(7) MO_CASE(8) }
+#undef MO_CASE
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_pack_weights_bf16(const float* w, int K, int N, int w_is_nk, const float* bias, const float* gamma, const float* beta,
+                            const float* mean, const float* var, uint16_t* wt, float* bias_out, void* stream)
+{
+    MYOLO_REQUIRE(w && wt && K > 0 && N > 0, "pack_weights_bf16: bad arguments");
+    MYOLO_REQUIRE(!gamma || (beta && mean && var && bias_out), "pack_weights_bf16: BN folding needs beta/mean/var/bias_out");
+    const long long total = (long long)N * K;
+    hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3((unsigned)cdiv64(total, 256)), dim3(256), 0, (hipStream_t)stream, w, K, N, w_is_nk,
+                       bias, gamma, beta, mean, var, wt, bias_out);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+}  // extern "C"

@@ -80,6 +80,13 @@ class Config(object):
     # them as [y1,x1,y2,x2].  "xyxy_as_yxyx" reproduces that; "yxyx" corrects it.
     ROI_BOX_ORDER = "xyxy_as_yxyx"
 
+    # ---- MI355X additions ---------------------------------------------------
+    # "fp32": every layer in fp32 (the reference's precision).  "bf16": the mask head of the inference
+    # graph (ROIAlign output, 4x conv3x3 with the frozen BN folded, deconv) stores bf16 and accumulates
+    # fp32 on the bf16 matrix cores; the trunk, the decode and the final sigmoid stay fp32.
+    # Training is always fp32.  (BASELINE.json configs[3].)
+    INFERENCE_DTYPE = "fp32"
+
     def __init__(self):
         self.finalize()
 

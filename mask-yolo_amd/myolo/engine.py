@@ -412,6 +412,48 @@ class Net(object):
         self.tape["mask"] = (convs, x, d)
         return p
 
+    def mask_head_fwd_bf16(self, Fm, fshape, rois):
+        """Inference-only mask head with bf16 activations / fp32 accumulation (cfg.INFERENCE_DTYPE == "bf16").
+        Same graph as mask_head_fwd(train=False) (model.py:680-714); the frozen BN of each conv is folded
+        into bf16 weights packed here from the live fp32 parameters (so training and load_weights need no hook)."""
+        cfg = self.cfg
+        B, R = rois.shape[:2]
+        n, h, w, cf = fshape
+        ps = cfg.MASK_POOL_SIZE
+        if cfg.ROI_BOX_ORDER == "xyxy_as_yxyx":
+            boxes = rois.reshape(B * R, 4)
+        else:
+            boxes = rois.reshape(B * R, 4)[:, [1, 0, 3, 2]].contiguous()
+        bind = torch.arange(B, device=self.dev, dtype=torch.int32).repeat_interleave(R).contiguous()
+        NR = B * R
+        bf = torch.bfloat16
+        x = self._new(NR * ps * ps, cf, dtype=bf)
+        self._call_timed("roialign_fwd", "myolo_crop_and_resize_bf16_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
+                         n, h, w, cf, NR, ps, ps, X.stream())
+        cin = cf
+        for i in range(1, 5):
+            cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
+            wt = self._new(MASK_FILTERS, 9 * cin, dtype=bf)
+            bfold = self._new(MASK_FILTERS)
+            X.call("myolo_pack_weights_bf16", X.ptr(self.p[cn + "/kernel"]), 9 * cin, MASK_FILTERS, 0, X.ptr(self.p[cn + "/bias"]),
+                   X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(self.s[bn + "/moving_mean"]),
+                   X.ptr(self.s[bn + "/moving_variance"]), X.ptr(wt), X.ptr(bfold), X.stream())
+            y = self._new(NR * ps * ps, MASK_FILTERS, dtype=bf)
+            self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(bfold), X.ptr(y),
+                             NR, ps, ps, cin, MASK_FILTERS, ACT_RELU, X.stream())
+            x, cin = y, MASK_FILTERS
+        wt = self._new(4 * MASK_FILTERS, MASK_FILTERS, dtype=bf)
+        X.call("myolo_pack_weights_bf16", X.ptr(self.p["myolo_mask_deconv/kernel"]), MASK_FILTERS, 4 * MASK_FILTERS, 1, None,
+               None, None, None, None, X.ptr(wt), None, X.stream())
+        d = self._new(NR * 4 * ps * ps, MASK_FILTERS, dtype=bf)
+        self._call_timed("mask_deconv_fwd", "myolo_deconv2x2s2_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(self.p["myolo_mask_deconv/bias"]),
+                         X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, X.stream())
+        C = cfg.NUM_CLASSES
+        p = self._new(NR * 4 * ps * ps, C)
+        X.call("myolo_mask_head_out_bf16_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
+               NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
+        return p
+
     def mask_head_bwd(self, dz):
         """dz [NR*mh*mw, C] gradient wrt the pre-sigmoid mask logits.  Returns dF."""
         cfg = self.cfg
@@ -656,7 +698,12 @@ class Net(object):
         det = self._new(B, R, 6)
         X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
         rois = det[..., :4].contiguous()
-        pred = self.mask_head_fwd(Fm, fshape, rois, False)
+        if cfg.INFERENCE_DTYPE == "bf16":
+            pred = self.mask_head_fwd_bf16(Fm, fshape, rois)
+        elif cfg.INFERENCE_DTYPE == "fp32":
+            pred = self.mask_head_fwd(Fm, fshape, rois, False)
+        else:
+            raise ValueError("INFERENCE_DTYPE must be 'fp32' or 'bf16' (got %r)" % (cfg.INFERENCE_DTYPE,))
         self.tape = {}
         return yo.view(B, G, G, A, 5 + C), det, pred.view(B, R, mh, mw, C)
 

@@ -1,0 +1,221 @@
+"""GPU parity tests of the bf16 inference path of the mask head (BASELINE.json configs[3]: Rice 416x416, 5 anchors,
+28x28 mask head, bf16, inference-only).
+
+Tolerance model, written out: activations and packed weights are rounded to bf16 (8 significant bits, relative
+step 2^-8 = 3.9e-3); accumulation is fp32.  Op tests feed the oracle the SAME bf16-rounded operands, so the only
+differences left are fp32 accumulation order and the final bf16 rounding of the stored result:
+    |got - ref| <= 2^-8 |ref| + 1e-3 max|ref|.
+End-to-end, six bf16 roundings sit between the fp32 feature map and the sigmoid; the bound on the mask
+probabilities is 3e-2 absolute (north-star fp32 bound 1e-3 does not apply to a bf16 storage path)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_ops as O, np_model               # noqa: E402
+from myolo import _ext as X                            # noqa: E402
+from myolo.config import make_config, ShapesConfig, RiceConfig  # noqa: E402
+from myolo.model import MaskYOLO                       # noqa: E402
+
+DEV = "cuda:0"
+BF16_STEP = 2.0 ** -8
+_KEEP = []
+
+
+@pytest.fixture(autouse=True)
+def _keepalive():
+    yield
+    torch.cuda.synchronize()
+    del _KEEP[:]
+
+
+def dt(a):
+    t = torch.as_tensor(np.ascontiguousarray(a), device=DEV)
+    _KEEP.append(t)
+    return t
+
+
+def bf16_round(a):
+    """fp32 -> nearest-even bf16 -> fp32 (numpy restatement of the kernel's f2bf)."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def to_bf16_dev(a):
+    """bf16-representable fp32 array -> device bf16 tensor (exact)."""
+    t = torch.as_tensor(np.ascontiguousarray(a), device=DEV).to(torch.bfloat16)
+    _KEEP.append(t)
+    return t
+
+
+def from_bf16(t):
+    return t.float().cpu().numpy()
+
+
+def check_bf16(got, ref, what):
+    ref = np.asarray(ref, np.float64)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert np.isfinite(got).all(), what + ": non-finite output"
+    bound = BF16_STEP * np.abs(ref) + 1e-3 * np.abs(ref).max()
+    bad = np.abs(got - ref) > bound
+    assert not bad.any(), "%s: %d elements beyond the bf16 bound (worst %.3e)" % (what, bad.sum(), np.abs(got - ref).max())
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+def test_bf16_round_helper_matches_torch():
+    rng = np.random.default_rng(0)
+    a = rnd(rng, 100000) * np.exp(rng.uniform(-20, 20, 100000)).astype(np.float32)
+    assert np.array_equal(bf16_round(a), torch.from_numpy(a).to(torch.bfloat16).float().numpy())
+
+
+@pytest.mark.parametrize("K,N,nk,fold", [(9 * 64, 256, 0, True), (256, 1024, 1, False), (9 * 256, 256, 0, True), (64, 48, 0, False)])
+def test_pack_weights(K, N, nk, fold):
+    rng = np.random.default_rng(1)
+    w = rnd(rng, N, K, scale=0.1) if nk else rnd(rng, K, N, scale=0.1)
+    bias = rnd(rng, N)
+    gamma, beta, mean = 1 + 0.2 * rnd(rng, N), rnd(rng, N, scale=0.1), rnd(rng, N, scale=0.3)
+    var = rng.uniform(0.5, 2.0, N).astype(np.float32)
+    wt = torch.zeros(N, K, dtype=torch.bfloat16, device=DEV)
+    bo = torch.full((N,), float("nan"), device=DEV)
+    args = [X.ptr(dt(gamma)), X.ptr(dt(beta)), X.ptr(dt(mean)), X.ptr(dt(var))] if fold else [None] * 4
+    X.call("myolo_pack_weights_bf16", X.ptr(dt(w)), K, N, nk, X.ptr(dt(bias)), *args, X.ptr(wt), X.ptr(bo), X.stream())
+    g = (gamma / np.sqrt(var + np.float32(1e-3))).astype(np.float32) if fold else np.ones(N, np.float32)
+    wnk = w if nk else w.T
+    assert np.array_equal(from_bf16(wt), bf16_round(wnk * g[:, None])), "packed weights are not the RNE bf16 of w*g"
+    bref = bias * g + (beta - mean * g) if fold else bias
+    assert np.abs(bo.cpu().numpy() - bref).max() < 1e-6
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 64, 256), (5, 14, 14, 256, 256), (2, 7, 9, 128, 48), (1, 28, 28, 64, 130)])
+def test_conv3x3_bf16(N, H, W, Cin, Cout):
+    rng = np.random.default_rng(2)
+    x = bf16_round(rnd(rng, N, H, W, Cin))
+    w = bf16_round(rnd(rng, 3, 3, Cin, Cout, scale=0.05))
+    b = rnd(rng, Cout)
+    wt = to_bf16_dev(w.reshape(9 * Cin, Cout).T)
+    y = torch.zeros(N, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    X.call("myolo_conv3x3_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(wt), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, 1, X.stream())
+    ref = O.relu(O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64))
+    check_bf16(from_bf16(y), ref, "conv3x3 bf16")
+    # no activation, no bias
+    X.call("myolo_conv3x3_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(wt), None, X.ptr(y), N, H, W, Cin, Cout, 0, X.stream())
+    check_bf16(from_bf16(y), O.conv2d(x, w, pads=(1, 1, 1, 1), acc=np.float64), "conv3x3 bf16 linear")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 256, 256), (2, 5, 7, 64, 40)])
+def test_deconv2x2s2_bf16(N, H, W, Cin, Cout):
+    rng = np.random.default_rng(3)
+    x = bf16_round(rnd(rng, N, H, W, Cin))
+    w = bf16_round(rnd(rng, 2, 2, Cout, Cin, scale=0.05))
+    b = rnd(rng, Cout)
+    y = torch.zeros(N, 2 * H, 2 * W, Cout, dtype=torch.bfloat16, device=DEV)
+    X.call("myolo_deconv2x2s2_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)), X.ptr(y),
+           N, H, W, Cin, Cout, 1, X.stream())
+    ref = O.relu(O.deconv2x2s2(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)))
+    check_bf16(from_bf16(y), ref, "deconv bf16")
+
+
+def _boxes(rng, nb):
+    c = rng.uniform(0.1, 0.9, (nb, 2))
+    hw = rng.uniform(0.05, 0.6, (nb, 2))
+    return np.concatenate([c - hw / 2, c + hw / 2], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("B,H,W,C,nb,crop", [(2, 26, 26, 256, 40, 14), (3, 7, 9, 16, 11, 5)])
+def test_crop_and_resize_bf16_is_rounded_fp32_kernel(B, H, W, C, nb, crop):
+    """same sampling arithmetic as the fp32 kernel: the bf16 output is the RNE rounding of the fp32 output up to one
+    bf16 step (fma contraction may differ between the two translation units)."""
+    rng = np.random.default_rng(7)
+    img, boxes = rnd(rng, B, H, W, C), _boxes(rng, nb)
+    bind = rng.integers(0, B, nb).astype(np.int32)
+    o32 = torch.zeros(nb, crop, crop, C, device=DEV)
+    o16 = torch.zeros(nb, crop, crop, C, dtype=torch.bfloat16, device=DEV)
+    a = (X.ptr(dt(img)), X.ptr(dt(boxes)), X.ptr(dt(bind)))
+    X.call("myolo_crop_and_resize_fwd", *a, X.ptr(o32), B, H, W, C, nb, crop, crop, X.stream())
+    X.call("myolo_crop_and_resize_bf16_fwd", *a, X.ptr(o16), B, H, W, C, nb, crop, crop, X.stream())
+    ref = O.crop_and_resize(img, boxes, bind, (crop, crop))
+    check_bf16(from_bf16(o16), ref, "crop bf16 vs oracle")
+    d = np.abs(from_bf16(o16) - o32.cpu().numpy())
+    assert (d <= BF16_STEP * np.abs(o32.cpu().numpy()) + 1e-6).all()
+
+
+@pytest.mark.parametrize("C", [1, 2, 4])
+def test_mask_head_out_bf16(C):
+    rng = np.random.default_rng(9)
+    M, Cin = 2 * 28 * 28, 256
+    x = bf16_round(np.maximum(rnd(rng, M, Cin), 0))
+    w, b = rnd(rng, Cin, C, scale=0.1), rnd(rng, C)
+    p = torch.full((M, C), float("nan"), device=DEV)
+    X.call("myolo_mask_head_out_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(p), M, Cin, C, X.stream())
+    ref = 1 / (1 + np.exp(-(x.astype(np.float64) @ w + b)))
+    assert np.abs(p.cpu().numpy() - ref).max() < 1e-5
+
+
+def test_bad_arguments_fail_loudly():
+    z = torch.zeros(16, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        X.call("myolo_conv3x3_bf16_fwd", X.ptr(z), X.ptr(z), None, X.ptr(z), 1, 4, 4, 32, 32, 0, X.stream())
+    with pytest.raises(RuntimeError, match="bad arguments"):
+        X.call("myolo_conv3x3_bf16_fwd", None, X.ptr(z), None, X.ptr(z), 1, 4, 4, 64, 32, 0, X.stream())
+
+
+def _nontrivial_bn(P, rng):
+    for k in list(P):
+        if k.startswith("myolo_mask_bn"):
+            n = P[k].shape[0]
+            if k.endswith("moving_mean"):
+                P[k] = (0.2 * rng.standard_normal(n)).astype(np.float32)
+            elif k.endswith("moving_variance"):
+                P[k] = rng.uniform(0.5, 1.5, n).astype(np.float32)
+            elif k.endswith("gamma"):
+                P[k] = (1 + 0.1 * rng.standard_normal(n)).astype(np.float32)
+            elif k.endswith("beta"):
+                P[k] = (0.1 * rng.standard_normal(n)).astype(np.float32)
+
+
+def test_inference_bf16_small_matches_oracle():
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=2, INFERENCE_DTYPE="bf16")
+    P = np_model.init_params(cfg, seed=3, bias_scale=0.05)
+    _nontrivial_bn(P, np.random.default_rng(11))
+    rng = np.random.default_rng(4)
+    images = rng.random((2, 128, 128, 3), dtype=np.float32)
+    ref = np_model.inference_fwd(P, images, cfg)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    yo, det, mask = model.keras_model.predict([images])
+    assert np.abs(yo - ref["yolo_output"]).max() / np.abs(ref["yolo_output"]).max() < 1e-3     # trunk stays fp32
+    d = np.abs(mask - ref["myolo_mask"])
+    # ROI rows on the extrapolation boundary may flip to zero rows (see test_gpu_step.decision_margins): judge by
+    # the bulk -- 99.9 % of the probabilities within the bf16 bound, none off by more than a boundary flip can explain
+    assert np.quantile(d, 0.999) < 3e-2, np.quantile(d, 0.999)
+    assert d.mean() < 3e-3, d.mean()
+
+
+def test_inference_bf16_rice_416_close_to_fp32_path():
+    """configs[3] shape: the bf16 mask head against this library's own fp32 mask head (itself pinned to the oracle in
+    test_gpu_step.test_inference_rice_416_matches_oracle).  The trunk is the same fp32 code, so yolo_output and the
+    detections are bit-identical and the ROIs are the same: the comparison isolates the bf16 storage error."""
+    cfg32 = make_config(RiceConfig, BATCH_SIZE=1)
+    cfg16 = make_config(RiceConfig, BATCH_SIZE=1, INFERENCE_DTYPE="bf16")
+    P = np_model.init_params(cfg32, seed=5, bias_scale=0.05)
+    _nontrivial_bn(P, np.random.default_rng(12))
+    images = np.random.default_rng(5).random((1, 416, 416, 3), dtype=np.float32)
+    outs = []
+    for cfg in (cfg32, cfg16):
+        model = MaskYOLO(mode="inference", config=cfg)
+        model.load_state_dict(P)
+        outs.append(model.keras_model.predict([images]))
+    (yo32, det32, m32), (yo16, det16, m16) = outs
+    assert np.array_equal(yo32, yo16) and np.array_equal(det32, det16)
+    assert m16.shape == (1, 845, 28, 28, 2)
+    d = np.abs(m16 - m32)
+    assert d.max() < 3e-2, d.max()
+    assert d.mean() < 2e-3, d.mean()
+    # the binarised masks (threshold 0.5, myolo_utils.py unmold) agree except where fp32 itself is within the bound of 0.5
+    decided = np.abs(m32 - 0.5) > 3e-2
+    assert np.array_equal((m16 > 0.5)[decided], (m32 > 0.5)[decided])

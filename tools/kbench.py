@@ -41,7 +41,20 @@ def main():
     NR, ps, C = a.rois, 14, 256
     M = NR * ps * ps
     st = X.stream()
-    if a.which.startswith("conv3x3"):
+    if a.which in ("conv3x3_bf16_fwd", "deconv_bf16_fwd"):
+        bf = torch.bfloat16
+        x, b = rn(M, C).to(bf), rn(C)
+        if a.which == "conv3x3_bf16_fwd":
+            wt, y = (rn(C, 9 * C) * 0.02).to(bf), torch.empty(M, C, dtype=bf, device=dev)
+            flop = 2.0 * M * 9 * C * C
+            fn = lambda: X.call("myolo_conv3x3_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, 1, st)   # noqa: E731
+        else:
+            wt, y = (rn(4 * C, C) * 0.02).to(bf), torch.empty(4 * M, C, dtype=bf, device=dev)
+            flop = 2.0 * M * C * 4 * C
+            fn = lambda: X.call("myolo_deconv2x2s2_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, 1, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("%s M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500 bf16 dense)" % (a.which, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0))
+    elif a.which.startswith("conv3x3"):
         Co = a.cout
         x, w, b, y = rn(M, C), rn(3, 3, C, Co) * 0.02, rn(Co), torch.empty(M, Co, device=dev)
         flop = 2.0 * M * 9 * C * Co
