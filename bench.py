@@ -106,6 +106,9 @@ def main():
                     help="3 = self-consistent Shapes head (R=147, primary); 5 = repository-HEAD head (R=245)")
     ap.add_argument("--cpu-images", type=int, default=8, help="images in the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--mask-head-rois", choices=["all", "positives"], default="all",
+                    help="cfg.TRAIN_MASK_HEAD_ROIS of the run that produces `value` (default: all ROIs, as the reference graph)")
+    ap.add_argument("--no-variant", action="store_true", help="skip the extra timed run of the other TRAIN_MASK_HEAD_ROIS setting")
     args = ap.parse_args()
 
     from myolo import dist as mdist
@@ -118,7 +121,8 @@ def main():
     torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     base = ShapesConfig if args.nbox == 3 else ShapesHeadConfig
-    cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch)
+    cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch,
+                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois)
     model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
     net = model.net
     reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)])
@@ -150,15 +154,39 @@ def main():
         elapsed = float(t.item())
     loss = float(out["yolo_terms"][0]) + float(out["mask_terms"][0])
     assert np.isfinite(loss), "non-finite loss in the timed region"
+    conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
+    roi_ms, _ = net.kernel_ms("roialign_fwd")
+
+    # the same K steps with the other TRAIN_MASK_HEAD_ROIS setting (reported beside `value`, never as `value`)
+    variant = None
+    if not args.no_variant:
+        net.timed_tags = set()
+        net.sparse_mask_fwd = not net.sparse_mask_fwd
+        for i in range(2):
+            net.train_step(dbs[i % nb], args.lr)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            net.train_step(dbs[i % nb], args.lr)
+        barrier()
+        el2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el2 = float(t.item())
+        variant = {"TRAIN_MASK_HEAD_ROIS": "positives" if net.sparse_mask_fwd else "all",
+                   "value": args.batch * world * args.steps / el2, "unit": "images/sec", "ms_per_step": 1e3 * el2 / args.steps,
+                   "note": "same loss, gradients, weights and BN state as the all-ROI forward (tests/test_gpu_step.py::"
+                           "test_positives_only_forward_equals_full_forward); conv2-4/deconv/myolo_mask forward run on the positive "
+                           "ROIs only, whose outputs are the only ones the training graph reads"}
+        net.sparse_mask_fwd = not net.sparse_mask_fwd
 
     if rank == 0:
         R = cfg.TRAIN_ROIS_PER_IMAGE
         ps = cfg.MASK_POOL_SIZE
         M = args.batch * R * ps * ps
-        conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
         flop = 2.0 * M * (9 * 256) * 256                      # algorithmic FLOPs of one mask-head 3x3 conv launch
         achieved = flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-        roi_ms, _ = net.kernel_ms("roialign_fwd")
         roi_bytes = args.batch * R * ps * ps * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
         traffic = None      # HBM-side bytes per launch of the dominant kernel, from the separate --pmc passes (tools/collect_profiles.sh)
         try:
@@ -176,8 +204,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
-                                   "(fwd+bwd+Adam%s)" % (args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
-                                                        "+RCCL all-reduce" if world > 1 else ""),
+                                   "(fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
+                                       args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
+                                       "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": {"kernel": "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M,
                          "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
@@ -189,6 +218,8 @@ def main():
                                        "frac": (roi_bytes / (roi_ms * 1e-3) / 1e9 / 8000.0) if roi_ms > 0 else 0.0,
                                        "avg_launch_ms": roi_ms}},
         }
+        if variant is not None:
+            res["variant"] = variant
         if args.cpu_images > 0 and world == 1:
             res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_images)
         elif args.cpu_images > 0:

@@ -11,6 +11,7 @@
 //     fragment read (8 bf16 of one row) is bank-conflict-free, double-buffered, one barrier per K tile.
 //     EPI PLAIN stores bf16 [M, N]; EPI DECONV scatters the 2x2/s2 transposed-conv output (bf16).
 #include "myolo_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -201,6 +202,185 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16(Bf16Args p)
         }
 }
 
+// ---- the same GEMM staged by LDS-DMA (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write pass ----
+// LDS image per operand and buffer: 128 rows x 128 B (64 bf16), unpadded (the DMA destination is wave-uniform base +
+// lane x 16 B, so padding is impossible); bank conflicts are avoided by an XOR swizzle of the 16-B chunk index with
+// bits 1..3 of the row, applied on the per-lane SOURCE address when filling and on the ds_read_b128 address when reading.
+// One wave instruction fills 8 rows; wave w fills rows 32w..32w+31 of A and of B (8 DMA instructions per K tile).
+// The MFMA operands are swapped (weights first) so a lane ends up with 4 consecutive output channels of one row:
+// the epilogue packs them to 8 B, transposes the tile through LDS and stores full 256-B row segments.
+#define CS_ROW 264           // bytes per row of the epilogue staging tile (256 + 8: conflict-free ds_write_b64 / ds_read_b64)
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16_glds(Bf16Args p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2][2][TBM * 128];   // [buffer][A|B]  64 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntn = (p.N + TBN - 1) / TBN;
+    long long bid;
+    {
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tn = (int)(bid % ntn);
+    const long long m0 = (bid / ntn) * TBM;
+    const int n0 = tn * TBN;
+    const long long hw = (long long)p.H * p.W;
+
+    long long base_row, end_row, row_elems;
+    if (AMODE == AM_PLAIN) { base_row = m0; end_row = (m0 + TBM < p.M) ? m0 + TBM : p.M; row_elems = p.K; }
+    else {
+        base_row = m0 - (p.W + 1); if (base_row < 0) base_row = 0;
+        end_row = m0 + TBM + p.W + 1; if (end_row > p.M) end_row = p.M;
+        row_elems = p.Cc;
+    }
+    const __amdgpu_buffer_rsrc_t ra = mk_rsrc(p.A + base_row * row_elems, (end_row - base_row) * row_elems * 2);
+    const __amdgpu_buffer_rsrc_t rb = mk_rsrc(p.Wt, (long long)p.N * p.K * 2);
+
+    // per-lane source offsets of the 4 A rows and 4 B rows this lane fills
+    unsigned arow[4], brow[4], amask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = wave * 32 + j * 8 + (lane >> 3);
+        const unsigned chunk = (unsigned)((lane & 7) ^ ((lrow >> 1) & 7));
+        const long long am = m0 + lrow;
+        const bool av = am < p.M;
+        const long long amc = av ? am : m0;
+        arow[j] = (unsigned)((amc - base_row) * row_elems) * 2u + chunk * 16u;
+        amask[j] = av ? 0x1ffu : 0u;
+        if (AMODE == AM_CONV3 && av) {
+            const int rem = (int)(am - (am / hw) * hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = t / 3, tx = t - ty * 3;
+                if ((unsigned)(y + ty - 1) < (unsigned)p.H && (unsigned)(x + tx - 1) < (unsigned)p.W) mk |= 1u << t;
+            }
+            amask[j] = mk;
+        }
+        const int bn = n0 + lrow;
+        brow[j] = bn < p.N ? (unsigned)((long long)bn * p.K) * 2u + chunk * 16u : OOB_OFF;
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nk = p.K / TBK;
+    int tap = 0, c0 = 0;
+    auto fill = [&](int kt, int buf) {
+        unsigned ashift, abit;
+        if (AMODE == AM_PLAIN) { ashift = (unsigned)(kt * TBK) * 2u; abit = 0; }
+        else {
+            const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
+            ashift = (unsigned)((((ty - 1) * p.W + (tx - 1)) * p.Cc + c0) * 2);
+            abit = (unsigned)tap;
+            c0 += TBK;
+            if (c0 == p.Cc) { c0 = 0; ++tap; }
+        }
+        const unsigned bshift = (unsigned)(kt * TBK) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ao = ((amask[j] >> abit) & 1u) ? arow[j] + ashift : OOB_OFF;
+            const unsigned bo = brow[j] == OOB_OFF ? OOB_OFF : brow[j] + bshift;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)&lds[buf][0][(wave * 32 + j * 8) * 128], 16, (int)ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)&lds[buf][1][(wave * 32 + j * 8) * 128], 16, (int)bo, 0, 0, 0);
+        }
+    };
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned rsw = (unsigned)((l31 >> 1) & 7);
+    if (nk > 0) fill(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fill(kt + 1, cur ^ 1);
+        const unsigned char* Ab = &lds[cur][0][(wm * 64 + l31) * 128];
+        const unsigned char* Bb = &lds[cur][1][(wn * 64 + l31) * 128];
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            const unsigned co = (((unsigned)(ks * 2 + half)) ^ rsw) * 16u;
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(Ab + co);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(Ab + 32 * 128 + co);
+            const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(Bb + co);
+            const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(Bb + 32 * 128 + co);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: bias + activation, pack 4 channels, transpose through LDS, row-contiguous stores ----
+    unsigned char* Cs = &lds[0][0][0];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + u * 32 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + nl + e;
+                    float b = 0.f;
+                    if (p.bias && n < p.N) b = p.bias[EPI == EP_DECONV ? n % p.Co : n];
+                    v[e] = acc[t][u][4 * g + e] + b;
+                    if (p.act == MYOLO_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(Cs + (wm * 64 + t * 32 + l31) * CS_ROW + nl * 2) = pk;
+            }
+    __syncthreads();
+    const bool vec_ok = (p.N & 3) == 0 && (EPI == EP_PLAIN || (p.Co & 3) == 0);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int idx = it * 256 + tid;
+        const int row = idx >> 5, cq = idx & 31;
+        const long long m = m0 + row;
+        const int n = n0 + cq * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const uint2 pk = *reinterpret_cast<const uint2*>(Cs + row * CS_ROW + cq * 8);
+        long long pix = m;
+        if (EPI == EP_DECONV) {
+            const long long n_img = m / hw;
+            const int rem = (int)(m - n_img * hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+            pix = n_img * 4 * hw + (long long)y * 4 * p.W + 2 * x;
+        }
+        if (vec_ok) {
+            long long off;
+            if (EPI == EP_PLAIN) off = pix * p.N + n;
+            else { const int tp = n / p.Co, co = n - tp * p.Co; off = (pix + (long long)(tp >> 1) * 2 * p.W + (tp & 1)) * p.Co + co; }
+            *reinterpret_cast<uint2*>(p.C + off) = pk;
+        } else {
+            const uint16_t e4[4] = {(uint16_t)(pk.x & 0xffff), (uint16_t)(pk.x >> 16), (uint16_t)(pk.y & 0xffff), (uint16_t)(pk.y >> 16)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (n + e >= p.N) break;
+                long long off;
+                if (EPI == EP_PLAIN) off = pix * p.N + n + e;
+                else { const int tp = (n + e) / p.Co, co = (n + e) - tp * p.Co; off = (pix + (long long)(tp >> 1) * 2 * p.W + (tp & 1)) * p.Co + co; }
+                p.C[off] = e4[e];
+            }
+        }
+    }
+}
+
 // ROIAlign (crop_and_resize) with fp32 feature map in, bf16 out -- same coordinate arithmetic as crop_fwd_kernel
 __device__ __forceinline__ bool crop_coord_b(float lo, float hi, int size, int crop, int idx, float& in)
 {
@@ -320,7 +500,10 @@ template <int AMODE, int EPI>
 static void launch_bf16(const Bf16Args& a, hipStream_t s)
 {
     const long long tiles = cdiv64(a.M, TBM) * ((a.N + TBN - 1) / TBN);
-    if (tiles > 0) hipLaunchKernelGGL((gemm_bf16<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    if (tiles <= 0) return;
+    static const bool regstage = getenv("MYOLO_BF16_REGSTAGE") != nullptr;    // ablation: register-staged variant
+    if (regstage) hipLaunchKernelGGL((gemm_bf16<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_bf16_glds<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
 }
 
 extern "C" {

@@ -325,6 +325,18 @@ __global__ __launch_bounds__(256) void gather_groups_kernel(const float* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void gather_groups_scalar_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                                   float* __restrict__ dst, int n, long long ge)
+{
+    const long long total = (long long)n * ge;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < total; i += stride) {
+        const long long g = i / ge, o = i - g * ge;
+        dst[i] = src[(long long)idx[g] * ge + o];
+    }
+}
+
 // Row-sparse training-mode BN backward: the upstream gradient is non-zero only in the row groups
 // listed in idx (compact tensor dyc [n*grows, C]); x is dense [M, C].
 struct OpBnBwdSparse {
@@ -1050,7 +1062,14 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
 
 int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n, int64_t group_elems, void* stream)
 {
-    MYOLO_REQUIRE(src && idx && dst && n > 0 && group_elems > 0 && (group_elems & 3) == 0, "gather_groups: bad arguments");
+    MYOLO_REQUIRE(src && idx && dst && n > 0 && group_elems > 0, "gather_groups: bad arguments");
+    if (group_elems & 3) {           // 4-byte elements of any type, e.g. one class id per ROI
+        const long long tot1 = (long long)n * group_elems;
+        hipLaunchKernelGGL(gather_groups_scalar_kernel, dim3(ew_blocks(tot1)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n,
+                           (long long)group_elems);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     const long long total = (long long)n * (group_elems / 4);
     hipLaunchKernelGGL(gather_groups_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n,
                        (long long)(group_elems / 4));

@@ -86,6 +86,10 @@ class Config(object):
     # fp32 on the bf16 matrix cores; the trunk, the decode and the final sigmoid stay fp32.
     # Training is always fp32.  (BASELINE.json configs[3].)
     INFERENCE_DTYPE = "fp32"
+    # "all": the training forward runs the mask head on all G*G*N_BOX ROIs, as the reference graph does.
+    # "positives": conv2-4 / deconv / myolo_mask run on the positive ROIs only -- the same loss, gradients and
+    # BN state (engine.Net.mask_head_fwd_positives explains why this is exact); the backward always uses this sparsity.
+    TRAIN_MASK_HEAD_ROIS = "all"
 
     def __init__(self):
         self.finalize()

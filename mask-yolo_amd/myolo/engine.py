@@ -157,6 +157,10 @@ class Net(object):
         self.grad_scale = 1.0
         # exact-sparsity backward of the mask head (see mask_head_bwd_sparse); False = dense reference path
         self.sparse_mask_bwd = True
+        # exact-sparsity FORWARD of the mask head (see mask_head_fwd_positives): conv2-4 / deconv / myolo_mask only on
+        # the positive ROIs.  Same loss, gradients and BN state; the training graph's unused myolo_mask rows of the
+        # non-positive ROIs are not produced.  Off by default (cfg.TRAIN_MASK_HEAD_ROIS = "all").
+        self.sparse_mask_fwd = getattr(cfg, "TRAIN_MASK_HEAD_ROIS", "all") == "positives"
         self._copy_stream = torch.cuda.Stream(device=self.dev)
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
@@ -508,6 +512,80 @@ class Net(object):
             self._npos_pinned.copy_(npos, non_blocking=True)
             self._npos_ready.record(self._copy_stream)
 
+    def _positive_index(self, B, R):
+        """(NP, idx_d, inv_d): flat ROI indices of the positives (the first n_pos rows of each image,
+        model.py:593) and the inverse map, from the async copy started by _start_npos_copy."""
+        self._npos_ready.synchronize()
+        npos_h = self._npos_pinned.numpy()
+        pos = np.concatenate([np.arange(b * R, b * R + int(npos_h[b]), dtype=np.int32) for b in range(B)]) if B else np.zeros(0, np.int32)
+        NP = int(pos.shape[0])
+        if NP == 0:
+            return 0, None, None
+        inv = np.full(B * R, -1, np.int32)
+        inv[pos] = np.arange(NP, dtype=np.int32)
+        return NP, torch.from_numpy(pos).to(self.dev, non_blocking=True), torch.from_numpy(inv).to(self.dev, non_blocking=True)
+
+    def mask_head_fwd_positives(self, Fm, fshape, rois, tmask, tcls):
+        """Training forward of the mask head that spends conv2-4 / deconv / myolo_mask on the positive ROIs only.
+        Exact, not approximate: the mask loss reads only positive ROIs (model.py:739-746) and bn2-4 are frozen
+        (model.py:696,702,708: no batch statistics, no moving-average update), so nothing downstream of bn1 in a
+        non-positive ROI reaches the loss, a gradient or any state.  ROIAlign, conv1 and bn1's batch statistics
+        (model.py:690) still cover every ROI.  Returns (pred_p [NP*mh*mw, C] | None, tmask_p, tcls_p)."""
+        cfg = self.cfg
+        B, R = rois.shape[:2]
+        n, h, w, cf = fshape
+        ps = cfg.MASK_POOL_SIZE
+        q = ps * ps
+        if cfg.ROI_BOX_ORDER == "xyxy_as_yxyx":
+            boxes = rois.reshape(B * R, 4)
+        else:
+            boxes = rois.reshape(B * R, 4)[:, [1, 0, 3, 2]].contiguous()
+        bind = torch.arange(B, device=self.dev, dtype=torch.int32).repeat_interleave(R).contiguous()
+        NR = B * R
+        x = self._new(NR * q, cf)
+        self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
+                         n, h, w, cf, NR, ps, ps, X.stream())
+        self.tape["roi"] = (boxes, bind, fshape, NR)
+        y1 = self._new(NR * q, MASK_FILTERS)
+        self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_conv1/kernel"]),
+                         X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, ps, ps, cf, MASK_FILTERS, *self._wsargs(), X.stream())
+        bn = "myolo_mask_bn1"
+        buf = self.bnbuf[bn]
+        X.call("myolo_bn_stats", X.ptr(y1), X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
+               X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]), X.ptr(buf[3]),
+               X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+               NR * q, MASK_FILTERS, *self._wsargs(), X.stream())
+        self.tape[bn] = (y1, ACT_RELU, True)
+        NP, idx_d, inv_d = self._positive_index(B, R)
+        self.tape["compact"] = (NP, idx_d, inv_d)
+        if NP == 0:
+            self.tape["mask"] = ([x], None, None)
+            return None, None, None
+        c1_p = self._gather(y1, idx_d, NP, q)
+        a = self._new(NP * q, MASK_FILTERS)
+        X.call("myolo_bn_apply_act", X.ptr(c1_p), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(a), NP * q, MASK_FILTERS, ACT_RELU, X.stream())
+        convs = [x]
+        for i in range(2, 5):
+            cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
+            convs.append(a)
+            y = self._new(NP * q, MASK_FILTERS)
+            X.call("myolo_conv3x3_fwd", X.ptr(a), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(y),
+                   NP, ps, ps, MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+            a = self.bn_act_fwd(bn, y, ACT_RELU, False)          # keeps the pre-BN tensor for backward
+        d = self._new(NP * 4 * q, MASK_FILTERS)
+        X.call("myolo_deconv2x2s2_fwd", X.ptr(a), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
+               X.ptr(d), NP, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
+        C = cfg.NUM_CLASSES
+        pred = self._new(NP * 4 * q, C)
+        X.call("myolo_mask_head_out_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(pred),
+               NP * 4 * q, MASK_FILTERS, C, X.stream())
+        self.tape["mask"] = (convs, a, d)
+        tmask_p = self._new(NP, 4 * q)
+        X.call("myolo_gather_groups", X.ptr(tmask), X.ptr(idx_d), X.ptr(tmask_p), NP, 4 * q, X.stream())
+        tcls_p = self._new(NP, dtype=torch.int32)
+        X.call("myolo_gather_groups", X.ptr(tcls), X.ptr(idx_d), X.ptr(tcls_p), NP, 1, X.stream())
+        return pred, tmask_p, tcls_p
+
     def mask_head_bwd_sparse(self, dz, B, R):
         """Same gradients as mask_head_bwd, exploiting a structural zero: bn2-4 are frozen affine maps
         (model.py:696,702,708) and the mask loss only reads positive ROIs (model.py:739-746), so behind bn1
@@ -521,10 +599,8 @@ class Net(object):
         ps = cfg.MASK_POOL_SIZE
         C = cfg.NUM_CLASSES
         n, h, w, cf = fshape
-        self._npos_ready.synchronize()
-        npos_h = self._npos_pinned.numpy()
-        pos = np.concatenate([np.arange(b * R, b * R + int(npos_h[b]), dtype=np.int32) for b in range(B)]) if B else np.zeros(0, np.int32)
-        NP = int(pos.shape[0])
+        compact = "compact" in self.tape          # forward already ran on the positives only
+        NP, idx_d, inv_d = self.tape["compact"] if compact else self._positive_index(B, R)
         lo, hi = self.bucket_ranges[2]
         if NP == 0:                       # no positive ROI: mask loss is the constant 0 (model.py:750-752)
             self.flat_g[lo:hi].zero_()
@@ -532,18 +608,15 @@ class Net(object):
             if self.on_bucket_ready:
                 self.on_bucket_ready(2)
             return dF
-        inv = np.full(NR, -1, np.int32)
-        inv[pos] = np.arange(NP, dtype=np.int32)
-        idx_d = torch.from_numpy(pos).to(self.dev, non_blocking=True)
-        inv_d = torch.from_numpy(inv).to(self.dev, non_blocking=True)
         q = ps * ps
-        dz_p = self._gather(dz, idx_d, NP, 4 * q)
-        d_p = self._gather(d, idx_d, NP, 4 * q)
+        gather = (lambda t, rows: t) if compact else (lambda t, rows: self._gather(t, idx_d, NP, rows))
+        dz_p = gather(dz, 4 * q)
+        d_p = gather(d, 4 * q)
         Md = NP * 4 * q
         dd = self._new(Md, MASK_FILTERS)
         X.call("myolo_mask_head_out_bwd", X.ptr(d_p), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(dz_p), X.ptr(dd),
                X.ptr(self.g["myolo_mask/kernel"]), X.ptr(self.g["myolo_mask/bias"]), Md, MASK_FILTERS, C, *self._wsargs(), X.stream())
-        a4_p = self._gather(a4, idx_d, NP, q)
+        a4_p = gather(a4, q)
         X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_p), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
         self.colsum(dd, self.g["myolo_mask_deconv/bias"])
@@ -552,7 +625,7 @@ class Net(object):
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
         for i in range(4, 1, -1):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
-            xin = self._gather(convs[i - 1], idx_d, NP, q)
+            xin = gather(convs[i - 1], q)
             if self.tape[bn][0] is None:
                 # the fused forward never wrote the pre-BN tensor: recompute it for the positive ROIs with the
                 # same kernel (same k order per output element -> the same fp32 values)
@@ -560,7 +633,7 @@ class Net(object):
                 X.call("myolo_conv3x3_fwd", X.ptr(xin), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(c_p),
                        NP, ps, ps, MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
             else:
-                c_p = self._gather(self.tape[bn][0], idx_d, NP, q)
+                c_p = gather(self.tape[bn][0], q)
             dy = self.bn_act_bwd(bn, da, y_override=c_p)
             X.call("myolo_conv3x3_bwd_weight", X.ptr(xin), X.ptr(dy), X.ptr(self.g[cn + "/kernel"]), NP, ps, ps, MASK_FILTERS,
                    MASK_FILTERS, *self._wsargs(), X.stream())
@@ -631,7 +704,13 @@ class Net(object):
                X.ptr(rois), X.ptr(tcls), X.ptr(tmask), X.ptr(npos), B, R, T, H, W, mh, mw, X.stream())
         if self.sparse_mask_bwd:
             self._start_npos_copy(npos)
-        pred = self.mask_head_fwd(Fm, fshape, rois, True)
+        if self.sparse_mask_fwd:
+            if not self.sparse_mask_bwd:
+                raise RuntimeError("TRAIN_MASK_HEAD_ROIS='positives' needs the sparse backward (sparse_mask_bwd=True)")
+            pred, tmask_l, tcls_l = self.mask_head_fwd_positives(Fm, fshape, rois, tmask, tcls)
+        else:
+            pred = self.mask_head_fwd(Fm, fshape, rois, True)
+            tmask_l, tcls_l = tmask, tcls
         w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
         w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
         yterms = self._new(8)
@@ -639,14 +718,22 @@ class Net(object):
         X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
                X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
                float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
-        mterms = self._new(2)
-        dz = self._new(pred.shape[0], pred.shape[1])
-        X.call("myolo_mask_bce", X.ptr(tmask), X.ptr(tcls), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), B * R, mh, mw, C,
-               *self._wsargs(), X.stream())
+        if pred is None:                  # positives-only forward without a positive ROI (model.py:750-752)
+            mterms = torch.zeros(2, dtype=torch.float32, device=self.dev)
+            dz = None
+        else:
+            mterms = self._new(2)
+            dz = self._new(pred.shape[0], pred.shape[1])
+            X.call("myolo_mask_bce", X.ptr(tmask_l), X.ptr(tcls_l), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), tcls_l.numel(), mh, mw, C,
+                   *self._wsargs(), X.stream())
         dF = self.mask_head_bwd_sparse(dz, B, R) if self.sparse_mask_bwd else self.mask_head_bwd(dz)
         self.trunk_bwd(dF, dyolo)
+        if self.sparse_mask_fwd:          # the positives' masks only, in positive order (see mask_head_fwd_positives)
+            mm = None if pred is None else pred.view(-1, mh, mw, C)
+        else:
+            mm = pred.view(B, R, mh, mw, C)
         return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_proposals=proposals, output_rois=rois,
-                    myolo_mask=pred.view(B, R, mh, mw, C), target_class_ids=tcls, target_mask=tmask, n_pos=npos,
+                    myolo_mask=mm, target_class_ids=tcls, target_mask=tmask, n_pos=npos,
                     yolo_terms=yterms, mask_terms=mterms, feature_map=Fm.view(*fshape), loss_weights=(w1, w2))
 
     def forward_backward_yolo(self, db):

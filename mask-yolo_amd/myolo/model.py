@@ -161,8 +161,9 @@ class MaskYOLO(object):
         yt = out["yolo_terms"].cpu().numpy()
         mt = out["mask_terms"].cpu().numpy()
         w1, w2 = out["loss_weights"]
-        res = {k: out[k].cpu().numpy() for k in ("yolo_output", "yolo_proposals", "output_rois", "myolo_mask",
-                                                 "target_class_ids", "target_mask", "n_pos", "feature_map")}
+        res = {k: (None if out[k] is None else out[k].cpu().numpy())
+               for k in ("yolo_output", "yolo_proposals", "output_rois", "myolo_mask", "target_class_ids", "target_mask", "n_pos",
+                         "feature_map")}
         res.update(yolo_sum_loss=float(yt[0]), mask_loss=float(mt[0]), loss=float(yt[0] * w1 + mt[0] * w2),
                    loss_xy=float(yt[1]), loss_wh=float(yt[2]), loss_conf=float(yt[3]), loss_class=float(yt[4]),
                    recall=float(yt[5]))

@@ -204,6 +204,60 @@ def test_sparse_mask_backward_equals_dense():
     assert worst < 1e-4, worst
 
 
+def test_positives_only_forward_equals_full_forward():
+    """cfg.TRAIN_MASK_HEAD_ROIS='positives' (conv2-4/deconv/myolo_mask forward on the positive ROIs only) is an
+    exact elimination of values nothing reads: loss terms, every gradient, the Adam-updated weights and the BN
+    moving statistics agree with the all-ROI forward to fp32 summation-order noise (the compact convs take the
+    split-K path), and the positives' predicted masks are the matching rows of the full myolo_mask."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    res = []
+    for rois in ("all", "positives"):
+        c = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4, TRAIN_MASK_HEAD_ROIS=rois)
+        model = MaskYOLO(mode="training", config=c)
+        model.load_state_dict(P)
+        assert model.net.sparse_mask_fwd == (rois == "positives")
+        out = model.train_on_batch(batch, learning_rate=1e-3)
+        res.append((out, model.net.grads_dict(), model.state_dict()))
+    (o0, g0, s0), (o1, g1, s1) = res
+    assert np.array_equal(o0["n_pos"], o1["n_pos"]) and o0["n_pos"].sum() >= 2
+    for k in ("yolo_sum_loss", "mask_loss", "loss"):
+        assert abs(o0[k] - o1[k]) <= 1e-6 * max(1.0, abs(o0[k])), k
+    R = o0["myolo_mask"].shape[1]
+    pos = np.concatenate([np.arange(b * R, b * R + n) for b, n in enumerate(o0["n_pos"])])
+    full = o0["myolo_mask"].reshape((-1,) + o0["myolo_mask"].shape[2:])
+    assert o1["myolo_mask"].shape == (len(pos),) + full.shape[1:]
+    assert np.abs(o1["myolo_mask"] - full[pos]).max() < 1e-5
+    worst = 0.0
+    for k in g0:
+        if np.abs(g0[k]).max() < 1e-12 or k == "myolo_mask_conv1/bias":
+            continue
+        worst = max(worst, rel(g1[k], g0[k]))
+    assert worst < 1e-4, worst
+    for k in s0:                                  # weights after one Adam step and BN moving statistics
+        assert np.abs(s1[k] - s0[k]).max() <= 1e-5 * max(1.0, np.abs(s0[k]).max()), k
+
+
+def test_positives_only_forward_without_positives():
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    b2 = [a.copy() for a in batch]
+    b2[3][:] = 0
+    b2[4][:] = 0
+    b2[5][:] = False
+    c = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4, TRAIN_MASK_HEAD_ROIS="positives")
+    outs = []
+    for cc in (cfg, c):
+        model = MaskYOLO(mode="training", config=cc)
+        model.load_state_dict(P)
+        out = model.train_on_batch(b2, learning_rate=1e-3)
+        outs.append((out, model.net.grads_dict(), model.state_dict()))
+    (o0, g0, s0), (o1, g1, s1) = outs
+    assert o1["mask_loss"] == 0.0 and o1["myolo_mask"] is None and o1["n_pos"].sum() == 0
+    assert abs(o0["loss"] - o1["loss"]) <= 1e-6 * max(1.0, abs(o0["loss"]))
+    assert all(np.abs(v).max() == 0 for k, v in g1.items() if k.startswith("myolo_mask"))
+    for k in s0:                                  # bn1's moving statistics still see every ROI
+        assert np.abs(s1[k] - s0[k]).max() <= 1e-5 * max(1.0, np.abs(s0[k]).max()), k
+
+
 def test_no_positive_rois_gives_zero_mask_loss_and_grads():
     """empty-GT batch: every ROI negative, mask loss 0 (model.py:750-752), mask-head gradients 0."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
