@@ -159,3 +159,29 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_keras_h5_name_mapping_roundtrip():
+    """tools/h5_to_npz.py mapping (model.py:1157-1196 checkpoint schema): Keras weight names ->
+    state_dict keys and back, including the nested 'yolo_model' group and the depthwise multiplier axis."""
+    import importlib.util
+    import os
+    from myolo.config import make_config, ShapesConfig
+    from myolo.engine import init_state_dict
+    spec = importlib.util.spec_from_file_location("h5_to_npz", os.path.join(os.path.dirname(__file__), "..", "tools", "h5_to_npz.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    cfg = make_config(ShapesConfig, ALPHA=0.25)
+    sd = init_state_dict(cfg, seed=1)
+    groups = m.state_to_keras_weights(sd)
+    assert "yolo_model" in groups and "conv_dw_7" not in groups and "conv_dw_6" in groups and "myolo_mask_deconv" in groups
+    inner = {n.split("/")[0] for n, _ in groups["yolo_model"]}
+    assert inner == set(m.nested_layers()) and "conv_23" in inner
+    dw = dict(groups["conv_dw_1"])["conv_dw_1/depthwise_kernel:0"]
+    assert dw.shape == (3, 3, 8, 1)
+    flat = {n: a for items in groups.values() for n, a in items}
+    back = m.keras_weights_to_state(flat)
+    assert set(back) == set(sd)
+    assert all(np.array_equal(back[k], sd[k]) for k in sd)
+    # tf.keras-style prefixed names map to the same keys
+    assert set(m.keras_weights_to_state({"yolo_model/conv_23/kernel:0": sd["conv_23/kernel"]})) == {"conv_23/kernel"}
