@@ -202,6 +202,19 @@ int myolo_mask_bce(const float* target_masks, const int32_t* target_class_ids, c
 int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* ---- Winograd F(4x4,3x3) form of the dense 3x3/s1/SAME convolutions (same contracts as myolo_conv3x3_* above:
+ * myolo_mask_conv1-4 model.py:687-709 and their gradients); fp32 operands and accumulation, 4x fewer multiplications
+ * per full tile.  ws_bytes(which): 0 forward, 1 data gradient, 2 weight gradient.
+ * fwd: optional scale/shift = folded frozen BatchNorm applied after the bias (as conv3x3_affine_act_fwd); v_keep
+ * (nullable) receives the transformed input [36][N*ceil(H/4)*ceil(W/4)][Cin] so bwd_weight can reuse it (v_saved). ---- */
+size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int which);
+int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
+                           int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
+                                void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W,
+                                  int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- bf16 inference path of the mask head (BASELINE.json configs[3]: Rice 416x416, bf16, inference-only) ----
  * Activations are bf16 (uint16_t bit patterns, NHWC), accumulation fp32 on v_mfma_f32_32x32x16_bf16.  All four
  * BatchNorm layers of build_mask_graph are frozen in inference (model.py:690-708), so they are folded into the

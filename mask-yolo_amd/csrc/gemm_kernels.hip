@@ -47,6 +47,8 @@ struct GemmArgs {
     int ksplits;             // NN fast path: >1 = split the K tiles over blockIdx.y, raw partials to `part`
     float* part;             // [ksplits][M][N] fp32 partial sums (workspace)
     long long m_per_split;   // TN only
+    long long sA, sB, sC;    // fast kernels: batch strides in elements (grid z = batch index; 0 = not batched)
+    int batch;               // TN split partial layout [split][batch][K*N]
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -430,6 +432,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.N + BN_ - 1) / BN_;
+    p.A += (long long)blockIdx.z * p.sA;       // batched launch (Winograd: one GEMM per transform point)
+    p.B += (long long)blockIdx.z * p.sB;
+    p.C += (long long)blockIdx.z * p.sC;
     // XCD-aware order: workgroup b runs on XCD b % 8 (observed; used for speed only).  Give each XCD a
     // contiguous run of tiles so the N-tiles that share an A tile are consecutive on ONE L2.
     long long bid;
@@ -678,6 +683,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int ntn = (p.N + BN - 1) / BN;
+    p.A += (long long)blockIdx.z * p.sA;
+    p.B += (long long)blockIdx.z * p.sB;
     const int tn = blockIdx.x % ntn;
     const int tka = blockIdx.x / ntn;
     const int ka0 = tka * BM, n0 = tn * BN;
@@ -812,7 +819,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
             cur ^= 1;
         }
     }
-    float* Cp = p.C + (long long)blockIdx.y * p.K * p.N;
+    const int nb = p.batch > 1 ? p.batch : 1;
+    float* Cp = p.C + ((long long)blockIdx.y * nb + blockIdx.z) * p.K * p.N;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -1026,6 +1034,66 @@ static int launch_tn(GemmArgs a, float* out, void* ws, size_t ws_bytes, hipStrea
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)ws, out, n, splits);
+    }
+    return MYOLO_OK;
+}
+
+// ---- batched plain GEMMs for wino_kernels.hip (one GEMM per Winograd transform point, grid z = point) ----
+// C[z] (M x N) = A[z] (M x K) * B[z] (K x N); all row-major and dense.
+int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M, int K, int N, int batch, hipStream_t s)
+{
+    if ((K % BK) || (N & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) {
+        myolo_set_error("gemm_nn_batched: needs K %% %d == 0, N %% 4 == 0 and 16-byte aligned operands", BK);
+        return MYOLO_EINVAL;
+    }
+    GemmArgs a = {};
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = N; a.ldc = N; a.act = MYOLO_ACT_NONE;
+    a.sA = M * (long long)K; a.sB = (long long)K * N; a.sC = M * (long long)N; a.batch = batch;
+    a.nt = 0;          // the product is read back at once by the output transform
+    const long long tiles = cdiv64(M, BM) * ((N + BN - 1) / BN);
+    if (tiles <= 0 || batch <= 0) return MYOLO_OK;
+    hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN>), dim3((unsigned)tiles, 1, batch), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}
+
+size_t myolo_gemm_tn_batched_ws_bytes(long long M, int Ka, int N, int batch)
+{
+    const long long tiles = (long long)((Ka + BM - 1) / BM) * ((N + BN - 1) / BN) * batch;
+    long long splits = 1024 / tiles;
+    const long long max_by_rows = cdiv64(M, 8 * BK);
+    if (splits > max_by_rows) splits = max_by_rows;
+    if (splits < 1) splits = 1;
+    return splits > 1 ? (size_t)splits * batch * Ka * N * sizeof(float) : 0;
+}
+
+// C[z] (Ka x N) = A[z]^T (M x Ka)^T * B[z] (M x N): the sum over the M rows is split so that tiles x batch x splits fills the chip
+int myolo_gemm_tn_batched(const float* A, const float* B, float* C, long long M, int Ka, int N, int batch, void* ws, size_t ws_bytes,
+                          hipStream_t s)
+{
+    if ((N & 3) || (Ka & 3) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) {
+        myolo_set_error("gemm_tn_batched: needs Ka %% 4 == 0, N %% 4 == 0 and 16-byte aligned operands");
+        return MYOLO_EINVAL;
+    }
+    const size_t need = myolo_gemm_tn_batched_ws_bytes(M, Ka, N, batch);
+    if (need > ws_bytes || (need && !ws)) {
+        myolo_set_error("gemm_tn_batched: workspace too small (%zu needed, %zu given)", need, ws_bytes);
+        return MYOLO_EWORKSPACE;
+    }
+    const long long per = (long long)batch * Ka * N;
+    const int splits = need ? (int)(need / (per * sizeof(float))) : 1;
+    GemmArgs a = {};
+    a.A = A; a.B = B; a.M = M; a.N = N; a.K = Ka; a.lda = Ka; a.ldb = N;
+    a.sA = M * (long long)Ka; a.sB = M * (long long)N; a.batch = batch;
+    long long mps = cdiv64(M, splits);
+    a.m_per_split = cdiv64(mps, BK) * BK;
+    a.C = splits > 1 ? (float*)ws : C;
+    const int tiles = ((Ka + BM - 1) / BM) * ((N + BN - 1) / BN);
+    hipLaunchKernelGGL((gemm_tn_fast<AM_PLAIN>), dim3(tiles, splits, batch), dim3(256), 0, s, a);
+    if (splits > 1) {
+        int blocks = (int)((per / 4 + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(splitk_reduce, dim3(blocks), dim3(256), 0, s, (const float*)ws, C, per, splits);
     }
     return MYOLO_OK;
 }

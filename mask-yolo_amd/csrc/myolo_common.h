@@ -38,3 +38,9 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 #define BN_EPS_F 1e-3f
 #define BN_MOMENTUM_F 0.99f
+
+// internal (C++ linkage) batched GEMM launchers of gemm_kernels.hip, used by wino_kernels.hip
+int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M, int K, int N, int batch, hipStream_t s);
+size_t myolo_gemm_tn_batched_ws_bytes(long long M, int Ka, int N, int batch);
+int myolo_gemm_tn_batched(const float* A, const float* B, float* C, long long M, int Ka, int N, int batch, void* ws, size_t ws_bytes,
+                          hipStream_t s);

@@ -1,0 +1,360 @@
+// Winograd F(4x4, 3x3) for the dense 3x3 / stride-1 / SAME convolutions of the mask head (myolo_mask_conv1-4,
+// model.py:687-709) in fp32: 36 multiplications per 4x4 output tile and channel pair instead of 144, i.e. 4x fewer
+// (3.06x at 14x14, where the 4x4 tiling covers 16x16).  Same arithmetic type as the direct kernel (fp32 operands,
+// fp32 MFMA accumulation); only the association order of the sums differs.
+//
+//   forward      Y  = A^T [ sum_ci U(ci,co) .* V(ci) ] A        V = B^T d B  (6x6 input patch d, stride 4, pad 1)
+//                                                               U = G g G^T  (3x3 filter g)
+//   data grad    the same algorithm on dY with the filter rotated by 180 degrees and (ci,co) exchanged
+//   weight grad  dU(ci,co) = sum_tiles V(ci) .* (A dY A^T)(co),  dW = G^T dU G
+//
+// Data layout: V / M planes are [36][T][C] (T = N*TH*TW tiles, TH = ceil(H/4)); the 36 per-point products are ONE batched
+// launch of the plain fp32 MFMA GEMM (gemm_kernels.hip, grid z = transform point).  The transforms are HBM-bound
+// streaming kernels: one lane = 4 channels of one tile, every access a contiguous 16 B per lane.
+#include "myolo_common.h"
+
+__device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
+__device__ __forceinline__ float4 operator+(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 operator-(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+__device__ __forceinline__ float4 operator*(float s, float4 a) { return make_float4(s * a.x, s * a.y, s * a.z, s * a.w); }
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void stg4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// B^T (6x6) on a 6-vector
+template <typename T>
+__device__ __forceinline__ void bt6(const T d[6], T t[6])
+{
+    t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+    t[1] = d[3] + d[4] - 4.f * (d[1] + d[2]);
+    t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+    t[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+    t[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+    t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+// A^T (4x6) on a 6-vector
+template <typename T>
+__device__ __forceinline__ void at6(const T m[6], T y[4])
+{
+    const T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    y[0] = m[0] + s12 + s34;
+    y[1] = d12 + 2.f * d34;
+    y[2] = s12 + 4.f * s34;
+    y[3] = d12 + 8.f * d34 + m[5];
+}
+// A (6x4) on a 4-vector
+template <typename T>
+__device__ __forceinline__ void a4(const T d[4], T q[6])
+{
+    const T e = d[0] + d[2], o = d[1] + d[3], e4 = d[0] + 4.f * d[2], o4 = 2.f * d[1] + 8.f * d[3];
+    q[0] = d[0];
+    q[1] = e + o;
+    q[2] = e - o;
+    q[3] = e4 + o4;
+    q[4] = e4 - o4;
+    q[5] = d[3];
+}
+// G (6x3) on a 3-vector
+__device__ __forceinline__ void g3(const float g[3], float u[6])
+{
+    u[0] = g[0] * 0.25f;
+    u[1] = -(g[0] + g[1] + g[2]) * (1.f / 6.f);
+    u[2] = -(g[0] - g[1] + g[2]) * (1.f / 6.f);
+    u[3] = g[0] * (1.f / 24.f) + g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    u[4] = g[0] * (1.f / 24.f) - g[1] * (1.f / 12.f) + g[2] * (1.f / 6.f);
+    u[5] = g[2];
+}
+// G^T (3x6) on a 6-vector
+__device__ __forceinline__ void gt6(const float d[6], float w[3])
+{
+    w[0] = d[0] * 0.25f - (d[1] + d[2]) * (1.f / 6.f) + (d[3] + d[4]) * (1.f / 24.f);
+    w[1] = (d[2] - d[1]) * (1.f / 6.f) + (d[3] - d[4]) * (1.f / 12.f);
+    w[2] = -(d[1] + d[2]) * (1.f / 6.f) + (d[3] + d[4]) * (1.f / 6.f) + d[5];
+}
+
+struct TileGeom {
+    int H, W, TH, TW;
+    long long T;       // tiles in total
+};
+
+// X [N,H,W,C] -> V [36][T][C]
+__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, TileGeom g, int C)
+{
+    const int c4n = C >> 2;
+    const long long total = g.T * c4n;
+    const long long plane = g.T * (long long)C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long t = idx / c4n;
+        const int c = (int)(idx - t * c4n) * 4;
+        const long long img = t / (g.TH * g.TW);
+        const int rem = (int)(t - img * (g.TH * g.TW));
+        const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        const float* base = x + img * (long long)g.H * g.W * C + c;
+        float4 tmp[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 d[6], r[6];
+            const int xx = x0 + j;
+            const bool xin = (unsigned)xx < (unsigned)g.W;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int yy = y0 + i;
+                d[i] = (xin && (unsigned)yy < (unsigned)g.H) ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+            }
+            bt6(d, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
+        }
+        float* out = V + t * C + c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float4 r[6];
+            bt6(tmp[i], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+        }
+    }
+}
+
+// M [36][T][C] -> Y [N,H,W,C], + bias, optional per-channel affine (folded frozen BN), activation
+__global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ M, float* __restrict__ y, const float* __restrict__ bias,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift, TileGeom g, int C,
+                                                       int act)
+{
+    const int c4n = C >> 2;
+    const long long total = g.T * c4n;
+    const long long plane = g.T * (long long)C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long t = idx / c4n;
+        const int c = (int)(idx - t * c4n) * 4;
+        const long long img = t / (g.TH * g.TW);
+        const int rem = (int)(t - img * (g.TH * g.TW));
+        const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        const float* in = M + t * C + c;
+        float4 tmp[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 m[6], r[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = ldg4(in + (long long)(i * 6 + j) * plane);
+            at6(m, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tmp[i][j] = r[i];
+        }
+        const float4 b = bias ? ldg4(bias + c) : f4(0.f);
+        const float4 sc = scale ? ldg4(scale + c) : f4(1.f);
+        const float4 sh = scale ? ldg4(shift + c) : f4(0.f);
+        float* obase = y + img * (long long)g.H * g.W * C + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 r[4];
+            at6(tmp[i], r);
+            const int yy = 4 * ty + i;
+            if (yy >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = 4 * tx + j;
+                if (xx >= g.W) continue;
+                float4 v = r[j] + b;
+                if (scale) v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                if (act == MYOLO_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                else if (act == MYOLO_ACT_RELU6)
+                    v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f),
+                                    fminf(fmaxf(v.w, 0.f), 6.f));
+                stg4(obase + ((long long)yy * g.W + xx) * C, v);
+            }
+        }
+    }
+}
+
+// dY [N,H,W,C] -> Q [36][T][C] = A dY_tile A^T (weight gradient)
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Q, TileGeom g, int C)
+{
+    const int c4n = C >> 2;
+    const long long total = g.T * c4n;
+    const long long plane = g.T * (long long)C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long t = idx / c4n;
+        const int c = (int)(idx - t * c4n) * 4;
+        const long long img = t / (g.TH * g.TW);
+        const int rem = (int)(t - img * (g.TH * g.TW));
+        const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        const float* base = dy + img * (long long)g.H * g.W * C + c;
+        float4 tmp[6][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 d[4], r[6];
+            const int xx = 4 * tx + j;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int yy = 4 * ty + i;
+                d[i] = (xx < g.W && yy < g.H) ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+            }
+            a4(d, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
+        }
+        float* out = Q + t * C + c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float4 r[6];
+            a4(tmp[i], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+        }
+    }
+}
+
+// w [3,3,Ci,Co] -> U [36][Ci][Co]   (flip = 0)
+//                  U'[36][Co][Ci] of the 180-degree rotated filter with (ci,co) exchanged (flip = 1: data gradient)
+__global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int flip)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ci * Co) return;
+    const int ci = idx / Co, co = idx - ci * Co;
+    float g[3][3], tmp[6][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx) * Ci + ci) * (long long)Co + co];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const float col[3] = {g[0][kx], g[1][kx], g[2][kx]};
+        float u[6];
+        g3(col, u);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tmp[i][kx] = u[i];
+    }
+    const long long plane = (long long)Ci * Co;
+    const long long o = flip ? (long long)co * Ci + ci : (long long)ci * Co + co;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        float u[6];
+        g3(tmp[i], u);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) U[(i * 6 + j) * plane + o] = u[j];
+    }
+}
+
+// dU [36][Ci][Co] -> dw [3,3,Ci,Co] = G^T dU G
+__global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Ci, int Co)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ci * Co) return;
+    const long long plane = (long long)Ci * Co;
+    float tmp[3][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        float col[6], r[3];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) col[i] = dU[(i * 6 + j) * plane + idx];
+        gt6(col, r);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tmp[k][j] = r[k];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float r[3];
+        gt6(tmp[ky], r);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) dw[(ky * 3 + kx) * plane + idx] = r[kx];
+    }
+}
+
+static TileGeom geom(int N, int H, int W)
+{
+    TileGeom g;
+    g.H = H; g.W = W; g.TH = (H + 3) / 4; g.TW = (W + 3) / 4;
+    g.T = (long long)N * g.TH * g.TW;
+    return g;
+}
+static unsigned ew_grid(long long total)
+{
+    long long b = (total + 255) / 256;
+    if (b > (1 << 20)) b = 1 << 20;
+    return (unsigned)(b < 1 ? 1 : b);
+}
+static size_t plane_bytes(const TileGeom& g, int C) { return align256((size_t)36 * g.T * C * sizeof(float)); }
+static size_t u_bytes(int Ci, int Co) { return align256((size_t)36 * Ci * Co * sizeof(float)); }
+
+extern "C" {
+
+size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int which)
+{
+    const TileGeom g = geom(N, H, W);
+    switch (which) {
+        case 0: return u_bytes(Cin, Cout) + plane_bytes(g, Cin) + plane_bytes(g, Cout);                   // fwd: U, V, M
+        case 1: return u_bytes(Cin, Cout) + plane_bytes(g, Cout) + plane_bytes(g, Cin);                   // bwd data: U', V(dy), M
+        default: return u_bytes(Cin, Cout) + plane_bytes(g, Cin) + plane_bytes(g, Cout) +                 // bwd weight: dU, V, Q, partials
+                        align256(myolo_gemm_tn_batched_ws_bytes(g.T, Cin, Cout, 36));
+    }
+}
+
+int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
+                           int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && N > 0 && H > 0 && W > 0, "conv3x3_wino_fwd: bad arguments");
+    MYOLO_REQUIRE((Cin % 16) == 0 && (Cout & 3) == 0, "conv3x3_wino_fwd: needs Cin %% 16 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
+    MYOLO_REQUIRE(!scale == !shift, "conv3x3_wino_fwd: scale and shift go together");
+    const TileGeom g = geom(N, H, W);
+    const size_t ub = u_bytes(Cin, Cout), vb = v_keep ? 0 : plane_bytes(g, Cin), mb = plane_bytes(g, Cout);
+    MYOLO_NEED_WS(ub + vb + mb);
+    hipStream_t s = (hipStream_t)stream;
+    float* U = (float*)ws;
+    float* V = v_keep ? v_keep : (float*)((char*)ws + ub);
+    float* Mp = (float*)((char*)ws + ub + vb);
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 0);
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin);
+    const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cin, Cout, 36, s);
+    if (rc != MYOLO_OK) return rc;
+    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, Mp, y, bias, scale, shift, g, Cout, act);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, void* ws,
+                                size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && w && dx && N > 0 && H > 0 && W > 0, "conv3x3_wino_bwd_data: bad arguments");
+    MYOLO_REQUIRE((Cout % 16) == 0 && (Cin & 3) == 0, "conv3x3_wino_bwd_data: needs Cout %% 16 == 0 and Cin %% 4 == 0 (got %d, %d)", Cout, Cin);
+    const TileGeom g = geom(N, H, W);
+    const size_t ub = u_bytes(Cin, Cout), vb = plane_bytes(g, Cout), mb = plane_bytes(g, Cin);
+    MYOLO_NEED_WS(ub + vb + mb);
+    hipStream_t s = (hipStream_t)stream;
+    float* U = (float*)ws;
+    float* V = (float*)((char*)ws + ub);
+    float* Mp = (float*)((char*)ws + ub + vb);
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 1);
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout);
+    const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cout, Cin, 36, s);
+    if (rc != MYOLO_OK) return rc;
+    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, Mp, dx, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, g, Cin, MYOLO_ACT_NONE);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                                  void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE((x || v_saved) && dy && dw && N > 0 && H > 0 && W > 0, "conv3x3_wino_bwd_weight: bad arguments");
+    MYOLO_REQUIRE((Cin & 3) == 0 && (Cout & 3) == 0, "conv3x3_wino_bwd_weight: needs Cin %% 4 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
+    const TileGeom g = geom(N, H, W);
+    const size_t ub = u_bytes(Cin, Cout), vb = v_saved ? 0 : plane_bytes(g, Cin), qb = plane_bytes(g, Cout);
+    const size_t pb = align256(myolo_gemm_tn_batched_ws_bytes(g.T, Cin, Cout, 36));
+    MYOLO_NEED_WS(ub + vb + qb + pb);
+    hipStream_t s = (hipStream_t)stream;
+    float* dU = (float*)ws;
+    float* V = (float*)((char*)ws + ub);
+    float* Q = (float*)((char*)ws + ub + vb);
+    void* part = (char*)ws + ub + vb + qb;
+    if (!v_saved) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin);
+    hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout);
+    const int rc = myolo_gemm_tn_batched(v_saved ? v_saved : V, Q, dU, g.T, Cin, Cout, 36, part, pb, s);
+    if (rc != MYOLO_OK) return rc;
+    hipLaunchKernelGGL(wino_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+}  // extern "C"

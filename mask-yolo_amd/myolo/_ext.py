@@ -49,6 +49,9 @@ SIGS = {
     "myolo_unmold_masks": [P, P, P, I, I, I, I, I, I, P],
     "myolo_mask_targets": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_mask_head_out_fwd": [P, P, P, P, L, I, I, P],
+    "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],
+    "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_pack_weights_bf16": [P, I, I, I, P, P, P, P, P, P, P, P],
     "myolo_crop_and_resize_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_conv3x3_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],
@@ -79,12 +82,14 @@ def load():
     lib.myolo_last_error_string.restype = ctypes.c_char_p
     lib.myolo_workspace_bytes.argtypes = [L, I, I]
     lib.myolo_workspace_bytes.restype = Z
+    lib.myolo_conv3x3_wino_ws_bytes.argtypes = [I, I, I, I, I, I]
+    lib.myolo_conv3x3_wino_ws_bytes.restype = Z
     _LIB = lib
     return lib
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes"]
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes"]
 
 
 def ptr(t):
@@ -108,3 +113,8 @@ def call(name, *args):
 
 def workspace_bytes(rows, cin, cout):
     return int(load().myolo_workspace_bytes(int(rows), int(cin), int(cout)))
+
+
+def wino_ws_bytes(n, h, w, cin, cout, which):
+    """scratch bytes of myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2)."""
+    return int(load().myolo_conv3x3_wino_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(which)))

@@ -99,6 +99,39 @@ def test_conv3x3(N, H, W, Cin, Cout):
     check(db, rdb, what="colsum")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 32, 64), (2, 7, 9, 16, 48), (1, 28, 28, 128, 256), (5, 14, 14, 256, 256),
+                                            (2, 16, 12, 64, 32), (40, 14, 14, 256, 256)])
+def test_conv3x3_winograd(N, H, W, Cin, Cout):
+    """Winograd F(4x4,3x3) form of the same three operators, same oracle, same 1e-3 bound (ragged tiles: 14 = 3.5 tiles,
+    7x9, and exact multiples of 4)."""
+    rng = np.random.default_rng(2)
+    x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout)
+    dy = rnd(rng, N, H, W, Cout)
+    wsb = torch.empty(max(X.wino_ws_bytes(N, H, W, Cin, Cout, k) for k in (0, 1, 2)), dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    wsa = (wsb.data_ptr(), wsb.numel())
+    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    y, vk = new(N, H, W, Cout), new(36, T, Cin)
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), None, None, X.ptr(y), N, H, W, Cin, Cout, 0,
+           X.ptr(vk), *wsa, X.stream())
+    ref = O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64)
+    check(y, ref, what="wino fwd")
+    # folded-BN affine + ReLU epilogue, V in the workspace
+    sc, sh = (1 + 0.1 * rnd(rng, Cout)), rnd(rng, Cout, scale=0.1)
+    y2 = new(N, H, W, Cout)
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(sc)), X.ptr(dt(sh)), X.ptr(y2), N, H, W, Cin,
+           Cout, 1, None, *wsa, X.stream())
+    check(y2, np.maximum(ref * sc + sh, 0), what="wino fwd affine relu")
+    rdx, rdw, rdb = O.conv2d_bwd(x, w, dy, pads=(1, 1, 1, 1), acc=np.float64)
+    dx, dw, dw2 = new(N, H, W, Cin), new(3, 3, Cin, Cout), new(3, 3, Cin, Cout)
+    X.call("myolo_conv3x3_wino_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, Cin, Cout, *wsa, X.stream())
+    check(dx, rdx, what="wino dx")
+    X.call("myolo_conv3x3_wino_bwd_weight", None, X.ptr(vk), X.ptr(dt(dy)), X.ptr(dw), N, H, W, Cin, Cout, *wsa, X.stream())
+    check(dw, rdw, what="wino dw (saved V)")
+    X.call("myolo_conv3x3_wino_bwd_weight", X.ptr(dt(x)), None, X.ptr(dt(dy)), X.ptr(dw2), N, H, W, Cin, Cout, *wsa, X.stream())
+    check(dw2, rdw, what="wino dw (from x)")
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 256, 256), (2, 5, 7, 32, 64)])
 def test_deconv2x2s2(N, H, W, Cin, Cout):
     rng = np.random.default_rng(3)

@@ -54,6 +54,23 @@ def main():
             fn = lambda: X.call("myolo_deconv2x2s2_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, 1, st)   # noqa: E731
         ms = timeit(fn, a.iters)
         print("%s M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500 bf16 dense)" % (a.which, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0))
+    elif a.which.startswith("wino"):
+        x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
+        T = NR * 16
+        vk = torch.empty(36, T, C, device=dev)
+        wsz = max(X.wino_ws_bytes(NR, ps, ps, C, C, k) for k in (0, 1, 2))
+        wsw = torch.empty(wsz, dtype=torch.uint8, device=dev)
+        flop = 2.0 * M * 9 * C * C
+        if a.which == "wino_fwd":
+            fn = lambda: X.call("myolo_conv3x3_wino_fwd", X.ptr(x), X.ptr(w), X.ptr(b), None, None, X.ptr(y), NR, ps, ps, C, C, 0, X.ptr(vk), wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
+        elif a.which == "wino_bwd_data":
+            fn = lambda: X.call("myolo_conv3x3_wino_bwd_data", X.ptr(x), X.ptr(w), X.ptr(y), NR, ps, ps, C, C, wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
+        else:
+            dw = torch.empty(3, 3, C, C, device=dev)
+            X.call("myolo_conv3x3_wino_fwd", X.ptr(x), X.ptr(w), X.ptr(b), None, None, X.ptr(y), NR, ps, ps, C, C, 0, X.ptr(vk), wsw.data_ptr(), wsw.numel(), st)
+            fn = lambda: X.call("myolo_conv3x3_wino_bwd_weight", None, X.ptr(vk), X.ptr(y), X.ptr(dw), NR, ps, ps, C, C, wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("%s M=%d: %.3f ms  %.1f direct-equivalent TFLOP/s (direct-conv FLOPs / time)" % (a.which, M, ms, flop / ms / 1e9))
     elif a.which.startswith("conv3x3"):
         Co = a.cout
         x, w, b, y = rn(M, C), rn(3, 3, C, Co) * 0.02, rn(Co), torch.empty(M, Co, device=dev)
