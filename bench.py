@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--mask-head-rois", choices=["all", "positives"], default="all",
                     help="cfg.TRAIN_MASK_HEAD_ROIS of the run that produces `value` (default: all ROIs, as the reference graph)")
     ap.add_argument("--no-variant", action="store_true", help="skip the extra timed run of the other TRAIN_MASK_HEAD_ROIS setting")
+    ap.add_argument("--conv3x3", choices=["auto", "direct", "winograd"], default="auto", help="cfg.CONV3X3_ALGO")
     args = ap.parse_args()
 
     from myolo import dist as mdist
@@ -122,7 +123,7 @@ def main():
     dev = "cuda:%d" % local
     base = ShapesConfig if args.nbox == 3 else ShapesHeadConfig
     cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch,
-                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois)
+                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois, CONV3X3_ALGO=args.conv3x3)
     model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
     net = model.net
     reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)])
@@ -141,7 +142,7 @@ def main():
     for i in range(args.warmup):
         net.train_step(dbs[i % nb], args.lr)
     barrier()
-    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd"}
+    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "wino_multiply"}
     net.timings = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -155,6 +156,7 @@ def main():
     loss = float(out["yolo_terms"][0]) + float(out["mask_terms"][0])
     assert np.isfinite(loss), "non-finite loss in the timed region"
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
+    mul_ms, mul_n = net.kernel_ms("wino_multiply")
     roi_ms, _ = net.kernel_ms("roialign_fwd")
 
     # the same K steps with the other TRAIN_MASK_HEAD_ROIS setting (reported beside `value`, never as `value`)
@@ -185,12 +187,25 @@ def main():
         R = cfg.TRAIN_ROIS_PER_IMAGE
         ps = cfg.MASK_POOL_SIZE
         M = args.batch * R * ps * ps
-        flop = 2.0 * M * (9 * 256) * 256                      # algorithmic FLOPs of one mask-head 3x3 conv launch
-        achieved = flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+        flop = 2.0 * M * (9 * 256) * 256                      # algorithmic FLOPs of one mask-head 3x3 conv as a direct convolution
+        wino = mul_n > 0
+        if wino:
+            # CONV3X3_ALGO auto/winograd: the dominant kernel is the batched GEMM of the 36 Winograd points,
+            # M_t = tiles, K = N = 256; its algorithmic FLOPs are what the Winograd form needs, not the direct conv's
+            tiles_w = args.batch * R * ((ps + 3) // 4) ** 2
+            kflop = 2.0 * 36 * tiles_w * 256 * 256
+            kms, kn = mul_ms, mul_n
+            kname = "gemm_nn_fast<PLAIN> x36 batched (Winograd F(4x4,3x3) multiply stage of the mask-head 3x3 convs, M=%d K=256 N=256 per point)" % tiles_w
+            kbytes = 36.0 * tiles_w * (256 + 256) * 4 + 36 * 256 * 256 * 4
+        else:
+            kflop, kms, kn = flop, conv_ms, conv_n
+            kname = "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M
+            kbytes = 2.0 * M * 256 * 4 + 9 * 256 * 256 * 4
+        achieved = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         roi_bytes = args.batch * R * ps * ps * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
         traffic = None      # HBM-side bytes per launch of the dominant kernel, from the separate --pmc passes (tools/collect_profiles.sh)
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_conv3x3_fwd.json")))
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_wino_multiply.json" if wino else "r1_pmc_conv3x3_fwd.json")))
             if args.batch * R == 32 * 147:        # the counters were collected at exactly this shape
                 traffic = pj["traffic_bytes_per_launch_corrected"]
         except Exception:
@@ -206,12 +221,15 @@ def main():
             "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
                                    "(fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
                                        args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
-                                       "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS),
+                                       "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + ", 3x3 convs: " + cfg.CONV3X3_ALGO,
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
-            "roofline": {"kernel": "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M,
+            "roofline": {"kernel": kname,
                          "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": achieved / 157.3, "traffic": traffic,
-                         "algorithmic_bytes": 2.0 * M * 256 * 4 + 9 * 256 * 256 * 4, "algorithmic_flop": flop, "launches_timed": conv_n, "avg_launch_ms": conv_ms,
+                         "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
+                         "conv_op": {"algo": "winograd_f4x4_3x3" if wino else "direct", "avg_ms": conv_ms, "ops_timed": conv_n,
+                                     "direct_conv_flop": flop,
+                                     "direct_equivalent_tflops": flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0},
                          "secondary": {"kernel": "crop_fwd_kernel (ROIAlign fwd)", "bound": "hbm",
                                        "achieved": roi_bytes / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
                                        "peak": 8000.0, "unit": "GB/s",

@@ -210,6 +210,13 @@ int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
 size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int which);
 int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
                            int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
+/* the forward's four stages, callable on their own: U [36][Cin][Cout] (flip=1: rotated, [36][Cout][Cin], for the data
+ * gradient), V [36][T][Cin], M [36][T][Cout] with T = N*ceil(H/4)*ceil(W/4) */
+int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream);
+int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
+int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
+int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
+                                int N, int H, int W, int C, int act, void* stream);
 int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
                                 void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W,

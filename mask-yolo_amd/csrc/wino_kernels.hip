@@ -290,6 +290,45 @@ size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int w
     }
 }
 
+/* ---- the four stages on their own (the engine times the multiply stage for bench.py's roofline) ---- */
+int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream)
+{
+    MYOLO_REQUIRE(w && U && Cin > 0 && Cout > 0, "wino_weight_transform: bad arguments");
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, flip);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream)
+{
+    MYOLO_REQUIRE(x && V && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "wino_input_transform: bad arguments (C %% 4 == 0)");
+    const TileGeom g = geom(N, H, W);
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, V, g, C);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(V && U && M && N > 0 && H > 0 && W > 0, "wino_multiply: bad arguments");
+    const TileGeom g = geom(N, H, W);
+    const int rc = myolo_gemm_nn_batched(V, U, M, g.T, Cin, Cout, 36, (hipStream_t)stream);
+    if (rc != MYOLO_OK) return rc;
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
+                                int N, int H, int W, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "wino_output_transform: bad arguments (C %% 4 == 0)");
+    MYOLO_REQUIRE(!scale == !shift, "wino_output_transform: scale and shift go together");
+    const TileGeom g = geom(N, H, W);
+    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, M, y, bias, scale, shift, g, C, act);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
 int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
                            int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream)
 {

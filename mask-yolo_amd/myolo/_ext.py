@@ -52,6 +52,10 @@ SIGS = {
     "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_wino_weight_transform": [P, P, I, I, I, P],
+    "myolo_wino_input_transform": [P, P, I, I, I, I, P],
+    "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],
+    "myolo_wino_output_transform": [P, P, P, P, P, I, I, I, I, I, P],
     "myolo_pack_weights_bf16": [P, I, I, I, P, P, P, P, P, P, P, P],
     "myolo_crop_and_resize_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_conv3x3_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],

@@ -24,6 +24,9 @@ YOLO_BLOCKS = [(512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1), (1024
 MASK_FILTERS = 256                                                                                 # model.py:688-711
 
 
+WINO_MIN_ROWS = 32768      # CONV3X3_ALGO='auto': output pixels from which the Winograd form of a 3x3 conv is used
+
+
 def layer_table(cfg):
     """[(layer name, kind, shape, bucket)] -- names are the reference's Keras layer names (the
     checkpoint schema).  bucket: 0 backbone, 1 yolo head + feature_map, 2 mask head."""
@@ -156,6 +159,9 @@ class Net(object):
         self.before_optimizer = None      # callable() -- waits for the all-reduce
         self.grad_scale = 1.0
         # exact-sparsity backward of the mask head (see mask_head_bwd_sparse); False = dense reference path
+        self.conv3x3_algo = getattr(cfg, "CONV3X3_ALGO", "auto")
+        if self.conv3x3_algo not in ("auto", "direct", "winograd"):
+            raise ValueError("CONV3X3_ALGO must be 'auto', 'direct' or 'winograd' (got %r)" % (self.conv3x3_algo,))
         self.sparse_mask_bwd = True
         # exact-sparsity FORWARD of the mask head (see mask_head_fwd_positives): conv2-4 / deconv / myolo_mask only on
         # the positive ROIs.  Same loss, gradients and BN state; the training graph's unused myolo_mask rows of the
@@ -259,6 +265,72 @@ class Net(object):
         X.call("myolo_colsum", X.ptr(x2d), X.ptr(out), M, C, *self._wsargs(), X.stream())
 
     # ---- depthwise-separable block ------------------------------------------
+    # ---- 3x3 / s1 / SAME convolution: direct implicit GEMM or Winograd F(4x4,3x3) -------------------------
+    def _wino_ok(self, nimg, h, w, cin, cout):
+        """cfg.CONV3X3_ALGO: 'direct' | 'winograd' | 'auto' (Winograd for the big dense launches, where its 3x fewer
+        multiplications outweigh two extra streaming passes; the direct kernel for the small / compacted ones)."""
+        algo = self.conv3x3_algo
+        if algo == "direct":
+            return False
+        fits = cin % 16 == 0 and cout % 16 == 0 and h >= 4 and w >= 4
+        if algo == "winograd":
+            return fits
+        return fits and nimg * h * w >= WINO_MIN_ROWS
+
+    def _timed(self, tag):
+        """(start, stop) closures bracketing a multi-launch op with HIP events on the launch stream, if `tag` is measured."""
+        if tag is None or tag not in self.timed_tags:
+            return (lambda: None), (lambda: None)
+        st = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def stop():
+            e1.record(st)
+            self.timings.setdefault(tag, []).append((e0, e1))
+        return (lambda: e0.record(st)), stop
+
+    def conv3x3_fwd(self, x, layer, y, nimg, h, w, cin, cout, scale=None, shift=None, act=ACT_NONE, keep_v=False, tag=None):
+        """y = act(affine(conv3x3(x) + bias)) with the layer's kernel/bias; affine (scale, shift) optional.
+        Returns the Winograd-transformed input when keep_v (for conv3x3_bwd_weight), else None."""
+        kern, bias = self.p[layer + "/kernel"], self.p[layer + "/bias"]
+        start, stop = self._timed(tag)
+        start()
+        v = None
+        if self._wino_ok(nimg, h, w, cin, cout):
+            T = nimg * ((h + 3) // 4) * ((w + 3) // 4)
+            U, V, M = self._new(36, cin, cout), self._new(36, T, cin), self._new(36, T, cout)
+            X.call("myolo_wino_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, 0, X.stream())
+            X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V), nimg, h, w, cin, X.stream())
+            self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), nimg, h, w, cin, cout, X.stream())
+            X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(scale), X.ptr(shift), X.ptr(y), nimg, h, w, cout, act,
+                   X.stream())
+            v = V if keep_v else None
+        elif scale is not None or act != ACT_NONE:
+            X.call("myolo_conv3x3_affine_act_fwd", X.ptr(x), X.ptr(kern), X.ptr(bias), X.ptr(scale), X.ptr(shift), X.ptr(y), nimg, h, w,
+                   cin, cout, act, *self._wsargs(), X.stream())
+        else:
+            X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(kern), X.ptr(bias), X.ptr(y), nimg, h, w, cin, cout, *self._wsargs(), X.stream())
+        stop()
+        return v
+
+    def conv3x3_bwd_weight(self, x, v_saved, dy, layer, nimg, h, w, cin, cout):
+        dw = self.g[layer + "/kernel"]
+        if self._wino_ok(nimg, h, w, cin, cout):
+            self.ws.ensure(X.wino_ws_bytes(nimg, h, w, cin, cout, 2))
+            X.call("myolo_conv3x3_wino_bwd_weight", None if v_saved is not None else X.ptr(x), X.ptr(v_saved), X.ptr(dy), X.ptr(dw),
+                   nimg, h, w, cin, cout, *self._wsargs(), X.stream())
+        else:
+            X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), nimg, h, w, cin, cout, *self._wsargs(), X.stream())
+
+    def conv3x3_bwd_data(self, dy, layer, dx, nimg, h, w, cin, cout):
+        if self._wino_ok(nimg, h, w, cout, cin):
+            self.ws.ensure(X.wino_ws_bytes(nimg, h, w, cin, cout, 1))
+            X.call("myolo_conv3x3_wino_bwd_data", X.ptr(dy), X.ptr(self.p[layer + "/kernel"]), X.ptr(dx), nimg, h, w, cin, cout,
+                   *self._wsargs(), X.stream())
+        else:
+            X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[layer + "/kernel"]), X.ptr(dx), nimg, h, w, cin, cout,
+                   *self._wsargs(), X.stream())
+
     def dw_block_fwd(self, bid, a, shape, stride, train):
         """a [N*H*W, C] activation, shape=(N,H,W,C).  Returns (activation, new shape)."""
         N, H, W, C = shape
@@ -396,14 +468,16 @@ class Net(object):
                 X.call("myolo_bn_frozen_coeffs", X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
                        X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
                        X.ptr(buf[2]), X.ptr(buf[3]), MASK_FILTERS, X.stream())
-                self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_affine_act_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
-                                 X.ptr(self.p[cn + "/bias"]), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps, cin,
-                                 MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
+                self.conv3x3_fwd(x, cn, y, NR, ps, ps, cin, MASK_FILTERS, scale=buf[2], shift=buf[3], act=ACT_RELU,
+                                 tag="mask_conv3x3_fwd")
                 self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
                 x = y
             else:
-                self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p[cn + "/kernel"]),
-                                 X.ptr(self.p[cn + "/bias"]), X.ptr(y), NR, ps, ps, cin, MASK_FILTERS, *self._wsargs(), X.stream())
+                # conv1 in training: its transformed input is kept for the dense weight gradient
+                v = self.conv3x3_fwd(x, cn, y, NR, ps, ps, cin, MASK_FILTERS, keep_v=train and i == 1 and self.sparse_mask_bwd,
+                                     tag="mask_conv3x3_fwd")
+                if v is not None:
+                    self.tape["conv1_V"] = v
                 x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
             cin = MASK_FILTERS
         d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
@@ -481,12 +555,10 @@ class Net(object):
             dy = self.bn_act_bwd("myolo_mask_bn%d" % i, da)
             xin = convs[i - 1]
             cin = xin.shape[1]
-            X.call("myolo_conv3x3_bwd_weight", X.ptr(xin), X.ptr(dy), X.ptr(self.g[cn + "/kernel"]), NR, ps, ps, cin, MASK_FILTERS,
-                   *self._wsargs(), X.stream())
+            self.conv3x3_bwd_weight(xin, None, dy, cn, NR, ps, ps, cin, MASK_FILTERS)
             self.colsum(dy, self.g[cn + "/bias"])
             da = self._new(NR * ps * ps, cin)
-            X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[cn + "/kernel"]), X.ptr(da), NR, ps, ps, cin, MASK_FILTERS,
-                   *self._wsargs(), X.stream())
+            self.conv3x3_bwd_data(dy, cn, da, NR, ps, ps, cin, MASK_FILTERS)
         n, h, w, cf = fshape
         dF = self._new(n * h * w, cf)
         X.call("myolo_roialign_bwd_grouped", X.ptr(da), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
@@ -547,8 +619,9 @@ class Net(object):
                          n, h, w, cf, NR, ps, ps, X.stream())
         self.tape["roi"] = (boxes, bind, fshape, NR)
         y1 = self._new(NR * q, MASK_FILTERS)
-        self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_conv1/kernel"]),
-                         X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, ps, ps, cf, MASK_FILTERS, *self._wsargs(), X.stream())
+        v = self.conv3x3_fwd(x, "myolo_mask_conv1", y1, NR, ps, ps, cf, MASK_FILTERS, keep_v=True, tag="mask_conv3x3_fwd")
+        if v is not None:
+            self.tape["conv1_V"] = v
         bn = "myolo_mask_bn1"
         buf = self.bnbuf[bn]
         X.call("myolo_bn_stats", X.ptr(y1), X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
@@ -569,8 +642,7 @@ class Net(object):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             convs.append(a)
             y = self._new(NP * q, MASK_FILTERS)
-            X.call("myolo_conv3x3_fwd", X.ptr(a), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(y),
-                   NP, ps, ps, MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+            self.conv3x3_fwd(a, cn, y, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
             a = self.bn_act_fwd(bn, y, ACT_RELU, False)          # keeps the pre-BN tensor for backward
         d = self._new(NP * 4 * q, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_fwd", X.ptr(a), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
@@ -630,17 +702,14 @@ class Net(object):
                 # the fused forward never wrote the pre-BN tensor: recompute it for the positive ROIs with the
                 # same kernel (same k order per output element -> the same fp32 values)
                 c_p = self._new(NP * q, MASK_FILTERS)
-                X.call("myolo_conv3x3_fwd", X.ptr(xin), X.ptr(self.p[cn + "/kernel"]), X.ptr(self.p[cn + "/bias"]), X.ptr(c_p),
-                       NP, ps, ps, MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+                self.conv3x3_fwd(xin, cn, c_p, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
             else:
                 c_p = gather(self.tape[bn][0], q)
             dy = self.bn_act_bwd(bn, da, y_override=c_p)
-            X.call("myolo_conv3x3_bwd_weight", X.ptr(xin), X.ptr(dy), X.ptr(self.g[cn + "/kernel"]), NP, ps, ps, MASK_FILTERS,
-                   MASK_FILTERS, *self._wsargs(), X.stream())
+            self.conv3x3_bwd_weight(xin, None, dy, cn, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
             self.colsum(dy, self.g[cn + "/bias"])
             da = self._new(NP * q, MASK_FILTERS)
-            X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[cn + "/kernel"]), X.ptr(da), NP, ps, ps, MASK_FILTERS,
-                   MASK_FILTERS, *self._wsargs(), X.stream())
+            self.conv3x3_bwd_data(dy, cn, da, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
         # bn1: batch statistics -> dense dx from the row-sparse upstream gradient
         c1, act, _ = self.tape["myolo_mask_bn1"]
         buf = self.bnbuf["myolo_mask_bn1"]
@@ -651,12 +720,10 @@ class Net(object):
                M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
         x0 = convs[0]
         cin = x0.shape[1]
-        X.call("myolo_conv3x3_bwd_weight", X.ptr(x0), X.ptr(dc1), X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
-               MASK_FILTERS, *self._wsargs(), X.stream())
+        self.conv3x3_bwd_weight(x0, self.tape.pop("conv1_V", None), dc1, "myolo_mask_conv1", NR, ps, ps, cin, MASK_FILTERS)
         self.colsum(dc1, self.g["myolo_mask_conv1/bias"])
         dp0 = self._new(M1, cin)
-        X.call("myolo_conv3x3_bwd_data", X.ptr(dc1), X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, ps, ps, cin,
-               MASK_FILTERS, *self._wsargs(), X.stream())
+        self.conv3x3_bwd_data(dc1, "myolo_mask_conv1", dp0, NR, ps, ps, cin, MASK_FILTERS)
         dF = self._new(n * h * w, cf)
         X.call("myolo_roialign_bwd_grouped", X.ptr(dp0), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
         if self.on_bucket_ready:
