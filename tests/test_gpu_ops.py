@@ -132,6 +132,27 @@ def test_conv3x3_winograd(N, H, W, Cin, Cout):
     check(dw2, rdw, what="wino dw (from x)")
 
 
+def test_winograd_error_is_at_fp32_level():
+    """The Winograd form is the same fp32 arithmetic with the sums associated differently; its error against a float64
+    convolution must stay at fp32 rounding level (a reduced-precision product would sit at 1e-3), recorded here against
+    the direct kernel's on the mask-head shape (14x14, 256 -> 256, activations O(1), glorot-scale weights)."""
+    rng = np.random.default_rng(5)
+    N, H, W, C = 24, 14, 14, 256
+    x = np.maximum(rnd(rng, N, H, W, C), 0)                       # post-ReLU activations
+    w, b = rnd(rng, 3, 3, C, C, scale=0.03), rnd(rng, C, scale=0.1)
+    ref = O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64)
+    wsb = torch.empty(X.wino_ws_bytes(N, H, W, C, C, 0), dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    yd, yw = new(N, H, W, C), new(N, H, W, C)
+    X.call("myolo_conv3x3_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(yd), N, H, W, C, C, *ws(), X.stream())
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), None, None, X.ptr(yw), N, H, W, C, C, 0, None,
+           wsb.data_ptr(), wsb.numel(), X.stream())
+    ed, ew = relerr(yd, ref), relerr(yw, ref)
+    rms = lambda a: float(np.sqrt(np.mean((a.cpu().numpy() - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)))   # noqa: E731
+    print("max-norm rel err: direct %.2e  winograd %.2e;  rms rel err: direct %.2e  winograd %.2e" % (ed, ew, rms(yd), rms(yw)))
+    assert ed < 5e-6 and ew < 5e-5, (ed, ew)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 256, 256), (2, 5, 7, 32, 64)])
 def test_deconv2x2s2(N, H, W, Cin, Cout):
     rng = np.random.default_rng(3)

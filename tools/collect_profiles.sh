@@ -31,13 +31,15 @@ PY
 # 2. un-profiled bench line (the number of record)
 python bench.py --steps 10 --warmup 3 2> /dev/null | tail -1 > $OUT/${TAG}_bench.json
 # 3. single-kernel micro-benchmarks
-for k in conv3x3_fwd conv3x3_bwd_data conv3x3_bwd_weight deconv_fwd roialign_fwd roialign_bwd dw; do python tools/kbench.py $k --iters 20 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_kbench.txt
+for k in wino_fwd wino_bwd_data wino_bwd_weight conv3x3_fwd conv3x3_bwd_data conv3x3_bwd_weight deconv_fwd roialign_fwd roialign_bwd conv3x3_bf16_fwd deconv_bf16_fwd dw; do python tools/kbench.py $k --iters 20 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_kbench.txt
 # 4. PMC passes on the dominant kernel (+ a pure streaming kernel to calibrate FETCH_SIZE / WRITE_SIZE units)
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -o p -- python tools/kbench.py conv3x3_fwd --iters 3 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/wino_$c -o p -- python tools/kbench.py wino_fwd --iters 3 > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/cal_$c -o p -- python tools/kbench.py roialign_fwd --iters 3 > /dev/null 2>&1
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq -o p -- python tools/kbench.py conv3x3_fwd --iters 3 > /dev/null 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/wino_sq -o p -- python tools/kbench.py wino_fwd --iters 3 > /dev/null 2>&1
 python - "$OUT" "$TAG" <<'PY'
 import csv, collections, json, sys
 out, tag = sys.argv[1], sys.argv[2]
@@ -63,9 +65,34 @@ if "GRBM_GUI_ACTIVE" in v:
     cyc = v["GRBM_GUI_ACTIVE"] / xcds
     res["effective_clock_GHz"] = cyc / ns
     res["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cyc
+res["traffic_bytes_per_launch_corrected"] = 1024.0 * (2 * res["FETCH_SIZE_KB_per_launch"] + res["WRITE_SIZE_KB_per_launch"])
+res["correction"] = "2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B; checked on crop_fwd above) + WRITE_SIZE, KB -> bytes"
 json.dump(res, open("%s/%s_pmc_conv3x3_fwd.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res, indent=1))
+# Winograd forward: the multiply stage (batched GEMM) and the two transforms, same passes
+w = {"op": "myolo_conv3x3_wino_fwd NR=4704 14x14 256->256 (tools/kbench.py wino_fwd)"}
+for kname, key in (("gemm_nn_fast", "multiply"), ("wino_in_kernel", "input_transform"), ("wino_out_kernel", "output_transform")):
+    e = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        v, ns, n = per_launch("wino_" + c, kname)
+        e[c + "_KB_per_launch"] = v.get(c); e["avg_ns"] = ns
+    e["traffic_bytes_per_launch_corrected"] = 1024.0 * (2 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"])
+    w[key] = e
+T = 4704 * 16
+w["multiply"]["algorithmic_bytes"] = 36.0 * T * 512 * 4 + 36 * 256 * 256 * 4
+w["input_transform"]["algorithmic_bytes"] = 4704 * 196 * 256 * 4 + 36.0 * T * 256 * 4
+w["output_transform"]["algorithmic_bytes"] = 4704 * 196 * 256 * 4 + 36.0 * T * 256 * 4
+v, ns, n = per_launch("wino_sq", "gemm_nn_fast")
+w["multiply"]["sq_per_launch"] = v
+if "GRBM_GUI_ACTIVE" in v:
+    cyc = v["GRBM_GUI_ACTIVE"] / xcds
+    w["multiply"]["effective_clock_GHz"] = cyc / ns
+    w["multiply"]["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / simds / cyc
+w["traffic_bytes_per_launch_corrected"] = w["multiply"]["traffic_bytes_per_launch_corrected"]
+json.dump(w, open("%s/%s_pmc_wino_multiply.json" % (out, tag), "w"), indent=1)
+print(json.dumps(w, indent=1))
 PY
 head -8 $OUT/${TAG}_bench_kernel_by_grid.csv | cut -c1-170
 cat $OUT/${TAG}_kbench.txt | grep -v "^dw  \|^dw 1"
 cat $OUT/${TAG}_bench.json | cut -c1-400
+python tools/bench_infer.py --batch 4 > $OUT/${TAG}_bench_infer.json 2>/dev/null; cat $OUT/${TAG}_bench_infer.json
