@@ -202,6 +202,14 @@ int myolo_mask_bce(const float* target_masks, const int32_t* target_class_ids, c
 int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
                     float lr_t, float beta1, float beta2, float eps, float grad_scale, void* stream);
 
+/* ---- myolo_mask_deconv + ReLU + myolo_mask 1x1 + sigmoid (model.py:711-714) in one pass: the [N,2H,2W,Cout]
+ * activation is never written.  w [2,2,Cout,Cin], w2 [Cout][ncls], p_out [N,2H,2W,ncls] probabilities.
+ * Needs Cout % 128 == 0, Cin % 16 == 0, ncls <= 4; results equal deconv2x2s2_fwd + mask_head_out_fwd up to fp32
+ * summation order (partial sums over 64-channel slabs are added in a fixed order: bit-reproducible). ---- */
+size_t myolo_deconv2x2s2_mask_ws_bytes(int N, int H, int W, int Cin, int Cout, int ncls);
+int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
+                               int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- Winograd F(4x4,3x3) form of the dense 3x3/s1/SAME convolutions (same contracts as myolo_conv3x3_* above:
  * myolo_mask_conv1-4 model.py:687-709 and their gradients); fp32 operands and accumulation, 4x fewer multiplications
  * per full tile.  ws_bytes(which): 0 forward, 1 data gradient, 2 weight gradient.

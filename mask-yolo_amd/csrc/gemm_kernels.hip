@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define LDAS (BM + 2)
 
 enum { AM_PLAIN = 0, AM_CONV3 = 1, AM_DECONV = 2 };
-enum { EP_PLAIN = 0, EP_DECONV = 1 };
+enum { EP_PLAIN = 0, EP_DECONV = 1, EP_DECONV_MASK = 2 };
 
 struct GemmArgs {
     const float* A;
@@ -49,6 +49,8 @@ struct GemmArgs {
     long long m_per_split;   // TN only
     long long sA, sB, sC;    // fast kernels: batch strides in elements (grid z = batch index; 0 = not batched)
     int batch;               // TN split partial layout [split][batch][K*N]
+    const float* w2;         // EP_DECONV_MASK: the 1x1 mask conv's kernel [Co][ncls]
+    int ncls;                // EP_DECONV_MASK: classes (<= 4); partial logits go to `part` [slab][4*M][ncls]
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -627,6 +629,62 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
             }
         return;
     }
+    if constexpr (EPI == EP_DECONV_MASK && WNT == 2) {
+        // myolo_mask_deconv + ReLU + the 1x1 myolo_mask conv (model.py:711-714) without ever writing the
+        // [N,2H,2W,Co] tensor: this tile holds 128 of the Co channels of ONE tap (Co % 128 == 0) for 128 input pixels.
+        // Per class, each lane forms relu(acc + bias) * w2 for its 32 row slots and 2 columns, then a 5-step
+        // reduce-scatter butterfly over the 32 lanes of its half leaves lane l the sum of row slot l over the wave's
+        // 64 columns.  The (Co/128)*2 column slabs are summed in fixed order by deconv_mask_finish (deterministic).
+        float cbm[WNT];
+        int cow[WNT];
+        int tap = 0;
+#pragma unroll
+        for (int u = 0; u < WNT; ++u) {
+            const int col = n0 + wn * 32 * WNT + u * 32 + l31;
+            tap = col / p.Co;
+            cow[u] = col - tap * p.Co;
+            cbm[u] = p.bias ? p.bias[cow[u]] : 0.f;
+        }
+        // After the butterfly lane l31 owns row slot r = l31 & 15 of the 32-row block t = l31 >> 4.
+        const int rr = l31 & 15;
+        const long long row = m0 + wm * 64 + (l31 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        float* dst = nullptr;
+        if (row < p.M) {
+            const long long n_img = row / hw;
+            const int rem = (int)(row - n_img * hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+            const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
+            const int slab = ((n0 - tap * p.Co) / BN_) * 2 + wn;
+            dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
+        }
+#pragma unroll 1
+        for (int c = 0; c < p.ncls; ++c) {          // one class and one 32-row block at a time: live set = acc + 16 values
+            const float w0 = p.w2[cow[0] * p.ncls + c], w1 = p.w2[cow[1] * p.ncls + c];
+            float outv = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float cur[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    cur[j] = fmaf(fmaxf(acc[t][1][j] + cbm[1], 0.f), w1, fmaxf(acc[t][0][j] + cbm[0], 0.f) * w0);
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {     // reduce-scatter over the 16 lanes sharing l31 >> 4 ...
+                    const int m = 1 << st;
+                    const bool bit = (l31 >> st) & 1;
+#pragma unroll
+                    for (int i = 0; i < (8 >> st); ++i) {
+                        const float a = cur[2 * i], b = cur[2 * i + 1];
+                        const float keep = bit ? b : a, send = bit ? a : b;
+                        cur[i] = keep + __shfl_xor(send, m, 64);
+                    }
+                }
+                const float tot = cur[0] + __shfl_xor(cur[0], 16, 64);      // ... then add the other 16 lanes' columns
+                if ((l31 >> 4) == t) outv = tot;
+            }
+            if (dst) dst[c] = outv;
+        }
+        return;
+    }
     // ---- epilogue: per-column parameters are loaded once, then 64 row-contiguous 128-byte stores per wave ----
     float cb[WNT], cs[WNT], ct[WNT];
     int ccol[WNT], ctap[WNT];
@@ -927,6 +985,18 @@ __global__ void transpose_batched(const float* __restrict__ in, float* __restric
     }
 }
 
+// p[pix][c] = sigmoid(b2[c] + sum over the column slabs of the fused deconv epilogue), slabs in fixed order
+__global__ __launch_bounds__(256) void deconv_mask_finish(const float* __restrict__ part, const float* __restrict__ b2,
+                                                          float* __restrict__ out, long long npix, int ncls, int nslabs)
+{
+    const long long total = npix * ncls;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float sacc = b2[(int)(i % ncls)];
+        for (int k = 0; k < nslabs; ++k) sacc += part[(long long)k * total + i];
+        out[i] = 1.f / (1.f + expf(-sacc));
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
@@ -1049,7 +1119,7 @@ int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M,
     GemmArgs a = {};
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = N; a.ldc = N; a.act = MYOLO_ACT_NONE;
     a.sA = M * (long long)K; a.sB = (long long)K * N; a.sC = M * (long long)N; a.batch = batch;
-    a.nt = 0;          // the product is read back at once by the output transform
+    a.nt = getenv("MYOLO_WINO_NT") ? 1 : 0;          // the product is read back at once by the output transform
     const long long tiles = cdiv64(M, BM) * ((N + BN - 1) / BN);
     if (tiles <= 0 || batch <= 0) return MYOLO_OK;
     hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN>), dim3((unsigned)tiles, 1, batch), dim3(256), 0, s, a);
@@ -1222,6 +1292,38 @@ int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, flo
     a.A = x; a.B = (const float*)ws; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
     a.lda = Cin; a.ldb = 4 * Cout; a.H = H; a.W = W; a.Co = Cout; a.act = act;
     launch_nn<AM_PLAIN, EP_DECONV>(a, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+size_t myolo_deconv2x2s2_mask_ws_bytes(int N, int H, int W, int Cin, int Cout, int ncls)
+{
+    return align256((size_t)4 * Cin * Cout * sizeof(float)) +
+           (size_t)(Cout / BN) * 2 * 4 * N * H * W * ncls * sizeof(float);
+}
+
+int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
+                               int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && bias && w2 && b2 && p_out && N > 0 && H > 0 && W > 0, "deconv2x2s2_mask_fwd: bad arguments");
+    MYOLO_REQUIRE(Cout % BN == 0 && Cin % BK == 0 && (Cin & 3) == 0 && ncls >= 1 && ncls <= 4,
+                  "deconv2x2s2_mask_fwd: needs Cout %% %d == 0, Cin %% %d == 0, 1 <= classes <= 4 (got %d, %d, %d)", BN, BK, Cout, Cin, ncls);
+    const size_t wb = align256((size_t)4 * Cin * Cout * sizeof(float));
+    MYOLO_NEED_WS(myolo_deconv2x2s2_mask_ws_bytes(N, H, W, Cin, Cout, ncls));
+    hipStream_t s = (hipStream_t)stream;
+    launch_transpose(w, (float*)ws, 4 * Cout, Cin, 1, 0, s);     // ws[ci][(ky,kx,co)]
+    GemmArgs a = {};
+    a.A = x; a.B = (const float*)ws; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
+    a.lda = Cin; a.ldb = 4 * Cout; a.H = H; a.W = W; a.Co = Cout; a.act = MYOLO_ACT_RELU;
+    a.w2 = w2; a.ncls = ncls; a.part = (float*)((char*)ws + wb);
+    MYOLO_REQUIRE(((uintptr_t)x & 15) == 0, "deconv2x2s2_mask_fwd: x must be 16-byte aligned");
+    const long long tiles = cdiv64(a.M, BM) * (a.N / BN);
+    hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    const long long npix = 4 * a.M;
+    long long blocks = (npix * ncls + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(deconv_mask_finish, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.part, b2, p_out, npix, ncls,
+                       (Cout / BN) * 2);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -52,6 +52,7 @@ SIGS = {
     "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_deconv2x2s2_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_wino_weight_transform": [P, P, I, I, I, P],
     "myolo_wino_input_transform": [P, P, I, I, I, I, P],
     "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],
@@ -88,12 +89,15 @@ def load():
     lib.myolo_workspace_bytes.restype = Z
     lib.myolo_conv3x3_wino_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_conv3x3_wino_ws_bytes.restype = Z
+    lib.myolo_deconv2x2s2_mask_ws_bytes.argtypes = [I, I, I, I, I, I]
+    lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
     _LIB = lib
     return lib
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes"]
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes",
+                              "myolo_deconv2x2s2_mask_ws_bytes"]
 
 
 def ptr(t):
@@ -122,3 +126,7 @@ def workspace_bytes(rows, cin, cout):
 def wino_ws_bytes(n, h, w, cin, cout, which):
     """scratch bytes of myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2)."""
     return int(load().myolo_conv3x3_wino_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(which)))
+
+
+def deconv_mask_ws_bytes(n, h, w, cin, cout, ncls):
+    return int(load().myolo_deconv2x2s2_mask_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(ncls)))

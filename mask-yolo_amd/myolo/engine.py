@@ -480,13 +480,22 @@ class Net(object):
                     self.tape["conv1_V"] = v
                 x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
             cin = MASK_FILTERS
-        d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
-        X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
-               X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
         C = cfg.NUM_CLASSES
         p = self._new(NR * 4 * ps * ps, C)
-        X.call("myolo_mask_head_out_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
-               NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
+        if fuse and C <= 4 and MASK_FILTERS % 128 == 0:
+            # deconv + ReLU + 1x1 + sigmoid in one pass; the 28x28x256 tensor is never written.  The sparse backward
+            # recomputes it for the positive ROIs (mask_head_bwd_sparse); the dense backward needs it whole.
+            self.ws.ensure(X.deconv_mask_ws_bytes(NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C))
+            X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]),
+                   X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
+                   X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, *self._wsargs(), X.stream())
+            d = None
+        else:
+            d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
+            X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
+                   X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
+            X.call("myolo_mask_head_out_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
+                   NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
         self.tape["mask"] = (convs, x, d)
         return p
 
@@ -683,12 +692,18 @@ class Net(object):
         q = ps * ps
         gather = (lambda t, rows: t) if compact else (lambda t, rows: self._gather(t, idx_d, NP, rows))
         dz_p = gather(dz, 4 * q)
-        d_p = gather(d, 4 * q)
+        a4_p = gather(a4, q)
+        if d is None:          # fused forward (deconv + 1x1 in one pass): rebuild the deconv output of the positives
+            d_p = self._new(NP * 4 * q, MASK_FILTERS)
+            X.call("myolo_deconv2x2s2_fwd", X.ptr(a4_p), X.ptr(self.p["myolo_mask_deconv/kernel"]),
+                   X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(d_p), NP, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU,
+                   *self._wsargs(), X.stream())
+        else:
+            d_p = gather(d, 4 * q)
         Md = NP * 4 * q
         dd = self._new(Md, MASK_FILTERS)
         X.call("myolo_mask_head_out_bwd", X.ptr(d_p), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(dz_p), X.ptr(dd),
                X.ptr(self.g["myolo_mask/kernel"]), X.ptr(self.g["myolo_mask/bias"]), Md, MASK_FILTERS, C, *self._wsargs(), X.stream())
-        a4_p = gather(a4, q)
         X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_p), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
         self.colsum(dd, self.g["myolo_mask_deconv/bias"])

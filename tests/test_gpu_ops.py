@@ -170,6 +170,30 @@ def test_deconv2x2s2(N, H, W, Cin, Cout):
     check(dw, rdw, what="deconv dw")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,C", [(3, 14, 14, 256, 256, 4), (5, 14, 14, 256, 256, 2), (2, 5, 7, 32, 128, 1), (37, 14, 14, 64, 128, 3)])
+def test_deconv_mask_fused(N, H, W, Cin, Cout, C):
+    """deconv + ReLU + 1x1 + sigmoid in one pass == oracle, and == the two-kernel path up to summation order."""
+    rng = np.random.default_rng(4)
+    x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 2, 2, Cout, Cin, scale=0.05), rnd(rng, Cout)
+    w2, b2 = rnd(rng, Cout, C, scale=0.1), rnd(rng, C)
+    wsb = torch.empty(X.deconv_mask_ws_bytes(N, H, W, Cin, Cout, C), dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    p = new(N, 2 * H, 2 * W, C)
+    X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p), N, H, W, Cin, Cout,
+           C, wsb.data_ptr(), wsb.numel(), X.stream())
+    d = O.relu(O.deconv2x2s2(x, w, b)).astype(np.float64)
+    ref = 1 / (1 + np.exp(-(d.reshape(-1, Cout) @ w2 + b2))).reshape(N, 2 * H, 2 * W, C)
+    check(p, ref, 1e-5, "fused deconv+mask")
+    y, p2 = new(N, 2 * H, 2 * W, Cout), new(N, 2 * H, 2 * W, C)
+    X.call("myolo_deconv2x2s2_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, 1, *ws(), X.stream())
+    X.call("myolo_mask_head_out_fwd", X.ptr(y), X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p2), N * 4 * H * W, Cout, C, X.stream())
+    assert float((p - p2).abs().max()) < 2e-6
+    p3 = new(N, 2 * H, 2 * W, C)
+    X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p3), N, H, W, Cin, Cout,
+           C, wsb.data_ptr(), wsb.numel(), X.stream())
+    assert torch.equal(p, p3), "fused deconv+mask is not bit-reproducible"
+
+
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 32, 2), (3, 7, 7, 128, 1), (1, 14, 10, 64, 2),
                                             (2, 9, 13, 16, 1)])
 def test_dwconv3x3(N, H, W, C, stride):

@@ -86,6 +86,14 @@ def main():
             fn = lambda: X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(y), X.ptr(dw), NR, ps, ps, C, C, ws.data_ptr(), ws.numel(), st)   # noqa: E731
         ms = timeit(fn, a.iters)
         print("%s M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 157.3)" % (a.which, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 1.573))
+    elif a.which == "deconv_mask_fwd":
+        x, w, b = rn(M, C), rn(2, 2, C, C) * 0.02, rn(C)
+        w2, b2, pp = rn(C, 4) * 0.1, rn(4), torch.empty(4 * M, 4, device=dev)
+        wsw = torch.empty(X.deconv_mask_ws_bytes(NR, ps, ps, C, C, 4), dtype=torch.uint8, device=dev)
+        fn = lambda: X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(w2), X.ptr(b2), X.ptr(pp), NR, ps, ps, C, C, 4, wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        flop = 2.0 * M * C * 4 * C
+        print("deconv_mask_fwd (fused deconv+relu+1x1+sigmoid) M=%d: %.3f ms  %.1f TFLOP/s" % (M, ms, flop / ms / 1e9))
     elif a.which == "deconv_fwd":
         x, w, b, y = rn(M, C), rn(2, 2, C, C) * 0.02, rn(C), torch.empty(4 * M, C, device=dev)
         fn = lambda: X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(w), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, 1, ws.data_ptr(), ws.numel(), st)   # noqa: E731
