@@ -92,7 +92,7 @@ class Config(object):
     TRAIN_MASK_HEAD_ROIS = "all"
     # 3x3/s1 convolutions of the mask head: "direct" = implicit-GEMM kernel, "winograd" = F(4x4,3x3) in fp32 (3x fewer
     # multiplications at 14x14, same operand and accumulator type, sums associated differently: agrees with the direct
-    # kernel to ~1e-5 relative), "auto" = Winograd for launches of >= 32768 output pixels, direct below.
+    # kernel to ~1e-5 relative), "auto" = Winograd for launches of >= 16384 output pixels, direct below.
     CONV3X3_ALGO = "auto"
 
     def __init__(self):

@@ -24,7 +24,7 @@ YOLO_BLOCKS = [(512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1), (1024
 MASK_FILTERS = 256                                                                                 # model.py:688-711
 
 
-WINO_MIN_ROWS = 32768      # CONV3X3_ALGO='auto': output pixels from which the Winograd form of a 3x3 conv is used
+WINO_MIN_ROWS = 16384      # CONV3X3_ALGO='auto': output pixels from which the Winograd form of a 3x3 conv is used
 
 
 def layer_table(cfg):
@@ -383,8 +383,7 @@ class Net(object):
         n, h, w, c = c4shape
         Cf = cfg.TOP_FEATURE_MAP_DEPTH
         Fm = self._new(n * h * w, Cf)
-        X.call("myolo_conv3x3_fwd", X.ptr(C4), X.ptr(self.p["feature_map/kernel"]), X.ptr(self.p["feature_map/bias"]), X.ptr(Fm),
-               n, h, w, c, Cf, *self._wsargs(), X.stream())
+        self.conv3x3_fwd(C4, "feature_map", Fm, n, h, w, c, Cf)
         for f, s in YOLO_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
@@ -417,10 +416,10 @@ class Net(object):
             dC4 = da
         else:
             Cf = dF.shape[1]
-            X.call("myolo_conv3x3_bwd_weight", X.ptr(C4), X.ptr(dF), X.ptr(self.g["feature_map/kernel"]), n, h, w, c, Cf, *self._wsargs(), X.stream())
+            self.conv3x3_bwd_weight(C4, None, dF, "feature_map", n, h, w, c, Cf)
             self.colsum(dF, self.g["feature_map/bias"])
             dC4 = self._new(n * h * w, c)
-            X.call("myolo_conv3x3_bwd_data", X.ptr(dF), X.ptr(self.p["feature_map/kernel"]), X.ptr(dC4), n, h, w, c, Cf, *self._wsargs(), X.stream())
+            self.conv3x3_bwd_data(dF, "feature_map", dC4, n, h, w, c, Cf)
             X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
         if self.on_bucket_ready:
             self.on_bucket_ready(1)
