@@ -246,6 +246,10 @@ int myolo_conv3x3_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* b
 /* myolo_mask_deconv (model.py:711-712): wt [4*Cout][Cin] bf16, y [N,2H,2W,Cout] bf16 */
 int myolo_deconv2x2s2_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, uint16_t* y,
                                int N, int H, int W, int Cin, int Cout, int act, void* stream);
+/* deconv + ReLU + myolo_mask 1x1 + sigmoid in one pass from bf16 activations (see myolo_deconv2x2s2_mask_fwd); ws holds
+ * (Cout/128)*2 partial-logit slabs of 4*N*H*W*ncls floats */
+int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, const float* w2, const float* b2, float* p_out,
+                                    int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream);
 /* myolo_mask 1x1 + sigmoid (model.py:713-714) from bf16 activations; fp32 weights and probabilities */
 int myolo_mask_head_out_bf16_fwd(const uint16_t* x, const float* w, const float* bias, float* p,
                                  int64_t M, int Cin, int C, void* stream);

@@ -24,7 +24,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define OOB_OFF 0x7fffff00u
 
 enum { AM_PLAIN = 0, AM_CONV3 = 1 };
-enum { EP_PLAIN = 0, EP_DECONV = 1 };
+enum { EP_PLAIN = 0, EP_DECONV = 1, EP_DECONV_MASK = 2 };
 
 struct Bf16Args {
     const uint16_t* A;       // bf16 bits
@@ -35,6 +35,9 @@ struct Bf16Args {
     int N, K;
     int H, W, Cc, Co;
     int act;
+    const float* w2;         // EP_DECONV_MASK: 1x1 mask conv kernel [Co][ncls] (fp32)
+    float* part;             // EP_DECONV_MASK: partial logits [slab][4*M][ncls]
+    int ncls;
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, long long nbytes)
@@ -322,6 +325,54 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds(Bf16Args p)
         cur ^= 1;
     }
 
+    if constexpr (EPI == EP_DECONV_MASK) {
+        // deconv + ReLU + the 1x1 mask conv: with the swapped operands a lane owns two rows (t) and 32 of the wave's 64
+        // columns, so the channel sum is almost entirely in registers; the two halves meet with one shuffle.  The tile's
+        // 128 columns are 128 of the Co channels of ONE tap (Co % 128 == 0); column slabs are summed by the finish kernel.
+        const int tap = n0 / p.Co;
+        const int cbase = n0 - tap * p.Co + wn * 64;
+        float ps[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ps[t][c] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cbase + u * 32 + 8 * g + 4 * half + e;
+                    const float b = p.bias ? p.bias[co] : 0.f;
+                    const float v0 = fmaxf(acc[0][u][4 * g + e] + b, 0.f), v1 = fmaxf(acc[1][u][4 * g + e] + b, 0.f);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float wv = c < p.ncls ? p.w2[co * p.ncls + c] : 0.f;
+                        ps[0][c] = fmaf(v0, wv, ps[0][c]);
+                        ps[1][c] = fmaf(v1, wv, ps[1][c]);
+                    }
+                }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
+        if (half == 0) {
+            const int slab = ((n0 - tap * p.Co) / TBN) * 2 + wn;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const long long row = m0 + wm * 64 + t * 32 + l31;
+                if (row >= p.M) continue;
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
+                float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.ncls) dst[c] = ps[t][c];
+            }
+        }
+        return;
+    }
     // ---- epilogue: bias + activation, pack 4 channels, transpose through LDS, row-contiguous stores ----
     unsigned char* Cs = &lds[0][0][0];
 #pragma unroll
@@ -530,6 +581,25 @@ int myolo_deconv2x2s2_bf16_fwd(const uint16_t* x, const uint16_t* wt, const floa
     a.A = x; a.Wt = wt; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
     a.H = H; a.W = W; a.Co = Cout; a.act = act;
     launch_bf16<AM_PLAIN, EP_DECONV>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const float* bias, const float* w2, const float* b2, float* p_out,
+                                    int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && wt && bias && w2 && b2 && p_out && N > 0 && H > 0 && W > 0, "deconv2x2s2_mask_bf16_fwd: bad arguments");
+    MYOLO_REQUIRE(Cin % TBK == 0 && Cout % TBN == 0 && ncls >= 1 && ncls <= 4,
+                  "deconv2x2s2_mask_bf16_fwd: needs Cin %% %d == 0, Cout %% %d == 0, 1 <= classes <= 4 (got %d, %d, %d)", TBK, TBN, Cin, Cout, ncls);
+    const long long M = (long long)N * H * W;
+    const int nslabs = (Cout / TBN) * 2;
+    MYOLO_NEED_WS((size_t)nslabs * 4 * M * ncls * sizeof(float));
+    Bf16Args a = {};
+    a.A = x; a.Wt = wt; a.bias = bias; a.M = M; a.N = 4 * Cout; a.K = Cin; a.H = H; a.W = W; a.Co = Cout; a.act = MYOLO_ACT_RELU;
+    a.w2 = w2; a.part = (float*)ws; a.ncls = ncls;
+    const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
+    hipLaunchKernelGGL((gemm_bf16_glds<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    myolo_launch_deconv_mask_finish(a.part, b2, p_out, 4 * M, ncls, nslabs, (hipStream_t)stream);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

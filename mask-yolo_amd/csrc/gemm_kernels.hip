@@ -1296,6 +1296,17 @@ int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, flo
     return MYOLO_OK;
 }
 
+}  // extern "C"
+
+void myolo_launch_deconv_mask_finish(const float* part, const float* b2, float* out, long long npix, int ncls, int nslabs, hipStream_t s)
+{
+    long long blocks = (npix * ncls + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(deconv_mask_finish, dim3((unsigned)blocks), dim3(256), 0, s, part, b2, out, npix, ncls, nslabs);
+}
+
+extern "C" {
+
 size_t myolo_deconv2x2s2_mask_ws_bytes(int N, int H, int W, int Cin, int Cout, int ncls)
 {
     return align256((size_t)4 * Cin * Cout * sizeof(float)) +
@@ -1319,11 +1330,7 @@ int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias
     MYOLO_REQUIRE(((uintptr_t)x & 15) == 0, "deconv2x2s2_mask_fwd: x must be 16-byte aligned");
     const long long tiles = cdiv64(a.M, BM) * (a.N / BN);
     hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-    const long long npix = 4 * a.M;
-    long long blocks = (npix * ncls + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(deconv_mask_finish, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)a.part, b2, p_out, npix, ncls,
-                       (Cout / BN) * 2);
+    myolo_launch_deconv_mask_finish(a.part, b2, p_out, 4 * a.M, ncls, (Cout / BN) * 2, s);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -44,3 +44,5 @@ int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M,
 size_t myolo_gemm_tn_batched_ws_bytes(long long M, int Ka, int N, int batch);
 int myolo_gemm_tn_batched(const float* A, const float* B, float* C, long long M, int Ka, int N, int batch, void* ws, size_t ws_bytes,
                           hipStream_t s);
+// p[pix][c] = sigmoid(b2[c] + sum_k part[k][pix][c]) over the column slabs of a fused deconv + 1x1 epilogue (gemm_kernels.hip)
+void myolo_launch_deconv_mask_finish(const float* part, const float* b2, float* out, long long npix, int ncls, int nslabs, hipStream_t s);

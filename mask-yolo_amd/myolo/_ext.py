@@ -61,6 +61,7 @@ SIGS = {
     "myolo_crop_and_resize_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_conv3x3_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],
     "myolo_deconv2x2s2_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],
+    "myolo_deconv2x2s2_mask_bf16_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_mask_head_out_bf16_fwd": [P, P, P, P, L, I, I, P],
     "myolo_mask_head_out_bwd": [P, P, P, P, P, P, L, I, I, P, Z, P],
     "myolo_mask_bce": [P, P, P, F, P, P, I, I, I, I, P, Z, P],

@@ -531,11 +531,17 @@ class Net(object):
         wt = self._new(4 * MASK_FILTERS, MASK_FILTERS, dtype=bf)
         X.call("myolo_pack_weights_bf16", X.ptr(self.p["myolo_mask_deconv/kernel"]), MASK_FILTERS, 4 * MASK_FILTERS, 1, None,
                None, None, None, None, X.ptr(wt), None, X.stream())
+        C = cfg.NUM_CLASSES
+        p = self._new(NR * 4 * ps * ps, C)
+        if C <= 4 and MASK_FILTERS % 128 == 0:       # deconv + ReLU + 1x1 + sigmoid fused: the 28x28x256 tensor is never written
+            self.ws.ensure((MASK_FILTERS // 128) * 2 * 4 * NR * ps * ps * C * 4)
+            self._call_timed("mask_deconv_fwd", "myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(x), X.ptr(wt),
+                             X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
+                             X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, *self._wsargs(), X.stream())
+            return p
         d = self._new(NR * 4 * ps * ps, MASK_FILTERS, dtype=bf)
         self._call_timed("mask_deconv_fwd", "myolo_deconv2x2s2_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(self.p["myolo_mask_deconv/bias"]),
                          X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, X.stream())
-        C = cfg.NUM_CLASSES
-        p = self._new(NR * 4 * ps * ps, C)
         X.call("myolo_mask_head_out_bf16_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
                NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
         return p

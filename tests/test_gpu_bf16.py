@@ -120,6 +120,25 @@ def test_deconv2x2s2_bf16(N, H, W, Cin, Cout):
     check_bf16(from_bf16(y), ref, "deconv bf16")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,C", [(3, 14, 14, 256, 256, 2), (2, 5, 7, 64, 128, 4), (9, 14, 14, 128, 256, 1)])
+def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C):
+    """fused deconv + ReLU + 1x1 + sigmoid from bf16 activations: the deconv output stays in fp32 registers (it is never
+    rounded to bf16, unlike the two-kernel path), so the result sits within fp32 summation noise of the float64 oracle."""
+    rng = np.random.default_rng(3)
+    x = bf16_round(rnd(rng, N, H, W, Cin))
+    w = bf16_round(rnd(rng, 2, 2, Cout, Cin, scale=0.05))
+    b, w2, b2 = rnd(rng, Cout), rnd(rng, Cout, C, scale=0.1), rnd(rng, C)
+    M = N * H * W
+    wsb = torch.empty((Cout // 128) * 2 * 4 * M * C * 4, dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    p = torch.full((N, 2 * H, 2 * W, C), float("nan"), device=DEV)
+    X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)),
+           X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())
+    d = O.relu(O.deconv2x2s2(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)))
+    ref = 1 / (1 + np.exp(-(d.reshape(-1, Cout) @ w2 + b2))).reshape(N, 2 * H, 2 * W, C)
+    assert np.abs(p.cpu().numpy() - ref).max() < 1e-5
+
+
 def _boxes(rng, nb):
     c = rng.uniform(0.1, 0.9, (nb, 2))
     hw = rng.uniform(0.05, 0.6, (nb, 2))
