@@ -124,14 +124,31 @@ __global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int 
     }
 }
 
-// sum partials over row blocks: tot[v*C + c] (double).  8 outputs x 32 block-lanes per workgroup.
-__global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc)
+// sum partials over row blocks: tot[v*C + c] (double).  8 outputs x 32 block-lanes per workgroup.  The consumer's own
+// finishing arithmetic (double -> float, BN coefficients, ...) runs in the same kernel through FIN, so a reduction costs
+// two launches, not three.
+struct FinNone {
+    static constexpr int PAIR = 0;
+    __device__ void operator()(int, double) const {}
+};
+struct FinD2F {                      // out[i] = (float)tot[i]
+    static constexpr int PAIR = 0;
+    float* out;
+    __device__ void operator()(int i, double t) const { out[i] = (float)t; }
+};
+
+template <class FIN>
+__global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc, int C,
+                                                        FIN fin)
 {
     __shared__ double red[32][9];
+    __shared__ double fin_tot[8];
     const int ol = threadIdx.x & 7, bl = threadIdx.x >> 3;
-    const int i = blockIdx.x * 8 + ol;
+    // PAIR (NV == 2): a workgroup owns 4 channels x both sums, so FIN sees (sum0, sum1) of a channel together
+    const int i = FIN::PAIR ? (ol >> 2) * C + blockIdx.x * 4 + (ol & 3) : blockIdx.x * 8 + ol;
+    const bool ok = FIN::PAIR ? (blockIdx.x * 4 + (ol & 3)) < C : i < nvc;
     double s0 = 0, s1 = 0;
-    if (i < nvc) {
+    if (ok) {
         int b = bl;
         for (; b + 32 < nblk; b += 64) {
             s0 += part[(long long)b * nvc + i];
@@ -141,22 +158,35 @@ __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict
     }
     red[bl][ol] = s0 + s1;
     __syncthreads();
-    if (bl == 0 && i < nvc) {
+    if (bl == 0) {
         double t = 0;
 #pragma unroll
         for (int k = 0; k < 32; ++k) t += red[k][ol];
-        tot[i] = t;
+        if (ok) tot[i] = t;
+        if constexpr (FIN::PAIR != 0) fin_tot[ol] = t;
+        else if (ok) fin(i, t);
+    }
+    if constexpr (FIN::PAIR != 0) {
+        __syncthreads();
+        if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) fin.pair(blockIdx.x * 4 + threadIdx.x, fin_tot[threadIdx.x], fin_tot[4 + threadIdx.x]);
     }
 }
 
-template <class OP>
-static int run_colreduce(OP op, long long M, int C, double* part, double* tot, hipStream_t s)
+template <class OP, class FIN>
+static int run_colreduce(OP op, long long M, int C, double* part, double* tot, hipStream_t s, FIN fin)
 {
+    static_assert(!FIN::PAIR || OP::NV == 2, "paired finish needs exactly two sums per channel");
     ColGeom g = col_geom(M, C);
     hipLaunchKernelGGL((colreduce_kernel<OP>), dim3(g.rblocks, g.cgroups), dim3(256), 0, s, op, M, C, g, part);
     const int nvc = OP::NV * C;
-    hipLaunchKernelGGL(colreduce_finish, dim3((nvc + 7) / 8), dim3(256), 0, s, part, tot, g.rblocks, nvc);
+    const int blocks = FIN::PAIR ? (C + 3) / 4 : (nvc + 7) / 8;
+    hipLaunchKernelGGL((colreduce_finish<FIN>), dim3(blocks), dim3(256), 0, s, part, tot, g.rblocks, nvc, C, fin);
     return 0;
+}
+template <class OP>
+static int run_colreduce(OP op, long long M, int C, double* part, double* tot, hipStream_t s)
+{
+    return run_colreduce(op, M, C, part, tot, s, FinNone{});
 }
 
 // ---------------------------------------------------------------------------------------
@@ -193,27 +223,31 @@ struct OpStats {
     }
 };
 
-__global__ void bn_stats_finish(const double* __restrict__ tot, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* mean, float* var, float* scale,
-                                float* shift, float* mmean, float* mvar, double M, int C)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mu = tot[c] / M;
-    double vr = tot[C + c] / M - mu * mu;
-    if (vr < 0) vr = 0;
-    const float rstd = (float)(1.0 / sqrt(vr + (double)BN_EPS_F));
-    const float sc = gamma[c] * rstd;
-    mean[c] = (float)mu;
-    var[c] = (float)vr;
-    scale[c] = sc;
-    shift[c] = beta[c] - (float)mu * sc;
-    if (mmean) {
-        const float vu = (float)vr * ((float)M / ((float)M - (1.0f + BN_EPS_F)));
-        mmean[c] = mmean[c] * BN_MOMENTUM_F + (float)mu * (1.0f - BN_MOMENTUM_F);
-        mvar[c] = mvar[c] * BN_MOMENTUM_F + vu * (1.0f - BN_MOMENTUM_F);
+struct FinBnStats {                  // batch statistics -> mean / var / folded scale, shift / moving averages
+    static constexpr int PAIR = 1;
+    const float* gamma;
+    const float* beta;
+    float *mean, *var, *scale, *shift, *mmean, *mvar;
+    double M;
+    __device__ void operator()(int, double) const {}
+    __device__ void pair(int c, double sum, double sumsq) const
+    {
+        const double mu = sum / M;
+        double vr = sumsq / M - mu * mu;
+        if (vr < 0) vr = 0;
+        const float rstd = (float)(1.0 / sqrt(vr + (double)BN_EPS_F));
+        const float sc = gamma[c] * rstd;
+        mean[c] = (float)mu;
+        var[c] = (float)vr;
+        scale[c] = sc;
+        shift[c] = beta[c] - (float)mu * sc;
+        if (mmean) {
+            const float vu = (float)vr * ((float)M / ((float)M - (1.0f + BN_EPS_F)));
+            mmean[c] = mmean[c] * BN_MOMENTUM_F + (float)mu * (1.0f - BN_MOMENTUM_F);
+            mvar[c] = mvar[c] * BN_MOMENTUM_F + vu * (1.0f - BN_MOMENTUM_F);
+        }
     }
-}
+};
 
 __global__ void bn_frozen_kernel(const float* gamma, const float* beta, const float* mm, const float* mv,
                                  float* scale, float* shift, int C)
@@ -270,13 +304,17 @@ struct OpBnBwd {
 };
 
 // tot = {dbeta[C], dgamma[C]} (double) -> write float grads
-__global__ void bn_bwd_finish(const double* __restrict__ tot, float* dgamma, float* dbeta, int C)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    dbeta[c] = (float)tot[c];
-    dgamma[c] = (float)tot[C + c];
-}
+struct FinBnBwd {                    // dbeta = sum(dz), dgamma = sum(dz * xhat)
+    static constexpr int PAIR = 1;
+    float* dgamma;
+    float* dbeta;
+    __device__ void operator()(int, double) const {}
+    __device__ void pair(int c, double t0, double t1) const
+    {
+        dbeta[c] = (float)t0;
+        dgamma[c] = (float)t1;
+    }
+};
 
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
@@ -379,6 +417,35 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_sparse_kernel(const float* __re
     const float* xg = x + g * (long long)grows * C;
     float* dxg = dx + g * (long long)grows * C;
     const float* dyg = slot >= 0 ? dyc + (long long)slot * grows * C : nullptr;
+    if (blockDim.x % (unsigned)cq == 0) {
+        // a thread keeps its 4 channels for the whole group: per-channel terms are formed once.
+        // dx = sc*dz - sc*(db + xh*dg)/M  with xh = (x - mean)*rstd   ==   sc*dz + (ka + kb*x)
+        const int c = (int)(threadIdx.x % (unsigned)cq) * 4;
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        float ka[4], kb[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float rstd = rsqrtf(var[c + k] + BN_EPS_F);
+            const float db = (float)tot[c + k], dg = (float)tot[C + c + k];
+            kb[k] = -scv[k] * invM * dg * rstd;
+            ka[k] = -scv[k] * invM * db - kb[k] * mean[c + k];
+        }
+        for (unsigned e = threadIdx.x; e < gq; e += blockDim.x) {
+            const float4 v = ld4g(xg + (long long)e * 4);
+            float4 gv4 = f4zero();
+            if (dyg) gv4 = ld4g(dyg + (long long)e * 4);
+            const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, xv[4] = {v.x, v.y, v.z, v.w};
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float dz = gv[k] * actmask(fmaf(xv[k], scv[k], shv[k]), act);
+                o[k] = fmaf(scv[k], dz, fmaf(kb[k], xv[k], ka[k]));
+            }
+            st4g_nt(dxg + (long long)e * 4, make_float4(o[0], o[1], o[2], o[3]));
+        }
+        return;
+    }
     for (unsigned e = threadIdx.x; e < gq; e += blockDim.x) {
         const int c = (int)(e % (unsigned)cq) * 4;
         const float4 v = ld4g(xg + (long long)e * 4);
@@ -994,8 +1061,7 @@ int myolo_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t 
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpSum op{x, C};
-    run_colreduce(op, M, C, part, tot, s);
-    hipLaunchKernelGGL(d2f_kernel, dim3((C + 255) / 256), dim3(256), 0, s, tot, out, C);
+    run_colreduce(op, M, C, part, tot, s, FinD2F{out});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1011,9 +1077,7 @@ int myolo_bn_stats(const float* x, const float* gamma, const float* beta, float*
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpStats op{x, C};
-    run_colreduce(op, M, C, part, tot, s);
-    hipLaunchKernelGGL(bn_stats_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, gamma, beta, mean, var, scale, shift,
-                       moving_mean, moving_var, (double)M, C);
+    run_colreduce(op, M, C, part, tot, s, FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1051,8 +1115,7 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpBnBwd op{dy, x, scale, shift, mean, var, C, act};
-    run_colreduce(op, M, C, part, tot, s);
-    hipLaunchKernelGGL(bn_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, dgamma, dbeta, C);
+    run_colreduce(op, M, C, part, tot, s, FinBnBwd{dgamma, dbeta});
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq,
                        C, act, batch_stats, 1.0f / (float)M);
@@ -1090,8 +1153,7 @@ int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const in
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpBnBwdSparse op{dy_compact, x, idx, scale, shift, mean, var, C, act, group_rows};
-    run_colreduce(op, Mc, C, part, tot, s);
-    hipLaunchKernelGGL(bn_bwd_finish, dim3((C + 255) / 256), dim3(256), 0, s, tot, dgamma, dbeta, C);
+    run_colreduce(op, Mc, C, part, tot, s, FinBnBwd{dgamma, dbeta});
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_dx_sparse_kernel, dim3((unsigned)(M / group_rows)), dim3(256), 0, s, dy_compact, x, inv, scale, shift, mean,
                        var, tot, dx, nq, C, act, group_rows, 1.0f / (float)M);
@@ -1120,8 +1182,7 @@ int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, in
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpConv1Dw op{x, dy, H, W, Cout};
-    run_colreduce(op, M, Cout, part, tot, s);
-    hipLaunchKernelGGL(d2f_kernel, dim3((27 * Cout + 255) / 256), dim3(256), 0, s, tot, dw, 27 * Cout);
+    run_colreduce(op, M, Cout, part, tot, s, FinD2F{dw});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -1169,8 +1230,7 @@ int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int N
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpDwDw op{x, dy, H, W, C, Ho, Wo, stride};
-    run_colreduce(op, M, C, part, tot, s);
-    hipLaunchKernelGGL(d2f_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, s, tot, dw, 9 * C);
+    run_colreduce(op, M, C, part, tot, s, FinD2F{dw});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
