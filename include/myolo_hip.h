@@ -225,6 +225,11 @@ int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, in
 int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
 int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
                                 int N, int H, int W, int C, int act, void* stream);
+/* layer boundary between two Winograd convs in one pass per image: M of conv_i -> (+bias, affine, act) -> V of conv_{i+1}
+ * through LDS; the activation itself goes to y only for images with flags[img] != 0 (flags NULL: all; y NULL: none).
+ * Needs C % 32 == 0 and ceil(H/4)*ceil(W/4) <= 32 (14x14: 16 tiles). */
+int myolo_wino_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
+                                      const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream);
 int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
                                 void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W,

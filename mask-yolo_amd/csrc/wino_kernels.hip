@@ -261,6 +261,92 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
     }
 }
 
+// Layer boundary conv_i -> conv_{i+1} in one pass per image (ROI): M_i [36][T][C] -> output transform (+bias, folded-BN
+// affine, activation) -> the H x W x 32-channel activation tile in LDS -> input transform -> V_{i+1} [36][T][C].
+// The activation is written to y only where it is needed later (flags[img] != 0; flags == NULL: always; y == NULL: never),
+// so between two Winograd convs it neither makes the round trip through HBM nor, for most images, exists at all.
+// Workgroup = (image, 32-channel slice); thread = (tile, 4 channels); needs TH*TW*8 <= 256 threads and H*W*128 B of LDS.
+#define WOI_CS 32
+__global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restrict__ M, float* __restrict__ Vn, float* __restrict__ y,
+                                                          const int32_t* __restrict__ flags, const float* __restrict__ bias,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift, TileGeom g,
+                                                          int C, int act)
+{
+    extern __shared__ __attribute__((aligned(16))) float ysm[];       // [H][W][WOI_CS]
+    const int img = blockIdx.x;
+    const int c = blockIdx.y * WOI_CS + (threadIdx.x & 7) * 4;
+    const int tl = threadIdx.x >> 3;                                   // tile inside the image
+    const int ty = tl / g.TW, tx = tl - ty * g.TW;
+    const long long t = (long long)img * (g.TH * g.TW) + tl;
+    const long long plane = g.T * (long long)C;
+    const bool wr = y && (!flags || flags[img] != 0);
+    {
+        const float* in = M + t * C + c;
+        float4 tmp[4][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 m[6], r[4];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) m[i] = ldg4(in + (long long)(i * 6 + j) * plane);
+            at6(m, r);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tmp[i][j] = r[i];
+        }
+        const float4 b = bias ? ldg4(bias + c) : f4(0.f);
+        const float4 sc = scale ? ldg4(scale + c) : f4(1.f);
+        const float4 sh = scale ? ldg4(shift + c) : f4(0.f);
+        float* obase = y + (long long)img * g.H * g.W * C + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float4 r[4];
+            at6(tmp[i], r);
+            const int yy = 4 * ty + i;
+            if (yy >= g.H) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = 4 * tx + j;
+                if (xx >= g.W) continue;
+                float4 v = r[j] + b;
+                if (scale) v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
+                if (act == MYOLO_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+                else if (act == MYOLO_ACT_RELU6)
+                    v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f),
+                                    fminf(fmaxf(v.w, 0.f), 6.f));
+                *reinterpret_cast<float4*>(&ysm[(yy * g.W + xx) * WOI_CS + (threadIdx.x & 7) * 4]) = v;
+                if (wr) stg4(obase + ((long long)yy * g.W + xx) * C, v);
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        float4 tmp[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 d[6], r[6];
+            const int xx = x0 + j;
+            const bool xin = (unsigned)xx < (unsigned)g.W;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const int yy = y0 + i;
+                d[i] = (xin && (unsigned)yy < (unsigned)g.H)
+                           ? *reinterpret_cast<const float4*>(&ysm[(yy * g.W + xx) * WOI_CS + (threadIdx.x & 7) * 4]) : f4(0.f);
+            }
+            bt6(d, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
+        }
+        float* out = Vn + t * C + c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float4 r[6];
+            bt6(tmp[i], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+        }
+    }
+}
+
 static TileGeom geom(int N, int H, int W)
 {
     TileGeom g;
@@ -325,6 +411,20 @@ int myolo_wino_output_transform(const float* M, const float* bias, const float* 
     MYOLO_REQUIRE(!scale == !shift, "wino_output_transform: scale and shift go together");
     const TileGeom g = geom(N, H, W);
     hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, M, y, bias, scale, shift, g, C, act);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
+                                      const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && V_next && N > 0 && H > 0 && W > 0 && C > 0, "wino_output_input_transform: bad arguments");
+    MYOLO_REQUIRE(!scale == !shift, "wino_output_input_transform: scale and shift go together");
+    const TileGeom g = geom(N, H, W);
+    MYOLO_REQUIRE((C % WOI_CS) == 0 && g.TH * g.TW * 8 <= 256 && (size_t)H * W * WOI_CS * sizeof(float) <= 65536,
+                  "wino_output_input_transform: needs C %% 32 == 0 and at most 32 tiles per image (got C=%d, %dx%d)", C, H, W);
+    hipLaunchKernelGGL(wino_out_in_kernel, dim3(N, C / WOI_CS), dim3(g.TH * g.TW * 8), (size_t)H * W * WOI_CS * sizeof(float),
+                       (hipStream_t)stream, M, V_next, y, flags, bias, scale, shift, g, C, act);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -57,6 +57,7 @@ SIGS = {
     "myolo_wino_input_transform": [P, P, I, I, I, I, P],
     "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_transform": [P, P, P, P, P, I, I, I, I, I, P],
+    "myolo_wino_output_input_transform": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "myolo_pack_weights_bf16": [P, I, I, I, P, P, P, P, P, P, P, P],
     "myolo_crop_and_resize_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_conv3x3_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],

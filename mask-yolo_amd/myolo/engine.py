@@ -436,7 +436,7 @@ class Net(object):
             self.on_bucket_ready(0)
 
     # ---- mask head -----------------------------------------------------------
-    def mask_head_fwd(self, Fm, fshape, rois, train):
+    def mask_head_fwd(self, Fm, fshape, rois, train, pos_flags=None):
         """rois [B,R,4] (x1,y1,x2,y2).  Returns pred masks [B*R, mh*mw, C] (post-sigmoid)."""
         cfg = self.cfg
         B, R = rois.shape[:2]
@@ -455,7 +455,58 @@ class Net(object):
         cin = cf
         convs = []
         fuse = self.sparse_mask_bwd or not train     # frozen BN + ReLU folded into the conv epilogue
-        for i in range(1, 5):
+        q = ps * ps
+        # Winograd chain: where conv_i's epilogue is foldable (frozen BN) and conv_{i+1} is a Winograd conv too, the layer
+        # boundary is ONE pass per ROI through LDS (M_i -> V_{i+1}); the activation in between is written only for the ROIs
+        # the sparse backward will gather (pos_flags), and not at all in inference.
+        chain = (fuse and self._wino_ok(NR, ps, ps, cf, MASK_FILTERS) and self._wino_ok(NR, ps, ps, MASK_FILTERS, MASK_FILTERS)
+                 and MASK_FILTERS % 32 == 0 and ((ps + 3) // 4) ** 2 <= 32 and q * 128 <= 65536
+                 and (not train or pos_flags is not None))
+        Vcur = None
+        for i in range(1, 5 if chain else 1):
+            cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
+            batch_stats = train and i == 1
+            fold = not batch_stats
+            T = NR * ((ps + 3) // 4) ** 2
+            start, stop = self._timed("mask_conv3x3_fwd")
+            start()
+            if Vcur is None:
+                Vcur = self._new(36, T, cin)
+                X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
+            U, M = self._new(36, cin, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
+            X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
+            self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, ps, ps, cin, MASK_FILTERS,
+                             X.stream())
+            if i == 1 and train:
+                self.tape["conv1_V"] = Vcur          # reused by conv1's weight gradient
+            convs.append(x)                          # for i >= 3 in training: valid only in the rows of flagged ROIs
+            bias = self.p[cn + "/bias"]
+            buf = self.bnbuf[bn]
+            if fold:
+                X.call("myolo_bn_frozen_coeffs", X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
+                       X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+                       X.ptr(buf[2]), X.ptr(buf[3]), MASK_FILTERS, X.stream())
+                self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
+            if fold and i < 4:
+                ykeep = self._new(NR * q, MASK_FILTERS) if train else None
+                Vn = self._new(36, T, MASK_FILTERS)
+                X.call("myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(ykeep),
+                       X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS, ACT_RELU, X.stream())
+                x, Vcur = ykeep, Vn
+            else:
+                y = self._new(NR * q, MASK_FILTERS)
+                if fold:
+                    X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps,
+                           MASK_FILTERS, ACT_RELU, X.stream())
+                    x = y
+                else:
+                    X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), None, None, X.ptr(y), NR, ps, ps, MASK_FILTERS,
+                           ACT_NONE, X.stream())
+                    x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
+                Vcur = None
+            stop()
+            cin = MASK_FILTERS
+        for i in range(1 if not chain else 5, 5):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             y = self._new(NR * ps * ps, MASK_FILTERS)
             convs.append(x)
@@ -796,7 +847,10 @@ class Net(object):
                 raise RuntimeError("TRAIN_MASK_HEAD_ROIS='positives' needs the sparse backward (sparse_mask_bwd=True)")
             pred, tmask_l, tcls_l = self.mask_head_fwd_positives(Fm, fshape, rois, tmask, tcls)
         else:
-            pred = self.mask_head_fwd(Fm, fshape, rois, True)
+            # the ROIs whose activations the sparse backward will gather: the first n_pos rows of each image (exactly the
+            # index set of _positive_index, whatever their class id)
+            flags = (torch.arange(R, device=self.dev, dtype=torch.int32).view(1, R) < npos.view(B, 1)).to(torch.int32).contiguous()
+            pred = self.mask_head_fwd(Fm, fshape, rois, True, pos_flags=flags.view(-1) if self.sparse_mask_bwd else None)
             tmask_l, tcls_l = tmask, tcls
         w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
         w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
