@@ -74,6 +74,55 @@ def test_mask_conv3x3_adjoint_linear_and_sampled_oracle(gen):
         assert np.abs(got - ref).max() <= 1e-3 * np.abs(ref).max()
 
 
+def test_winograd_full_size_adjoint_agrees_with_direct_and_chain(gen):
+    """The Winograd F(4x4,3x3) triple at the full config-2 size: adjointness pins its two gradients to its forward, its
+    forward agrees with the direct kernel (itself oracle-pinned) to 1e-4 of the tensor maximum, and the chained layer
+    boundary (M_i -> V_{i+1} through LDS, activation written for flagged ROIs only) equals two separate convolutions."""
+    x, w, bias = rn(gen, M, C), rn(gen, 3, 3, C, C, scale=0.02), rn(gen, C, scale=0.1)
+    dy = rn(gen, M, C)
+    nb = max(X.wino_ws_bytes(NR, PS, PS, C, C, k) for k in (0, 1, 2))
+    wsb = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    wsa = (wsb.data_ptr(), wsb.numel())
+    T = NR * 16
+    zero = torch.zeros(C, device=DEV)
+    y, yd, dx = (torch.empty(M, C, device=DEV) for _ in range(3))
+    dw = torch.empty(3, 3, C, C, device=DEV)
+    V = torch.empty(36, T, C, device=DEV)
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), None, None, X.ptr(y), NR, PS, PS, C, C, 0, X.ptr(V), *wsa, X.stream())
+    X.call("myolo_conv3x3_wino_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), NR, PS, PS, C, C, *wsa, X.stream())
+    X.call("myolo_conv3x3_wino_bwd_weight", None, X.ptr(V), X.ptr(dy), X.ptr(dw), NR, PS, PS, C, C, *wsa, X.stream())
+    a = dot(dy, y)
+    close(a, dot(x, dx))
+    close(a, dot(w, dw))
+    X.call("myolo_conv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(zero), X.ptr(yd), NR, PS, PS, C, C, *ws(), X.stream())
+    assert float((y - yd).abs().max()) <= 1e-4 * float(yd.abs().max())
+    del dx, dw, yd, V
+    # chain: conv(w) + bias, ReLU -> conv(w2) as [in, multiply, out_in, multiply, out] vs two separate Winograd convs
+    w2 = rn(gen, 3, 3, C, C, scale=0.02)
+    a1, ref = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(x), X.ptr(w), X.ptr(bias), None, None, X.ptr(a1), NR, PS, PS, C, C, 1, None, *wsa, X.stream())
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(a1), X.ptr(w2), X.ptr(zero), None, None, X.ptr(ref), NR, PS, PS, C, C, 0, None, *wsa, X.stream())
+    U, U2 = torch.empty(36, C, C, device=DEV), torch.empty(36, C, C, device=DEV)
+    V1, Mp, V2 = (torch.empty(36, T, C, device=DEV) for _ in range(3))
+    flags = torch.zeros(NR, dtype=torch.int32, device=DEV)
+    flags[::7] = 1
+    akeep = torch.full((M, C), float("nan"), device=DEV)
+    st = X.stream()
+    X.call("myolo_wino_weight_transform", X.ptr(w), X.ptr(U), C, C, 0, st)
+    X.call("myolo_wino_weight_transform", X.ptr(w2), X.ptr(U2), C, C, 0, st)
+    X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V1), NR, PS, PS, C, st)
+    X.call("myolo_wino_multiply", X.ptr(V1), X.ptr(U), X.ptr(Mp), NR, PS, PS, C, C, st)
+    X.call("myolo_wino_output_input_transform", X.ptr(Mp), X.ptr(bias), None, None, X.ptr(akeep), X.ptr(flags), X.ptr(V2), NR, PS, PS, C, 1, st)
+    X.call("myolo_wino_multiply", X.ptr(V2), X.ptr(U2), X.ptr(Mp), NR, PS, PS, C, C, st)
+    got = torch.empty(M, C, device=DEV)
+    X.call("myolo_wino_output_transform", X.ptr(Mp), None, None, None, X.ptr(got), NR, PS, PS, C, 0, st)
+    # same formulas in both routes; the compiler may contract a*b+c differently in the two kernels -> rounding-level only
+    err = float((got - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-6, "chained boundary differs from two separate Winograd convolutions: %.3e" % err
+    ak = akeep.view(NR, PS * PS * C)
+    assert torch.equal(ak[::7], a1.view(NR, -1)[::7]) and bool(torch.isnan(ak[1::7]).all()), "activation must be written for flagged ROIs only"
+
+
 def test_deconv_adjoint_full_size(gen):
     x, w = rn(gen, M, C), rn(gen, 2, 2, C, C, scale=0.05)
     dy = rn(gen, 4 * M, C)
