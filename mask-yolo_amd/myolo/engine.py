@@ -301,7 +301,9 @@ class Net(object):
             U, V, M = self._new(36, cin, cout), self._new(36, T, cin), self._new(36, T, cout)
             X.call("myolo_wino_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, 0, X.stream())
             X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V), nimg, h, w, cin, X.stream())
-            self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), nimg, h, w, cin, cout, X.stream())
+            # only the dense mask-head launches (tag given) feed bench.py's roofline; feature_map / compacted ones do not
+            self._call_timed("wino_multiply" if tag == "mask_conv3x3_fwd" else None, "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M),
+                             nimg, h, w, cin, cout, X.stream())
             X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(scale), X.ptr(shift), X.ptr(y), nimg, h, w, cout, act,
                    X.stream())
             v = V if keep_v else None
