@@ -169,9 +169,10 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for i in range(args.steps):
-            net.train_step(dbs[i % nb], args.lr)
+            out2 = net.train_step(dbs[i % nb], args.lr)
         barrier()
         el2 = time.perf_counter() - t1
+        assert np.isfinite(float(out2["yolo_terms"][0]) + float(out2["mask_terms"][0])), "non-finite loss in the variant run"
         if world > 1:
             t = torch.tensor([el2], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,7 +240,10 @@ def main():
         if variant is not None:
             res["variant"] = variant
         if args.cpu_images > 0 and world == 1:
-            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_images)
+            try:
+                res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_images)
+            except Exception as e:            # the GPU line must not be lost to a host-side problem
+                res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         elif args.cpu_images > 0:
             res["cpu_baseline"] = None
         print(json.dumps(res))

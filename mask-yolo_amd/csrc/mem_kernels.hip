@@ -9,6 +9,7 @@
 // a shared-memory tree combines the row lanes, per-block partials go to the caller's workspace
 // in double and a second tiny kernel finishes -- deterministic, no atomics.
 #include "myolo_common.h"
+#include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
 
@@ -807,6 +808,73 @@ __global__ __launch_bounds__(256) void crop_bwd_grouped_kernel(const float* __re
     }
 }
 
+// Same gather with the per-box terms (origin, step, reciprocal step) formed once per workgroup in LDS instead of once
+// per (pixel, box): with C = 256 a 256-thread workgroup is 4 consecutive pixels of ONE image (H*W % 4 == 0), so its
+// R boxes are shared.  The candidate window only has to be conservative (the exact floor/ceil test inside uses the
+// forward kernel's expressions), so multiplying by a reciprocal instead of dividing changes no result.
+__global__ __launch_bounds__(256) void crop_bwd_grouped_lds_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                                   float* __restrict__ dimg, int H, int W, int R, int ch, int cw)
+{
+    extern __shared__ __attribute__((aligned(16))) float sp[];      // [R][8]: y1 x1 y2 x2 | y0 1/sy x0 1/sx  (1/s = 0: degenerate)
+    constexpr int C = 256, cq = 64;
+    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = (threadIdx.x & 63) * 4;
+    const int b = (int)(pix / ((long long)H * W));
+    const int rem = (int)(pix - (long long)b * H * W);
+    const int y = rem / W, x = rem - y * W;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float4 bx = ld4g(boxes + ((long long)b * R + r) * 4);
+        const float sy = (ch > 1) ? (bx.z - bx.x) * (float)(H - 1) / (float)(ch - 1) : 0.f;
+        const float sx = (cw > 1) ? (bx.w - bx.y) * (float)(W - 1) / (float)(cw - 1) : 0.f;
+        const float y0 = (ch > 1) ? bx.x * (float)(H - 1) : 0.5f * (bx.x + bx.z) * (float)(H - 1);
+        const float x0 = (cw > 1) ? bx.y * (float)(W - 1) : 0.5f * (bx.y + bx.w) * (float)(W - 1);
+        *reinterpret_cast<float4*>(&sp[r * 8]) = bx;
+        *reinterpret_cast<float4*>(&sp[r * 8 + 4]) =
+            make_float4(y0, fabsf(sy) > 1e-6f ? 1.f / sy : 0.f, x0, fabsf(sx) > 1e-6f ? 1.f / sx : 0.f);
+    }
+    __syncthreads();
+    float4 acc = f4zero();
+    const float fy = (float)y, fx = (float)x;
+    for (int r = 0; r < R; ++r) {
+        const float4 bx = *reinterpret_cast<const float4*>(&sp[r * 8]);
+        const float4 q = *reinterpret_cast<const float4*>(&sp[r * 8 + 4]);      // y0, 1/sy, x0, 1/sx
+        int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
+        if (q.y != 0.f) {
+            const float a = (fy - 1.f - q.x) * q.y, cc = (fy + 1.f - q.x) * q.y;
+            pya = max(0, (int)floorf(fminf(a, cc)) - 2);
+            pyb = min(ch - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+        } else if (fabsf(q.x - fy) > 1.5f) continue;
+        if (q.w != 0.f) {
+            const float a = (fx - 1.f - q.z) * q.w, cc = (fx + 1.f - q.z) * q.w;
+            pxa = max(0, (int)floorf(fminf(a, cc)) - 2);
+            pxb = min(cw - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+        } else if (fabsf(q.z - fx) > 1.5f) continue;
+        if (pya > pyb || pxa > pxb) continue;
+        const long long bi = (long long)b * R + r;
+        for (int py = pya; py <= pyb; ++py) {
+            float iny;
+            if (!crop_coord(bx.x, bx.z, H, ch, py, iny)) continue;
+            const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+            if (ty != y && by != y) continue;
+            const float ly = iny - (float)ty;
+            const float wyv = (ty == y ? (1.f - ly) : 0.f) + (by == y ? ly : 0.f);
+            for (int px = pxa; px <= pxb; ++px) {
+                float inx;
+                if (!crop_coord(bx.y, bx.w, W, cw, px, inx)) continue;
+                const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+                if (lx != x && rx != x) continue;
+                const float lxw = inx - (float)lx;
+                const float wxv = (lx == x ? (1.f - lxw) : 0.f) + (rx == x ? lxw : 0.f);
+                const float wgt = wyv * wxv;
+                const float4 g = ld4g(dout + ((bi * ch + py) * cw + px) * C + c);
+                acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
+                acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+            }
+        }
+    }
+    st4g(dimg + (pix * cq + (threadIdx.x & 63)) * 4, acc);
+}
+
 // ---------------------------------------------------------------------------------------
 // final mask conv 1x1 (Cin -> C<=8) + bias + sigmoid.  One wave per row: each lane owns
 // channel quads {lane, lane+64, ...}, partial dots are combined with a wave butterfly.
@@ -1268,6 +1336,12 @@ int myolo_roialign_bwd_grouped(const float* dout, const float* boxes, float* dim
 {
     MYOLO_REQUIRE(dout && boxes && dimage && B > 0 && R > 0 && (C & 3) == 0, "roialign_bwd_grouped: bad arguments");
     const long long total = (long long)B * H * W * (C / 4);
+    if (C == 256 && ((long long)H * W) % 4 == 0 && R <= 1536 && !getenv("MYOLO_CROP_BWD_NOLDS")) {
+        hipLaunchKernelGGL(crop_bwd_grouped_lds_kernel, dim3((unsigned)(total / 256)), dim3(256), (size_t)R * 8 * sizeof(float),
+                           (hipStream_t)stream, dout, boxes, dimage, H, W, R, crop_h, crop_w);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     long long blocks = (total + 255) / 256;
     if (blocks > 65536) blocks = 65536;
     hipLaunchKernelGGL(crop_bwd_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, dout, boxes, dimage, B, H,
