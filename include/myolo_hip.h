@@ -225,6 +225,15 @@ int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, in
 int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
 int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
                                 int N, int H, int W, int C, int act, void* stream);
+/* input transform with the producing layer's BatchNorm apply + activation folded into the load (scale/shift per channel) */
+int myolo_wino_input_transform_affine(const float* x, const float* scale, const float* shift, int act, float* V, int N, int H, int W,
+                                      int C, void* stream);
+/* output transform (+bias) that also produces the training-mode BatchNorm statistics of what it writes: same outputs as
+ * myolo_bn_stats (mean, var, folded scale/shift, moving averages; model.py:690).  C/4 must divide 256. */
+size_t myolo_wino_output_transform_bn_ws_bytes(int C);
+int myolo_wino_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int H, int W, int C, const float* gamma,
+                                         const float* beta, float* mean, float* var, float* scale, float* shift, float* moving_mean,
+                                         float* moving_var, void* ws, size_t ws_bytes, void* stream);
 /* layer boundary between two Winograd convs in one pass per image: M of conv_i -> (+bias, affine, act) -> V of conv_{i+1}
  * through LDS; the activation itself goes to y only for images with flags[img] != 0 (flags NULL: all; y NULL: none).
  * Needs C % 32 == 0 and ceil(H/4)*ceil(W/4) <= 32 (14x14: 16 tiles). */

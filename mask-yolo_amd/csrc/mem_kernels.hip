@@ -1112,6 +1112,15 @@ static int mask_out_bwd_impl(const float* x, const float* w, const float* dz, fl
     return MYOLO_OK;
 }
 
+// BN batch statistics from per-workgroup partial sums produced by another translation unit (wino_kernels.hip's
+// output transform): part [nblk][2*C] doubles (sum, then sum of squares).
+void myolo_bn_stats_from_partials(const double* part, double* tot, int nblk, int C, double M, const float* gamma, const float* beta,
+                                  float* mean, float* var, float* scale, float* shift, float* mmean, float* mvar, hipStream_t s)
+{
+    hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C,
+                       FinBnStats{gamma, beta, mean, var, scale, shift, mmean, mvar, M});
+}
+
 // =======================================================================================
 extern "C" {
 

@@ -46,3 +46,6 @@ int myolo_gemm_tn_batched(const float* A, const float* B, float* C, long long M,
                           hipStream_t s);
 // p[pix][c] = sigmoid(b2[c] + sum_k part[k][pix][c]) over the column slabs of a fused deconv + 1x1 epilogue (gemm_kernels.hip)
 void myolo_launch_deconv_mask_finish(const float* part, const float* b2, float* out, long long npix, int ncls, int nslabs, hipStream_t s);
+// BN batch statistics (mean / var / folded scale, shift / moving averages) from [nblk][2*C] double partial sums (mem_kernels.hip)
+void myolo_bn_stats_from_partials(const double* part, double* tot, int nblk, int C, double M, const float* gamma, const float* beta,
+                                  float* mean, float* var, float* scale, float* shift, float* mmean, float* mvar, hipStream_t s);

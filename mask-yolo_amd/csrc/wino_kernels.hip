@@ -76,8 +76,19 @@ struct TileGeom {
     long long T;       // tiles in total
 };
 
-// X [N,H,W,C] -> V [36][T][C]
-__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, TileGeom g, int C)
+__device__ __forceinline__ float4 affine_act4(float4 v, float4 sc, float4 sh, int act)
+{
+    v = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    if (act == MYOLO_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+    else if (act == MYOLO_ACT_RELU6)
+        v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f), fminf(fmaxf(v.w, 0.f), 6.f));
+    return v;
+}
+
+// X [N,H,W,C] -> V [36][T][C].  Optional per-channel affine + activation applied to every in-bounds pixel as it is loaded
+// (BatchNorm apply + ReLU of the producing layer: the normalised activation is never written); the zero padding stays zero.
+__global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, TileGeom g, int C,
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, int act)
 {
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
@@ -90,6 +101,8 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
         const int ty = rem / g.TW, tx = rem - ty * g.TW;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
         const float* base = x + img * (long long)g.H * g.W * C + c;
+        const float4 sc = scale ? ldg4(scale + c) : f4(1.f);
+        const float4 sh = scale ? ldg4(shift + c) : f4(0.f);
         float4 tmp[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -99,7 +112,9 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int yy = y0 + i;
-                d[i] = (xin && (unsigned)yy < (unsigned)g.H) ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+                const bool in = xin && (unsigned)yy < (unsigned)g.H;
+                d[i] = in ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+                if (scale && in) d[i] = affine_act4(d[i], sc, sh, act);
             }
             bt6(d, r);
 #pragma unroll
@@ -116,11 +131,15 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
     }
 }
 
-// M [36][T][C] -> Y [N,H,W,C], + bias, optional per-channel affine (folded frozen BN), activation
+// M [36][T][C] -> Y [N,H,W,C], + bias, optional per-channel affine (folded frozen BN), activation.
+// stats != NULL (training-mode BatchNorm behind this conv): every workgroup also leaves the per-channel sum and sum of
+// squares of the values it wrote in stats[blockIdx.x][2*C] (double); needs (gridDim.x * 256) % (C/4) == 0 so that a thread
+// keeps its channels across the grid-stride loop.
 __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__ M, float* __restrict__ y, const float* __restrict__ bias,
                                                        const float* __restrict__ scale, const float* __restrict__ shift, TileGeom g, int C,
-                                                       int act)
+                                                       int act, double* __restrict__ stats)
 {
+    float4 s1 = f4(0.f), s2 = f4(0.f);
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
     const long long plane = g.T * (long long)C;
@@ -162,6 +181,27 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
                     v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f),
                                     fminf(fmaxf(v.w, 0.f), 6.f));
                 stg4(obase + ((long long)yy * g.W + xx) * C, v);
+                if (stats) {
+                    s1 = s1 + v;
+                    s2 = make_float4(fmaf(v.x, v.x, s2.x), fmaf(v.y, v.y, s2.y), fmaf(v.z, v.z, s2.z), fmaf(v.w, v.w, s2.w));
+                }
+            }
+        }
+    }
+    if (stats) {       // threads t, t + c4n, t + 2*c4n, ... of the workgroup hold the same channels
+        __shared__ double red[2][256][4];
+        const double a1[4] = {s1.x, s1.y, s1.z, s1.w}, a2[4] = {s2.x, s2.y, s2.z, s2.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { red[0][threadIdx.x][k] = a1[k]; red[1][threadIdx.x][k] = a2[k]; }
+        __syncthreads();
+        if ((int)threadIdx.x < c4n) {
+            double* dst = stats + (long long)blockIdx.x * 2 * C;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double t1 = 0, t2 = 0;
+                for (int j = threadIdx.x; j < 256; j += c4n) { t1 += red[0][j][k]; t2 += red[1][j][k]; }
+                dst[threadIdx.x * 4 + k] = t1;
+                dst[C + threadIdx.x * 4 + k] = t2;
             }
         }
     }
@@ -387,9 +427,16 @@ int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int
 
 int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream)
 {
+    return myolo_wino_input_transform_affine(x, nullptr, nullptr, MYOLO_ACT_NONE, V, N, H, W, C, stream);
+}
+
+int myolo_wino_input_transform_affine(const float* x, const float* scale, const float* shift, int act, float* V, int N, int H, int W,
+                                      int C, void* stream)
+{
     MYOLO_REQUIRE(x && V && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "wino_input_transform: bad arguments (C %% 4 == 0)");
+    MYOLO_REQUIRE(!scale == !shift, "wino_input_transform: scale and shift go together");
     const TileGeom g = geom(N, H, W);
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, V, g, C);
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, V, g, C, scale, shift, act);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -410,7 +457,33 @@ int myolo_wino_output_transform(const float* M, const float* bias, const float* 
     MYOLO_REQUIRE(M && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "wino_output_transform: bad arguments (C %% 4 == 0)");
     MYOLO_REQUIRE(!scale == !shift, "wino_output_transform: scale and shift go together");
     const TileGeom g = geom(N, H, W);
-    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, M, y, bias, scale, shift, g, C, act);
+    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, M, y, bias, scale, shift, g, C, act, (double*)nullptr);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+#define WOUT_STATS_BLOCKS 2048
+size_t myolo_wino_output_transform_bn_ws_bytes(int C) { return align256((size_t)WOUT_STATS_BLOCKS * 2 * C * sizeof(double)) + 2 * C * sizeof(double); }
+
+/* conv + bias -> y, and the training-mode BatchNorm statistics of y in the same pass (model.py:690: bn1 of the mask head
+ * has no training= argument): mean / var / folded scale, shift and the moving averages, exactly as myolo_bn_stats. */
+int myolo_wino_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int H, int W, int C, const float* gamma,
+                                         const float* beta, float* mean, float* var, float* scale, float* shift, float* moving_mean,
+                                         float* moving_var, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(M && y && gamma && beta && mean && var && scale && shift && N > 0 && H > 0 && W > 0, "wino_output_transform_bn_stats: bad arguments");
+    MYOLO_REQUIRE(C > 0 && (C & 3) == 0 && 256 % (C / 4) == 0, "wino_output_transform_bn_stats: C/4 must divide 256 (got C=%d)", C);
+    MYOLO_NEED_WS(myolo_wino_output_transform_bn_ws_bytes(C));
+    const TileGeom g = geom(N, H, W);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned blocks = ew_grid(g.T * (C / 4));
+    if (blocks > WOUT_STATS_BLOCKS) blocks = WOUT_STATS_BLOCKS;
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256((size_t)WOUT_STATS_BLOCKS * 2 * C * sizeof(double)));
+    hipLaunchKernelGGL(wino_out_kernel, dim3(blocks), dim3(256), 0, s, M, y, bias, (const float*)nullptr, (const float*)nullptr, g, C,
+                       MYOLO_ACT_NONE, part);
+    myolo_bn_stats_from_partials(part, tot, (int)blocks, C, (double)N * H * W, gamma, beta, mean, var, scale, shift, moving_mean,
+                                 moving_var, s);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -443,10 +516,10 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     float* V = v_keep ? v_keep : (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 0);
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin);
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0);
     const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cin, Cout, 36, s);
     if (rc != MYOLO_OK) return rc;
-    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, Mp, y, bias, scale, shift, g, Cout, act);
+    hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, Mp, y, bias, scale, shift, g, Cout, act, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -464,11 +537,11 @@ int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int 
     float* V = (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 1);
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout);
+    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0);
     const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cout, Cin, 36, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, Mp, dx, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, g, Cin, MYOLO_ACT_NONE);
+                       (const float*)nullptr, (const float*)nullptr, g, Cin, MYOLO_ACT_NONE, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -487,7 +560,7 @@ int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const fl
     float* V = (float*)((char*)ws + ub);
     float* Q = (float*)((char*)ws + ub + vb);
     void* part = (char*)ws + ub + vb + qb;
-    if (!v_saved) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin);
+    if (!v_saved) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0);
     hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout);
     const int rc = myolo_gemm_tn_batched(v_saved ? v_saved : V, Q, dU, g.T, Cin, Cout, 36, part, pb, s);
     if (rc != MYOLO_OK) return rc;

@@ -58,6 +58,8 @@ SIGS = {
     "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_transform": [P, P, P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_input_transform": [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "myolo_wino_input_transform_affine": [P, P, P, I, P, I, I, I, I, P],
+    "myolo_wino_output_transform_bn_stats": [P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, Z, P],
     "myolo_pack_weights_bf16": [P, I, I, I, P, P, P, P, P, P, P, P],
     "myolo_crop_and_resize_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_conv3x3_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],
@@ -93,13 +95,15 @@ def load():
     lib.myolo_conv3x3_wino_ws_bytes.restype = Z
     lib.myolo_deconv2x2s2_mask_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
+    lib.myolo_wino_output_transform_bn_ws_bytes.argtypes = [I]
+    lib.myolo_wino_output_transform_bn_ws_bytes.restype = Z
     _LIB = lib
     return lib
 
 
 def exported_symbols():
     return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes",
-                              "myolo_deconv2x2s2_mask_ws_bytes"]
+                              "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
 def ptr(t):
@@ -132,3 +136,7 @@ def wino_ws_bytes(n, h, w, cin, cout, which):
 
 def deconv_mask_ws_bytes(n, h, w, cin, cout, ncls):
     return int(load().myolo_deconv2x2s2_mask_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(ncls)))
+
+
+def wino_out_bn_ws_bytes(c):
+    return int(load().myolo_wino_output_transform_bn_ws_bytes(int(c)))

@@ -501,11 +501,26 @@ class Net(object):
                     X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps,
                            MASK_FILTERS, ACT_RELU, X.stream())
                     x = y
+                    Vcur = None
+                elif 256 % (MASK_FILTERS // 4) == 0 and i < 4:
+                    # training-mode BN behind this conv (bn1): its statistics come out of the output transform, and its
+                    # apply + ReLU go into the next conv's input transform -- the normalised activation is never written
+                    # (the sparse backward re-applies it to the positive ROIs' rows)
+                    self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
+                    X.call("myolo_wino_output_transform_bn_stats", X.ptr(M), X.ptr(bias), X.ptr(y), NR, ps, ps, MASK_FILTERS,
+                           X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
+                           X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+                           *self._wsargs(), X.stream())
+                    self.tape[bn] = (y, ACT_RELU, True)
+                    Vcur = self._new(36, T, MASK_FILTERS)
+                    X.call("myolo_wino_input_transform_affine", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, X.ptr(Vcur),
+                           NR, ps, ps, MASK_FILTERS, X.stream())
+                    x = ("lazy_bn", y, bn)
                 else:
                     X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), None, None, X.ptr(y), NR, ps, ps, MASK_FILTERS,
                            ACT_NONE, X.stream())
                     x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
-                Vcur = None
+                    Vcur = None
             stop()
             cin = MASK_FILTERS
         for i in range(1 if not chain else 5, 5):
@@ -686,15 +701,31 @@ class Net(object):
                          n, h, w, cf, NR, ps, ps, X.stream())
         self.tape["roi"] = (boxes, bind, fshape, NR)
         y1 = self._new(NR * q, MASK_FILTERS)
-        v = self.conv3x3_fwd(x, "myolo_mask_conv1", y1, NR, ps, ps, cf, MASK_FILTERS, keep_v=True, tag="mask_conv3x3_fwd")
-        if v is not None:
-            self.tape["conv1_V"] = v
         bn = "myolo_mask_bn1"
         buf = self.bnbuf[bn]
-        X.call("myolo_bn_stats", X.ptr(y1), X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
-               X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]), X.ptr(buf[3]),
-               X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
-               NR * q, MASK_FILTERS, *self._wsargs(), X.stream())
+        if self._wino_ok(NR, ps, ps, cf, MASK_FILTERS) and 256 % (MASK_FILTERS // 4) == 0:
+            T = NR * ((ps + 3) // 4) ** 2
+            start, stop = self._timed("mask_conv3x3_fwd")
+            start()
+            V, U, M = self._new(36, T, cf), self._new(36, cf, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
+            X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V), NR, ps, ps, cf, X.stream())
+            X.call("myolo_wino_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, 0, X.stream())
+            self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, ps, ps, cf, MASK_FILTERS, X.stream())
+            self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
+            X.call("myolo_wino_output_transform_bn_stats", X.ptr(M), X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, ps, ps,
+                   MASK_FILTERS, X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
+                   X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]), *self._wsargs(),
+                   X.stream())
+            stop()
+            self.tape["conv1_V"] = V
+        else:
+            v = self.conv3x3_fwd(x, "myolo_mask_conv1", y1, NR, ps, ps, cf, MASK_FILTERS, keep_v=True, tag="mask_conv3x3_fwd")
+            if v is not None:
+                self.tape["conv1_V"] = v
+            X.call("myolo_bn_stats", X.ptr(y1), X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
+                   X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]), X.ptr(buf[3]),
+                   X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+                   NR * q, MASK_FILTERS, *self._wsargs(), X.stream())
         self.tape[bn] = (y1, ACT_RELU, True)
         NP, idx_d, inv_d = self._positive_index(B, R)
         self.tape["compact"] = (NP, idx_d, inv_d)
@@ -770,7 +801,15 @@ class Net(object):
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
         for i in range(4, 1, -1):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
-            xin = gather(convs[i - 1], q)
+            src = convs[i - 1]
+            if isinstance(src, tuple):        # ("lazy_bn", pre-BN tensor, bn layer): the forward normalised on load
+                _, ypre, bsrc = src
+                yp = gather(ypre, q)
+                xin = self._new(NP * q, MASK_FILTERS)
+                X.call("myolo_bn_apply_act", X.ptr(yp), X.ptr(self.bnbuf[bsrc][2]), X.ptr(self.bnbuf[bsrc][3]), X.ptr(xin), NP * q,
+                       MASK_FILTERS, ACT_RELU, X.stream())
+            else:
+                xin = gather(src, q)
             if self.tape[bn][0] is None:
                 # the fused forward never wrote the pre-BN tensor: recompute it for the positive ROIs with the
                 # same kernel (same k order per output element -> the same fp32 values)

@@ -132,6 +132,44 @@ def test_conv3x3_winograd(N, H, W, Cin, Cout):
     check(dw2, rdw, what="wino dw (from x)")
 
 
+@pytest.mark.parametrize("N,H,W,C", [(7, 14, 14, 256), (3, 9, 6, 64), (40, 14, 14, 128)])
+def test_winograd_transforms_with_folded_batchnorm(N, H, W, C):
+    """(a) output transform that also yields the training-mode BN statistics == plain output transform + myolo_bn_stats;
+    (b) input transform with BN apply + ReLU folded into the load == input transform of the separately normalised tensor."""
+    rng = np.random.default_rng(11)
+    T = N * ((H + 3) // 4) * ((W + 3) // 4)
+    Mw, bias = rnd(rng, 36, T, C), rnd(rng, C)
+    gamma, beta = 1 + 0.1 * rnd(rng, C), rnd(rng, C, scale=0.1)
+    mm0, mv0 = rnd(rng, C, scale=0.1), (1 + 0.1 * rng.random(C)).astype(np.float32)
+    y_ref, y = new(N * H * W, C), new(N * H * W, C)
+    st = X.stream()
+    X.call("myolo_wino_output_transform", X.ptr(dt(Mw)), X.ptr(dt(bias)), None, None, X.ptr(y_ref), N, H, W, C, 0, st)
+    outs = []
+    for fused in (False, True):
+        mean, var, sc, sh = new(C), new(C), new(C), new(C)
+        mm, mv = dt(mm0.copy()), dt(mv0.copy())
+        if fused:
+            X.call("myolo_wino_output_transform_bn_stats", X.ptr(dt(Mw)), X.ptr(dt(bias)), X.ptr(y), N, H, W, C, X.ptr(dt(gamma)),
+                   X.ptr(dt(beta)), X.ptr(mean), X.ptr(var), X.ptr(sc), X.ptr(sh), X.ptr(mm), X.ptr(mv), *ws(), st)
+        else:
+            X.call("myolo_bn_stats", X.ptr(y_ref), X.ptr(dt(gamma)), X.ptr(dt(beta)), X.ptr(mean), X.ptr(var), X.ptr(sc), X.ptr(sh),
+                   X.ptr(mm), X.ptr(mv), N * H * W, C, *ws(), st)
+        outs.append([t.cpu().numpy() for t in (mean, var, sc, sh, mm, mv)])
+    assert torch.equal(y, y_ref)
+    for a, b, name in zip(outs[0], outs[1], ("mean", "var", "scale", "shift", "moving_mean", "moving_var")):
+        assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max()), name
+    ym = y_ref.cpu().numpy().astype(np.float64)
+    assert np.abs(outs[1][0] - ym.mean(0)).max() < 1e-5 and np.abs(outs[1][1] - ym.var(0)).max() < 1e-4 * max(1.0, ym.var(0).max())
+    # (b)
+    sc, sh = dt(outs[1][2]), dt(outs[1][3])
+    a = new(N * H * W, C)
+    X.call("myolo_bn_apply_act", X.ptr(y_ref), X.ptr(sc), X.ptr(sh), X.ptr(a), N * H * W, C, 1, st)
+    V1, V2 = new(36, T, C), new(36, T, C)
+    X.call("myolo_wino_input_transform", X.ptr(a), X.ptr(V1), N, H, W, C, st)
+    X.call("myolo_wino_input_transform_affine", X.ptr(y_ref), X.ptr(sc), X.ptr(sh), 1, X.ptr(V2), N, H, W, C, st)
+    assert float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())
+
+
 def test_winograd_error_is_at_fp32_level():
     """The Winograd form is the same fp32 arithmetic with the sums associated differently; its error against a float64
     convolution must stay at fp32 rounding level (a reduced-precision product would sit at 1e-3), recorded here against
