@@ -1122,6 +1122,12 @@ int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M,
     a.nt = getenv("MYOLO_WINO_NT") ? 1 : 0;          // the product is read back at once by the output transform
     const long long tiles = cdiv64(M, BM) * ((N + BN - 1) / BN);
     if (tiles <= 0 || batch <= 0) return MYOLO_OK;
+    static const bool w256 = getenv("MYOLO_WINO_W256") != nullptr;      // tuning knob: 128x256 tiles (A read once)
+    if (w256 && (N % 256) == 0) {
+        const long long tiles256 = cdiv64(M, BM) * (N / 256);
+        hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN, 0, 4>), dim3((unsigned)tiles256, 1, batch), dim3(256), 0, s, a);
+        return MYOLO_OK;
+    }
     hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN>), dim3((unsigned)tiles, 1, batch), dim3(256), 0, s, a);
     return MYOLO_OK;
 }

@@ -464,8 +464,35 @@ class Net(object):
         chain = (fuse and self._wino_ok(NR, ps, ps, cf, MASK_FILTERS) and self._wino_ok(NR, ps, ps, MASK_FILTERS, MASK_FILTERS)
                  and MASK_FILTERS % 32 == 0 and ((ps + 3) // 4) ** 2 <= 32 and q * 128 <= 65536
                  and (not train or pos_flags is not None))
+        if chain:
+            x = self._mask_convs_winograd_chain(x, convs, NR, ps, cf, train, pos_flags)
+        else:
+            x = self._mask_convs_layerwise(x, convs, NR, ps, cf, train, fuse)
+        C = cfg.NUM_CLASSES
+        p = self._new(NR * 4 * ps * ps, C)
+        if fuse and C <= 4 and MASK_FILTERS % 128 == 0:
+            # deconv + ReLU + 1x1 + sigmoid in one pass; the 28x28x256 tensor is never written.  The sparse backward
+            # recomputes it for the positive ROIs (mask_head_bwd_sparse); the dense backward needs it whole.
+            self.ws.ensure(X.deconv_mask_ws_bytes(NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C))
+            X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]),
+                   X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
+                   X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, *self._wsargs(), X.stream())
+            d = None
+        else:
+            d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
+            X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
+                   X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
+            X.call("myolo_mask_head_out_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
+                   NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
+        self.tape["mask"] = (convs, x, d)
+        return p
+
+    def _mask_convs_winograd_chain(self, x, convs, NR, ps, cin, train, pos_flags):
+        """myolo_mask_conv1-4 (+bn, ReLU) as a chain of Winograd stages; appends each conv's input to `convs` (an input the
+        forward never materialised is recorded as ("lazy_bn", pre-BN tensor, bn layer)).  Returns conv4's activation."""
+        q = ps * ps
         Vcur = None
-        for i in range(1, 5 if chain else 1):
+        for i in range(1, 5):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             batch_stats = train and i == 1
             fold = not batch_stats
@@ -523,7 +550,11 @@ class Net(object):
                     Vcur = None
             stop()
             cin = MASK_FILTERS
-        for i in range(1 if not chain else 5, 5):
+        return x
+
+    def _mask_convs_layerwise(self, x, convs, NR, ps, cin, train, fuse):
+        """myolo_mask_conv1-4 one self-contained conv op at a time (direct kernels or un-chained Winograd)."""
+        for i in range(1, 5):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             y = self._new(NR * ps * ps, MASK_FILTERS)
             convs.append(x)
@@ -547,24 +578,7 @@ class Net(object):
                     self.tape["conv1_V"] = v
                 x = self.bn_act_fwd(bn, y, ACT_RELU, batch_stats)
             cin = MASK_FILTERS
-        C = cfg.NUM_CLASSES
-        p = self._new(NR * 4 * ps * ps, C)
-        if fuse and C <= 4 and MASK_FILTERS % 128 == 0:
-            # deconv + ReLU + 1x1 + sigmoid in one pass; the 28x28x256 tensor is never written.  The sparse backward
-            # recomputes it for the positive ROIs (mask_head_bwd_sparse); the dense backward needs it whole.
-            self.ws.ensure(X.deconv_mask_ws_bytes(NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C))
-            X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]),
-                   X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
-                   X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, *self._wsargs(), X.stream())
-            d = None
-        else:
-            d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
-            X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
-                   X.ptr(d), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU, *self._wsargs(), X.stream())
-            X.call("myolo_mask_head_out_fwd", X.ptr(d), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]), X.ptr(p),
-                   NR * 4 * ps * ps, MASK_FILTERS, C, X.stream())
-        self.tape["mask"] = (convs, x, d)
-        return p
+        return x
 
     def mask_head_fwd_bf16(self, Fm, fshape, rois):
         """Inference-only mask head with bf16 activations / fp32 accumulation (cfg.INFERENCE_DTYPE == "bf16").
