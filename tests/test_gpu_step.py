@@ -317,6 +317,30 @@ def test_inference_forward_matches_oracle():
     assert rel(mask, ref["myolo_mask"]) < TOL
 
 
+def test_minimum_legal_size_grid_of_one():
+    """smallest shape the reference accepts (model.py:791-794: multiples of 32): 32x32 -> GRID 1x1, R = 3 ROIs per image,
+    feature map 4x4, batch 1.  Forward against the oracle; one training step must run and stay finite (every kernel's
+    tail / single-tile path)."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[32, 32, 3], ALPHA=0.25, BATCH_SIZE=1)
+    assert (cfg.GRID_W, cfg.TRAIN_ROIS_PER_IMAGE) == (1, 3)
+    P = np_model.init_params(cfg, seed=2, bias_scale=0.05)
+    images = np.random.default_rng(3).random((1, 32, 32, 3), dtype=np.float32)
+    ref = np_model.inference_fwd(P, images, cfg)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    yo, det, mask = model.keras_model.predict([images])
+    assert yo.shape == (1, 1, 1, 3, 5 + cfg.NUM_CLASSES) and mask.shape == (1, 3, 28, 28, cfg.NUM_CLASSES)
+    assert rel(yo, ref["yolo_output"]) < TOL
+    assert rel(det[..., :5], ref["detections"][..., :5]) < TOL
+    assert np.abs(mask - ref["myolo_mask"]).max() < 5e-3        # 3 ROIs on a 4x4 map: no margin selection possible
+    samples = make_shapes_samples(1, cfg)
+    batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
+    tm = MaskYOLO(mode="training", config=cfg)
+    tm.load_state_dict(P)
+    out = tm.train_on_batch(batch, learning_rate=1e-3)
+    assert np.isfinite(out["loss"]) and all(np.isfinite(v).all() for v in tm.state_dict().values())
+
+
 def test_two_runs_bit_identical_forward():
     """determinism: everything except the ROIAlign scatter-add (fp32 atomics) is order-fixed."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
