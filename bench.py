@@ -142,7 +142,7 @@ def main():
     for i in range(args.warmup):
         net.train_step(dbs[i % nb], args.lr)
     barrier()
-    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "wino_multiply"}
+    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "wino_multiply", "wino_in", "wino_out_in"}
     net.timings = {}
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -157,6 +157,8 @@ def main():
     assert np.isfinite(loss), "non-finite loss in the timed region"
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
     mul_ms, mul_n = net.kernel_ms("wino_multiply")
+    win_ms, win_n = net.kernel_ms("wino_in")
+    woi_ms, woi_n = net.kernel_ms("wino_out_in")
     roi_ms, _ = net.kernel_ms("roialign_fwd")
 
     # the same K steps with the other TRAIN_MASK_HEAD_ROIS setting (reported beside `value`, never as `value`)
@@ -237,6 +239,17 @@ def main():
                                        "frac": (roi_bytes / (roi_ms * 1e-3) / 1e9 / 8000.0) if roi_ms > 0 else 0.0,
                                        "avg_launch_ms": roi_ms}},
         }
+        if wino and win_n and woi_n:
+            # the HBM-bound stages of the Winograd op (18 % of the step), against 8 TB/s: algorithmic bytes / measured time
+            vbytes = 36.0 * tiles_w * 256 * 4
+            xbytes = float(M) * 256 * 4
+            res["roofline"]["hbm_stages"] = [
+                {"kernel": "wino_in_kernel (conv1 input transform: ROIAlign output -> V)", "bound": "hbm", "algorithmic_bytes": xbytes + vbytes,
+                 "avg_launch_ms": win_ms, "achieved": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                 "frac": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9 / 8000.0},
+                {"kernel": "wino_out_in_kernel (layer boundary M_i -> V_{i+1} through LDS)", "bound": "hbm", "algorithmic_bytes": 2 * vbytes,
+                 "avg_launch_ms": woi_ms, "achieved": 2 * vbytes / (woi_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                 "frac": 2 * vbytes / (woi_ms * 1e-3) / 1e9 / 8000.0}]
         if variant is not None:
             res["variant"] = variant
         if args.cpu_images > 0 and world == 1:

@@ -501,7 +501,7 @@ class Net(object):
             start()
             if Vcur is None:
                 Vcur = self._new(36, T, cin)
-                X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
+                self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
             U, M = self._new(36, cin, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
             X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
             self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, ps, ps, cin, MASK_FILTERS,
@@ -519,8 +519,9 @@ class Net(object):
             if fold and i < 4:
                 ykeep = self._new(NR * q, MASK_FILTERS) if train else None
                 Vn = self._new(36, T, MASK_FILTERS)
-                X.call("myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(ykeep),
-                       X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS, ACT_RELU, X.stream())
+                self._call_timed("wino_out_in", "myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
+                                 X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS,
+                                 ACT_RELU, X.stream())
                 x, Vcur = ykeep, Vn
             else:
                 y = self._new(NR * q, MASK_FILTERS)
