@@ -224,7 +224,8 @@ def main():
             "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
                                    "(fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
                                        args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
-                                       "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + ", 3x3 convs: " + cfg.CONV3X3_ALGO,
+                                       "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + ", 3x3 convs: " + {"auto": "fp32 Winograd F(4x4,3x3) for launches >= 16384 pixels, direct implicit GEMM below",
+                                                          "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO],
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
             "roofline": {"kernel": kname,
                          "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
