@@ -255,16 +255,28 @@ class MaskYOLO(object):
         normed = np.expand_dims(image / 255., axis=0).astype(np.float32)
         x = torch.as_tensor(np.ascontiguousarray(normed), device=self.net.dev)
         yolo_output, det_d, mask_d = self.net.predict(x)                   # device tensors
-        boxes, class_ids, scores, full_masks = self._decode_masks_device(det_d[0], mask_d[0], image.shape)
+        # decode_masks (model.py:1330-1391) unmolds every box and the caller then keeps <= 10 of them (model.py:1290-1304);
+        # the selection needs only boxes / scores / classes, so it runs first and only the survivors are unmolded
+        # (same output: full_masks[:, :, nmb] of the all-box result).
+        det_h = det_d[0].cpu().numpy()
+        boxes, scores, class_ids = det_h[:, :4], det_h[:, 4], det_h[:, 5].astype(np.int32)
+        keep = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0)[0]     # model.py:1373-1380
+        boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
         top10 = np.argsort(scores)[::-1][:10]
         kept = np.array([i for i in top10 if scores[i] >= cs_threshold], dtype=np.int64)
         nmb = mutils.NMB(boxes[kept], class_ids[kept], kept, cfg.IMAGE_SHAPE, nms_threshold=0.7) if len(kept) else kept
         nmb = np.asarray(nmb, dtype=np.int64)
+        if len(nmb):
+            sel = torch.as_tensor(keep[nmb], device=det_d.device)
+            _, _, _, full_masks = self._decode_masks_device(det_d[0].index_select(0, sel).contiguous(),
+                                                            mask_d[0].index_select(0, sel).contiguous(), image.shape)
+        else:
+            full_masks = np.empty((int(image.shape[0]), int(image.shape[1]), 0), dtype=bool)
         return [{
             "bboxes": boxes[nmb],
             "class_ids": class_ids[nmb],
             "confidence_scores": scores[nmb],
-            "full_masks": full_masks[:, :, nmb],
+            "full_masks": full_masks,
         }]
 
     def _decode_masks_device(self, det, masks, image_shape):
