@@ -94,6 +94,8 @@ class Config(object):
     # multiplications at 14x14, same operand and accumulator type, sums associated differently: agrees with the direct
     # kernel to ~1e-5 relative), "auto" = Winograd for launches of >= 16384 output pixels, direct below.
     CONV3X3_ALGO = "auto"
+    # detect(): replay the inference forward from a captured hipGraph (one capture per input shape) instead of ~150 launches
+    INFERENCE_HIP_GRAPH = True
 
     def __init__(self):
         self.finalize()

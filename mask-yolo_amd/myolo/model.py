@@ -254,7 +254,8 @@ class MaskYOLO(object):
             self.load_weights(weights_dir)
         normed = np.expand_dims(image / 255., axis=0).astype(np.float32)
         x = torch.as_tensor(np.ascontiguousarray(normed), device=self.net.dev)
-        yolo_output, det_d, mask_d = self.net.predict(x)                   # device tensors
+        predict = self.net.predict_graphed if getattr(cfg, "INFERENCE_HIP_GRAPH", True) else self.net.predict
+        yolo_output, det_d, mask_d = predict(x)                            # device tensors
         # decode_masks (model.py:1330-1391) unmolds every box and the caller then keeps <= 10 of them (model.py:1290-1304);
         # the selection needs only boxes / scores / classes, so it runs first and only the survivors are unmolded
         # (same output: full_masks[:, :, nmb] of the all-box result).

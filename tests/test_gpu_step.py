@@ -341,6 +341,25 @@ def test_minimum_legal_size_grid_of_one():
     assert np.isfinite(out["loss"]) and all(np.isfinite(v).all() for v in tm.state_dict().values())
 
 
+def test_inference_hip_graph_replay_equals_eager_and_sees_weight_updates():
+    """Net.predict_graphed: the captured hipGraph replays the same kernels on the same weight buffers -- outputs are
+    bit-identical to the eager forward, for a new input and after the weights change."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=2)
+    P = np_model.init_params(cfg, seed=3, bias_scale=0.05)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+    rng = np.random.default_rng(8)
+    for it in range(3):
+        x = torch.as_tensor(rng.random((2, 128, 128, 3), dtype=np.float32), device=net.dev)
+        if it == 2:
+            net.flat_p.mul_(1.01)                   # weights change between replays
+        g = [t.clone() for t in net.predict_graphed(x)]
+        e = net.predict(x)
+        assert all(torch.equal(a, b) for a, b in zip(g, e)), "graph replay differs from eager at iteration %d" % it
+    assert len(net._graphs) == 1
+
+
 def test_two_runs_bit_identical_forward():
     """determinism: everything except the ROIAlign scatter-add (fp32 atomics) is order-fixed."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
