@@ -226,7 +226,8 @@ def main():
                                        args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
                                        "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + ", 3x3 convs: " + {"auto": "fp32 Winograd F(4x4,3x3) for launches >= 16384 pixels, direct implicit GEMM below",
                                                           "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO],
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss},
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
+                       "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
             "roofline": {"kernel": kname,
                          "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": achieved / 157.3, "traffic": traffic,
