@@ -317,6 +317,31 @@ def test_inference_forward_matches_oracle():
     assert rel(mask, ref["myolo_mask"]) < TOL
 
 
+def test_overfitting_one_batch_drives_the_mask_loss_down():
+    """No oracle here: 500 Adam steps on one fixed batch must take the mask loss from chance level (0.69 once boxes start to
+    match) below 0.15 while the YOLO loss falls too -- the forward, both losses, every gradient and the optimiser pull in
+    the same direction.  tools/overfit_check.py is the full-size version (224x224, 1500 steps): mask loss 0.01, and detect()
+    on the training images returns ground-truth classes with pasted-mask IoU 0.83-0.90."""
+    B = 4
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], BATCH_SIZE=B)
+    samples = make_shapes_samples(B, cfg)
+    batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
+    m = MaskYOLO(mode="training", config=cfg, seed=1)
+    m.set_trainable(".*")
+    m.compile(1e-3, 0.9)
+    db = m.net.to_device_batch(batch)
+    early, y0 = 0.0, None                         # no positive ROI (mask loss 0) until the boxes start to fit
+    for i in range(500):
+        out = m.net.train_step(db, 1e-3 if i < 350 else 3e-4)
+        if i == 0:
+            y0 = float(out["yolo_terms"][0])
+        if i < 150:
+            early = max(early, float(out["mask_terms"][0]))
+    last, y1 = float(out["mask_terms"][0]), float(out["yolo_terms"][0])
+    assert early > 0.5 and last < 0.15, (early, last)
+    assert y1 < 0.5 * y0, (y0, y1)
+
+
 def test_minimum_legal_size_grid_of_one():
     """smallest shape the reference accepts (model.py:791-794: multiples of 32): 32x32 -> GRID 1x1, R = 3 ROIs per image,
     feature map 4x4, batch 1.  Forward against the oracle; one training step must run and stay finite (every kernel's
