@@ -150,7 +150,11 @@ class Net(object):
         for name, kind, shp, _ in self.table:
             if kind == "bn":
                 self.bnbuf[name] = torch.zeros(4, shp, **f32)        # mean, var, scale, shift
-        self.ws = Workspace(self.dev)
+        self._ws_main = Workspace(self.dev)
+        self._ws_side = Workspace(self.dev)    # scratch of the YOLO-head backward running on the side stream
+        self._ws_active = self._ws_main
+        self._yolo_stream = torch.cuda.Stream(device=self.dev)
+        self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
         self.adam_t = 0
@@ -205,6 +209,10 @@ class Net(object):
     # ------------------------------------------------------------------ helpers
     def _new(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    @property
+    def ws(self):
+        return self._ws_active
 
     def _wsargs(self):
         return self.ws.ptr, self.ws.size
@@ -399,7 +407,8 @@ class Net(object):
         self.tape["trunk"] = (C4, c4shape, a, shape)
         return Fm, (n, h, w, Cf), yo
 
-    def trunk_bwd(self, dF, dyolo):
+    def yolo_head_bwd(self, dyolo):
+        """conv_23 and the YOLO blocks (conv_dw/pw_7..14) backward: returns the gradient reaching C4 through the YOLO head."""
         C4, c4shape, a14, s14 = self.tape["trunk"]
         n2, h2, w2, c2 = s14
         D = dyolo.shape[1]
@@ -412,11 +421,41 @@ class Net(object):
         for _ in YOLO_BLOCKS:
             da = self.dw_block_bwd(bid, da)
             bid -= 1
+        return da
+
+    def start_yolo_head_bwd(self, dyolo):
+        """Launch yolo_head_bwd on the side stream (its own scratch buffer).  It depends only on the trunk forward and the YOLO
+        loss, so it runs underneath the mask head's forward and backward; its small 7x7 / 14x14 kernels fill a fraction of the
+        chip on their own.  trunk_bwd joins it before adding the two gradients of C4.  Same kernels, same results."""
+        cur = torch.cuda.current_stream()
+        self._yolo_stream.wait_stream(cur)
+        self._ws_active = self._ws_side
+        try:
+            with torch.cuda.stream(self._yolo_stream):
+                da = self.yolo_head_bwd(dyolo)
+        finally:
+            self._ws_active = self._ws_main
+        self.tape["yolo_bwd"] = da
+
+    def trunk_bwd(self, dF, dyolo):
+        C4, c4shape, a14, s14 = self.tape["trunk"]
+        da = self.tape.pop("yolo_bwd", None)
+        started = da is not None                # launched earlier on the side stream (start_yolo_head_bwd)
+        if not started:
+            da = self.yolo_head_bwd(dyolo)
+
+        def join():
+            if started:
+                cur = torch.cuda.current_stream()
+                cur.wait_stream(self._yolo_stream)
+                da.record_stream(cur)
+        bid = len(BACKBONE_BLOCKS)
         n, h, w, c = c4shape
         if dF is None:
             # 'yolo' mode (model.py:906-920): feature_map and the mask head are not in the graph, their gradients are zero
             self.g["feature_map/kernel"].zero_()
             self.g["feature_map/bias"].zero_()
+            join()
             dC4 = da
         else:
             Cf = dF.shape[1]
@@ -424,6 +463,7 @@ class Net(object):
             self.colsum(dF, self.g["feature_map/bias"])
             dC4 = self._new(n * h * w, c)
             self.conv3x3_bwd_data(dF, "feature_map", dC4, n, h, w, c, Cf)
+            join()
             X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
         if self.on_bucket_ready:
             self.on_bucket_ready(1)
@@ -908,6 +948,15 @@ class Net(object):
                X.ptr(rois), X.ptr(tcls), X.ptr(tmask), X.ptr(npos), B, R, T, H, W, mh, mw, X.stream())
         if self.sparse_mask_bwd:
             self._start_npos_copy(npos)
+        w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
+        w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
+        yterms = self._new(8)
+        dyolo = self._new(yo.shape[0], yo.shape[1])
+        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+               X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
+               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+        if self.overlap_yolo_bwd:
+            self.start_yolo_head_bwd(dyolo)
         if self.sparse_mask_fwd:
             if not self.sparse_mask_bwd:
                 raise RuntimeError("TRAIN_MASK_HEAD_ROIS='positives' needs the sparse backward (sparse_mask_bwd=True)")
@@ -918,13 +967,6 @@ class Net(object):
             flags = (torch.arange(R, device=self.dev, dtype=torch.int32).view(1, R) < npos.view(B, 1)).to(torch.int32).contiguous()
             pred = self.mask_head_fwd(Fm, fshape, rois, True, pos_flags=flags.view(-1) if self.sparse_mask_bwd else None)
             tmask_l, tcls_l = tmask, tcls
-        w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
-        w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
-        yterms = self._new(8)
-        dyolo = self._new(yo.shape[0], yo.shape[1])
-        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
-               X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
-               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
         if pred is None:                  # positives-only forward without a positive ROI (model.py:750-752)
             mterms = torch.zeros(2, dtype=torch.float32, device=self.dev)
             dz = None
