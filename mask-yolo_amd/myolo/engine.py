@@ -955,8 +955,6 @@ class Net(object):
         X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
                X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
                float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
-        if self.overlap_yolo_bwd:
-            self.start_yolo_head_bwd(dyolo)
         if self.sparse_mask_fwd:
             if not self.sparse_mask_bwd:
                 raise RuntimeError("TRAIN_MASK_HEAD_ROIS='positives' needs the sparse backward (sparse_mask_bwd=True)")
@@ -975,6 +973,10 @@ class Net(object):
             dz = self._new(pred.shape[0], pred.shape[1])
             X.call("myolo_mask_bce", X.ptr(tmask_l), X.ptr(tcls_l), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), tcls_l.numel(), mh, mw, C,
                    *self._wsargs(), X.stream())
+        if self.overlap_yolo_bwd:
+            # under the compacted part of the mask head's backward (small launches on the positive ROIs), not under the big
+            # forward GEMMs: two streams of small kernels fill the chip together, and the dense kernels keep it to themselves
+            self.start_yolo_head_bwd(dyolo)
         dF = self.mask_head_bwd_sparse(dz, B, R) if self.sparse_mask_bwd else self.mask_head_bwd(dz)
         self.trunk_bwd(dF, dyolo)
         if self.sparse_mask_fwd:          # the positives' masks only, in positive order (see mask_head_fwd_positives)
