@@ -5,12 +5,11 @@ oracle is pinned by (1) the hand-derived KATs below -- each states the closed fo
 (2) agreement of its analytic backward with an independent torch-autograd composition in float64,
 (3) property tests.  PARITY UNPINNED against TensorFlow itself; see oracle/np_ops.py header."""
 import numpy as np
-import pytest
 from hypothesis import given, settings, strategies as st
 
 from oracle import np_ops as O
 from oracle import np_model
-from myolo.config import make_config, ShapesConfig, Config
+from myolo.config import make_config, ShapesConfig
 
 F32 = np.float32
 

@@ -84,7 +84,6 @@ def test_gpu_shapes_producer_matches_host_pipeline(base, size):
     reproduces the host pipeline (ShapesDataset -> load_image_gt -> BatchGenerator) bit for bit, 64 images."""
     import torch
     from myolo.shapes import ShapesProducer, make_shapes_samples
-    from myolo.engine import Net
     cfg = make_config(base, IMAGE_SHAPE=[size, size, 3], BATCH_SIZE=64)
     start = 40
     samples = make_shapes_samples(64, cfg, start_index=start)

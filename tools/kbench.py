@@ -9,7 +9,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mask-yolo_amd")]
-import numpy as np   # noqa: E402
 import torch         # noqa: E402
 from myolo import _ext as X   # noqa: E402
 

@@ -4,16 +4,15 @@ run detect() on those images with the trained weights.  Expected on an MI355X (2
 0.01, every detection has the class of a ground-truth instance and its pasted mask overlaps that instance with IoU > 0.8.
   python tools/overfit_check.py
 """
-import sys, time
+import sys
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "mask-yolo_amd")]
-import numpy as np, torch
+import numpy as np
 from myolo.config import make_config, ShapesConfig
 from myolo.model import MaskYOLO
-from myolo.shapes import make_shapes_samples, ShapesDataset
+from myolo.shapes import make_shapes_samples
 from myolo.myolo_utils import BatchGenerator
-from myolo import myolo_utils as mutils
 B = 8
 cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], BATCH_SIZE=B)
 samples = make_shapes_samples(B, cfg)
