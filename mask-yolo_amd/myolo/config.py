@@ -96,6 +96,10 @@ class Config(object):
     CONV3X3_ALGO = "auto"
     # detect(): replay the inference forward from a captured hipGraph (one capture per input shape) instead of ~150 launches
     INFERENCE_HIP_GRAPH = True
+    # detect() keeps at most 10 boxes (model.py:1290-1304).  True: ROIAlign + mask head run on those survivors only instead
+    # of on all G*G*N_BOX boxes (the reference's graph, model.py:926-931, has no score gate) -- same detect() output up to the
+    # kernels' summation order; keras_model.predict() still returns every box's mask.
+    DETECT_MASKS_FOR_SELECTED_ONLY = False
 
     def __init__(self):
         self.finalize()

@@ -1045,6 +1045,30 @@ class Net(object):
         self.tape = {}
         return yo.view(B, G, G, A, 5 + C), det, pred.view(B, R, mh, mw, C)
 
+    def predict_detections(self, images):
+        """first half of the inference graph: -> yolo_output, detections [B,R,6], and the feature map the mask head reads."""
+        cfg = self.cfg
+        self.tape = {}
+        B = images.shape[0]
+        G, A, C = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES
+        Fm, fshape, yo = self.trunk_fwd(images, False)
+        det = self._new(B, G * G * A, 6)
+        X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
+        self.tape = {}
+        return yo.view(B, G, G, A, 5 + C), det, (Fm, fshape)
+
+    def predict_masks(self, feature, rois):
+        """second half for a chosen subset of boxes: rois [B, n, 4] (the first four detection columns) -> [B, n, mh, mw, C]."""
+        cfg = self.cfg
+        Fm, fshape = feature
+        self.tape = {}
+        B, n = rois.shape[:2]
+        mh, mw = cfg.MASK_SHAPE
+        rois = rois.contiguous()
+        pred = self.mask_head_fwd_bf16(Fm, fshape, rois) if cfg.INFERENCE_DTYPE == "bf16" else self.mask_head_fwd(Fm, fshape, rois, False)
+        self.tape = {}
+        return pred.view(B, n, mh, mw, cfg.NUM_CLASSES)
+
     def predict_graphed(self, images):
         """predict() replayed from a captured hipGraph (one per input shape): the ~150 launches of an inference forward cost
         one graph launch on the host.  Same kernels, same buffers for the weights (updates are seen), static input / output

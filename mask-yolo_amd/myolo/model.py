@@ -254,8 +254,13 @@ class MaskYOLO(object):
             self.load_weights(weights_dir)
         normed = np.expand_dims(image / 255., axis=0).astype(np.float32)
         x = torch.as_tensor(np.ascontiguousarray(normed), device=self.net.dev)
-        predict = self.net.predict_graphed if getattr(cfg, "INFERENCE_HIP_GRAPH", True) else self.net.predict
-        yolo_output, det_d, mask_d = predict(x)                            # device tensors
+        selected_only = bool(getattr(cfg, "DETECT_MASKS_FOR_SELECTED_ONLY", False))
+        if selected_only:
+            yolo_output, det_d, feature = self.net.predict_detections(x)   # the mask head runs below, on the survivors only
+            mask_d = None
+        else:
+            predict = self.net.predict_graphed if getattr(cfg, "INFERENCE_HIP_GRAPH", True) else self.net.predict
+            yolo_output, det_d, mask_d = predict(x)                        # device tensors
         # decode_masks (model.py:1330-1391) unmolds every box and the caller then keeps <= 10 of them (model.py:1290-1304);
         # the selection needs only boxes / scores / classes, so it runs first and only the survivors are unmolded
         # (same output: full_masks[:, :, nmb] of the all-box result).
@@ -269,8 +274,12 @@ class MaskYOLO(object):
         nmb = np.asarray(nmb, dtype=np.int64)
         if len(nmb):
             sel = torch.as_tensor(keep[nmb], device=det_d.device)
-            _, _, _, full_masks = self._decode_masks_device(det_d[0].index_select(0, sel).contiguous(),
-                                                            mask_d[0].index_select(0, sel).contiguous(), image.shape)
+            det_s = det_d[0].index_select(0, sel).contiguous()
+            if selected_only:
+                mask_s = self.net.predict_masks(feature, det_s[:, :4].unsqueeze(0))[0]
+            else:
+                mask_s = mask_d[0].index_select(0, sel).contiguous()
+            _, _, _, full_masks = self._decode_masks_device(det_s, mask_s, image.shape)
         else:
             full_masks = np.empty((int(image.shape[0]), int(image.shape[1]), 0), dtype=bool)
         return [{

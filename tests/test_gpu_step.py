@@ -385,6 +385,27 @@ def test_inference_hip_graph_replay_equals_eager_and_sees_weight_updates():
     assert len(net._graphs) == 1
 
 
+def test_detect_masks_for_selected_only_matches_full_detect():
+    """cfg.DETECT_MASKS_FOR_SELECTED_ONLY: the mask head on the <= 10 surviving boxes gives the detect() output of the
+    all-box graph (boxes, classes, scores identical; pasted masks equal except where a probability sits within 1e-4 of 0.5)."""
+    img = (np.random.default_rng(2).random((416, 416, 3)) * 255).astype(np.uint8)
+    P = None
+    outs = []
+    for sel in (False, True):
+        cfg = make_config(RiceConfig, BATCH_SIZE=1, DETECT_MASKS_FOR_SELECTED_ONLY=sel)
+        m = MaskYOLO(mode="inference", config=cfg, seed=4)
+        if P is None:
+            P = m.state_dict()
+        m.load_state_dict(P)
+        outs.append(m.detect(img, cs_threshold=0.0)[0])
+    a, b = outs
+    assert a["full_masks"].shape[2] >= 1
+    for k in ("bboxes", "class_ids", "confidence_scores"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["full_masks"].shape == b["full_masks"].shape
+    assert (a["full_masks"] != b["full_masks"]).mean() < 1e-4
+
+
 def test_two_runs_bit_identical_forward():
     """determinism: everything except the ROIAlign scatter-add (fp32 atomics) is order-fixed."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
