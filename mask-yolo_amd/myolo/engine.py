@@ -1085,10 +1085,19 @@ class Net(object):
                     self.predict(static_in)
             cur.wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                outs = self.predict(static_in)
-            ent = self._graphs[key] = (graph, static_in, outs)
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    outs = self.predict(static_in)
+                ent = (graph, static_in, outs)
+            except Exception as e:                   # capture is a launch mechanism, not a compute path: the same kernels run eagerly
+                import warnings
+                warnings.warn("hipGraph capture of the inference forward failed (%s: %s); launching eagerly" % (type(e).__name__, e))
+                torch.cuda.synchronize()
+                ent = (None, None, None)
+            self._graphs[key] = ent
+        if ent[0] is None:
+            return self.predict(images)
         graph, static_in, outs = ent
         static_in.copy_(images)
         graph.replay()
