@@ -234,6 +234,19 @@ size_t myolo_wino_output_transform_bn_ws_bytes(int C);
 int myolo_wino_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int H, int W, int C, const float* gamma,
                                          const float* beta, float* mean, float* var, float* scale, float* shift, float* moving_mean,
                                          float* moving_var, void* ws, size_t ws_bytes, void* stream);
+/* conv gradients whose incoming gradient sits behind a training-mode BatchNorm + activation with a row-sparse upstream
+ * gradient (bn1 of the mask head, model.py:690 -- only the positive ROIs carry gradient, myolo_mask_loss_graph
+ * model.py:739-746): bn_bwd_rowsparse_coeffs reduces dgamma / dbeta and leaves the per-channel terms ka, kb of
+ * dx = scale*dz + ka + kb*x; the *_lazybn gradients form dx while loading the pre-BN tensor, so it is never written. */
+int myolo_bn_bwd_rowsparse_coeffs(const float* dy_compact, const float* x, const int32_t* idx, const float* mean, const float* var,
+                                  const float* scale, const float* shift, float* dgamma, float* dbeta, float* ka, float* kb, int64_t M,
+                                  int C, int n_groups, int group_rows, int act, void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_wino_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
+                                       const float* shift, const float* ka, const float* kb, int act, const float* w, float* dx, int N,
+                                       int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_wino_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv,
+                                         const float* scale, const float* shift, const float* ka, const float* kb, int act, float* dw,
+                                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 /* layer boundary between two Winograd convs in one pass per image: M of conv_i -> (+bias, affine, act) -> V of conv_{i+1}
  * through LDS; the activation itself goes to y only for images with flags[img] != 0 (flags NULL: all; y NULL: none).
  * Needs C % 32 == 0 and ceil(H/4)*ceil(W/4) <= 32 (14x14: 16 tiles). */

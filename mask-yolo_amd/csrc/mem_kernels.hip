@@ -317,6 +317,23 @@ struct FinBnBwd {                    // dbeta = sum(dz), dgamma = sum(dz * xhat)
     }
 };
 
+struct FinBnBwdCoef {                // FinBnBwd + the per-channel terms of dx = scale*dz + (ka + kb*x), see bn_bwd_dx_sparse_kernel
+    static constexpr int PAIR = 1;
+    float *dgamma, *dbeta, *ka, *kb;
+    const float *scale, *mean, *var;
+    float invM;
+    __device__ void operator()(int, double) const {}
+    __device__ void pair(int c, double t0, double t1) const
+    {
+        dbeta[c] = (float)t0;
+        dgamma[c] = (float)t1;
+        const float rstd = rsqrtf(var[c] + BN_EPS_F);
+        const float b = -scale[c] * invM * (float)t1 * rstd;
+        kb[c] = b;
+        ka[c] = -scale[c] * invM * (float)t0 - b * mean[c];
+    }
+};
+
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ var,
@@ -1234,6 +1251,23 @@ int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const in
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_dx_sparse_kernel, dim3((unsigned)(M / group_rows)), dim3(256), 0, s, dy_compact, x, inv, scale, shift, mean,
                        var, tot, dx, nq, C, act, group_rows, 1.0f / (float)M);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_bwd_rowsparse_coeffs(const float* dy_compact, const float* x, const int32_t* idx, const float* mean, const float* var,
+                                  const float* scale, const float* shift, float* dgamma, float* dbeta, float* ka, float* kb, int64_t M,
+                                  int C, int n_groups, int group_rows, int act, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy_compact && x && idx && mean && var && scale && shift && dgamma && dbeta && ka && kb, "bn_bwd_rowsparse_coeffs: null pointer");
+    MYOLO_REQUIRE(M > 0 && (C & 3) == 0 && n_groups > 0 && group_rows > 0 && M % group_rows == 0, "bn_bwd_rowsparse_coeffs: bad sizes");
+    const long long Mc = (long long)n_groups * group_rows;
+    const size_t pb = col_ws_bytes(Mc, C, 2);
+    MYOLO_NEED_WS(align256(pb) + 2 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    OpBnBwdSparse op{dy_compact, x, idx, scale, shift, mean, var, C, act, group_rows};
+    run_colreduce(op, Mc, C, part, tot, (hipStream_t)stream, FinBnBwdCoef{dgamma, dbeta, ka, kb, scale, mean, var, 1.0f / (float)M});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -85,10 +85,37 @@ __device__ __forceinline__ float4 affine_act4(float4 v, float4 sc, float4 sh, in
     return v;
 }
 
+// "Lazy" operand: the gradient reaching a conv through a training-mode BatchNorm + activation whose upstream gradient is
+// row-sparse (non-zero only in the images listed by inv[img] >= 0, stored compactly in dyc).  Instead of materialising
+//     dx = scale*dz + (ka + kb*x),   dz = dyc * [act passes](scale*x + shift)      (bn_bwd_dx_sparse_kernel)
+// the transforms form it per element while loading the pre-BN tensor x: one read of x replaces a write and two reads of dx.
+struct LazyBn {
+    const float* dyc;        // [n_pos images][H*W][C] compact upstream gradient (NULL: plain operand)
+    const int32_t* inv;      // [N] compact slot of an image or -1
+    const float* scale;
+    const float* shift;
+    const float* ka;
+    const float* kb;
+    int act;
+};
+struct LazyBnCh { float4 sc, sh, ka, kb; };
+__device__ __forceinline__ float lazy1(float x, float g, float sc, float sh, float ka, float kb, int act)
+{
+    const float t = fmaf(x, sc, sh);
+    const float pass = act == MYOLO_ACT_RELU ? (t > 0.f ? 1.f : 0.f) : act == MYOLO_ACT_RELU6 ? ((t > 0.f && t < 6.f) ? 1.f : 0.f) : 1.f;
+    return fmaf(sc, g * pass, fmaf(kb, x, ka));
+}
+__device__ __forceinline__ float4 lazy4(float4 x, float4 g, const LazyBnCh& k, int act)
+{
+    return make_float4(lazy1(x.x, g.x, k.sc.x, k.sh.x, k.ka.x, k.kb.x, act), lazy1(x.y, g.y, k.sc.y, k.sh.y, k.ka.y, k.kb.y, act),
+                       lazy1(x.z, g.z, k.sc.z, k.sh.z, k.ka.z, k.kb.z, act), lazy1(x.w, g.w, k.sc.w, k.sh.w, k.ka.w, k.kb.w, act));
+}
+
 // X [N,H,W,C] -> V [36][T][C].  Optional per-channel affine + activation applied to every in-bounds pixel as it is loaded
 // (BatchNorm apply + ReLU of the producing layer: the normalised activation is never written); the zero padding stays zero.
+template <bool LAZY>
 __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ x, float* __restrict__ V, TileGeom g, int C,
-                                                      const float* __restrict__ scale, const float* __restrict__ shift, int act)
+                                                      const float* __restrict__ scale, const float* __restrict__ shift, int act, LazyBn lz)
 {
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
@@ -103,18 +130,33 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
         const float* base = x + img * (long long)g.H * g.W * C + c;
         const float4 sc = scale ? ldg4(scale + c) : f4(1.f);
         const float4 sh = scale ? ldg4(shift + c) : f4(0.f);
+        LazyBnCh lk;
+        const float* gbase = nullptr;
+        if (LAZY) {
+            lk.sc = ldg4(lz.scale + c); lk.sh = ldg4(lz.shift + c); lk.ka = ldg4(lz.ka + c); lk.kb = ldg4(lz.kb + c);
+            const int slot = lz.inv[img];
+            if (slot >= 0) gbase = lz.dyc + (long long)slot * g.H * g.W * C + c;
+        }
         float4 tmp[6][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             float4 d[6], r[6];
             const int xx = x0 + j;
             const bool xin = (unsigned)xx < (unsigned)g.W;
+            float4 gq[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {           // all loads of the column first (memory-level parallelism), arithmetic after
+                const int yy = y0 + i;
+                const bool in = xin && (unsigned)yy < (unsigned)g.H;
+                d[i] = in ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+                if (LAZY) gq[i] = (in && gbase) ? ldg4(gbase + ((long long)yy * g.W + xx) * C) : f4(0.f);
+            }
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 const int yy = y0 + i;
                 const bool in = xin && (unsigned)yy < (unsigned)g.H;
-                d[i] = in ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
-                if (scale && in) d[i] = affine_act4(d[i], sc, sh, act);
+                if (LAZY) { if (in) d[i] = lazy4(d[i], gq[i], lk, lz.act); }
+                else if (scale && in) d[i] = affine_act4(d[i], sc, sh, act);
             }
             bt6(d, r);
 #pragma unroll
@@ -208,7 +250,8 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 }
 
 // dY [N,H,W,C] -> Q [36][T][C] = A dY_tile A^T (weight gradient)
-__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Q, TileGeom g, int C)
+template <bool LAZY>
+__global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ dy, float* __restrict__ Q, TileGeom g, int C, LazyBn lz)
 {
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
@@ -220,15 +263,30 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
         const int rem = (int)(t - img * (g.TH * g.TW));
         const int ty = rem / g.TW, tx = rem - ty * g.TW;
         const float* base = dy + img * (long long)g.H * g.W * C + c;
+        LazyBnCh lk;
+        const float* gbase = nullptr;
+        if (LAZY) {
+            lk.sc = ldg4(lz.scale + c); lk.sh = ldg4(lz.shift + c); lk.ka = ldg4(lz.ka + c); lk.kb = ldg4(lz.kb + c);
+            const int slot = lz.inv[img];
+            if (slot >= 0) gbase = lz.dyc + (long long)slot * g.H * g.W * C + c;
+        }
         float4 tmp[6][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float4 d[4], r[6];
             const int xx = 4 * tx + j;
+            float4 gq[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int yy = 4 * ty + i;
-                d[i] = (xx < g.W && yy < g.H) ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+                const bool in = xx < g.W && yy < g.H;
+                d[i] = in ? ldg4(base + ((long long)yy * g.W + xx) * C) : f4(0.f);
+                if (LAZY) gq[i] = (in && gbase) ? ldg4(gbase + ((long long)yy * g.W + xx) * C) : f4(0.f);
+            }
+            if (LAZY) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (xx < g.W && 4 * ty + i < g.H) d[i] = lazy4(d[i], gq[i], lk, lz.act);
             }
             a4(d, r);
 #pragma unroll
@@ -436,7 +494,7 @@ int myolo_wino_input_transform_affine(const float* x, const float* scale, const 
     MYOLO_REQUIRE(x && V && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0, "wino_input_transform: bad arguments (C %% 4 == 0)");
     MYOLO_REQUIRE(!scale == !shift, "wino_input_transform: scale and shift go together");
     const TileGeom g = geom(N, H, W);
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, V, g, C, scale, shift, act);
+    hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, V, g, C, scale, shift, act, LazyBn{});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -516,7 +574,7 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     float* V = v_keep ? v_keep : (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 0);
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0);
+    hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cin, Cout, 36, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, Mp, y, bias, scale, shift, g, Cout, act, (double*)nullptr);
@@ -524,8 +582,10 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     return MYOLO_OK;
 }
 
-int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, void* ws,
-                                size_t ws_bytes, void* stream)
+}  // extern "C"
+
+static int wino_bwd_data_impl(const float* dy, const LazyBn* lazy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
+                              void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(dy && w && dx && N > 0 && H > 0 && W > 0, "conv3x3_wino_bwd_data: bad arguments");
     MYOLO_REQUIRE((Cout % 16) == 0 && (Cin & 3) == 0, "conv3x3_wino_bwd_data: needs Cout %% 16 == 0 and Cin %% 4 == 0 (got %d, %d)", Cout, Cin);
@@ -537,7 +597,8 @@ int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int 
     float* V = (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 1);
-    hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0);
+    if (lazy) hipLaunchKernelGGL(wino_in_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, *lazy);
+    else hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cout, Cin, 36, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, Mp, dx, (const float*)nullptr,
@@ -546,8 +607,8 @@ int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int 
     return MYOLO_OK;
 }
 
-int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout,
-                                  void* ws, size_t ws_bytes, void* stream)
+static int wino_bwd_weight_impl(const float* x, const float* v_saved, const float* dy, const LazyBn* lazy, float* dw, int N, int H, int W,
+                                int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE((x || v_saved) && dy && dw && N > 0 && H > 0 && W > 0, "conv3x3_wino_bwd_weight: bad arguments");
     MYOLO_REQUIRE((Cin & 3) == 0 && (Cout & 3) == 0, "conv3x3_wino_bwd_weight: needs Cin %% 4 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
@@ -560,13 +621,49 @@ int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const fl
     float* V = (float*)((char*)ws + ub);
     float* Q = (float*)((char*)ws + ub + vb);
     void* part = (char*)ws + ub + vb + qb;
-    if (!v_saved) hipLaunchKernelGGL(wino_in_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0);
-    hipLaunchKernelGGL(wino_dy_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout);
+    if (!v_saved) hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
+    if (lazy) hipLaunchKernelGGL(wino_dy_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout, *lazy);
+    else hipLaunchKernelGGL(wino_dy_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout, LazyBn{});
     const int rc = myolo_gemm_tn_batched(v_saved ? v_saved : V, Q, dU, g.T, Cin, Cout, 36, part, pb, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
+}
+
+extern "C" {
+
+int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout, void* ws,
+                                size_t ws_bytes, void* stream)
+{
+    return wino_bwd_data_impl(dy, nullptr, w, dx, N, H, W, Cin, Cout, ws, ws_bytes, stream);
+}
+
+int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W, int Cin, int Cout,
+                                  void* ws, size_t ws_bytes, void* stream)
+{
+    return wino_bwd_weight_impl(x, v_saved, dy, nullptr, dw, N, H, W, Cin, Cout, ws, ws_bytes, stream);
+}
+
+/* The same two gradients when dy is the gradient behind a training-mode BatchNorm + activation with a row-sparse upstream
+ * gradient (bn1 of the mask head, model.py:690): y_pre is that BN's input (= this conv's output), dy_compact / inv / ka / kb
+ * as produced by myolo_bn_bwd_rowsparse_coeffs.  dy itself is never materialised. */
+int myolo_conv3x3_wino_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
+                                       const float* shift, const float* ka, const float* kb, int act, const float* w, float* dx, int N,
+                                       int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(y_pre && inv && scale && shift && ka && kb, "conv3x3_wino_bwd_data_lazybn: bad arguments");
+    const LazyBn lz{dy_compact, inv, scale, shift, ka, kb, act};
+    return wino_bwd_data_impl(y_pre, &lz, w, dx, N, H, W, Cin, Cout, ws, ws_bytes, stream);
+}
+
+int myolo_conv3x3_wino_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv,
+                                         const float* scale, const float* shift, const float* ka, const float* kb, int act, float* dw,
+                                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(v_saved && y_pre && inv && scale && shift && ka && kb, "conv3x3_wino_bwd_weight_lazybn: bad arguments");
+    const LazyBn lz{dy_compact, inv, scale, shift, ka, kb, act};
+    return wino_bwd_weight_impl(nullptr, v_saved, y_pre, &lz, dw, N, H, W, Cin, Cout, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -155,6 +155,7 @@ class Net(object):
         self._ws_active = self._ws_main
         self._yolo_stream = torch.cuda.Stream(device=self.dev)
         self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
+        self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
         self.adam_t = 0
@@ -891,16 +892,34 @@ class Net(object):
         c1, act, _ = self.tape["myolo_mask_bn1"]
         buf = self.bnbuf["myolo_mask_bn1"]
         M1 = NR * q
-        dc1 = self._new(M1, MASK_FILTERS)
-        X.call("myolo_bn_act_bwd_rowsparse", X.ptr(da), X.ptr(c1), X.ptr(idx_d), X.ptr(inv_d), X.ptr(buf[0]), X.ptr(buf[1]),
-               X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dc1), X.ptr(self.g["myolo_mask_bn1/gamma"]), X.ptr(self.g["myolo_mask_bn1/beta"]),
-               M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
         x0 = convs[0]
         cin = x0.shape[1]
-        self.conv3x3_bwd_weight(x0, self.tape.pop("conv1_V", None), dc1, "myolo_mask_conv1", NR, ps, ps, cin, MASK_FILTERS)
-        self.colsum(dc1, self.g["myolo_mask_conv1/bias"])
+        v1 = self.tape.pop("conv1_V", None)
         dp0 = self._new(M1, cin)
-        self.conv3x3_bwd_data(dc1, "myolo_mask_conv1", dp0, NR, ps, ps, cin, MASK_FILTERS)
+        if self.lazy_bn1_bwd and v1 is not None and self._wino_ok(NR, ps, ps, MASK_FILTERS, cin):
+            # dc1 = d loss / d conv1-output is dense (batch statistics spread the gradient over every ROI) but it is an affine
+            # function of conv1's output outside the positive ROIs: conv1's two gradients form it while loading that output
+            # (Winograd transforms with a lazy operand) and it is never written.  Its column sums -- conv1's bias gradient --
+            # cancel exactly through the batch statistics (sum dz - M*(sum dz)/M + 0), so that gradient is set to 0.
+            kab = self._new(2, MASK_FILTERS)
+            X.call("myolo_bn_bwd_rowsparse_coeffs", X.ptr(da), X.ptr(c1), X.ptr(idx_d), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
+                   X.ptr(buf[3]), X.ptr(self.g["myolo_mask_bn1/gamma"]), X.ptr(self.g["myolo_mask_bn1/beta"]), X.ptr(kab[0]),
+                   X.ptr(kab[1]), M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
+            lazy = (X.ptr(c1), X.ptr(da), X.ptr(inv_d), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(kab[0]), X.ptr(kab[1]), act)
+            self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)))
+            X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
+                   MASK_FILTERS, *self._wsargs(), X.stream())
+            self.g["myolo_mask_conv1/bias"].zero_()
+            X.call("myolo_conv3x3_wino_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, ps, ps, cin,
+                   MASK_FILTERS, *self._wsargs(), X.stream())
+        else:
+            dc1 = self._new(M1, MASK_FILTERS)
+            X.call("myolo_bn_act_bwd_rowsparse", X.ptr(da), X.ptr(c1), X.ptr(idx_d), X.ptr(inv_d), X.ptr(buf[0]), X.ptr(buf[1]),
+                   X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dc1), X.ptr(self.g["myolo_mask_bn1/gamma"]), X.ptr(self.g["myolo_mask_bn1/beta"]),
+                   M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
+            self.conv3x3_bwd_weight(x0, v1, dc1, "myolo_mask_conv1", NR, ps, ps, cin, MASK_FILTERS)
+            self.colsum(dc1, self.g["myolo_mask_conv1/bias"])
+            self.conv3x3_bwd_data(dc1, "myolo_mask_conv1", dp0, NR, ps, ps, cin, MASK_FILTERS)
         dF = self._new(n * h * w, cf)
         X.call("myolo_roialign_bwd_grouped", X.ptr(dp0), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
         if self.on_bucket_ready:

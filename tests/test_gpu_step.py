@@ -258,6 +258,29 @@ def test_positives_only_forward_without_positives():
         assert np.abs(s1[k] - s0[k]).max() <= 1e-5 * max(1.0, np.abs(s0[k]).max()), k
 
 
+def test_lazy_bn1_backward_equals_materialised():
+    """Net.lazy_bn1_bwd: conv1's weight / data gradients formed from bn1's input gradient on load (never written) equal the
+    path that materialises it, to fp32 rounding (same formula, evaluated inside another kernel); conv1's bias gradient is the
+    analytic 0 instead of rounding noise."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    grads = []
+    for lazy in (False, True):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        model.net.lazy_bn1_bwd = lazy
+        model.train_on_batch(batch, learning_rate=0.0)
+        grads.append(model.net.grads_dict())
+    assert np.abs(grads[1]["myolo_mask_conv1/bias"]).max() == 0.0
+    scale = max(np.abs(grads[0]["myolo_mask_conv1/kernel"]).max(), 1e-12)
+    assert np.abs(grads[0]["myolo_mask_conv1/bias"]).max() < 1e-3 * scale * 256 * 9, "the materialised bias gradient should be noise"
+    worst = 0.0
+    for k in grads[0]:
+        if np.abs(grads[0][k]).max() < 1e-12 or k == "myolo_mask_conv1/bias":
+            continue
+        worst = max(worst, rel(grads[1][k], grads[0][k]))
+    assert worst < 2e-5, worst
+
+
 def test_no_positive_rois_gives_zero_mask_loss_and_grads():
     """empty-GT batch: every ROI negative, mask loss 0 (model.py:750-752), mask-head gradients 0."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
