@@ -206,6 +206,10 @@ def main():
             kbytes = 2.0 * M * 256 * 4 + 9 * 256 * 256 * 4
         achieved = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         roi_bytes = args.batch * R * ps * ps * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
+        roi_kernel = "crop_fwd_kernel (ROIAlign fwd)"
+        if wino:          # ROIAlign is fused into conv1's input transform: it writes V (36 planes of tiles) instead of the crops
+            roi_bytes = 36.0 * args.batch * R * ((ps + 3) // 4) ** 2 * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
+            roi_kernel = "wino_in_crop_kernel (ROIAlign fused into conv1's Winograd input transform: feature map -> V)"
         traffic = None      # HBM-side bytes per launch of the dominant kernel, from the separate --pmc passes (tools/collect_profiles.sh)
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_wino_multiply.json" if wino else "r1_pmc_conv3x3_fwd.json")))
@@ -235,20 +239,20 @@ def main():
                          "conv_op": {"algo": "winograd_f4x4_3x3" if wino else "direct", "avg_ms": conv_ms, "ops_timed": conv_n,
                                      "direct_conv_flop": flop,
                                      "direct_equivalent_tflops": flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0},
-                         "secondary": {"kernel": "crop_fwd_kernel (ROIAlign fwd)", "bound": "hbm",
+                         "secondary": {"kernel": roi_kernel, "bound": "hbm", "algorithmic_bytes": roi_bytes,
                                        "achieved": roi_bytes / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
                                        "peak": 8000.0, "unit": "GB/s",
                                        "frac": (roi_bytes / (roi_ms * 1e-3) / 1e9 / 8000.0) if roi_ms > 0 else 0.0,
                                        "avg_launch_ms": roi_ms}},
         }
-        if wino and win_n and woi_n:
+        if wino and woi_n:
             # the HBM-bound stages of the Winograd op (18 % of the step), against 8 TB/s: algorithmic bytes / measured time
             vbytes = 36.0 * tiles_w * 256 * 4
             xbytes = float(M) * 256 * 4
-            res["roofline"]["hbm_stages"] = [
-                {"kernel": "wino_in_kernel (conv1 input transform: ROIAlign output -> V)", "bound": "hbm", "algorithmic_bytes": xbytes + vbytes,
+            res["roofline"]["hbm_stages"] = ([
+                {"kernel": "wino_in_kernel (input transform: activation -> V)", "bound": "hbm", "algorithmic_bytes": xbytes + vbytes,
                  "avg_launch_ms": win_ms, "achieved": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                 "frac": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9 / 8000.0},
+                 "frac": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9 / 8000.0}] if win_n else []) + [
                 {"kernel": "wino_out_in_kernel (layer boundary M_i -> V_{i+1} through LDS)", "bound": "hbm", "algorithmic_bytes": 2 * vbytes,
                  "avg_launch_ms": woi_ms, "achieved": 2 * vbytes / (woi_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
                  "frac": 2 * vbytes / (woi_ms * 1e-3) / 1e9 / 8000.0}]

@@ -225,6 +225,10 @@ int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, in
 int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
 int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
                                 int N, int H, int W, int C, int act, void* stream);
+/* ROIAlign (myolo_crop_and_resize_fwd: same boxes / box_ind / sampling) fused into the input transform of the conv that
+ * consumes the crops: V [36][nb*ceil(crop_h/4)*ceil(crop_w/4)][C] directly from the feature map [B,FH,FW,C] */
+int myolo_wino_input_transform_roialign(const float* feature, const float* boxes, const int32_t* box_ind, float* V, int B, int FH, int FW,
+                                        int C, int nb, int crop_h, int crop_w, void* stream);
 /* input transform with the producing layer's BatchNorm apply + activation folded into the load (scale/shift per channel) */
 int myolo_wino_input_transform_affine(const float* x, const float* scale, const float* shift, int act, float* V, int N, int H, int W,
                                       int C, void* stream);

@@ -173,6 +173,92 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
     }
 }
 
+// ROIAlign (tf.image.crop_and_resize, model.py:385-387) fused into the input transform of the conv that consumes it: the
+// [boxes, crop, crop, C] tensor is never written.  One lane = 4 channels of one 4x4 output tile of one box; it forms the 6
+// row and 6 column sample coordinates of its patch once (same float expressions as crop_fwd_kernel), bilinearly samples the
+// 36 patch positions from the feature map (L2-resident: a few MB per image) and transforms them.
+struct CropAxis { int lo, hi; float w; bool ok; };
+__device__ __forceinline__ CropAxis crop_axis(float b0, float b1, int size, int crop, int idx)
+{
+    CropAxis a;
+    a.ok = (unsigned)idx < (unsigned)crop;          // outside the crop = the conv's zero padding
+    float in;
+    if (crop > 1) {
+        const float scale = (b1 - b0) * (float)(size - 1) / (float)(crop - 1);
+        in = b0 * (float)(size - 1) + (float)idx * scale;
+    } else {
+        in = 0.5f * (b0 + b1) * (float)(size - 1);
+    }
+    if (in < 0.f || in > (float)(size - 1)) a.ok = false;      // extrapolation value 0
+    a.lo = (int)floorf(in); a.hi = (int)ceilf(in); a.w = in - (float)a.lo;
+    if (!a.ok) { a.lo = 0; a.hi = 0; a.w = 0.f; }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void wino_in_crop_kernel(const float* __restrict__ feat, const float* __restrict__ boxes,
+                                                           const int32_t* __restrict__ bind, float* __restrict__ V, TileGeom g, int C,
+                                                           int FH, int FW)
+{
+    const int c4n = C >> 2;
+    const long long total = g.T * c4n;
+    const long long plane = g.T * (long long)C;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const long long t = idx / c4n;
+        const int c = (int)(idx - t * c4n) * 4;
+        const long long roi = t / (g.TH * g.TW);
+        const int rem = (int)(t - roi * (g.TH * g.TW));
+        const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        const float4 bx = ldg4(boxes + roi * 4);               // y1, x1, y2, x2
+        const float* base = feat + (long long)bind[roi] * FH * FW * C + c;
+        CropAxis ay[6], ax[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            ay[i] = crop_axis(bx.x, bx.z, FH, g.H, 4 * ty - 1 + i);
+            ax[i] = crop_axis(bx.y, bx.w, FW, g.W, 4 * tx - 1 + i);
+        }
+        float4 tmp[6][6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            float4 d[6], r[6];
+#pragma unroll
+            for (int h3 = 0; h3 < 6; h3 += 3) {     // 3 rows x 4 corners in flight at a time (register budget)
+                float4 tl[3], tr[3], bl[3], br[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {       // padding / extrapolated positions read pixel (0,0) and are zeroed below
+                    const int i = h3 + k;
+                    tl[k] = ldg4(base + ((long long)ay[i].lo * FW + ax[j].lo) * C);
+                    tr[k] = ldg4(base + ((long long)ay[i].lo * FW + ax[j].hi) * C);
+                    bl[k] = ldg4(base + ((long long)ay[i].hi * FW + ax[j].lo) * C);
+                    br[k] = ldg4(base + ((long long)ay[i].hi * FW + ax[j].hi) * C);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int i = h3 + k;
+                    const float wx = ax[j].w, wy = ay[i].w;
+                    float4 o;
+                    float top, bot;
+                    top = tl[k].x + (tr[k].x - tl[k].x) * wx; bot = bl[k].x + (br[k].x - bl[k].x) * wx; o.x = top + (bot - top) * wy;
+                    top = tl[k].y + (tr[k].y - tl[k].y) * wx; bot = bl[k].y + (br[k].y - bl[k].y) * wx; o.y = top + (bot - top) * wy;
+                    top = tl[k].z + (tr[k].z - tl[k].z) * wx; bot = bl[k].z + (br[k].z - bl[k].z) * wx; o.z = top + (bot - top) * wy;
+                    top = tl[k].w + (tr[k].w - tl[k].w) * wx; bot = bl[k].w + (br[k].w - bl[k].w) * wx; o.w = top + (bot - top) * wy;
+                    d[i] = (ay[i].ok && ax[j].ok) ? o : f4(0.f);
+                }
+            }
+            bt6(d, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
+        }
+        float* out = V + t * C + c;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            float4 r[6];
+            bt6(tmp[i], r);
+#pragma unroll
+            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+        }
+    }
+}
+
 // M [36][T][C] -> Y [N,H,W,C], + bias, optional per-channel affine (folded frozen BN), activation.
 // stats != NULL (training-mode BatchNorm behind this conv): every workgroup also leaves the per-channel sum and sum of
 // squares of the values it wrote in stats[blockIdx.x][2*C] (double); needs (gridDim.x * 256) % (C/4) == 0 so that a thread
@@ -495,6 +581,18 @@ int myolo_wino_input_transform_affine(const float* x, const float* scale, const 
     MYOLO_REQUIRE(!scale == !shift, "wino_input_transform: scale and shift go together");
     const TileGeom g = geom(N, H, W);
     hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, V, g, C, scale, shift, act, LazyBn{});
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino_input_transform_roialign(const float* feature, const float* boxes, const int32_t* box_ind, float* V, int B, int FH, int FW,
+                                        int C, int nb, int crop_h, int crop_w, void* stream)
+{
+    MYOLO_REQUIRE(feature && boxes && box_ind && V && B > 0 && FH > 0 && FW > 0 && nb > 0 && crop_h > 0 && crop_w > 0 && C > 0 && (C & 3) == 0,
+                  "wino_input_transform_roialign: bad arguments (C %% 4 == 0)");
+    const TileGeom g = geom(nb, crop_h, crop_w);
+    hipLaunchKernelGGL(wino_in_crop_kernel, dim3(ew_grid(g.T * (C / 4))), dim3(256), 0, (hipStream_t)stream, feature, boxes, box_ind, V, g,
+                       C, FH, FW);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

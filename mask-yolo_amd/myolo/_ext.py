@@ -63,6 +63,7 @@ SIGS = {
     "myolo_bn_bwd_rowsparse_coeffs": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_data_lazybn": [P, P, P, P, P, P, P, I, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight_lazybn": [P, P, P, P, P, P, P, P, I, P, I, I, I, I, I, P, Z, P],
+    "myolo_wino_input_transform_roialign": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_pack_weights_bf16": [P, I, I, I, P, P, P, P, P, P, P, P],
     "myolo_crop_and_resize_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_conv3x3_bf16_fwd": [P, P, P, P, I, I, I, I, I, I, P],

@@ -501,9 +501,6 @@ class Net(object):
             boxes = rois.reshape(B * R, 4)[:, [1, 0, 3, 2]].contiguous()
         bind = self._box_image_index(B, R)
         NR = B * R
-        x = self._new(NR * ps * ps, cf)
-        self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
-                         n, h, w, cf, NR, ps, ps, X.stream())
         self.tape["roi"] = (boxes, bind, fshape, NR)
         cin = cf
         convs = []
@@ -516,8 +513,12 @@ class Net(object):
                  and MASK_FILTERS % 32 == 0 and ((ps + 3) // 4) ** 2 <= 32 and q * 128 <= 65536
                  and (not train or pos_flags is not None))
         if chain:
-            x = self._mask_convs_winograd_chain(x, convs, NR, ps, cf, train, pos_flags)
+            # ROIAlign is fused into conv1's input transform: the [NR,14,14,256] crops are never written
+            x = self._mask_convs_winograd_chain(None, convs, NR, ps, cf, train, pos_flags, roi=(Fm, boxes, bind, n, h, w))
         else:
+            x = self._new(NR * ps * ps, cf)
+            self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
+                             n, h, w, cf, NR, ps, ps, X.stream())
             x = self._mask_convs_layerwise(x, convs, NR, ps, cf, train, fuse)
         C = cfg.NUM_CLASSES
         p = self._new(NR * 4 * ps * ps, C)
@@ -538,7 +539,7 @@ class Net(object):
         self.tape["mask"] = (convs, x, d)
         return p
 
-    def _mask_convs_winograd_chain(self, x, convs, NR, ps, cin, train, pos_flags):
+    def _mask_convs_winograd_chain(self, x, convs, NR, ps, cin, train, pos_flags, roi=None):
         """myolo_mask_conv1-4 (+bn, ReLU) as a chain of Winograd stages; appends each conv's input to `convs` (an input the
         forward never materialised is recorded as ("lazy_bn", pre-BN tensor, bn layer)).  Returns conv4's activation."""
         q = ps * ps
@@ -552,7 +553,12 @@ class Net(object):
             start()
             if Vcur is None:
                 Vcur = self._new(36, T, cin)
-                self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
+                if x is None:                         # conv1: crops sampled from the feature map on the fly (roi)
+                    Fm, boxes, bind, fn, fh, fw = roi
+                    self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind),
+                                     X.ptr(Vcur), fn, fh, fw, cin, NR, ps, ps, X.stream())
+                else:
+                    self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
             U, M = self._new(36, cin, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
             X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
             self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, ps, ps, cin, MASK_FILTERS,
@@ -762,19 +768,18 @@ class Net(object):
             boxes = rois.reshape(B * R, 4)[:, [1, 0, 3, 2]].contiguous()
         bind = self._box_image_index(B, R)
         NR = B * R
-        x = self._new(NR * q, cf)
-        self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
-                         n, h, w, cf, NR, ps, ps, X.stream())
         self.tape["roi"] = (boxes, bind, fshape, NR)
         y1 = self._new(NR * q, MASK_FILTERS)
         bn = "myolo_mask_bn1"
         buf = self.bnbuf[bn]
+        x = None
         if self._wino_ok(NR, ps, ps, cf, MASK_FILTERS) and 256 % (MASK_FILTERS // 4) == 0:
             T = NR * ((ps + 3) // 4) ** 2
             start, stop = self._timed("mask_conv3x3_fwd")
             start()
             V, U, M = self._new(36, T, cf), self._new(36, cf, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
-            X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V), NR, ps, ps, cf, X.stream())
+            self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(V),
+                             n, h, w, cf, NR, ps, ps, X.stream())        # ROIAlign fused into the input transform
             X.call("myolo_wino_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, 0, X.stream())
             self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, ps, ps, cf, MASK_FILTERS, X.stream())
             self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
@@ -785,6 +790,9 @@ class Net(object):
             stop()
             self.tape["conv1_V"] = V
         else:
+            x = self._new(NR * q, cf)
+            self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
+                             n, h, w, cf, NR, ps, ps, X.stream())
             v = self.conv3x3_fwd(x, "myolo_mask_conv1", y1, NR, ps, ps, cf, MASK_FILTERS, keep_v=True, tag="mask_conv3x3_fwd")
             if v is not None:
                 self.tape["conv1_V"] = v
@@ -892,8 +900,8 @@ class Net(object):
         c1, act, _ = self.tape["myolo_mask_bn1"]
         buf = self.bnbuf["myolo_mask_bn1"]
         M1 = NR * q
-        x0 = convs[0]
-        cin = x0.shape[1]
+        x0 = convs[0]                           # None when ROIAlign was fused into conv1's input transform (V is kept instead)
+        cin = cf
         v1 = self.tape.pop("conv1_V", None)
         dp0 = self._new(M1, cin)
         if self.lazy_bn1_bwd and v1 is not None and self._wino_ok(NR, ps, ps, MASK_FILTERS, cin):

@@ -170,6 +170,23 @@ def test_winograd_transforms_with_folded_batchnorm(N, H, W, C):
     assert float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())
 
 
+@pytest.mark.parametrize("B,H,W,C,nb,crop", [(2, 28, 28, 256, 40, 14), (3, 7, 9, 16, 11, 5), (1, 16, 16, 64, 6, 8)])
+def test_winograd_input_transform_fused_with_roialign(B, H, W, C, nb, crop):
+    """V straight from the feature map == crop_and_resize followed by the input transform (same sampling expressions)."""
+    rng = np.random.default_rng(7)
+    img = rnd(rng, B, H, W, C)
+    boxes = _boxes(rng, nb)
+    boxes[0] = [-0.2, 0.1, 0.7, 1.3]                          # extrapolated samples (value 0) on two sides
+    bind = rng.integers(0, B, nb).astype(np.int32)
+    T = nb * ((crop + 3) // 4) ** 2
+    x, V1, V2 = new(nb, crop, crop, C), new(36, T, C), new(36, T, C)
+    a = (X.ptr(dt(img)), X.ptr(dt(boxes)), X.ptr(dt(bind)))
+    X.call("myolo_crop_and_resize_fwd", *a, X.ptr(x), B, H, W, C, nb, crop, crop, X.stream())
+    X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V1), nb, crop, crop, C, X.stream())
+    X.call("myolo_wino_input_transform_roialign", *a, X.ptr(V2), B, H, W, C, nb, crop, crop, X.stream())
+    assert float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())      # fma contraction differs between the two kernels
+
+
 def test_winograd_error_is_at_fp32_level():
     """The Winograd form is the same fp32 arithmetic with the sums associated differently; its error against a float64
     convolution must stay at fp32 rounding level (a reduced-precision product would sit at 1e-3), recorded here against
