@@ -41,6 +41,15 @@ def shard_range(global_batch, rank, world):
     return rank * per, (rank + 1) * per
 
 
+def dp_batch_indices(n_samples, batch, rank, world, n_batches=None):
+    """Batch indices rank `rank` trains on in one epoch: only FULL batches, the same count on every rank (a rank that skipped
+    a step would leave the others waiting in the all-reduce), rank r taking batches r, r+world, r+2*world, ..."""
+    n_full = n_samples // batch
+    if n_batches is not None:
+        n_full = min(n_full, n_batches)
+    return list(range(rank, n_full - (n_full % world), world))
+
+
 class GradReducer(object):
     """Bucketed, overlapped sum all-reduce of a flat gradient buffer.
 

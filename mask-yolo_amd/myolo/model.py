@@ -169,6 +169,19 @@ class MaskYOLO(object):
                    recall=float(yt[5]))
         return res
 
+    def _data_parallel(self):
+        """(rank, world): when torch.distributed is initialised with more than one rank (myolo.dist.init_from_env under
+        torchrun), hook the bucketed gradient all-reduce into the engine once and shard the work by rank -- every rank holds
+        the same seeded weights, trains on its own BATCH_SIZE images per step (global batch = world * BATCH_SIZE) and applies
+        the same averaged update.  Single process: (0, 1), nothing attached."""
+        import torch.distributed as tdist
+        if not (tdist.is_available() and tdist.is_initialized()) or tdist.get_world_size() == 1:
+            return 0, 1
+        if getattr(self, "_reducer", None) is None:
+            from .dist import GradReducer
+            self._reducer = GradReducer(self.net.flat_g, self.net.bucket_ranges).attach(self.net)
+        return tdist.get_rank(), tdist.get_world_size()
+
     def train(self, train_dataset, val_dataset, learning_rate, epochs, layers,
               augmentation=None, custom_callbacks=None, no_augmentation_sources=None, max_samples=None, verbose=1):
         """model.py:943-1060.  Returns the list of per-epoch mean training losses."""
@@ -190,10 +203,12 @@ class MaskYOLO(object):
         val_gen = mutils.BatchGenerator(val_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True) if val_info else None
         self.set_trainable(layers)
         self.compile(learning_rate, cfg.LEARNING_MOMENTUM)
+        rank, world = self._data_parallel()          # the generators must be seeded alike on every rank (same shuffle)
         history = []
         for ep in range(epochs):
             losses = []
-            for i in range(len(train_gen)):
+            from .dist import dp_batch_indices
+            for i in dp_batch_indices(len(train_info), cfg.BATCH_SIZE, rank, world, len(train_gen)):
                 inputs, _ = train_gen[i]
                 if len(inputs[0]) != cfg.BATCH_SIZE:
                     continue
@@ -203,7 +218,7 @@ class MaskYOLO(object):
                     print("epoch %d step %d/%d loss %.4f (yolo %.4f mask %.4f recall %.3f)" %
                           (ep + 1, i + 1, len(train_gen), out["loss"], out["yolo_sum_loss"], out["mask_loss"], out["recall"]))
             history.append(float(np.mean(losses)) if losses else float("nan"))
-            if self.model_dir:
+            if self.model_dir and rank == 0:
                 os.makedirs(self.model_dir, exist_ok=True)
                 stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
                 self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
@@ -221,9 +236,10 @@ class MaskYOLO(object):
         prod = ShapesProducer(cfg, seed=seed, device=self._device)
         self.set_trainable(".*")
         self.compile(cfg.LEARNING_RATE if learning_rate is None else learning_rate, cfg.LEARNING_MOMENTUM)
+        rank, world = self._data_parallel()          # rank r takes images [r*B, (r+1)*B) of each global batch of world*B
         losses = []
         for i in range(steps):
-            lo = start_index + i * cfg.BATCH_SIZE
+            lo = start_index + (i * world + rank) * cfg.BATCH_SIZE
             out = self.train_on_batch(prod.batch(list(range(lo, lo + cfg.BATCH_SIZE))))
             losses.append(out["loss"])
             if verbose:

@@ -10,7 +10,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from myolo.dist import GradReducer, shard_range
+from myolo.dist import GradReducer, shard_range, dp_batch_indices
 
 
 def _free_port():
@@ -98,3 +98,15 @@ def test_engine_bucket_ranges_cover_flat_buffer_contiguously():
     total = sum(sizes.values())
     assert 7296031 <= total < 7296031 + 4 * 200                        # SURVEY.md Appendix B count + alignment padding
     assert sizes[2] > sizes[0]                                          # mask head is the largest bucket but the backbone
+
+
+@pytest.mark.parametrize("n,batch,world", [(50, 8, 2), (64, 8, 8), (500, 32, 4), (7, 8, 2), (100, 8, 3)])
+def test_dp_batch_schedule_is_uniform_and_disjoint(n, batch, world):
+    """MaskYOLO.train under torchrun: every rank runs the same number of steps (no rank left waiting in the all-reduce),
+    on disjoint full batches."""
+    per_rank = [dp_batch_indices(n, batch, r, world) for r in range(world)]
+    assert len({len(p) for p in per_rank}) == 1
+    flat = sorted(i for p in per_rank for i in p)
+    assert flat == list(range(len(flat))) and len(flat) == (n // batch) - (n // batch) % world
+    assert all(i < n // batch for i in flat)
+    assert dp_batch_indices(n, batch, 0, 1) == list(range(n // batch))
