@@ -432,6 +432,209 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds(Bf16Args p)
     }
 }
 
+// ---- 256 x 256 x 64 tiles, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA blocks), same LDS-DMA fill and swizzle ----
+// One workgroup per CU (128 KB of LDS for the two buffers): per k step a wave reads 6 fragments for 8 MFMAs (0.75 per
+// MFMA against 1.0 in the 128^2 kernel) and the A tile is fetched once for all 256 output channels.  Used for the big
+// launches only (>= 6 rounds of 256 workgroups); the 128^2 kernel keeps the small ones and the 2-per-CU granularity.
+// EPI PLAIN (each wave transposes its own 128 x 64 block through a private LDS region) and EPI DECONV_MASK.
+#define T2M 256
+#define T2N 256
+#define W2_ROW 136           // bytes per row of a wave's private 128 x 64 bf16 staging block (128 + 8)
+
+template <int AMODE, int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[8 * 128 * W2_ROW > 2 * 2 * T2M * 128 ? 8 * 128 * W2_ROW : 2 * 2 * T2M * 128];
+    unsigned char (*buf)[2][T2M * 128] = reinterpret_cast<unsigned char (*)[2][T2M * 128]>(lds);      // [buffer][A|B][row*128 + chunk*16]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = (p.N + T2N - 1) / T2N;
+    long long bid;
+    {
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tn = (int)(bid % ntn);
+    const long long m0 = (bid / ntn) * T2M;
+    const int n0 = tn * T2N;
+    const long long hw = (long long)p.H * p.W;
+
+    long long base_row, end_row, row_elems;
+    if (AMODE == AM_PLAIN) { base_row = m0; end_row = (m0 + T2M < p.M) ? m0 + T2M : p.M; row_elems = p.K; }
+    else {
+        base_row = m0 - (p.W + 1); if (base_row < 0) base_row = 0;
+        end_row = m0 + T2M + p.W + 1; if (end_row > p.M) end_row = p.M;
+        row_elems = p.Cc;
+    }
+    const __amdgpu_buffer_rsrc_t ra = mk_rsrc(p.A + base_row * row_elems, (end_row - base_row) * row_elems * 2);
+    const __amdgpu_buffer_rsrc_t rb = mk_rsrc(p.Wt, (long long)p.N * p.K * 2);
+
+    unsigned arow[4], brow[4], amask[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = wave * 32 + j * 8 + (lane >> 3);
+        const unsigned chunk = (unsigned)((lane & 7) ^ ((lrow >> 1) & 7));
+        const long long am = m0 + lrow;
+        const bool av = am < p.M;
+        const long long amc = av ? am : m0;
+        arow[j] = (unsigned)((amc - base_row) * row_elems) * 2u + chunk * 16u;
+        amask[j] = av ? 0x1ffu : 0u;
+        if (AMODE == AM_CONV3 && av) {
+            const int rem = (int)(am - (am / hw) * hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ty = t / 3, tx = t - ty * 3;
+                if ((unsigned)(y + ty - 1) < (unsigned)p.H && (unsigned)(x + tx - 1) < (unsigned)p.W) mk |= 1u << t;
+            }
+            amask[j] = mk;
+        }
+        const int bn = n0 + lrow;
+        brow[j] = bn < p.N ? (unsigned)((long long)bn * p.K) * 2u + chunk * 16u : OOB_OFF;
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nk = p.K / TBK;
+    int tap = 0, c0 = 0;
+    auto fill = [&](int kt, int b) {
+        unsigned ashift, abit;
+        if (AMODE == AM_PLAIN) { ashift = (unsigned)(kt * TBK) * 2u; abit = 0; }
+        else {
+            const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
+            ashift = (unsigned)((((ty - 1) * p.W + (tx - 1)) * p.Cc + c0) * 2);
+            abit = (unsigned)tap;
+            c0 += TBK;
+            if (c0 == p.Cc) { c0 = 0; ++tap; }
+        }
+        const unsigned bshift = (unsigned)(kt * TBK) * 2u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned ao = ((amask[j] >> abit) & 1u) ? arow[j] + ashift : OOB_OFF;
+            const unsigned bo = brow[j] == OOB_OFF ? OOB_OFF : brow[j] + bshift;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)&buf[b][0][(wave * 32 + j * 8) * 128], 16, (int)ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)&buf[b][1][(wave * 32 + j * 8) * 128], 16, (int)bo, 0, 0, 0);
+        }
+    };
+
+    const int half = lane >> 5, l31 = lane & 31;
+    const unsigned rsw = (unsigned)((l31 >> 1) & 7);
+    if (nk > 0) fill(0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) fill(kt + 1, cur ^ 1);
+        const unsigned char* Ab = &buf[cur][0][(wm * 128 + l31) * 128];
+        const unsigned char* Bb = &buf[cur][1][(wn * 64 + l31) * 128];
+#pragma unroll
+        for (int ks = 0; ks < TBK / 16; ++ks) {
+            const unsigned co = (((unsigned)(ks * 2 + half)) ^ rsw) * 16u;
+            bf16x8 af[4], bfr[2];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const bf16x8*>(Ab + t * 32 * 128 + co);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) bfr[u] = *reinterpret_cast<const bf16x8*>(Bb + u * 32 * 128 + co);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u], af[t], acc[t][u], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if constexpr (EPI == EP_DECONV_MASK) {
+        const int tap2 = n0 / p.Co;
+        const int cbase = n0 - tap2 * p.Co + wn * 64;
+        float ps[4][4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ps[t][c] = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int co = cbase + u * 32 + 8 * g + 4 * half + e;
+                    const float b = p.bias ? p.bias[co] : 0.f;
+                    float wv[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) wv[c] = c < p.ncls ? p.w2[co * p.ncls + c] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float v = fmaxf(acc[t][u][4 * g + e] + b, 0.f);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ps[t][c] = fmaf(v, wv[c], ps[t][c]);
+                    }
+                }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
+        if (half == 0) {
+            const int slab = ((n0 - tap2 * p.Co) / 64) + wn;          // 64-column slabs: Co/64 of them per tap
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const long long row = m0 + wm * 128 + t * 32 + l31;
+                if (row >= p.M) continue;
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap2 >> 1)) * 2 * p.W + 2 * x + (tap2 & 1);
+                float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.ncls) dst[c] = ps[t][c];
+            }
+        }
+        return;
+    }
+    // ---- EP_PLAIN: bias + activation, each wave transposes its 128 x 64 block through its own LDS region ----
+    unsigned char* Ws = lds + wave * 128 * W2_ROW;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = u * 32 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wn * 64 + nl + e;
+                    float b = 0.f;
+                    if (p.bias && n < p.N) b = p.bias[n];
+                    v[e] = acc[t][u][4 * g + e] + b;
+                    if (p.act == MYOLO_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(Ws + (t * 32 + l31) * W2_ROW + nl * 2) = pk;
+            }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {                  // 128 rows x 16 chunks of 8 B per wave / 64 lanes
+        const int idx = it * 64 + lane;
+        const int row = idx >> 4, cq = idx & 15;
+        const long long m = m0 + wm * 128 + row;
+        const int n = n0 + wn * 64 + cq * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const uint2 pk = *reinterpret_cast<const uint2*>(Ws + row * W2_ROW + cq * 8);
+        *reinterpret_cast<uint2*>(p.C + m * p.N + n) = pk;
+    }
+}
+
 // ROIAlign (crop_and_resize) with fp32 feature map in, bf16 out -- same coordinate arithmetic as crop_fwd_kernel
 __device__ __forceinline__ bool crop_coord_b(float lo, float hi, int size, int crop, int idx, float& in)
 {
@@ -553,6 +756,15 @@ static void launch_bf16(const Bf16Args& a, hipStream_t s)
     const long long tiles = cdiv64(a.M, TBM) * ((a.N + TBN - 1) / TBN);
     if (tiles <= 0) return;
     static const bool regstage = getenv("MYOLO_BF16_REGSTAGE") != nullptr;    // ablation: register-staged variant
+    if constexpr (EPI == EP_PLAIN) {
+        // read per launch (tests flip them inside one process): MYOLO_BF16_NO256 / MYOLO_BF16_FORCE256
+        const bool no256 = getenv("MYOLO_BF16_NO256") != nullptr, force256 = getenv("MYOLO_BF16_FORCE256") != nullptr;
+        const long long tiles256 = cdiv64(a.M, T2M) * ((a.N + T2N - 1) / T2N);
+        if (!no256 && !regstage && (a.N % T2N) == 0 && (tiles256 >= 1536 || force256)) {
+            hipLaunchKernelGGL((gemm_bf16_256<AMODE, EP_PLAIN>), dim3((unsigned)tiles256), dim3(512), 0, s, a);
+            return;
+        }
+    }
     if (regstage) hipLaunchKernelGGL((gemm_bf16<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_bf16_glds<AMODE, EPI>), dim3((unsigned)tiles), dim3(256), 0, s, a);
 }
@@ -598,7 +810,12 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
     a.A = x; a.Wt = wt; a.bias = bias; a.M = M; a.N = 4 * Cout; a.K = Cin; a.H = H; a.W = W; a.Co = Cout; a.act = MYOLO_ACT_RELU;
     a.w2 = w2; a.part = (float*)ws; a.ncls = ncls;
     const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
-    hipLaunchKernelGGL((gemm_bf16_glds<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+    const long long tiles256 = cdiv64(M, T2M) * (a.N / T2N);
+    const bool no256 = getenv("MYOLO_BF16_NO256") != nullptr, force256 = getenv("MYOLO_BF16_FORCE256") != nullptr;
+    if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256))       // same Cout/64 column slabs in both kernels
+        hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((gemm_bf16_glds<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
     myolo_launch_deconv_mask_finish(a.part, b2, p_out, 4 * M, ncls, nslabs, (hipStream_t)stream);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
