@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict
     const int ol = threadIdx.x & 7, bl = threadIdx.x >> 3;
     // PAIR (NV == 2): a workgroup owns 4 channels x both sums, so FIN sees (sum0, sum1) of a channel together
     const int i = FIN::PAIR ? (ol >> 2) * C + blockIdx.x * 4 + (ol & 3) : blockIdx.x * 8 + ol;
-    const bool ok = FIN::PAIR ? (blockIdx.x * 4 + (ol & 3)) < C : i < nvc;
+    const bool ok = FIN::PAIR ? ((int)blockIdx.x * 4 + (ol & 3)) < C : i < nvc;
     double s0 = 0, s1 = 0;
     if (ok) {
         int b = bl;
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict
     }
     if constexpr (FIN::PAIR != 0) {
         __syncthreads();
-        if (threadIdx.x < 4 && blockIdx.x * 4 + threadIdx.x < C) fin.pair(blockIdx.x * 4 + threadIdx.x, fin_tot[threadIdx.x], fin_tot[4 + threadIdx.x]);
+        const int fc = (int)(blockIdx.x * 4 + threadIdx.x);
+        if (threadIdx.x < 4 && fc < C) fin.pair(fc, fin_tot[threadIdx.x], fin_tot[4 + threadIdx.x]);
     }
 }
 
