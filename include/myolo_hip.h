@@ -13,7 +13,8 @@
  *     at least myolo_workspace_bytes(...) bytes (forward convolutions accept ws = NULL: they then skip
  *     the split-K path used for small problems);
  *   - asynchronous on `stream` (a hipStream_t passed as void*), no implicit synchronisation,
- *     stateless and re-entrant;
+ *     re-entrant; the only process state is the set of integer tuning switches changed by
+ *     myolo_set_option() (all 0 by default) -- nothing in the launch path reads the environment;
  *   - returns 0 on success, a negative MYOLO_E* code otherwise (myolo_last_error_string()).
  */
 #ifndef MYOLO_HIP_H
@@ -30,6 +31,7 @@ extern "C" {
 #define MYOLO_EINVAL       -1   /* bad argument (shape / alignment / null pointer)  */
 #define MYOLO_EWORKSPACE   -2   /* workspace too small                               */
 #define MYOLO_ELAUNCH      -3   /* HIP launch error                                  */
+#define MYOLO_ECOMM        -4   /* RCCL unavailable or a collective failed           */
 
 #define MYOLO_ACT_NONE   0
 #define MYOLO_ACT_RELU   1
@@ -40,6 +42,23 @@ const char* myolo_last_error_string(void);
 /* upper bound of scratch any single call below needs for a problem with `rows` rows and
  * `cols` output channels (weights-gradient split-K partials dominate). */
 size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
+
+/* Tuning / ablation switches (process-wide ints, default 0 = shipped behaviour).  Names: "no_nt", "gemm_generic",
+ * "no_splitk", "gemm_w256", "wino_nt", "wino_w256", "bf16_regstage", "bf16_no256", "bf16_force256", "crop_bwd_nolds",
+ * "wino_fused".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract. */
+int myolo_set_option(const char* name, int value);
+int myolo_get_option(const char* name, int* value);
+
+/* ---- gradient exchange of the data-parallel step (the reference has none: GPU_COUNT = 0,
+ *      config.py:47).  Thin RCCL wrappers, librccl.so resolved lazily (MYOLO_ECOMM if it cannot be loaded).
+ *      rank 0 creates the 128-byte id and ships it to the other ranks by any side channel; every rank then calls
+ *      comm_init on its own HIP device; allreduce is in place, asynchronous on `stream`. ---- */
+#define MYOLO_COMM_ID_BYTES 128
+int myolo_comm_unique_id(void* id_out_128_bytes);
+int myolo_comm_init(int rank, int nranks, const void* unique_id_128_bytes, void** comm_out);
+int myolo_comm_size(void* comm, int* nranks_out);
+int myolo_allreduce_sum_f32(float* buf, int64_t n, void* comm, void* stream);
+int myolo_comm_destroy(void* comm);
 
 /* ---- conv1: ZeroPad(1,1) + Conv2D 3x3 stride 2 valid, Cin=3, no bias -- model.py:45-50 ---- */
 int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y,

@@ -755,10 +755,9 @@ static void launch_bf16(const Bf16Args& a, hipStream_t s)
 {
     const long long tiles = cdiv64(a.M, TBM) * ((a.N + TBN - 1) / TBN);
     if (tiles <= 0) return;
-    static const bool regstage = getenv("MYOLO_BF16_REGSTAGE") != nullptr;    // ablation: register-staged variant
+    const bool regstage = g_myolo_opt.bf16_regstage != 0;    // ablation: register-staged variant (myolo_set_option)
     if constexpr (EPI == EP_PLAIN) {
-        // read per launch (tests flip them inside one process): MYOLO_BF16_NO256 / MYOLO_BF16_FORCE256
-        const bool no256 = getenv("MYOLO_BF16_NO256") != nullptr, force256 = getenv("MYOLO_BF16_FORCE256") != nullptr;
+        const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
         const long long tiles256 = cdiv64(a.M, T2M) * ((a.N + T2N - 1) / T2N);
         if (!no256 && !regstage && (a.N % T2N) == 0 && (tiles256 >= 1536 || force256)) {
             hipLaunchKernelGGL((gemm_bf16_256<AMODE, EP_PLAIN>), dim3((unsigned)tiles256), dim3(512), 0, s, a);
@@ -811,7 +810,7 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
     a.w2 = w2; a.part = (float*)ws; a.ncls = ncls;
     const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
     const long long tiles256 = cdiv64(M, T2M) * (a.N / T2N);
-    const bool no256 = getenv("MYOLO_BF16_NO256") != nullptr, force256 = getenv("MYOLO_BF16_FORCE256") != nullptr;
+    const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
     if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256))       // same Cout/64 column slabs in both kernels
         hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);
     else

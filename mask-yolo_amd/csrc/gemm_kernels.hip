@@ -16,7 +16,6 @@
 // step t+1 are issued before the MFMAs of step t and written to LDS after them.
 // A tile is stored k-major ([k][m], row length 130) so fragment reads are conflict-free b32.
 #include "myolo_common.h"
-#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -417,11 +416,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, l
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1, fb1, acc[1][1], 0, 0, 0);         \
     }
 
-// ABL (tuning only, results are wrong for ABL != 0): 1 = no global loads / LDS stores in the loop,
-// 2 = additionally no barrier, 3 = additionally no LDS fragment reads.
 // WNT = MFMA 32x32 tiles per wave along N: 2 -> 128x128 block tile (4 waves/SIMD), 4 -> 128x256 (2 waves/SIMD,
 // A fetched once for 256 output channels, 25 % fewer loads and LDS reads per MFMA).
-template <int AMODE, int EPI, int ABL = 0, int WNT = 2>
+template <int AMODE, int EPI, int WNT = 2>
 __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 {
     __shared__ float As[2][BK][LDAS];
@@ -581,18 +578,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
     int cur = 0;
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if ((ABL == 0 || ABL == 4) && more) gload();
+        if (more) gload();
         float fa[2], fb[WNT];
         fa[0] = As[cur][half * 8][arow_l]; fa[1] = As[cur][half * 8][arow_l + 32];
 #pragma unroll
         for (int u = 0; u < WNT; ++u) fb[u] = Bs[cur][half * 8][bcol_l + 32 * u];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float na[2], nb[WNT];
-            na[0] = fa[0] + 1.f; na[1] = fa[1] + 1.f;
-#pragma unroll
-            for (int u = 0; u < WNT; ++u) nb[u] = fb[u] + 1.f;
-            if (j < 7 && ABL < 3) {
+            float na[2] = {0.f, 0.f}, nb[WNT] = {};
+            if (j < 7) {
                 const int kk = half * 8 + j + 1;
                 na[0] = As[cur][kk][arow_l]; na[1] = As[cur][kk][arow_l + 32];
 #pragma unroll
@@ -603,14 +597,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 #pragma unroll
                 for (int u = 0; u < WNT; ++u)
                     acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[t], fb[u], acc[t][u], 0, 0, 0);
-            if ((ABL == 0 || ABL == 5) && j == 3 && more) sstore(cur ^ 1);   // tile t+1 lands in the other buffer mid-sequence
+            if (j == 3 && more) sstore(cur ^ 1);   // tile t+1 lands in the other buffer mid-sequence
             fa[0] = na[0]; fa[1] = na[1];
 #pragma unroll
             for (int u = 0; u < WNT; ++u) fb[u] = nb[u];
         }
-        if (ABL < 2) __syncthreads();
-        if (ABL == 0) cur ^= 1;
-        if (ABL == 4) { asm volatile("" :: "v"(ra[0].x), "v"(ra[1].x), "v"(rb[0].x), "v"(rb[NB - 1].x)); }
+        __syncthreads();
+        cur ^= 1;
     }
 
     if (p.ksplits > 1) {          // raw partial sums; bias / affine / activation / scatter happen in splitk_epilogue
@@ -1015,31 +1008,23 @@ static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, si
     const bool aligned = (a.N & 3) == 0 && (a.ldb & 3) == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
     const bool kfast = (AMODE == AM_PLAIN) ? ((a.K % BK) == 0 && (a.lda & 3) == 0) : ((a.Cc % BK) == 0);
     GemmArgs& am = const_cast<GemmArgs&>(a);
-    am.nt = ((long long)a.M * a.N * 4 > (64ll << 20)) && !getenv("MYOLO_NO_NT");
-    const char* abl = getenv("MYOLO_GEMM_ABL");        // tuning only (tools/kbench.py)
-    if (aligned && kfast && abl && AMODE == AM_CONV3 && EPI == EP_PLAIN) {
-        if (abl[0] == '1') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 1>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        else if (abl[0] == '2') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 2>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        else if (abl[0] == '3') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 3>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        else if (abl[0] == '4') hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 4>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_nn_fast<AM_CONV3, EP_PLAIN, 5>), dim3((unsigned)tiles), dim3(256), 0, s, a);
-    } else if (aligned && kfast && !getenv("MYOLO_GEMM_GENERIC")) {
+    am.nt = ((long long)a.M * a.N * 4 > (64ll << 20)) && !g_myolo_opt.no_nt;
+    if (aligned && kfast && !g_myolo_opt.gemm_generic) {
         // under-filled grid (fewer tiles than the 1024 resident-workgroup slots) and a long K loop: split K so the
         // whole chip works on it; a lone 128x128 tile with K = 2304 takes ~185 us however few tiles there are
         const int nk = a.K / BK;
         int splits = 1;
         if (sk_ws && tiles < 512 && nk >= 16 && (a.N & 3) == 0 && (EPI == EP_PLAIN ? (a.ldc & 3) == 0 : (a.Co & 3) == 0) &&
-            !getenv("MYOLO_NO_SPLITK")) {
+            !g_myolo_opt.no_splitk) {
             splits = (int)(1024 / tiles);
             if (splits > nk / 8) splits = nk / 8;
             const size_t per = (size_t)a.M * a.N * sizeof(float);
             if ((size_t)splits * per > sk_ws_bytes) splits = (int)(sk_ws_bytes / per);
             if (splits < 2) splits = 1;
         }
-        static const bool w256 = getenv("MYOLO_GEMM_W256") != nullptr;
-        if (w256 && (a.N % 256) == 0 && tiles >= 1024) {
+        if (g_myolo_opt.gemm_w256 && (a.N % 256) == 0 && tiles >= 1024) {
             const long long tiles256 = cdiv64(a.M, BM) * (a.N / 256);
-            hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI, 0, 4>), dim3((unsigned)tiles256), dim3(256), 0, s, a);
+            hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI, 4>), dim3((unsigned)tiles256), dim3(256), 0, s, a);
             return MYOLO_OK;
         }
         if (splits > 1) {
@@ -1093,7 +1078,7 @@ static int launch_tn(GemmArgs a, float* out, void* ws, size_t ws_bytes, hipStrea
     const int tiles = ((a.K + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     const bool fast = (a.N & 3) == 0 && (a.ldb & 3) == 0 && (a.K & 3) == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0 &&
                       ((AMODE == AM_PLAIN) ? (a.lda & 3) == 0 : ((a.Cc & 3) == 0 && a.W >= 8 && a.H >= 2)) &&
-                      !getenv("MYOLO_GEMM_GENERIC");
+                      !g_myolo_opt.gemm_generic;
     if (fast)
         hipLaunchKernelGGL((gemm_tn_fast<AMODE>), dim3(tiles, splits), dim3(256), 0, s, a);
     else
@@ -1119,13 +1104,12 @@ int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M,
     GemmArgs a = {};
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = K; a.ldb = N; a.ldc = N; a.act = MYOLO_ACT_NONE;
     a.sA = M * (long long)K; a.sB = (long long)K * N; a.sC = M * (long long)N; a.batch = batch;
-    a.nt = getenv("MYOLO_WINO_NT") ? 1 : 0;          // the product is read back at once by the output transform
+    a.nt = g_myolo_opt.wino_nt ? 1 : 0;          // the product is read back at once by the output transform
     const long long tiles = cdiv64(M, BM) * ((N + BN - 1) / BN);
     if (tiles <= 0 || batch <= 0) return MYOLO_OK;
-    static const bool w256 = getenv("MYOLO_WINO_W256") != nullptr;      // tuning knob: 128x256 tiles (A read once)
-    if (w256 && (N % 256) == 0) {
+    if (g_myolo_opt.wino_w256 && (N % 256) == 0) {      // tuning knob: 128x256 tiles (A read once)
         const long long tiles256 = cdiv64(M, BM) * (N / 256);
-        hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN, 0, 4>), dim3((unsigned)tiles256, 1, batch), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN, 4>), dim3((unsigned)tiles256, 1, batch), dim3(256), 0, s, a);
         return MYOLO_OK;
     }
     hipLaunchKernelGGL((gemm_nn_fast<AM_PLAIN, EP_PLAIN>), dim3((unsigned)tiles, 1, batch), dim3(256), 0, s, a);

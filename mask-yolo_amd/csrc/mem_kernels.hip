@@ -25,7 +25,40 @@ extern "C" void myolo_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* myolo_last_error_string(void) { return g_err; }
-extern "C" int myolo_version(void) { return 100; }
+extern "C" int myolo_version(void) { return 200; }
+
+// ---------------------------------------------------------------------------------------
+// tuning switches (myolo_set_option): plain process-wide ints, no environment reads anywhere
+// ---------------------------------------------------------------------------------------
+MyoloOptions g_myolo_opt = {};
+static int* option_slot(const char* name)
+{
+    static const struct { const char* n; int MyoloOptions::*m; } tab[] = {
+        {"no_nt", &MyoloOptions::no_nt}, {"gemm_generic", &MyoloOptions::gemm_generic}, {"no_splitk", &MyoloOptions::no_splitk},
+        {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
+        {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256},
+        {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
+        {"wino_fused", &MyoloOptions::wino_fused},
+    };
+    if (!name) return nullptr;
+    for (const auto& e : tab)
+        if (strcmp(e.n, name) == 0) return &(g_myolo_opt.*(e.m));
+    return nullptr;
+}
+extern "C" int myolo_set_option(const char* name, int value)
+{
+    int* s = option_slot(name);
+    MYOLO_REQUIRE(s, "set_option: unknown option '%s'", name ? name : "(null)");
+    *s = value;
+    return MYOLO_OK;
+}
+extern "C" int myolo_get_option(const char* name, int* value)
+{
+    int* s = option_slot(name);
+    MYOLO_REQUIRE(s && value, "get_option: unknown option '%s'", name ? name : "(null)");
+    *value = *s;
+    return MYOLO_OK;
+}
 
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -1380,7 +1413,7 @@ int myolo_roialign_bwd_grouped(const float* dout, const float* boxes, float* dim
 {
     MYOLO_REQUIRE(dout && boxes && dimage && B > 0 && R > 0 && (C & 3) == 0, "roialign_bwd_grouped: bad arguments");
     const long long total = (long long)B * H * W * (C / 4);
-    if (C == 256 && ((long long)H * W) % 4 == 0 && R <= 1536 && !getenv("MYOLO_CROP_BWD_NOLDS")) {
+    if (C == 256 && ((long long)H * W) % 4 == 0 && R <= 1536 && !g_myolo_opt.crop_bwd_nolds) {
         hipLaunchKernelGGL(crop_bwd_grouped_lds_kernel, dim3((unsigned)(total / 256)), dim3(256), (size_t)R * 8 * sizeof(float),
                            (hipStream_t)stream, dout, boxes, dimage, H, W, R, crop_h, crop_w);
         MYOLO_CHECK_LAUNCH();

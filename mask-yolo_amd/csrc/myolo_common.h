@@ -7,6 +7,23 @@
 
 extern "C" void myolo_set_error(const char* fmt, ...);
 
+// Process-wide tuning switches, changed ONLY through myolo_set_option() (include/myolo_hip.h): the launch path reads
+// plain ints, never the environment.  All default to 0 = the shipped behaviour.
+struct MyoloOptions {
+    int no_nt;            // gemm: never use streaming (non-temporal) stores for large outputs
+    int gemm_generic;     // gemm: force the generic (guarded) kernels
+    int no_splitk;        // gemm: never split K for under-filled grids
+    int gemm_w256;        // gemm: 128x256 block tiles for big launches
+    int wino_nt;          // winograd multiply: streaming stores of the product
+    int wino_w256;        // winograd multiply: 128x256 block tiles
+    int bf16_regstage;    // bf16 gemm: register-staged variant instead of LDS-DMA
+    int bf16_no256;       // bf16 gemm: never the 256x256-tile kernel
+    int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
+    int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS
+    int wino_fused;       // 3x3 conv: fused Winograd kernel (transforms in LDS / registers), 1 = on where supported
+};
+extern MyoloOptions g_myolo_opt;
+
 #define MYOLO_REQUIRE(cond, ...)                                   \
     do {                                                           \
         if (!(cond)) {                                             \

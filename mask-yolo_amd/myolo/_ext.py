@@ -75,6 +75,13 @@ SIGS = {
     "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],
+    "myolo_set_option": [ctypes.c_char_p, I],
+    "myolo_get_option": [ctypes.c_char_p, P],
+    "myolo_comm_unique_id": [P],
+    "myolo_comm_init": [I, I, P, P],
+    "myolo_comm_size": [P, P],
+    "myolo_allreduce_sum_f32": [P, L, P, P],
+    "myolo_comm_destroy": [P],
 }
 
 
@@ -127,6 +134,31 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.myolo_last_error_string().decode()))
+
+
+def set_option(name, value):
+    """process-wide tuning switch of the library (include/myolo_hip.h: myolo_set_option); returns the previous value."""
+    lib = load()
+    old = ctypes.c_int(0)
+    if lib.myolo_get_option(name.encode(), ctypes.byref(old)) != 0:
+        raise RuntimeError("myolo_get_option failed: %s" % lib.myolo_last_error_string().decode())
+    call("myolo_set_option", name.encode(), int(value))
+    return old.value
+
+
+class option(object):
+    """with X.option("bf16_force256", 1): ...   (restores the previous value on exit)"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def workspace_bytes(rows, cin, cout):

@@ -108,10 +108,9 @@ def test_conv3x3_bf16(N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 64, 256), (7, 14, 14, 256, 256), (2, 7, 9, 128, 512)])
-def test_conv3x3_bf16_256_tile_kernel(N, H, W, Cin, Cout, monkeypatch):
+def test_conv3x3_bf16_256_tile_kernel(N, H, W, Cin, Cout):
     """the 256x256-tile kernel (normally chosen for launches of >= 1536 such tiles) forced onto small, ragged shapes: same
     oracle bound as the 128x128 kernel, and the two agree to the last bf16 step."""
-    import os
     rng = np.random.default_rng(2)
     x = bf16_round(rnd(rng, N, H, W, Cin))
     w = bf16_round(rnd(rng, 3, 3, Cin, Cout, scale=0.05))
@@ -119,15 +118,14 @@ def test_conv3x3_bf16_256_tile_kernel(N, H, W, Cin, Cout, monkeypatch):
     wt = to_bf16_dev(w.reshape(9 * Cin, Cout).T)
     ref = O.relu(O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64))
     outs = {}
-    for env in ("MYOLO_BF16_FORCE256", "MYOLO_BF16_NO256"):
-        monkeypatch.setenv(env, "1")
-        y = torch.zeros(N, H, W, Cout, dtype=torch.bfloat16, device=DEV)
-        X.call("myolo_conv3x3_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(wt), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, 1, X.stream())
-        torch.cuda.synchronize()
-        monkeypatch.delenv(env)
-        outs[env] = from_bf16(y)
-        check_bf16(outs[env], ref, "conv3x3 bf16 (%s)" % env)
-    d = np.abs(outs["MYOLO_BF16_FORCE256"] - outs["MYOLO_BF16_NO256"])
+    for opt in ("bf16_force256", "bf16_no256"):
+        with X.option(opt, 1):
+            y = torch.zeros(N, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+            X.call("myolo_conv3x3_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(wt), X.ptr(dt(b)), X.ptr(y), N, H, W, Cin, Cout, 1, X.stream())
+            torch.cuda.synchronize()
+        outs[opt] = from_bf16(y)
+        check_bf16(outs[opt], ref, "conv3x3 bf16 (%s)" % opt)
+    d = np.abs(outs["bf16_force256"] - outs["bf16_no256"])
     assert (d <= BF16_STEP * np.abs(ref) + 1e-6).all()
 
 
@@ -145,7 +143,7 @@ def test_deconv2x2s2_bf16(N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,C", [(3, 14, 14, 256, 256, 2), (2, 5, 7, 64, 128, 4), (9, 14, 14, 128, 256, 1)])
-def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C, monkeypatch):
+def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C):
     """fused deconv + ReLU + 1x1 + sigmoid from bf16 activations: the deconv output stays in fp32 registers (it is never
     rounded to bf16, unlike the two-kernel path), so the result sits within fp32 summation noise of the float64 oracle."""
     rng = np.random.default_rng(3)
@@ -162,11 +160,11 @@ def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C, monkeypatch):
     ref = 1 / (1 + np.exp(-(d.reshape(-1, Cout) @ w2 + b2))).reshape(N, 2 * H, 2 * W, C)
     assert np.abs(p.cpu().numpy() - ref).max() < 1e-5
     if Cout % 256 == 0:          # the 256x256-tile kernel forced onto this small shape
-        monkeypatch.setenv("MYOLO_BF16_FORCE256", "1")
-        p2 = torch.full((N, 2 * H, 2 * W, C), float("nan"), device=DEV)
-        X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)),
-               X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p2), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())
-        torch.cuda.synchronize()
+        with X.option("bf16_force256", 1):
+            p2 = torch.full((N, 2 * H, 2 * W, C), float("nan"), device=DEV)
+            X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)),
+                   X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p2), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())
+            torch.cuda.synchronize()
         assert np.abs(p2.cpu().numpy() - ref).max() < 1e-5
 
 
