@@ -1,19 +1,25 @@
 #!/usr/bin/env python
-"""bench.py -- Mask-YOLO training-step throughput on MI355X (BASELINE.json metric).
+"""bench.py -- Mask-YOLO hot-path throughput on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without torchrun env: re-launches itself under
+                                                          python -m torch.distributed.run, one rank per GPU)
+  python bench.py --config rice416-bf16                  (BASELINE configs[3]: inference throughput, bf16 mask head)
 
-A step = one full training step of the hot path on one synthetic Shapes batch per GPU:
-forward (backbone, YOLO head, decode, mask targets, ROIAlign, mask head, both losses), backward of all of
-it, gradient all-reduce (N>1) and the Adam update.  Inputs are resident in HBM before the timed region.
-Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- the dominant kernel (mask-head 3x3 implicit-GEMM, fp32 MFMA), timed live with HIP events
-  cpu_baseline -- the CPU restatement (oracle/torch_ref.py, torch-CPU, all host cores) on a bounded sample
+Default workload (configs[1]): a step = one full training step of the hot path on one synthetic Shapes batch per GPU:
+forward (backbone, YOLO head, decode, mask targets, ROIAlign, mask head on ALL ROIs, both losses), backward of all of it
+(the mask head behind bn1 on the positive ROIs only -- exact), gradient all-reduce (N>1) and the
+Adam update.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line (contract in the task
+statement) with:
+  roofline      -- the dominant kernel, timed live with HIP events on its launch stream inside the timed region, plus
+                   objects for the kernels north_star names: depthwise (14 layers), ROIAlign (SURVEY 8(d) bytes), pointwise
+  cpu_baseline  -- the CPU restatement (oracle/torch_ref.py, torch-CPU) timed on this box's host cores
+  variants      -- the same K steps with the dense mask-head backward / the positives-only forward / forced positive counts
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,6 +31,10 @@ for p in (ROOT, os.path.join(ROOT, "mask-yolo_amd")):
 import numpy as np          # noqa: E402
 import torch                # noqa: E402
 import torch.distributed as dist   # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md
+FP32_MFMA_PEAK = 157.3       # TFLOP/s
+BF16_MFMA_PEAK = 2500.0      # TFLOP/s dense
 
 
 def make_batches(cfg, rank, world, per_gpu, nbatches):
@@ -53,10 +63,40 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(cfg, sample_images, seed=0, budget_s=25.0):
-    """Time the CPU restatement (torch-CPU fp32 + autograd, oracle/torch_ref.py) on a bounded sample of the
-    same workload.  oneDNN scales poorly past a few dozen threads at this batch size, so the thread count is
-    min(usable cores, 32); that number is what 'cores' reports."""
+def host_mem_gb():
+    """memory this process may use: min(MemAvailable, cgroup limit), GiB."""
+    avail = 1e9
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                avail = int(line.split()[1]) / 2.0 ** 20
+    except Exception:
+        pass
+    try:
+        v = open("/sys/fs/cgroup/memory.max").read().strip()
+        if v != "max":
+            used = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            avail = min(avail, (int(v) - used) / 2.0 ** 30)
+    except Exception:
+        pass
+    return avail
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(cfg, want_images, seed=0, budget_s=75.0, infer=False):
+    """Time the CPU restatement (torch-CPU fp32, oracle/torch_ref.py: autograd training step + Keras Adam, or the inference
+    forward) on this box's host cores: SURVEY 8(d) protocol scaled to a bounded run -- one warm-up step, then up to 3 timed
+    steps at the full per-GPU batch (fewer images if host memory is short: the autograd tape of a 32-image step holds ~50 GB)
+    inside a wall-clock budget.  oneDNN stops scaling past a few dozen threads at this size: min(usable cores, 32) threads."""
     from myolo.config import make_config
     from myolo.shapes import make_shapes_samples
     from myolo.myolo_utils import BatchGenerator
@@ -65,69 +105,107 @@ def cpu_baseline(cfg, sample_images, seed=0, budget_s=25.0):
     avail = usable_cores()
     threads = max(1, min(avail, 32))
     torch.set_num_threads(threads)
+    mem = host_mem_gb()
+    n = int(want_images)
+    per_img_gb = 1.8 * (cfg.TRAIN_ROIS_PER_IMAGE / 147.0) * (0.35 if infer else 1.0)
+    while n > 1 and n * per_img_gb > 0.6 * mem:
+        n //= 2
+    ccfg = make_config(type(cfg).__mro__[1], IMAGE_SHAPE=list(cfg.IMAGE_SHAPE), ALPHA=cfg.ALPHA, BATCH_SIZE=n,
+                       N_BOX=cfg.N_BOX, ANCHORS=list(cfg.ANCHORS))
+    ref = TorchRef(np_model.init_params(ccfg, seed=seed), ccfg, torch.float32)
+    if infer:
+        images = np.random.default_rng(0).random((n,) + tuple(ccfg.IMAGE_SHAPE), dtype=np.float32)
 
-    def build(n):
-        ccfg = make_config(type(cfg).__mro__[1], IMAGE_SHAPE=list(cfg.IMAGE_SHAPE), ALPHA=cfg.ALPHA, BATCH_SIZE=n,
-                           N_BOX=cfg.N_BOX, ANCHORS=list(cfg.ANCHORS))
+        def step(i):
+            with torch.no_grad():
+                _, Fm, yo = ref.trunk(images, False)
+                det = __import__("oracle.np_ops", fromlist=["x"]).yolo_detections(yo.numpy(), ccfg.ANCHORS, ccfg.GRID_W)
+                ref.mask_head(Fm, det[..., :4], False)
+    else:
         samples = make_shapes_samples(n, ccfg)
         batch, _ = BatchGenerator(samples, ccfg, 'training', shuffle=False, norm=True)[0]
-        return TorchRef(np_model.init_params(ccfg, seed=seed), ccfg, torch.float32), batch
+        state = {}
 
-    ref, batch = build(1)
+        def step(i):
+            ref.train_step(batch)
+            ref.adam(state, i + 1, 1e-3)
     t0 = time.time()
-    ref.train_step(batch)
-    ref.adam({}, 1, 1e-3)
-    t_probe = time.time() - t0                     # 1-image probe (includes first-touch / oneDNN primitive creation)
-    n = int(max(1, min(sample_images, budget_s / max(t_probe, 1e-3))))
-    if n > 1:
-        ref, batch = build(n)
-        ref.train_step(batch)                      # warm-up at the timed batch size
-    state = {}
-    t0 = time.time()
-    ref.train_step(batch)
-    ref.adam(state, 1, 1e-3)
-    t = time.time() - t0
-    return dict(value=n / t, unit="images/sec", cores=threads, kind="port",
-                sample="1 timed training step (fwd+bwd+Adam) of the torch-CPU fp32 restatement (oracle/torch_ref.py) on %d Shapes "
-                       "%dx%d image(s), N_BOX=%d, after a warm-up step; %d threads of %d usable host cores (os.cpu_count()=%d); "
-                       "%.1f s timed, 1-image probe %.1f s"
-                       % (n, cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1], cfg.N_BOX, threads, avail, os.cpu_count() or 0, t, t_probe))
+    step(0)                                        # warm-up (first touch, oneDNN primitive creation)
+    t_warm = time.time() - t0
+    times = []
+    for i in range(3):
+        if times and (time.time() - t0) + times[-1] > budget_s:
+            break
+        t1 = time.time()
+        step(i + 1)
+        times.append(time.time() - t1)
+    t = float(np.median(times))
+    what = "inference forward" if infer else "training step (fwd+bwd+Adam)"
+    return dict(value=n / t, unit="images/sec", cores=threads, kind="port", cpu_model=cpu_model(),
+                sample="CPU restatement (torch-CPU fp32, oracle/torch_ref.py), NOT Keras: %d timed %s(s) after 1 warm-up on %d image(s) of "
+                       "%dx%d, N_BOX=%d (R=%d); %d threads of %d usable host cores (os.cpu_count()=%d, %s); median %.1f s/step "
+                       "(all: %s), warm-up %.1f s; host memory available %.0f GiB"
+                       % (len(times), what, n, cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1], cfg.N_BOX, cfg.TRAIN_ROIS_PER_IMAGE, threads, avail,
+                          os.cpu_count() or 0, cpu_model(), t, ["%.1f" % x for x in times], t_warm, mem))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
-    ap.add_argument("--size", type=int, default=224)
-    ap.add_argument("--alpha", type=float, default=1.0)
-    ap.add_argument("--nbox", type=int, default=3, choices=[3, 5],
-                    help="3 = self-consistent Shapes head (R=147, primary); 5 = repository-HEAD head (R=245)")
-    ap.add_argument("--cpu-images", type=int, default=8, help="images in the bounded CPU-baseline sample (0 = skip)")
-    ap.add_argument("--lr", type=float, default=1e-3)
-    ap.add_argument("--mask-head-rois", choices=["all", "positives"], default="all",
-                    help="cfg.TRAIN_MASK_HEAD_ROIS of the run that produces `value` (default: all ROIs, as the reference graph)")
-    ap.add_argument("--no-variant", action="store_true", help="skip the extra timed run of the other TRAIN_MASK_HEAD_ROIS setting")
-    ap.add_argument("--conv3x3", choices=["auto", "direct", "winograd"], default="auto", help="cfg.CONV3X3_ALGO")
-    args = ap.parse_args()
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def relaunch_under_torchrun(args_gpus):
+    """plain `python bench.py --gpus N`: become `python -m torch.distributed.run ... bench.py --gpus N ...` (one rank per GPU)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+class KernelTimer(object):
+    """aggregate of per-launch HIP-event timings collected by Net._call_timed for a family of tags."""
+
+    def __init__(self, net):
+        self.net = net
+
+    def total_ms_per_step(self, prefix, steps):
+        tot, n = 0.0, 0
+        for tag in list(self.net.timings):
+            if tag.startswith(prefix):
+                ms, k = self.net.kernel_ms(tag)
+                tot += ms * k
+                n += k
+        return tot / max(1, steps), n // max(1, steps)
+
+
+def timed_steps(net, dbs, steps, lr, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    out = None
+    for i in range(steps):
+        out = net.train_step(dbs[i % len(dbs)], lr)
+    barrier()
+    return time.perf_counter() - t0, out
+
+
+def bench_train(args, rank, world, local):
     from myolo import dist as mdist
     from myolo.config import make_config, ShapesConfig, ShapesHeadConfig
     from myolo.model import MaskYOLO
-
-    rank, world, local = mdist.init_from_env()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    torch.cuda.set_device(local)
     dev = "cuda:%d" % local
     base = ShapesConfig if args.nbox == 3 else ShapesHeadConfig
     cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch,
                       TRAIN_MASK_HEAD_ROIS=args.mask_head_rois, CONV3X3_ALGO=args.conv3x3)
     model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
     net = model.net
-    reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)])
+    reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1)
     reducer.attach(net)
+    ranks_seen = reducer.ranks_seen() if world > 1 else 1
 
     nb = 2
     host = make_batches(cfg, rank, world, args.batch, nb)
@@ -139,132 +217,305 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def maxr(x):
+        if world > 1:
+            t = torch.tensor([x], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return x
+
     for i in range(args.warmup):
         net.train_step(dbs[i % nb], args.lr)
-    barrier()
-    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "wino_multiply", "wino_in", "wino_out_in"}
+    # ---- the timed region: only the dominant kernel (and the conv op it belongs to) is bracketed with events
+    dom_tags = {"mask_conv3x3_fwd", "wino_multiply", "wino_fused"}
+    net.timed_tags = set(dom_tags)
     net.timings = {}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = net.train_step(dbs[i % nb], args.lr)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, out = timed_steps(net, dbs, args.steps, args.lr, barrier)
+    elapsed = maxr(elapsed)
     loss = float(out["yolo_terms"][0]) + float(out["mask_terms"][0])
     assert np.isfinite(loss), "non-finite loss in the timed region"
+    npos_mean = float(out["n_pos"].float().mean())          # positives per image in the last timed batch
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
     mul_ms, mul_n = net.kernel_ms("wino_multiply")
+    fus_ms, fus_n = net.kernel_ms("wino_fused")
+    bucket_ms = reducer.bucket_ms() if world > 1 else None
+
+    # ---- second pass (not part of `value`): per-launch timings of the kernels north_star names
+    net.timed_tags = {"roialign_fwd", "wino_in", "wino_out_in"} | {"dw%d_fwd" % i for i in range(1, 15)} | {"pw%d_fwd" % i for i in range(1, 15)}
+    net.timings = {}
+    ksteps = 3
+    for i in range(ksteps):
+        net.train_step(dbs[i % nb], args.lr)
+    torch.cuda.synchronize()
+    kt = KernelTimer(net)
+    dw_ms, _ = kt.total_ms_per_step("dw", ksteps)
+    pw_ms, _ = kt.total_ms_per_step("pw", ksteps)
+    roi_ms, _ = net.kernel_ms("roialign_fwd")
     win_ms, win_n = net.kernel_ms("wino_in")
     woi_ms, woi_n = net.kernel_ms("wino_out_in")
-    roi_ms, _ = net.kernel_ms("roialign_fwd")
+    net.timed_tags = set()
 
-    # the same K steps with the other TRAIN_MASK_HEAD_ROIS setting (reported beside `value`, never as `value`)
-    variant = None
-    if not args.no_variant:
-        net.timed_tags = set()
-        net.sparse_mask_fwd = not net.sparse_mask_fwd
-        for i in range(2):
-            net.train_step(dbs[i % nb], args.lr)
-        barrier()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            out2 = net.train_step(dbs[i % nb], args.lr)
-        barrier()
-        el2 = time.perf_counter() - t1
-        assert np.isfinite(float(out2["yolo_terms"][0]) + float(out2["mask_terms"][0])), "non-finite loss in the variant run"
-        if world > 1:
-            t = torch.tensor([el2], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el2 = float(t.item())
-        variant = {"TRAIN_MASK_HEAD_ROIS": "positives" if net.sparse_mask_fwd else "all",
-                   "value": args.batch * world * args.steps / el2, "unit": "images/sec", "ms_per_step": 1e3 * el2 / args.steps,
-                   "note": "same loss, gradients, weights and BN state as the all-ROI forward (tests/test_gpu_step.py::"
-                           "test_positives_only_forward_equals_full_forward); conv2-4/deconv/myolo_mask forward run on the positive "
-                           "ROIs only, whose outputs are the only ones the training graph reads"}
-        net.sparse_mask_fwd = not net.sparse_mask_fwd
+    # ---- variants (reported beside `value`, never as `value`)
+    variants = {}
+    if not args.no_variant:                   # every rank runs them in lockstep (barriers / all-reduces inside)
+        def run_variant(setup, restore, note):
+            setup()
+            for i in range(2):
+                net.train_step(dbs[i % nb], args.lr)
+            el, o = timed_steps(net, dbs, args.steps, args.lr, barrier)
+            el = maxr(el)
+            restore()
+            assert np.isfinite(float(o["yolo_terms"][0]) + float(o["mask_terms"][0])), "non-finite loss in a variant run"
+            return {"value": args.batch * world * args.steps / el, "unit": "images/sec", "ms_per_step": 1e3 * el / args.steps, "note": note}
 
-    if rank == 0:
-        R = cfg.TRAIN_ROIS_PER_IMAGE
-        ps = cfg.MASK_POOL_SIZE
-        M = args.batch * R * ps * ps
-        flop = 2.0 * M * (9 * 256) * 256                      # algorithmic FLOPs of one mask-head 3x3 conv as a direct convolution
-        wino = mul_n > 0
-        if wino:
-            # CONV3X3_ALGO auto/winograd: the dominant kernel is the batched GEMM of the 36 Winograd points,
-            # M_t = tiles, K = N = 256; its algorithmic FLOPs are what the Winograd form needs, not the direct conv's
-            tiles_w = args.batch * R * ((ps + 3) // 4) ** 2
-            kflop = 2.0 * 36 * tiles_w * 256 * 256
-            kms, kn = mul_ms, mul_n
-            kname = "gemm_nn_fast<PLAIN> x36 batched (Winograd F(4x4,3x3) multiply stage of the mask-head 3x3 convs, M=%d K=256 N=256 per point)" % tiles_w
-            kbytes = 36.0 * tiles_w * (256 + 256) * 4 + 36 * 256 * 256 * 4
-        else:
-            kflop, kms, kn = flop, conv_ms, conv_n
-            kname = "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M
-            kbytes = 2.0 * M * 256 * 4 + 9 * 256 * 256 * 4
-        achieved = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        roi_bytes = args.batch * R * ps * ps * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
-        roi_kernel = "crop_fwd_kernel (ROIAlign fwd)"
-        if wino:          # ROIAlign is fused into conv1's input transform: it writes V (36 planes of tiles) instead of the crops
-            roi_bytes = 36.0 * args.batch * R * ((ps + 3) // 4) ** 2 * 256 * 4 + args.batch * (args.size // 8) ** 2 * 256 * 4
-            roi_kernel = "wino_in_crop_kernel (ROIAlign fused into conv1's Winograd input transform: feature map -> V)"
-        traffic = None      # HBM-side bytes per launch of the dominant kernel, from the separate --pmc passes (tools/collect_profiles.sh)
+        variants["dense_mask_backward"] = run_variant(
+            lambda: setattr(net, "sparse_mask_bwd", False), lambda: setattr(net, "sparse_mask_bwd", True),
+            "mask-head backward on ALL ROIs (conv2-4 / deconv / myolo_mask dense): the structural zeros behind bn1 are not "
+            "exploited; same gradients (tests/test_gpu_step.py::test_sparse_mask_backward_equals_dense)")
+        if world == 1:
+            def flip_fwd():
+                net.sparse_mask_fwd = not net.sparse_mask_fwd
+            variants["mask_head_forward_on_positives_only"] = run_variant(
+                flip_fwd, flip_fwd,
+                "TRAIN_MASK_HEAD_ROIS='%s': conv2-4/deconv/myolo_mask forward on the positive ROIs only, whose outputs are the "
+                "only ones the training graph reads; same loss, gradients, weights and BN state" % ("all" if net.sparse_mask_fwd else "positives"))
+            # n_pos sweep: the first k proposals of every image are replaced by a ground-truth box (IoU 1 -> positive), so the
+            # sparse backward works on ~k positives per image whatever the random-init net predicts
+            sweep = {}
+            for k in (5, 10, 20):
+                def hook(proposals, db, k=k):
+                    gt = db["gt_boxes"].to(torch.float32)                       # [B,T,4] px, x1 y1 x2 y2
+                    H, W = float(cfg.IMAGE_SHAPE[0]), float(cfg.IMAGE_SHAPE[1])
+                    norm = (gt - torch.tensor([0., 0., 1., 1.], device=gt.device)) / torch.tensor([W - 1, H - 1, W - 1, H - 1], device=gt.device)
+                    first = norm[:, :1, :].expand(-1, k, -1)                    # every image has >= 1 instance
+                    proposals[:, :k, :] = first
+                v = run_variant(lambda: setattr(net, "proposals_hook", hook), lambda: setattr(net, "proposals_hook", None),
+                                "first %d proposals of every image forced onto a ground-truth box" % k)
+                sweep["n_pos_%d" % k] = {"images_per_sec": v["value"], "ms_per_step": v["ms_per_step"]}
+            variants["n_pos_sweep"] = sweep
+
+    if rank != 0:
+        return None
+    R = cfg.TRAIN_ROIS_PER_IMAGE
+    ps = cfg.MASK_POOL_SIZE
+    M = args.batch * R * ps * ps
+    flop_direct = 2.0 * M * (9 * 256) * 256                   # one mask-head 3x3 conv as a direct convolution
+    tiles_w = args.batch * R * ((ps + 3) // 4) ** 2
+    wflop = 2.0 * 36 * tiles_w * 256 * 256                    # Winograd F(4x4,3x3): 36 products per tile and channel pair
+    traffic, traffic_src = None, None
+    if fus_n:
+        kflop, kms, kn = wflop, fus_ms, fus_n
+        kname = "wino_fused_kernel (Winograd F(4x4,3x3) conv in ONE kernel: input transform -> LDS, 36 MFMA GEMMs, output transform from registers; T=%d tiles, Cin=Cout=256)" % tiles_w
+        kbytes = 2.0 * M * 256 * 4 + 36 * 256 * 256 * 4
+        pmc = "r2_pmc_wino_fused.json"
+    elif mul_n:
+        kflop, kms, kn = wflop, mul_ms, mul_n
+        kname = "gemm_nn_fast<PLAIN> x36 batched (Winograd F(4x4,3x3) multiply stage of the mask-head 3x3 convs, M=%d K=256 N=256 per point)" % tiles_w
+        kbytes = 36.0 * tiles_w * (256 + 256) * 4 + 36 * 256 * 256 * 4
+        pmc = "r1_pmc_wino_multiply.json"
+    else:
+        kflop, kms, kn = flop_direct, conv_ms, conv_n
+        kname = "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M
+        kbytes = 2.0 * M * 256 * 4 + 9 * 256 * 256 * 4
+        pmc = "r1_pmc_conv3x3_fwd.json"
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+        if args.batch * R == 32 * 147:        # the counters were collected at exactly this shape
+            traffic = pj["traffic_bytes_per_launch_corrected"]
+            traffic_src = "profiles/%s (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)" % pmc
+    except Exception:
+        pass
+    achieved = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+
+    # SURVEY 8(d) bytes
+    fm = args.size // 8
+    roi_bytes = float(M) * 256 * 4 + args.batch * fm * fm * 256 * 4
+    dwb = dw_bytes(args.size, args.alpha, args.batch)
+    pwf, pwb = pw_flops_bytes(args.size, args.alpha, args.batch)
+
+    def hbm_obj(kernel, nbytes, ms, **extra):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        d = {"kernel": kernel, "bound": "hbm", "algorithmic_bytes": nbytes, "avg_ms": ms, "achieved": gbs, "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
+        d.update(extra)
+        return d
+    roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
+                "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+                "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
+                "conv_op": {"algo": "winograd_f4x4_3x3_fused" if fus_n else ("winograd_f4x4_3x3" if mul_n else "direct"),
+                            "avg_ms": conv_ms, "ops_timed": conv_n, "direct_conv_flop": flop_direct,
+                            "direct_equivalent_tflops": flop_direct / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                            "winograd_flop_frac_of_peak": wflop / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if conv_ms > 0 else 0.0},
+                "depthwise": hbm_obj("dw_fwd_kernel, the 14 depthwise 3x3 layers of backbone + YOLO head (sum over the layers, one step)",
+                                     dwb, dw_ms, note="SURVEY 8(d): activation in + out once, 20.97 MB/img at 224^2 alpha 1"),
+                "roialign": hbm_obj("ROIAlign forward (fused into conv1's Winograd input transform when CONV3X3_ALGO != direct)", roi_bytes, roi_ms,
+                                    note="SURVEY 8(d) bytes: the [B*R,14,14,256] crops + one read of the feature map; the fused kernel "
+                                         "writes the 36-plane Winograd image instead (2.9x those bytes), or nothing at all in the fused conv"),
+                "pointwise": {"kernel": "gemm_nn<PLAIN> 1x1 convs, the 14 pointwise layers (sum over the layers, one step)", "bound": "mfma+hbm",
+                              "algorithmic_flop": pwf, "algorithmic_bytes": pwb, "avg_ms": pw_ms,
+                              "achieved_tflops": pwf / (pw_ms * 1e-3) / 1e12 if pw_ms > 0 else 0.0,
+                              "frac_of_fp32_mfma_peak": pwf / (pw_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if pw_ms > 0 else 0.0,
+                              "achieved_gbs": pwb / (pw_ms * 1e-3) / 1e9 if pw_ms > 0 else 0.0,
+                              "frac_of_hbm_peak": pwb / (pw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pw_ms > 0 else 0.0}}
+    if mul_n and woi_n:
+        vbytes = 36.0 * tiles_w * 256 * 4
+        roofline["hbm_stages"] = ([hbm_obj("wino_in_kernel (input transform: activation -> V)", float(M) * 256 * 4 + vbytes, win_ms)] if win_n else []) + [
+            hbm_obj("wino_out_in_kernel (layer boundary M_i -> V_{i+1} through LDS)", 2 * vbytes, woi_ms)]
+    res = {
+        "metric": "images/sec fwd+bwd, %dx%d Shapes batch %d, at %d MI355X" % (args.size, args.size, args.batch, world),
+        "value": args.batch * world * args.steps / elapsed,
+        "unit": "images/sec",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
+                               "(fwd+bwd+Adam%s); mask head FORWARD on %s ROIs; mask-head BACKWARD behind bn1 (conv2-4, deconv, myolo_mask) on "
+                               "the positive ROIs only -- exact: bn2-4 are frozen and the loss reads positives only, so the other ROIs' "
+                               "gradients are structural zeros (dense-backward time in variants.dense_mask_backward); " % (
+                                   args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
+                                   "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + "3x3 convs: " +
+                               {"auto": "fp32 Winograd F(4x4,3x3) for launches >= 16384 pixels, direct implicit GEMM below",
+                                "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO],
+                   "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
+                   "n_pos_mean": npos_mean, "rois_per_image": R,
+                   "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
+        "roofline": roofline,
+    }
+    if world > 1:
+        res["comm"] = {"backend": "RCCL via %s" % ("the C-ABI (myolo_comm_*)" if args.comm == "capi" else "torch.distributed (nccl)"),
+                       "rccl_ranks_seen": ranks_seen, "bucket_allreduce_ms": bucket_ms,
+                       "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
+                       "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
+                               "on the comm stream as soon as backward completes it"}
+    if variants:
+        res["variants"] = variants
+    if args.cpu_images > 0 and world == 1:
         try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_wino_multiply.json" if wino else "r1_pmc_conv3x3_fwd.json")))
-            if args.batch * R == 32 * 147:        # the counters were collected at exactly this shape
-                traffic = pj["traffic_bytes_per_launch_corrected"]
-        except Exception:
-            pass
-        res = {
-            "metric": "images/sec fwd+bwd, %dx%d Shapes batch %d, at %d MI355X" % (args.size, args.size, args.batch, world),
-            "value": args.batch * world * args.steps / elapsed,
-            "unit": "images/sec",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
-                                   "(fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
-                                       args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
-                                       "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + ", 3x3 convs: " + {"auto": "fp32 Winograd F(4x4,3x3) for launches >= 16384 pixels, direct implicit GEMM below",
-                                                          "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO],
-                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
-                       "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
-            "roofline": {"kernel": kname,
-                         "bound": "mfma", "achieved": achieved, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": achieved / 157.3, "traffic": traffic,
-                         "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
-                         "conv_op": {"algo": "winograd_f4x4_3x3" if wino else "direct", "avg_ms": conv_ms, "ops_timed": conv_n,
-                                     "direct_conv_flop": flop,
-                                     "direct_equivalent_tflops": flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0},
-                         "secondary": {"kernel": roi_kernel, "bound": "hbm", "algorithmic_bytes": roi_bytes,
-                                       "achieved": roi_bytes / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
-                                       "peak": 8000.0, "unit": "GB/s",
-                                       "frac": (roi_bytes / (roi_ms * 1e-3) / 1e9 / 8000.0) if roi_ms > 0 else 0.0,
-                                       "avg_launch_ms": roi_ms}},
-        }
-        if wino and woi_n:
-            # the HBM-bound stages of the Winograd op (18 % of the step), against 8 TB/s: algorithmic bytes / measured time
-            vbytes = 36.0 * tiles_w * 256 * 4
-            xbytes = float(M) * 256 * 4
-            res["roofline"]["hbm_stages"] = ([
-                {"kernel": "wino_in_kernel (input transform: activation -> V)", "bound": "hbm", "algorithmic_bytes": xbytes + vbytes,
-                 "avg_launch_ms": win_ms, "achieved": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                 "frac": (xbytes + vbytes) / (win_ms * 1e-3) / 1e9 / 8000.0}] if win_n else []) + [
-                {"kernel": "wino_out_in_kernel (layer boundary M_i -> V_{i+1} through LDS)", "bound": "hbm", "algorithmic_bytes": 2 * vbytes,
-                 "avg_launch_ms": woi_ms, "achieved": 2 * vbytes / (woi_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                 "frac": 2 * vbytes / (woi_ms * 1e-3) / 1e9 / 8000.0}]
-        if variant is not None:
-            res["variant"] = variant
-        if args.cpu_images > 0 and world == 1:
-            try:
-                res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_images)
-            except Exception as e:            # the GPU line must not be lost to a host-side problem
-                res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        elif args.cpu_images > 0:
-            res["cpu_baseline"] = None
+            res["cpu_baseline"] = cpu_baseline(cfg, args.cpu_images)
+        except Exception as e:            # the GPU line must not be lost to a host-side problem
+            res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    else:
+        res["cpu_baseline"] = None
+    return res
+
+
+def dw_layers(size, alpha):
+    """(H_in, C, stride) of the 14 depthwise layers (model.py:68-77, 256-268)."""
+    a = alpha
+    chans = [int(32 * a)] + [int(f * a) for f in (64, 64, 128, 256, 256, 512, 512, 512, 512, 512, 512, 512, 1024)]
+    strides = [1, 2, 1, 2, 1, 1, 2, 1, 1, 1, 1, 1, 2, 1]
+    h = size // 2
+    out = []
+    for c, s in zip(chans, strides):
+        out.append((h, c, s))
+        h //= s
+    return out
+
+
+def dw_bytes(size, alpha, batch):
+    return float(sum(batch * (h * h + (h // s) * (h // s)) * c * 4 for h, c, s in dw_layers(size, alpha)))
+
+
+def pw_flops_bytes(size, alpha, batch):
+    outs = [int(f * alpha) for f in (64, 64, 128, 256, 256, 512, 512, 512, 512, 512, 512, 512, 1024, 1024)]
+    fl, by = 0.0, 0.0
+    for (h, c, s), co in zip(dw_layers(size, alpha), outs):
+        m = batch * (h // s) * (h // s)
+        fl += 2.0 * m * c * co
+        by += 4.0 * (m * c + m * co + c * co)
+    return fl, by
+
+
+def bench_infer(args):
+    """BASELINE configs[3]: Rice 416x416, 5 anchors (R = 845), 28x28 mask head, inference forward (trunk + detections + ROIAlign
+    + mask head on all R boxes, model.py:922-936) with the bf16 mask head.  A step = one forward of `--batch` images."""
+    from myolo.config import make_config, RiceConfig
+    from myolo.engine import Net
+    dev = "cuda:0"
+    bsz = args.batch if args.batch_given else 4
+    cfg = make_config(RiceConfig, BATCH_SIZE=bsz, INFERENCE_DTYPE="bf16")
+    net = Net(cfg, device=dev, seed=0)
+    x = torch.rand(bsz, 416, 416, 3, device=dev)
+    for _ in range(max(2, args.warmup)):
+        net.predict(x)
+    net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "mask_deconv_fwd"}
+    net.timings = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net.predict(x)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
+    roi_ms, _ = net.kernel_ms("roialign_fwd")
+    R = cfg.TRAIN_ROIS_PER_IMAGE
+    M = bsz * R * 14 * 14
+    flop = 2.0 * M * 9 * 256 * 256
+    ach = flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    res = {"metric": "images/sec inference, Rice 416x416, 5 anchors, 28x28 mask head, bf16 mask head, 1 MI355X",
+           "value": bsz * args.steps / el, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": max(2, args.warmup),
+           "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "Rice 416x416 inference forward, batch %d, N_BOX=5 (R=845 boxes/img, all through the mask head as the "
+                                  "reference graph does, model.py:926-931), fp32 trunk + bf16 ROIAlign / 3x3 convs / deconv with fp32 accumulation" % bsz,
+                      "global_batch": bsz, "parallelism": "dp1"},
+           "roofline": {"kernel": "gemm_bf16_256<CONV3> (mask-head 3x3 conv, bf16 operands, fp32 accumulate, M=%d K=2304 N=256)" % M,
+                        "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
+                        "traffic": None, "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * M * 256 * 2 + 9 * 256 * 256 * 2,
+                        "launches_timed": conv_n, "avg_launch_ms": conv_ms,
+                        "roialign": {"kernel": "crop_fwd_bf16_kernel", "bound": "hbm", "avg_ms": roi_ms,
+                                     "algorithmic_bytes": M * 256 * 2.0 + bsz * 52 * 52 * 256 * 4.0,
+                                     "achieved": (M * 256 * 2.0 + bsz * 52 * 52 * 256 * 4.0) / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
+                                     "peak": HBM_PEAK_GBS, "unit": "GB/s"}}}
+    if args.cpu_images > 0:
+        try:
+            res["cpu_baseline"] = cpu_baseline(cfg, 1, infer=True, budget_s=60.0)
+        except Exception as e:
+            res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 32; 4 for --config rice416-bf16)")
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--alpha", type=float, default=1.0)
+    ap.add_argument("--nbox", type=int, default=3, choices=[3, 5],
+                    help="3 = self-consistent Shapes head (R=147, primary); 5 = repository-HEAD head (R=245)")
+    ap.add_argument("--config", choices=["shapes224-train", "rice416-bf16"], default="shapes224-train",
+                    help="shapes224-train = BASELINE configs[1] (the metric); rice416-bf16 = configs[3] inference throughput")
+    ap.add_argument("--cpu-images", type=int, default=32, help="images in the CPU-baseline step (0 = skip; halved while host memory is short)")
+    ap.add_argument("--lr", type=float, default=1e-3)
+    ap.add_argument("--mask-head-rois", choices=["all", "positives"], default="all",
+                    help="cfg.TRAIN_MASK_HEAD_ROIS of the run that produces `value` (default: all ROIs, as the reference graph)")
+    ap.add_argument("--no-variant", action="store_true", help="skip the extra timed runs (dense backward, positives-only forward, n_pos sweep)")
+    ap.add_argument("--conv3x3", choices=["auto", "direct", "winograd"], default="auto", help="cfg.CONV3X3_ALGO")
+    ap.add_argument("--comm", choices=["torch", "capi"], default="torch",
+                    help="N>1: gradient all-reduce through torch.distributed (nccl = RCCL) or through the library's own myolo_comm_* entry points")
+    args = ap.parse_args()
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 32
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+
+    from myolo import dist as mdist
+    rank, world, local = mdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torchrun --nproc-per-node %d, or plain `python bench.py --gpus %d`)"
+                         % (args.gpus, world, args.gpus, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    torch.cuda.set_device(local)
+    if args.config == "rice416-bf16":
+        res = bench_infer(args) if rank == 0 else None
+    else:
+        res = bench_train(args, rank, world, local)
+    if rank == 0:
         print(json.dumps(res))
     if world > 1:
         dist.barrier()

@@ -42,12 +42,18 @@ def shard_range(global_batch, rank, world):
 
 
 def dp_batch_indices(n_samples, batch, rank, world, n_batches=None):
-    """Batch indices rank `rank` trains on in one epoch: only FULL batches, the same count on every rank (a rank that skipped
-    a step would leave the others waiting in the all-reduce), rank r taking batches r, r+world, r+2*world, ..."""
-    n_full = n_samples // batch
+    """Batch indices rank `rank` trains on in one epoch.  The epoch has ceil(n_samples / batch) batches, as the reference's
+    steps_per_epoch = len(generator) (model.py:1048; BatchGenerator wraps the last batch back so that it is full-size,
+    myolo_utils.py:730-735).  Every rank runs the same number of steps (a rank that skipped one would leave the others waiting
+    in the all-reduce): rank r takes batches r, r+world, r+2*world, ... and the n_batches % world trailing batches are dropped
+    when world > 1.  Fewer samples than one batch is an error (the reference would train on a short batch; the engine's
+    buffers are sized for BATCH_SIZE)."""
+    if n_samples < batch:
+        raise ValueError("%d samples cannot fill one batch of %d" % (n_samples, batch))
+    nb = -(-n_samples // batch)
     if n_batches is not None:
-        n_full = min(n_full, n_batches)
-    return list(range(rank, n_full - (n_full % world), world))
+        nb = min(nb, n_batches)
+    return list(range(rank, nb - (nb % world), world))
 
 
 class GradReducer(object):
@@ -57,18 +63,83 @@ class GradReducer(object):
     wait() is called before the optimiser (Net.before_optimizer).  With world_size 1 both are no-ops,
     so the single-GPU path is bit-identical to running without a reducer."""
 
-    def __init__(self, flat_grad, bucket_ranges, group=None, always=False):
+    def __init__(self, flat_grad, bucket_ranges, group=None, always=False, backend="torch", timing=False):
+        """backend "torch": torch.distributed.all_reduce (nccl = RCCL on GPU tensors, gloo otherwise).
+        backend "capi": the library's own myolo_comm_* entry points (include/myolo_hip.h) -- RCCL driven through the C-ABI,
+        torch.distributed only carries the 128-byte unique id to the other ranks.  GPU tensors only.
+        timing=True brackets every bucket's collective with HIP events on the comm stream (bucket_ms())."""
         self.flat = flat_grad
         self.ranges = list(bucket_ranges)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
         self.handles = []
+        self.backend = backend
+        self.timing = bool(timing) and self.cuda
+        self.comm = None
+        if backend not in ("torch", "capi"):
+            raise ValueError("GradReducer backend must be 'torch' or 'capi' (got %r)" % (backend,))
         # always=True issues the collectives even in a 1-rank group (used to test the RCCL/stream path on one GPU)
-        self.active = self.world > 1 or (always and dist.is_initialized())
+        self.active = self.world > 1 or (always and (dist.is_initialized() or backend == "capi"))
         if self.cuda and self.active:
             self.comm_stream = torch.cuda.Stream(device=flat_grad.device)
-            self.done = [torch.cuda.Event() for _ in self.ranges]
+            self.done = [torch.cuda.Event(enable_timing=self.timing) for _ in self.ranges]
+            self.started = [torch.cuda.Event(enable_timing=True) for _ in self.ranges] if self.timing else None
+            self._ms = [[] for _ in self.ranges]
+            self._issued = [False] * len(self.ranges)
+        if backend == "capi" and self.active:
+            if not self.cuda:
+                raise ValueError("backend 'capi' (RCCL through the C-ABI) needs device tensors")
+            self._init_capi()
+
+    def _init_capi(self):
+        import ctypes
+        from . import _ext as X
+        rank = dist.get_rank(self.group) if dist.is_initialized() else 0
+        ident = (ctypes.c_char * 128)()
+        if rank == 0:
+            X.call("myolo_comm_unique_id", ctypes.addressof(ident))
+        if dist.is_initialized() and self.world > 1:
+            box = [bytes(ident.raw)]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            ident = (ctypes.c_char * 128).from_buffer_copy(box[0])
+        comm = ctypes.c_void_p()
+        with torch.cuda.device(self.flat.device):
+            X.call("myolo_comm_init", rank, self.world, ctypes.addressof(ident), ctypes.addressof(comm))
+        self.comm = comm
+
+    def ranks_seen(self):
+        """number of ranks that actually take part in a collective on this reducer's transport (a sum of ones)."""
+        if not self.active:
+            return 1
+        one = torch.ones(1, dtype=torch.float32, device=self.flat.device)
+        if self.backend == "capi":
+            from . import _ext as X
+            X.call("myolo_allreduce_sum_f32", one.data_ptr(), 1, self.comm, torch.cuda.current_stream().cuda_stream)
+        else:
+            dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.group)
+        return int(round(float(one.item())))
+
+    def bucket_ms(self):
+        """[mean ms of bucket i's all-reduce on the comm stream] since construction (timing=True; synchronises)."""
+        if not (self.timing and self.active):
+            return None
+        self._collect()
+        return [float(sum(v) / len(v)) if v else 0.0 for v in self._ms]
+
+    def _collect(self):
+        torch.cuda.synchronize(self.flat.device)
+        for i, was in enumerate(self._issued):
+            if was:
+                self._ms[i].append(self.started[i].elapsed_time(self.done[i]))
+                self._issued[i] = False
+
+    def close(self):
+        if self.comm is not None:
+            from . import _ext as X
+            torch.cuda.synchronize(self.flat.device)
+            X.call("myolo_comm_destroy", self.comm)
+            self.comm = None
 
     @property
     def grad_scale(self):
@@ -82,10 +153,20 @@ class GradReducer(object):
         if self.cuda:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
+            if self.timing and self._issued[i]:
+                self._collect()                      # the previous step's pair of this bucket, before its events are reused
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
+                if self.timing:
+                    self.started[i].record(self.comm_stream)
+                if self.backend == "capi":
+                    from . import _ext as X
+                    X.call("myolo_allreduce_sum_f32", view.data_ptr(), hi - lo, self.comm, self.comm_stream.cuda_stream)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 self.done[i].record(self.comm_stream)
+                if self.timing:
+                    self._issued[i] = True
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -87,13 +87,16 @@ def init_state_dict(cfg, seed=0):
 class Workspace(object):
     """One growable scratch buffer shared by every call on the compute stream."""
 
-    def __init__(self, device, nbytes=256 << 20):
+    def __init__(self, device, nbytes=256 << 20, on_realloc=None):
         self.device = device
         self.buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.on_realloc = on_realloc      # a captured hipGraph holds raw pointers into buf: the owner drops its graphs
 
     def ensure(self, nbytes):
         if self.buf.numel() < nbytes:
             torch.cuda.synchronize()
+            if self.on_realloc:
+                self.on_realloc()
             self.buf = torch.empty(int(nbytes * 1.25), dtype=torch.uint8, device=self.device)
 
     @property
@@ -150,7 +153,9 @@ class Net(object):
         for name, kind, shp, _ in self.table:
             if kind == "bn":
                 self.bnbuf[name] = torch.zeros(4, shp, **f32)        # mean, var, scale, shift
-        self._ws_main = Workspace(self.dev)
+        self._graphs = {}                 # predict_graphed: input shape -> (hipGraph, static input, static outputs)
+        # a captured graph bakes in pointers to the scratch buffer: growing it (a bigger launch on the same Net) drops the graphs
+        self._ws_main = Workspace(self.dev, on_realloc=self._graphs.clear)
         self._ws_side = Workspace(self.dev)    # scratch of the YOLO-head backward running on the side stream
         self._ws_active = self._ws_main
         self._yolo_stream = torch.cuda.Stream(device=self.dev)
@@ -160,6 +165,8 @@ class Net(object):
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
         self.adam_t = 0
         self.tape = {}
+        self.proposals_hook = None        # callable(proposals [B,R,4], device batch): in-place edit before target assignment (bench.py)
+        self.tape_hook = None             # callable(net) between forward and backward of forward_backward (tests: teacher-forcing)
         self.on_bucket_ready = None       # callable(bucket_index) -- set by myolo/dist.py
         self.before_optimizer = None      # callable() -- waits for the all-reduce
         self.grad_scale = 1.0
@@ -176,7 +183,6 @@ class Net(object):
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
         self._bind_cache = {}
-        self._graphs = {}                 # predict_graphed: input shape -> (hipGraph, static input, static outputs)
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
         self.timings = {}                 # tag -> [(start_event, end_event), ...]
         self.load_state_dict(init_state_dict(cfg, seed))
@@ -355,7 +361,8 @@ class Net(object):
         ad = self.bn_act_fwd(dwn + "_bn", y, ACT_RELU6, train)
         Co = self.p[pwn + "/kernel"].shape[3]
         y2 = self._new(N * Ho * Wo, Co)
-        X.call("myolo_pwconv1x1_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), None, X.ptr(y2), N * Ho * Wo, C, Co, X.stream())
+        self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), None, X.ptr(y2), N * Ho * Wo, C, Co,
+                         X.stream())
         ap = self.bn_act_fwd(pwn + "_bn", y2, ACT_RELU6, train)
         self.tape["blk%d" % bid] = (a, shape, stride, ad)
         return ap, (N, Ho, Wo, Co)
@@ -966,6 +973,8 @@ class Net(object):
         Fm, fshape, yo = self.trunk_fwd(images, True)
         proposals = self._new(B, R, 4)
         X.call("myolo_yolo_decode", X.ptr(yo), X.ptr(self.anchors), X.ptr(proposals), B, G, A, C, X.stream())
+        if self.proposals_hook:
+            self.proposals_hook(proposals, db)
         rois = self._new(B, R, 4)
         tcls = self._new(B, R, dtype=torch.int32)
         tmask = self._new(B, R, mh, mw)
@@ -1000,6 +1009,8 @@ class Net(object):
             dz = self._new(pred.shape[0], pred.shape[1])
             X.call("myolo_mask_bce", X.ptr(tmask_l), X.ptr(tcls_l), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), tcls_l.numel(), mh, mw, C,
                    *self._wsargs(), X.stream())
+        if self.tape_hook:
+            self.tape_hook(self)
         if self.overlap_yolo_bwd:
             # under the compacted part of the mask head's backward (small launches on the positive ROIs), not under the big
             # forward GEMMs: two streams of small kernels fill the chip together, and the dense kernels keep it to themselves
@@ -1013,6 +1024,47 @@ class Net(object):
         return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_proposals=proposals, output_rois=rois,
                     myolo_mask=mm, target_class_ids=tcls, target_mask=tmask, n_pos=npos,
                     yolo_terms=yterms, mask_terms=mterms, feature_map=Fm.view(*fshape), loss_weights=(w1, w2))
+
+    def forward_loss(self, db):
+        """Validation forward (Keras evaluate_generator as called by fit_generator, model.py:1053-1054): the TRAINING graph
+        -- decode, mask targets, ROIAlign, mask head, both losses (model.py:872-904) -- in Keras' test phase, i.e. every
+        BatchNormalization on its moving statistics, no gradient, no state change.  Returns the loss terms as device
+        tensors (yolo_terms[8], mask_terms[2]); 'yolo' mode batches (three arrays) give the YOLO loss only."""
+        cfg = self.cfg
+        self.tape = {}
+        images = db["images"]
+        B = images.shape[0]
+        G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+        R = G * G * A
+        mh, mw = cfg.MASK_SHAPE
+        Fm, fshape, yo = self.trunk_fwd(images, False)
+        w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
+        w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
+        yterms = self._new(8)
+        dyolo = self._new(yo.shape[0], yo.shape[1])          # the loss kernel always forms the gradient; unused here
+        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+               X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
+               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+        if "gt_masks" not in db:
+            self.tape = {}
+            return dict(yolo_terms=yterms, mask_terms=torch.zeros(2, dtype=torch.float32, device=self.dev), loss_weights=(w1, 0.0))
+        proposals = self._new(B, R, 4)
+        X.call("myolo_yolo_decode", X.ptr(yo), X.ptr(self.anchors), X.ptr(proposals), B, G, A, C, X.stream())
+        rois = self._new(B, R, 4)
+        tcls = self._new(B, R, dtype=torch.int32)
+        tmask = self._new(B, R, mh, mw)
+        npos = self._new(B, dtype=torch.int32)
+        H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+        X.call("myolo_mask_targets", X.ptr(proposals), X.ptr(db["gt_ids"]), X.ptr(db["gt_boxes"]), X.ptr(db["gt_masks"]),
+               X.ptr(rois), X.ptr(tcls), X.ptr(tmask), X.ptr(npos), B, R, T, H, W, mh, mw, X.stream())
+        pred = self.mask_head_fwd(Fm, fshape, rois, False)
+        mterms = self._new(2)
+        dz = self._new(pred.shape[0], pred.shape[1])
+        X.call("myolo_mask_bce", X.ptr(tmask), X.ptr(tcls), X.ptr(pred), w2, X.ptr(mterms), X.ptr(dz), tcls.numel(), mh, mw, C,
+               *self._wsargs(), X.stream())
+        self.tape = {}
+        return dict(yolo_terms=yterms, mask_terms=mterms, loss_weights=(w1, w2), yolo_output=yo.view(B, G, G, A, 5 + C),
+                    output_rois=rois, target_class_ids=tcls, myolo_mask=pred.view(B, R, mh, mw, C), n_pos=npos)
 
     def forward_backward_yolo(self, db):
         """'yolo' mode training step (model.py:906-920: outputs [yolo_output, yolo_sum_loss]): backbone + YOLO head

@@ -11,8 +11,11 @@ yolo_trainable=True)`` (model.py:767-785), ``build`` (:787), ``train`` (:943-944
 Deliberate differences: one finalized config object everywhere (the
 reference reads the base class from free functions, model.py:25); ``train`` uses every sample of
 the dataset unless ``max_samples`` is given (reference hard-codes 50/6, model.py:995,1002);
-``detect`` keeps the NMB result (reference overrides it with [109,130], model.py:1306) and does not
-mutate ``Config.BATCH_SIZE`` (model.py:1268); checkpoints are ``.npz`` keyed by Keras layer names
+``detect`` keeps the NMB result (reference overrides it with [109,130], model.py:1306), returns ``bboxes`` in
+PIXELS of the input image (x by its width, y by its height; the reference hard-codes ``* 224``, model.py:1307) and
+does not mutate ``Config.BATCH_SIZE`` (model.py:1268); ``train`` runs the validation pass Keras' fit_generator runs
+(model.py:1053-1054) and keeps the per-epoch numbers in ``self.history``; ``custom_callbacks`` (commented out in the
+reference, model.py:1037-1038) are honoured as plain callables ``cb(epoch, logs)``; checkpoints are ``.npz`` keyed by Keras layer names
 (h5py is not available); weights are cached by (path, mtime) instead of reloaded per call.
 """
 import datetime
@@ -147,6 +150,10 @@ class MaskYOLO(object):
         yolo_only = self.mode == 'yolo' or "gt_masks" not in db
         out = net.forward_backward_yolo(db) if yolo_only else net.forward_backward(db)
         if getattr(self, "_train_mask", None) is not None:
+            # data-parallel: the bucketed all-reduces run in place on flat_g on the reducer's stream -- join them BEFORE
+            # masking, or RCCL may overwrite zeroed entries / read half-masked data (frozen layers would then move)
+            if net.before_optimizer:
+                net.before_optimizer()
             net.flat_g.mul_(self._train_mask)          # torch used as a memory op on a flag vector only
         net.adam_step(lr)
         if yolo_only:
@@ -182,9 +189,25 @@ class MaskYOLO(object):
             self._reducer = GradReducer(self.net.flat_g, self.net.bucket_ranges).attach(self.net)
         return tdist.get_rank(), tdist.get_world_size()
 
+    def evaluate_on_batch(self, batch):
+        """Forward-only losses of one host batch in Keras' test phase (every BatchNormalization on its moving statistics):
+        what fit_generator's validation pass computes per batch (model.py:1053-1054).  No state is changed."""
+        net = self.net
+        db = batch if isinstance(batch, dict) else net.to_device_batch(batch)
+        out = net.forward_loss(db)
+        yt = out["yolo_terms"].cpu().numpy()
+        mt = out["mask_terms"].cpu().numpy()
+        w1, w2 = out["loss_weights"]
+        return dict(loss=float(yt[0] * w1 + mt[0] * w2), yolo_sum_loss=float(yt[0]), mask_loss=float(mt[0]),
+                    loss_xy=float(yt[1]), loss_wh=float(yt[2]), loss_conf=float(yt[3]), loss_class=float(yt[4]), recall=float(yt[5]))
+
     def train(self, train_dataset, val_dataset, learning_rate, epochs, layers,
-              augmentation=None, custom_callbacks=None, no_augmentation_sources=None, max_samples=None, verbose=1):
-        """model.py:943-1060.  Returns the list of per-epoch mean training losses."""
+              augmentation=None, custom_callbacks=None, no_augmentation_sources=None, max_samples=None, verbose=1, shuffle_seed=0):
+        """model.py:943-1060.  Returns the list of per-epoch mean training losses; ``self.history`` holds
+        {"loss": [...], "val_loss": [...]} like the Keras History the reference's fit_generator produces.
+        shuffle_seed: the generators' one-off shuffle (myolo_utils.py:711-712) draws from RandomState(shuffle_seed) -- the
+        same permutation on every data-parallel rank, so that dp_batch_indices really hands out disjoint samples; None =
+        the global numpy generator, as the reference (single process only)."""
         layer_regex = {"all": ".*"}
         if layers in layer_regex:
             layers = layer_regex[layers]
@@ -199,31 +222,44 @@ class MaskYOLO(object):
         train_info = collect(train_dataset)
         val_info = collect(val_dataset) if val_dataset is not None else []
         mode = self.mode if self.mode in ('yolo', 'training') else 'training'
-        train_gen = mutils.BatchGenerator(train_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True)
-        val_gen = mutils.BatchGenerator(val_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True) if val_info else None
+        rank, world = self._data_parallel()
+        if world > 1 and shuffle_seed is None:
+            raise ValueError("data-parallel train() needs a shuffle_seed: every rank must hold the same permutation")
+        rng = None if shuffle_seed is None else np.random.RandomState(shuffle_seed)
+        train_gen = mutils.BatchGenerator(train_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True, rng=rng)
+        val_gen = mutils.BatchGenerator(val_info, cfg, mode=mode, shuffle=True, jitter=False, norm=True, rng=rng) if val_info else None
         self.set_trainable(layers)
         self.compile(learning_rate, cfg.LEARNING_MOMENTUM)
-        rank, world = self._data_parallel()          # the generators must be seeded alike on every rank (same shuffle)
+        from .dist import dp_batch_indices
+        schedule = dp_batch_indices(len(train_info), cfg.BATCH_SIZE, rank, world, len(train_gen))   # raises if < one batch
         history = []
+        self.history = {"loss": [], "val_loss": []}
         for ep in range(epochs):
             losses = []
-            from .dist import dp_batch_indices
-            for i in dp_batch_indices(len(train_info), cfg.BATCH_SIZE, rank, world, len(train_gen)):
-                inputs, _ = train_gen[i]
-                if len(inputs[0]) != cfg.BATCH_SIZE:
-                    continue
+            for i in schedule:
+                inputs, _ = train_gen[i]               # the wrapped last batch is full-size (myolo_utils.py:730-735)
                 out = self.train_on_batch(inputs)
                 losses.append(out["loss"])
                 if verbose:
                     print("epoch %d step %d/%d loss %.4f (yolo %.4f mask %.4f recall %.3f)" %
                           (ep + 1, i + 1, len(train_gen), out["loss"], out["yolo_sum_loss"], out["mask_loss"], out["recall"]))
-            history.append(float(np.mean(losses)) if losses else float("nan"))
+            history.append(float(np.mean(losses)))
+            logs = {"loss": history[-1]}
+            if val_gen is not None and len(val_info) >= cfg.BATCH_SIZE:
+                # validation_data=val_generator, validation_steps=len(val_generator) (model.py:1053-1054): forward only, BN on
+                # moving statistics, batch-mean of the total loss.  Every rank evaluates the same (small) set.
+                vl = [self.evaluate_on_batch(val_gen[j][0])["loss"] for j in range(len(val_gen))]
+                logs["val_loss"] = float(np.mean(vl))
+                if verbose:
+                    print("epoch %d val_loss %.4f" % (ep + 1, logs["val_loss"]))
+            self.history["loss"].append(logs["loss"])
+            self.history["val_loss"].append(logs.get("val_loss", float("nan")))
             if self.model_dir and rank == 0:
                 os.makedirs(self.model_dir, exist_ok=True)
                 stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
                 self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
-            del val_gen
-            val_gen = None
+            for cb in (custom_callbacks or []):
+                (cb.on_epoch_end if hasattr(cb, "on_epoch_end") else cb)(ep, dict(logs))
         self.epoch = max(self.epoch, epochs)
         return history
 
@@ -298,8 +334,9 @@ class MaskYOLO(object):
             _, _, _, full_masks = self._decode_masks_device(det_s, mask_s, image.shape)
         else:
             full_masks = np.empty((int(image.shape[0]), int(image.shape[1]), 0), dtype=bool)
+        H_img, W_img = float(image.shape[0]), float(image.shape[1])
         return [{
-            "bboxes": boxes[nmb],
+            "bboxes": boxes[nmb] * np.array([W_img, H_img, W_img, H_img], dtype=boxes.dtype),     # pixels (model.py:1307)
             "class_ids": class_ids[nmb],
             "confidence_scores": scores[nmb],
             "full_masks": full_masks,

@@ -95,6 +95,7 @@ class Tape(object):
     def bn_act(self, name, x, act, frozen=False):
         P = self.P
         g, b = P[name + "/gamma"], P[name + "/beta"]
+        self.c[name + "/x"] = x          # pre-BN tensor (tests teacher-force the GPU backward's activation masks with it)
         if self.training and not frozen:
             y, cache = O.bn_train(x, g, b)
             n = x.size // x.shape[-1]
@@ -250,6 +251,26 @@ def train_step_fwd_bwd(P, batch, cfg):
                 target_class_ids=tcls, target_mask=tmask, n_pos=npos,
                 yolo_sum_loss=yl["loss"], mask_loss=ml, loss=loss, yolo_terms=yl,
                 feature_map=Fm, C4=C4, grads=G, moving=T.moving, tape=T)
+
+
+def val_step_fwd(P, batch, cfg):
+    """Validation forward of fit_generator (model.py:1053-1054: validation_data=val_generator): the training graph
+    (model.py:872-904) evaluated in Keras' test phase -- K.learning_phase() = 0, so EVERY BatchNormalization, bn1 of the
+    mask head included (model.py:690 has no training= argument and therefore follows the learning phase), normalises with
+    its moving statistics; nothing is updated.  Returns the loss terms Keras averages into val_loss."""
+    images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
+    T = Tape(P, cfg, training=False)
+    C4, Fm, yolo_out = T.trunk(images.astype(O.F32))
+    proposals = O.yolo_decode(yolo_out, cfg.ANCHORS, cfg.GRID_W)
+    rois, tcls, tmask, npos = O.mask_targets(proposals, gt_ids, gt_boxes, gt_masks, cfg)
+    pred = T.mask_head(Fm, rois)
+    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=False)
+    ml = O.mask_bce(tmask, tcls, pred, want_grad=False)
+    ml = ml[0] if isinstance(ml, tuple) else ml
+    w1 = O.F32(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
+    w2 = O.F32(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
+    return dict(yolo_output=yolo_out, output_rois=rois, target_class_ids=tcls, myolo_mask=pred, n_pos=npos,
+                yolo_sum_loss=yl["loss"], mask_loss=ml, loss=O.F32(yl["loss"] * w1 + ml * w2), yolo_terms=yl)
 
 
 def yolo_step_fwd_bwd(P, batch, cfg):

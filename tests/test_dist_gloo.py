@@ -100,13 +100,20 @@ def test_engine_bucket_ranges_cover_flat_buffer_contiguously():
     assert sizes[2] > sizes[0]                                          # mask head is the largest bucket but the backbone
 
 
-@pytest.mark.parametrize("n,batch,world", [(50, 8, 2), (64, 8, 8), (500, 32, 4), (7, 8, 2), (100, 8, 3)])
+@pytest.mark.parametrize("n,batch,world", [(50, 8, 2), (64, 8, 8), (500, 32, 4), (9, 8, 2), (100, 8, 3)])
 def test_dp_batch_schedule_is_uniform_and_disjoint(n, batch, world):
     """MaskYOLO.train under torchrun: every rank runs the same number of steps (no rank left waiting in the all-reduce),
-    on disjoint full batches."""
+    on disjoint batches; one rank runs the reference's ceil(n/batch) steps per epoch (model.py:1048), the wrapped last
+    batch included."""
+    nb = -(-n // batch)
     per_rank = [dp_batch_indices(n, batch, r, world) for r in range(world)]
     assert len({len(p) for p in per_rank}) == 1
     flat = sorted(i for p in per_rank for i in p)
-    assert flat == list(range(len(flat))) and len(flat) == (n // batch) - (n // batch) % world
-    assert all(i < n // batch for i in flat)
-    assert dp_batch_indices(n, batch, 0, 1) == list(range(n // batch))
+    assert flat == list(range(len(flat))) and len(flat) == nb - nb % world
+    assert all(i < nb for i in flat)
+    assert dp_batch_indices(n, batch, 0, 1) == list(range(nb))
+
+
+def test_dp_batch_schedule_rejects_less_than_one_batch():
+    with pytest.raises(ValueError):
+        dp_batch_indices(7, 8, 0, 1)

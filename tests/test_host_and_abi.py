@@ -185,3 +185,56 @@ def test_keras_h5_name_mapping_roundtrip():
     assert all(np.array_equal(back[k], sd[k]) for k in sd)
     # tf.keras-style prefixed names map to the same keys
     assert set(m.keras_weights_to_state({"yolo_model/conv_23/kernel:0": sd["conv_23/kernel"]})) == {"conv_23/kernel"}
+
+
+def test_set_option_roundtrip_and_unknown_name():
+    """tuning switches are plain ints behind myolo_set_option / myolo_get_option -- no environment reads in the library."""
+    from myolo import _ext
+    lib = _ext.load()
+    assert _ext.set_option("bf16_no256", 1) == 0
+    v = ctypes.c_int(-1)
+    assert lib.myolo_get_option(b"bf16_no256", ctypes.byref(v)) == 0 and v.value == 1
+    with _ext.option("bf16_no256", 0):
+        lib.myolo_get_option(b"bf16_no256", ctypes.byref(v))
+        assert v.value == 0
+    lib.myolo_get_option(b"bf16_no256", ctypes.byref(v))
+    assert v.value == 1
+    _ext.set_option("bf16_no256", 0)
+    assert lib.myolo_set_option(b"no_such_switch", 1) == -1 and b"unknown option" in lib.myolo_last_error_string()
+    for src in ("gemm_kernels.hip", "mem_kernels.hip", "bf16_kernels.hip", "wino_kernels.hip", "exact_kernels.hip", "comm_rccl.hip"):
+        assert "getenv" not in open(os.path.join(ROOT, "mask-yolo_amd", "csrc", src)).read(), src
+
+
+def test_comm_entry_points_validate_arguments_without_gpu():
+    from myolo import _ext
+    lib = _ext.load()
+    assert lib.myolo_comm_init(2, 2, None, None) == -1                  # rank out of range / null id: rejected before RCCL is touched
+    assert lib.myolo_allreduce_sum_f32(None, 4, None, None) == -1
+    assert lib.myolo_comm_destroy(None) == 0
+
+
+def test_bench_self_launches_under_torchrun(monkeypatch):
+    """plain `python bench.py --gpus 2` (no torchrun env) re-executes itself as one rank per GPU over 127.0.0.1."""
+    import importlib
+    import sys
+    import subprocess
+    bench = importlib.import_module("bench")
+    seen = {}
+    monkeypatch.setattr(subprocess, "call", lambda cmd, env=None: seen.update(cmd=cmd, env=env) or 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_algorithmic_work_matches_survey():
+    import importlib
+    bench = importlib.import_module("bench")
+    assert abs(bench.dw_bytes(224, 1.0, 1) / 1e6 - 20.97) < 0.01          # SURVEY 8(d): 20.97 MB / image over the 14 dw layers
+    fl, _ = bench.pw_flops_bytes(224, 1.0, 1)
+    assert abs(fl / 1e6 - (488.2 + 770.8)) < 1.0                          # backbone + YOLO-head pointwise MFLOP / image
