@@ -45,7 +45,10 @@ size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
 
 /* Tuning / ablation switches (process-wide ints, default 0 = shipped behaviour).  Names: "no_nt", "gemm_generic",
  * "no_splitk", "gemm_w256", "wino_nt", "wino_w256", "bf16_regstage", "bf16_no256", "bf16_force256", "crop_bwd_nolds",
- * "wino_fused".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract. */
+ * "wino_fused".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
+ * One semantic switch: "bn_fused_tf_variance" (default 1) -- the BatchNormalization moving-variance update of bn_stats
+ * restates Keras 2.2.x on TensorFlow 1.x's fused path (tf.nn.fused_batch_norm hands Keras the Bessel-corrected batch
+ * variance, Keras multiplies by n/(n-(1+eps)) on top); 0 = Keras' factor on the biased variance (non-fused backend). */
 int myolo_set_option(const char* name, int value);
 int myolo_get_option(const char* name, int* value);
 
@@ -112,7 +115,8 @@ int myolo_colsum(const float* x, float* out, int64_t M, int C, void* ws, size_t 
 /* ---- BatchNormalization(axis=-1, eps=1e-3, momentum=0.99) (model.py:51,690-708) ----
  * bn_stats: batch mean / biased variance of x[M,C]; writes mean,var and the fused affine
  *   scale = gamma*rsqrt(var+eps), shift = beta - mean*scale; if moving_* non-null updates them
- *   Keras-style (momentum 0.99, variance rescaled by M/(M-(1+eps))).
+ *   Keras-style (momentum 0.99, variance rescaled by M/(M-(1+eps)), on top of TF's fused-path M/(M-1): see
+ *   myolo_set_option "bn_fused_tf_variance").
  * bn_frozen_coeffs: same scale/shift from the moving statistics (inference / training=False).
  * bn_apply_act: y = act(x*scale + shift).
  * bn_act_bwd: dy is the gradient wrt act(...) output; recomputes the activation mask from x;

@@ -30,7 +30,8 @@ extern "C" int myolo_version(void) { return 200; }
 // ---------------------------------------------------------------------------------------
 // tuning switches (myolo_set_option): plain process-wide ints, no environment reads anywhere
 // ---------------------------------------------------------------------------------------
-MyoloOptions g_myolo_opt = {};
+static MyoloOptions default_options() { MyoloOptions o = {}; o.bn_fused_tf_variance = 1; return o; }
+MyoloOptions g_myolo_opt = default_options();
 static int* option_slot(const char* name)
 {
     static const struct { const char* n; int MyoloOptions::*m; } tab[] = {
@@ -38,7 +39,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"wino_fused", &MyoloOptions::wino_fused},
+        {"wino_fused", &MyoloOptions::wino_fused}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -264,6 +265,7 @@ struct FinBnStats {                  // batch statistics -> mean / var / folded 
     const float* beta;
     float *mean, *var, *scale, *shift, *mmean, *mvar;
     double M;
+    int fused_tf;       // moving variance fed with tf.nn.fused_batch_norm's Bessel-corrected batch variance (see below)
     __device__ void operator()(int, double) const {}
     __device__ void pair(int c, double sum, double sumsq) const
     {
@@ -277,7 +279,14 @@ struct FinBnStats {                  // batch statistics -> mean / var / folded 
         scale[c] = sc;
         shift[c] = beta[c] - (float)mu * sc;
         if (mmean) {
-            const float vu = (float)vr * ((float)M / ((float)M - (1.0f + BN_EPS_F)));
+            // Keras 2.2 BatchNormalization.call multiplies the batch variance it gets from the backend by n/(n-(1+eps))
+            // before the moving-average update.  On the TensorFlow backend a 4-D NHWC input with axis=-1 (every BN of this
+            // graph, the TimeDistributed ones included) goes through tf.nn.fused_batch_norm, whose batch_variance output is
+            // already Bessel-corrected (variance * n/(n-1), n > 1): both factors apply (option bn_fused_tf_variance = 1,
+            // default).  0 restates the non-fused backend path (Keras' factor on the biased variance only).
+            float vb = (float)vr;
+            if (fused_tf && M > 1.0) vb = vb * ((float)M / ((float)M - 1.0f));
+            const float vu = vb * ((float)M / ((float)M - (1.0f + BN_EPS_F)));
             mmean[c] = mmean[c] * BN_MOMENTUM_F + (float)mu * (1.0f - BN_MOMENTUM_F);
             mvar[c] = mvar[c] * BN_MOMENTUM_F + vu * (1.0f - BN_MOMENTUM_F);
         }
@@ -1169,7 +1178,7 @@ void myolo_bn_stats_from_partials(const double* part, double* tot, int nblk, int
                                   float* mean, float* var, float* scale, float* shift, float* mmean, float* mvar, hipStream_t s)
 {
     hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C,
-                       FinBnStats{gamma, beta, mean, var, scale, shift, mmean, mvar, M});
+                       FinBnStats{gamma, beta, mean, var, scale, shift, mmean, mvar, M, g_myolo_opt.bn_fused_tf_variance});
 }
 
 // =======================================================================================
@@ -1205,7 +1214,7 @@ int myolo_bn_stats(const float* x, const float* gamma, const float* beta, float*
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
     OpStats op{x, C};
-    run_colreduce(op, M, C, part, tot, s, FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M});
+    run_colreduce(op, M, C, part, tot, s, FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -8,7 +8,7 @@
 extern "C" void myolo_set_error(const char* fmt, ...);
 
 // Process-wide tuning switches, changed ONLY through myolo_set_option() (include/myolo_hip.h): the launch path reads
-// plain ints, never the environment.  All default to 0 = the shipped behaviour.
+// plain ints, never the environment.  Tuning switches default to 0 = the shipped behaviour.
 struct MyoloOptions {
     int no_nt;            // gemm: never use streaming (non-temporal) stores for large outputs
     int gemm_generic;     // gemm: force the generic (guarded) kernels
@@ -21,6 +21,10 @@ struct MyoloOptions {
     int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
     int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS
     int wino_fused;       // 3x3 conv: fused Winograd kernel (transforms in LDS / registers), 1 = on where supported
+    // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
+    // 1 = Keras 2.2.x on TF-1.x through tf.nn.fused_batch_norm (Bessel-corrected batch variance, then Keras' n/(n-(1+eps)));
+    // 0 = Keras' factor on the biased variance (non-fused backend path).
+    int bn_fused_tf_variance;
 };
 extern MyoloOptions g_myolo_opt;
 

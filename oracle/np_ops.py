@@ -215,9 +215,24 @@ def bn_train_bwd(cache, gamma, dy):
     return dx.astype(F32).reshape(dy.shape), dgamma.astype(F32), dbeta.astype(F32)
 
 
-def bn_moving_update(moving_mean, moving_var, mean, var, n):
-    """Keras 2.2 BatchNormalization.call: moving = moving*m + batch*(1-m), with the batch
-    variance rescaled by n/(n-(1+eps)) before the update."""
+# Which Keras / TensorFlow pair the moving-variance update restates (the reference pins neither: model.py:27-28 only
+# assert TF >= 1.3 and Keras >= 2.0.8; `get_keras_submodule`, model.py:18, implies Keras 2.2.x + keras_applications >= 1.0.5).
+#   True  (default): Keras 2.2.x on TensorFlow 1.x.  Every BatchNormalization of this graph sees a 4-D NHWC tensor with
+#          axis=-1 (TimeDistributed reshapes to [B*R,14,14,C]), which keras/backend/tensorflow_backend.py
+#          normalize_batch_in_training sends to tf.nn.fused_batch_norm; its `batch_variance` output is the Bessel-corrected
+#          estimate (tensorflow/core/kernels/fused_batch_norm_op.cc: variance * rest_size / (rest_size - 1)), and Keras'
+#          BatchNormalization.call multiplies whatever the backend returns by sample_size / (sample_size - (1 + epsilon)).
+#   False: the non-fused backend path: Keras' factor on the biased variance only.
+BN_FUSED_TF_VARIANCE = True
+
+
+def bn_moving_update(moving_mean, moving_var, mean, var, n, fused_tf=None):
+    """Keras 2.2 BatchNormalization.call: moving = moving*m + batch*(1-m), with the batch variance rescaled by
+    n/(n-(1+eps)) before the update -- applied to TF's fused-path (Bessel-corrected) variance when fused_tf."""
+    if fused_tf is None:
+        fused_tf = BN_FUSED_TF_VARIANCE
+    if fused_tf and n > 1:
+        var = var * (F32(n) / (F32(n) - F32(1.0)))
     var_u = var * (F32(n) / (F32(n) - (F32(1.0) + BN_EPS)))
     mm = moving_mean * BN_MOMENTUM + mean * (F32(1) - BN_MOMENTUM)
     mv = moving_var * BN_MOMENTUM + var_u * (F32(1) - BN_MOMENTUM)

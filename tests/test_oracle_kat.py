@@ -153,9 +153,12 @@ def test_bn_train_backward_finite_difference():
 
 
 def test_bn_moving_update_keras_formula():
-    mm, mv = O.bn_moving_update(np.zeros(1, F32), np.ones(1, F32), np.array([2.0], F32), np.array([4.0], F32), 10)
+    mm, mv = O.bn_moving_update(np.zeros(1, F32), np.ones(1, F32), np.array([2.0], F32), np.array([4.0], F32), 10, fused_tf=False)
     assert abs(mm[0] - 0.02) < 1e-7
     assert abs(mv[0] - (0.99 + 0.01 * 4.0 * 10 / (10 - 1.001))) < 1e-6
+    # default: Keras' factor on top of tf.nn.fused_batch_norm's Bessel-corrected batch variance (see tests/test_third_party_kats.py)
+    _, mv = O.bn_moving_update(np.zeros(1, F32), np.ones(1, F32), np.array([2.0], F32), np.array([4.0], F32), 10)
+    assert abs(mv[0] - (0.99 + 0.01 * 4.0 * (10 / 9.0) * 10 / (10 - 1.001))) < 1e-6
 
 
 def test_deconv_layout():
