@@ -137,10 +137,12 @@ def decode_masks(detections, myolo_mask, image_shape):
 
 
 def detect_post(detections, myolo_mask, image_shape, cs_threshold=0.35):
-    """model.py:1290-1321 minus the debug override at :1306."""
+    """model.py:1290-1321 minus the debug override at :1306 (`nmb_indices = [109, 130]`)."""
     boxes, class_ids, scores, full = decode_masks(detections, myolo_mask, image_shape)
     top10 = np.argsort(scores)[::-1][:10]
     kept = np.array([i for i in top10 if scores[i] >= cs_threshold], dtype=np.int64)
     idx = nmb(boxes[kept], class_ids[kept], kept, image_shape, nms_threshold=0.7) if len(kept) else kept
     idx = np.asarray(idx, dtype=np.int64)
-    return dict(bboxes=boxes[idx], class_ids=class_ids[idx], confidence_scores=scores[idx], full_masks=full[:, :, idx])
+    # model.py:1307 scales the kept boxes to pixels (`i * 224`, the reference's only image size): x by the width, y by the height
+    scale = np.array([image_shape[1], image_shape[0], image_shape[1], image_shape[0]], dtype=boxes.dtype)
+    return dict(bboxes=boxes[idx] * scale, class_ids=class_ids[idx], confidence_scores=scores[idx], full_masks=full[:, :, idx])
