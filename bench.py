@@ -300,8 +300,10 @@ def bench_train(args, rank, world, local):
     ps = cfg.MASK_POOL_SIZE
     M = args.batch * R * ps * ps
     flop_direct = 2.0 * M * (9 * 256) * 256                   # one mask-head 3x3 conv as a direct convolution
+    from myolo import _ext as X
     tiles_w = args.batch * R * ((ps + 3) // 4) ** 2
-    wflop = 2.0 * 36 * tiles_w * 256 * 256                    # Winograd F(4x4,3x3): 36 products per tile and channel pair
+    ptiles = X.wino_plane_elems(args.batch * R, ps, ps, 1)     # point-tiles: 36 per tile, fewer where the ragged edge uses F(2,3)
+    wflop = 2.0 * ptiles * 256 * 256                          # one 256x256 product per point-tile
     traffic, traffic_src = None, None
     if fus_n:
         kflop, kms, kn = wflop, fus_ms, fus_n
@@ -310,8 +312,9 @@ def bench_train(args, rank, world, local):
         pmc = "r2_pmc_wino_fused.json"
     elif mul_n:
         kflop, kms, kn = wflop, mul_ms, mul_n
-        kname = "gemm_nn_fast<PLAIN> x36 batched (Winograd F(4x4,3x3) multiply stage of the mask-head 3x3 convs, M=%d K=256 N=256 per point)" % tiles_w
-        kbytes = 36.0 * tiles_w * (256 + 256) * 4 + 36 * 256 * 256 * 4
+        kname = ("gemm_nn_fast<PLAIN> batched over the 36 Winograd points (multiply stage of the mask-head 3x3 convs; mixed F(4,3)/F(2,3) tiling: "
+                 "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (ptiles, ptiles / float(args.batch * R)))
+        kbytes = float(ptiles) * (256 + 256) * 4 + 36 * 256 * 256 * 4
         pmc = "r1_pmc_wino_multiply.json"
     else:
         kflop, kms, kn = flop_direct, conv_ms, conv_n
@@ -358,7 +361,7 @@ def bench_train(args, rank, world, local):
                               "achieved_gbs": pwb / (pw_ms * 1e-3) / 1e9 if pw_ms > 0 else 0.0,
                               "frac_of_hbm_peak": pwb / (pw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pw_ms > 0 else 0.0}}
     if mul_n and woi_n:
-        vbytes = 36.0 * tiles_w * 256 * 4
+        vbytes = float(ptiles) * 256 * 4
         roofline["hbm_stages"] = ([hbm_obj("wino_in_kernel (input transform: activation -> V)", float(M) * 256 * 4 + vbytes, win_ms)] if win_n else []) + [
             hbm_obj("wino_out_in_kernel (layer boundary M_i -> V_{i+1} through LDS)", 2 * vbytes, woi_ms)]
     res = {

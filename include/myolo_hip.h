@@ -45,7 +45,7 @@ size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
 
 /* Tuning / ablation switches (process-wide ints, default 0 = shipped behaviour).  Names: "no_nt", "gemm_generic",
  * "no_splitk", "gemm_w256", "wino_nt", "wino_w256", "bf16_regstage", "bf16_no256", "bf16_force256", "crop_bwd_nolds",
- * "wino_fused".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
+ * "wino_no_mixed", "wino_fused".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
  * One semantic switch: "bn_fused_tf_variance" (default 1) -- the BatchNormalization moving-variance update of bn_stats
  * restates Keras 2.2.x on TensorFlow 1.x's fused path (tf.nn.fused_batch_norm hands Keras the Bessel-corrected batch
  * variance, Keras multiplies by n/(n-(1+eps)) on top); 0 = Keras' factor on the biased variance (non-fused backend). */
@@ -239,10 +239,15 @@ int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias
  * fwd: optional scale/shift = folded frozen BatchNorm applied after the bias (as conv3x3_affine_act_fwd); v_keep
  * (nullable) receives the transformed input [36][N*ceil(H/4)*ceil(W/4)][Cin] so bwd_weight can reuse it (v_saved). ---- */
 size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int which);
+/* elements of the 36 transformed planes V (or M) of an [N,H,W,C] tensor (<= 36*N*ceil(H/4)*ceil(W/4)*C: with mixed tiling --
+ * F(2,3) on a last tile row / column that holds <= 2 outputs, e.g. 14 = 4+4+4+2 -- reduced tiles have no row in the planes of
+ * the points they do not use; at 14x14 that is 484 instead of 576 point-tiles per image) */
+size_t myolo_wino_plane_elems(int N, int H, int W, int C);
 int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
                            int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
 /* the forward's four stages, callable on their own: U [36][Cin][Cout] (flip=1: rotated, [36][Cout][Cin], for the data
- * gradient), V [36][T][Cin], M [36][T][Cout] with T = N*ceil(H/4)*ceil(W/4) */
+ * gradient), V and M = 36 planes of myolo_wino_plane_elems(N,H,W,C) elements in total (a buffer of 36*T*C floats,
+ * T = N*ceil(H/4)*ceil(W/4), always suffices); planes are ordered by point group, see csrc/wino_kernels.hip */
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream);
 int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);

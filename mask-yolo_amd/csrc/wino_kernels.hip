@@ -8,9 +8,19 @@
 //   data grad    the same algorithm on dY with the filter rotated by 180 degrees and (ci,co) exchanged
 //   weight grad  dU(ci,co) = sum_tiles V(ci) .* (A dY A^T)(co),  dW = G^T dU G
 //
-// Data layout: V / M planes are [36][T][C] (T = N*TH*TW tiles, TH = ceil(H/4)); the 36 per-point products are ONE batched
-// launch of the plain fp32 MFMA GEMM (gemm_kernels.hip, grid z = transform point).  The transforms are HBM-bound
-// streaming kernels: one lane = 4 channels of one tile, every access a contiguous 16 B per lane.
+// Mixed tiling: where the last tile row / column of an image holds at most 2 valid outputs (14 = 4+4+4+2), that direction uses
+// F(2,3) for those tiles.  Its interpolation points {0, 1, -1, inf} are a subset S = {0,1,2,5} of F(4,3)'s {0, 1, -1, 2, -2, inf}
+// and the transformed filters differ only by a per-point factor rho = (4, -3, -3, 1), which is folded into the data transform
+// of the reduced tiles -- so ONE set of 36 transformed filters serves every tile, a reduced tile simply has no row in the planes
+// of the points it does not use, and at 14x14 an image costs 484 point-tiles instead of 576 (16 % fewer multiplications,
+// 16 % smaller V / M planes), with F(2,3)'s better conditioning on those tiles.
+//
+// Data layout: 36 planes V[q] / M[q] of [rows_q][C]; q orders the points (i,j) by group: g0 = both indices in S (16 points,
+// rows = all N*TH*TW tiles), g1 = j outside S (8 points, tiles of the reduced column absent), g2 = i outside S (8 points), g3 =
+// neither (4 points).  Planes of one group are contiguous with the same row count, so the per-point products are one batched
+// launch of the plain fp32 MFMA GEMM per group (gemm_kernels.hip, grid z = point).  Without a reduced direction (H, W multiples
+// of 4 or remainder 3) every plane has T rows and the layout is [36][T][C] in q order.  The transforms are HBM-bound streaming
+// kernels: one lane = 4 channels of one tile, every access a contiguous 16 B per lane.
 #include "myolo_common.h"
 
 __device__ __forceinline__ float4 f4(float a) { return make_float4(a, a, a, a); }
@@ -71,10 +81,92 @@ __device__ __forceinline__ void gt6(const float d[6], float w[3])
     w[2] = -(d[1] + d[2]) * (1.f / 6.f) + (d[3] + d[4]) * (1.f / 6.f) + d[5];
 }
 
+// ---- F(2,3) in one direction, embedded in the F(4,3) point set S = {0,1,2,5} (rho folded into the data transform) ----
+// rho * B2^T on the first 4 entries of the patch (entries 4, 5 lie outside the image): t[3], t[4] are not produced
+template <typename T>
+__device__ __forceinline__ void bt6x(const T d[6], T t[6], bool red)
+{
+    if (red) {
+        t[0] = 4.f * (d[0] - d[2]);
+        t[1] = -3.f * (d[1] + d[2]);
+        t[2] = 3.f * (d[1] - d[2]);
+        t[3] = d[0] - d[0];
+        t[4] = t[3];
+        t[5] = d[1] - d[3];
+    } else {
+        bt6(d, t);
+    }
+}
+// A2^T (2x4) on (m0, m1, m2, m5): y[2], y[3] are not produced
+template <typename T>
+__device__ __forceinline__ void at6x(const T m[6], T y[4], bool red)
+{
+    if (red) {
+        y[0] = m[0] + m[1] + m[2];
+        y[1] = m[1] - m[2] - m[5];
+        y[2] = m[0] - m[0];
+        y[3] = y[2];
+    } else {
+        at6(m, y);
+    }
+}
+// A2 (4x2) on (d0, d1) -> (q0, q1, q2, q5)
+template <typename T>
+__device__ __forceinline__ void a4x(const T d[4], T q[6], bool red)
+{
+    if (red) {
+        q[0] = d[0];
+        q[1] = d[0] + d[1];
+        q[2] = d[0] - d[1];
+        q[3] = d[0] - d[0];
+        q[4] = q[3];
+        q[5] = q[3] - d[1];
+    } else {
+        a4(d, q);
+    }
+}
+
+__host__ __device__ constexpr bool in_s(int i) { return i < 3 || i == 5; }
+// plane index of transform point (i, j): group-major (see the header comment)
+__host__ __device__ constexpr int q_of(int i, int j)
+{
+    const int si = i == 5 ? 3 : i, sj = j == 5 ? 3 : j;          // index inside S
+    const int ni = i - 3, nj = j - 3;                             // index inside the complement {3, 4}
+    return in_s(i) ? (in_s(j) ? si * 4 + sj : 16 + si * 2 + nj) : (in_s(j) ? 24 + ni * 4 + sj : 32 + ni * 2 + nj);
+}
+__host__ __device__ constexpr int grp_of(int i, int j) { return (in_s(i) ? 0 : 2) + (in_s(j) ? 0 : 1); }
+__host__ __device__ constexpr int qfirst_of(int g) { return g == 0 ? 0 : g == 1 ? 16 : g == 2 ? 24 : 32; }
+
 struct TileGeom {
     int H, W, TH, TW;
-    long long T;       // tiles in total
+    int redv, redh;        // 1: the last tile row / column uses F(2,3) (it holds <= 2 valid outputs)
+    long long T;           // tiles in total
+    long long R[4];        // rows of a plane of group g
+    long long gstart[4];   // first row of group g's first plane (rows are counted across all planes)
+    long long rows;        // rows of all 36 planes together
 };
+
+// where one lane's tile lives in the planes: element offset of its row in the FIRST plane of each group (+ channel), and the
+// plane stride of the group.  Element (i, j) of the tile is at  base[g] + (q_of(i,j) - qfirst_of(g)) * stride[g].
+struct TileRows {
+    long long base[4], stride[4];
+    bool rv, rh;           // this tile is reduced vertically / horizontally
+};
+__device__ __forceinline__ TileRows tile_rows(const TileGeom& g, long long img, int ty, int tx, int C, int c)
+{
+    TileRows r;
+    r.rv = g.redv && ty == g.TH - 1;
+    r.rh = g.redh && tx == g.TW - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int nv = g.TH - ((k & 2) ? g.redv : 0), nh = g.TW - ((k & 1) ? g.redh : 0);
+        r.base[k] = (g.gstart[k] + img * (long long)(nv * nh) + (long long)ty * nh + tx) * C + c;      // unused when the tile is absent
+        r.stride[k] = g.R[k] * (long long)C;
+    }
+    return r;
+}
+#define WINO_ACTIVE(tr, i, j) ((in_s(i) || !(tr).rv) && (in_s(j) || !(tr).rh))
+#define WINO_ADDR(tr, i, j) ((tr).base[grp_of(i, j)] + (long long)(q_of(i, j) - qfirst_of(grp_of(i, j))) * (tr).stride[grp_of(i, j)])
 
 __device__ __forceinline__ float4 affine_act4(float4 v, float4 sc, float4 sh, int act)
 {
@@ -119,7 +211,6 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
 {
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
-    const long long plane = g.T * (long long)C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long t = idx / c4n;
         const int c = (int)(idx - t * c4n) * 4;
@@ -127,6 +218,7 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
         const int rem = (int)(t - img * (g.TH * g.TW));
         const int ty = rem / g.TW, tx = rem - ty * g.TW;
         const int y0 = 4 * ty - 1, x0 = 4 * tx - 1;
+        const TileRows tr = tile_rows(g, img, ty, tx, C, c);
         const float* base = x + img * (long long)g.H * g.W * C + c;
         const float4 sc = scale ? ldg4(scale + c) : f4(1.f);
         const float4 sh = scale ? ldg4(shift + c) : f4(0.f);
@@ -158,17 +250,17 @@ __global__ __launch_bounds__(256) void wino_in_kernel(const float* __restrict__ 
                 if (LAZY) { if (in) d[i] = lazy4(d[i], gq[i], lk, lz.act); }
                 else if (scale && in) d[i] = affine_act4(d[i], sc, sh, act);
             }
-            bt6(d, r);
+            bt6x(d, r, tr.rv);
 #pragma unroll
             for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
         }
-        float* out = V + t * C + c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             float4 r[6];
-            bt6(tmp[i], r);
+            bt6x(tmp[i], r, tr.rh);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+            for (int j = 0; j < 6; ++j)
+                if (WINO_ACTIVE(tr, i, j)) stg4(V + WINO_ADDR(tr, i, j), r[j]);
         }
     }
 }
@@ -201,13 +293,13 @@ __global__ __launch_bounds__(256) void wino_in_crop_kernel(const float* __restri
 {
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
-    const long long plane = g.T * (long long)C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long t = idx / c4n;
         const int c = (int)(idx - t * c4n) * 4;
         const long long roi = t / (g.TH * g.TW);
         const int rem = (int)(t - roi * (g.TH * g.TW));
         const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        const TileRows tr = tile_rows(g, roi, ty, tx, C, c);
         const float4 bx = ldg4(boxes + roi * 4);               // y1, x1, y2, x2
         const float* base = feat + (long long)bind[roi] * FH * FW * C + c;
         CropAxis ay[6], ax[6];
@@ -244,17 +336,17 @@ __global__ __launch_bounds__(256) void wino_in_crop_kernel(const float* __restri
                     d[i] = (ay[i].ok && ax[j].ok) ? o : f4(0.f);
                 }
             }
-            bt6(d, r);
+            bt6x(d, r, tr.rv);
 #pragma unroll
             for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
         }
-        float* out = V + t * C + c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             float4 r[6];
-            bt6(tmp[i], r);
+            bt6x(tmp[i], r, tr.rh);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+            for (int j = 0; j < 6; ++j)
+                if (WINO_ACTIVE(tr, i, j)) stg4(V + WINO_ADDR(tr, i, j), r[j]);
         }
     }
 }
@@ -270,21 +362,20 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
     float4 s1 = f4(0.f), s2 = f4(0.f);
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
-    const long long plane = g.T * (long long)C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long t = idx / c4n;
         const int c = (int)(idx - t * c4n) * 4;
         const long long img = t / (g.TH * g.TW);
         const int rem = (int)(t - img * (g.TH * g.TW));
         const int ty = rem / g.TW, tx = rem - ty * g.TW;
-        const float* in = M + t * C + c;
+        const TileRows tr = tile_rows(g, img, ty, tx, C, c);
         float4 tmp[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             float4 m[6], r[4];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = ldg4(in + (long long)(i * 6 + j) * plane);
-            at6(m, r);
+            for (int i = 0; i < 6; ++i) m[i] = WINO_ACTIVE(tr, i, j) ? ldg4(M + WINO_ADDR(tr, i, j)) : f4(0.f);
+            at6x(m, r, tr.rv);
 #pragma unroll
             for (int i = 0; i < 4; ++i) tmp[i][j] = r[i];
         }
@@ -295,7 +386,7 @@ __global__ __launch_bounds__(256) void wino_out_kernel(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 r[4];
-            at6(tmp[i], r);
+            at6x(tmp[i], r, tr.rh);
             const int yy = 4 * ty + i;
             if (yy >= g.H) continue;
 #pragma unroll
@@ -341,13 +432,13 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 {
     const int c4n = C >> 2;
     const long long total = g.T * c4n;
-    const long long plane = g.T * (long long)C;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
         const long long t = idx / c4n;
         const int c = (int)(idx - t * c4n) * 4;
         const long long img = t / (g.TH * g.TW);
         const int rem = (int)(t - img * (g.TH * g.TW));
         const int ty = rem / g.TW, tx = rem - ty * g.TW;
+        const TileRows tr = tile_rows(g, img, ty, tx, C, c);
         const float* base = dy + img * (long long)g.H * g.W * C + c;
         LazyBnCh lk;
         const float* gbase = nullptr;
@@ -374,22 +465,22 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
                 for (int i = 0; i < 4; ++i)
                     if (xx < g.W && 4 * ty + i < g.H) d[i] = lazy4(d[i], gq[i], lk, lz.act);
             }
-            a4(d, r);
+            a4x(d, r, tr.rv);
 #pragma unroll
             for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
         }
-        float* out = Q + t * C + c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             float4 r[6];
-            a4(tmp[i], r);
+            a4x(tmp[i], r, tr.rh);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+            for (int j = 0; j < 6; ++j)
+                if (WINO_ACTIVE(tr, i, j)) stg4(Q + WINO_ADDR(tr, i, j), r[j]);
         }
     }
 }
 
-// w [3,3,Ci,Co] -> U [36][Ci][Co]   (flip = 0)
+// w [3,3,Ci,Co] -> U [36][Ci][Co]   (flip = 0), planes in q order (q_of(i, j))
 //                  U'[36][Co][Ci] of the 180-degree rotated filter with (ci,co) exchanged (flip = 1: data gradient)
 __global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int flip)
 {
@@ -416,7 +507,7 @@ __global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w
         float u[6];
         g3(tmp[i], u);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) U[(i * 6 + j) * plane + o] = u[j];
+        for (int j = 0; j < 6; ++j) U[q_of(i, j) * plane + o] = u[j];
     }
 }
 
@@ -431,7 +522,7 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
     for (int j = 0; j < 6; ++j) {
         float col[6], r[3];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) col[i] = dU[(i * 6 + j) * plane + idx];
+        for (int i = 0; i < 6; ++i) col[i] = dU[q_of(i, j) * plane + idx];
         gt6(col, r);
 #pragma unroll
         for (int k = 0; k < 3; ++k) tmp[k][j] = r[k];
@@ -461,18 +552,16 @@ __global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restric
     const int c = blockIdx.y * WOI_CS + (threadIdx.x & 7) * 4;
     const int tl = threadIdx.x >> 3;                                   // tile inside the image
     const int ty = tl / g.TW, tx = tl - ty * g.TW;
-    const long long t = (long long)img * (g.TH * g.TW) + tl;
-    const long long plane = g.T * (long long)C;
+    const TileRows tr = tile_rows(g, img, ty, tx, C, c);
     const bool wr = y && (!flags || flags[img] != 0);
     {
-        const float* in = M + t * C + c;
         float4 tmp[4][6];
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             float4 m[6], r[4];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) m[i] = ldg4(in + (long long)(i * 6 + j) * plane);
-            at6(m, r);
+            for (int i = 0; i < 6; ++i) m[i] = WINO_ACTIVE(tr, i, j) ? ldg4(M + WINO_ADDR(tr, i, j)) : f4(0.f);
+            at6x(m, r, tr.rv);
 #pragma unroll
             for (int i = 0; i < 4; ++i) tmp[i][j] = r[i];
         }
@@ -483,7 +572,7 @@ __global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float4 r[4];
-            at6(tmp[i], r);
+            at6x(tmp[i], r, tr.rh);
             const int yy = 4 * ty + i;
             if (yy >= g.H) continue;
 #pragma unroll
@@ -516,17 +605,17 @@ __global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restric
                 d[i] = (xin && (unsigned)yy < (unsigned)g.H)
                            ? *reinterpret_cast<const float4*>(&ysm[(yy * g.W + xx) * WOI_CS + (threadIdx.x & 7) * 4]) : f4(0.f);
             }
-            bt6(d, r);
+            bt6x(d, r, tr.rv);
 #pragma unroll
             for (int i = 0; i < 6; ++i) tmp[i][j] = r[i];
         }
-        float* out = Vn + t * C + c;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             float4 r[6];
-            bt6(tmp[i], r);
+            bt6x(tmp[i], r, tr.rh);
 #pragma unroll
-            for (int j = 0; j < 6; ++j) stg4(out + (long long)(i * 6 + j) * plane, r[j]);
+            for (int j = 0; j < 6; ++j)
+                if (WINO_ACTIVE(tr, i, j)) stg4(Vn + WINO_ADDR(tr, i, j), r[j]);
         }
     }
 }
@@ -535,7 +624,19 @@ static TileGeom geom(int N, int H, int W)
 {
     TileGeom g;
     g.H = H; g.W = W; g.TH = (H + 3) / 4; g.TW = (W + 3) / 4;
+    // mixed tiling: F(2,3) for the last tile row / column when it holds <= 2 valid outputs (and is not the only one)
+    const bool mixed = !g_myolo_opt.wino_no_mixed;
+    g.redv = (mixed && g.TH > 1 && H - 4 * (g.TH - 1) <= 2) ? 1 : 0;
+    g.redh = (mixed && g.TW > 1 && W - 4 * (g.TW - 1) <= 2) ? 1 : 0;
     g.T = (long long)N * g.TH * g.TW;
+    long long at = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int nv = g.TH - ((k & 2) ? g.redv : 0), nh = g.TW - ((k & 1) ? g.redh : 0);
+        g.R[k] = (long long)N * nv * nh;
+        g.gstart[k] = at;
+        at += g.R[k] * (k == 0 ? 16 : k == 3 ? 4 : 8);
+    }
+    g.rows = at;
     return g;
 }
 static unsigned ew_grid(long long total)
@@ -544,8 +645,60 @@ static unsigned ew_grid(long long total)
     if (b > (1 << 20)) b = 1 << 20;
     return (unsigned)(b < 1 ? 1 : b);
 }
-static size_t plane_bytes(const TileGeom& g, int C) { return align256((size_t)36 * g.T * C * sizeof(float)); }
+static size_t plane_bytes(const TileGeom& g, int C) { return align256((size_t)g.rows * C * sizeof(float)); }
 static size_t u_bytes(int Ci, int Co) { return align256((size_t)36 * Ci * Co * sizeof(float)); }
+
+// runs of consecutive groups whose planes have the same row count: one batched GEMM launch each
+struct GroupRun { int q0, nq; long long rows, row0; };
+static int group_runs(const TileGeom& g, GroupRun out[4])
+{
+    static const int cnt[4] = {16, 8, 8, 4};
+    int n = 0, q = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (n && out[n - 1].rows == g.R[k]) out[n - 1].nq += cnt[k];
+        else { out[n].q0 = q; out[n].nq = cnt[k]; out[n].rows = g.R[k]; out[n].row0 = g.gstart[k]; ++n; }
+        q += cnt[k];
+    }
+    return n;
+}
+
+// M[q] = V[q] * U[q] for the 36 points
+static int wino_multiply_all(const float* V, const float* U, float* M, const TileGeom& g, int Cin, int Cout, hipStream_t s)
+{
+    GroupRun runs[4];
+    const int n = group_runs(g, runs);
+    for (int k = 0; k < n; ++k) {
+        if (runs[k].rows <= 0) continue;
+        const int rc = myolo_gemm_nn_batched(V + runs[k].row0 * Cin, U + (long long)runs[k].q0 * Cin * Cout, M + runs[k].row0 * Cout,
+                                             runs[k].rows, Cin, Cout, runs[k].nq, s);
+        if (rc != MYOLO_OK) return rc;
+    }
+    return MYOLO_OK;
+}
+static size_t wino_tn_ws_bytes(const TileGeom& g, int Cin, int Cout)
+{
+    GroupRun runs[4];
+    const int n = group_runs(g, runs);
+    size_t m = 0;
+    for (int k = 0; k < n; ++k) {
+        const size_t b = myolo_gemm_tn_batched_ws_bytes(runs[k].rows, Cin, Cout, runs[k].nq);
+        if (b > m) m = b;
+    }
+    return m;
+}
+// dU[q] = V[q]^T Q[q]
+static int wino_tn_all(const float* V, const float* Q, float* dU, const TileGeom& g, int Cin, int Cout, void* part, size_t part_bytes,
+                       hipStream_t s)
+{
+    GroupRun runs[4];
+    const int n = group_runs(g, runs);
+    for (int k = 0; k < n; ++k) {
+        const int rc = myolo_gemm_tn_batched(V + runs[k].row0 * Cin, Q + runs[k].row0 * Cout, dU + (long long)runs[k].q0 * Cin * Cout,
+                                             runs[k].rows, Cin, Cout, runs[k].nq, part, part_bytes, s);
+        if (rc != MYOLO_OK) return rc;
+    }
+    return MYOLO_OK;
+}
 
 extern "C" {
 
@@ -556,9 +709,13 @@ size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int w
         case 0: return u_bytes(Cin, Cout) + plane_bytes(g, Cin) + plane_bytes(g, Cout);                   // fwd: U, V, M
         case 1: return u_bytes(Cin, Cout) + plane_bytes(g, Cout) + plane_bytes(g, Cin);                   // bwd data: U', V(dy), M
         default: return u_bytes(Cin, Cout) + plane_bytes(g, Cin) + plane_bytes(g, Cout) +                 // bwd weight: dU, V, Q, partials
-                        align256(myolo_gemm_tn_batched_ws_bytes(g.T, Cin, Cout, 36));
+                        align256(wino_tn_ws_bytes(g, Cin, Cout));
     }
 }
+
+/* elements of the 36 V (or M) planes of an [N,H,W,C] tensor: <= 36 * N*ceil(H/4)*ceil(W/4) * C (mixed tiling drops the rows of
+ * reduced tiles from the planes of the points they do not use) */
+size_t myolo_wino_plane_elems(int N, int H, int W, int C) { return (size_t)geom(N, H, W).rows * (size_t)C; }
 
 /* ---- the four stages on their own (the engine times the multiply stage for bench.py's roofline) ---- */
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream)
@@ -601,7 +758,7 @@ int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, 
 {
     MYOLO_REQUIRE(V && U && M && N > 0 && H > 0 && W > 0, "wino_multiply: bad arguments");
     const TileGeom g = geom(N, H, W);
-    const int rc = myolo_gemm_nn_batched(V, U, M, g.T, Cin, Cout, 36, (hipStream_t)stream);
+    const int rc = wino_multiply_all(V, U, M, g, Cin, Cout, (hipStream_t)stream);
     if (rc != MYOLO_OK) return rc;
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
@@ -673,7 +830,7 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     float* Mp = (float*)((char*)ws + ub + vb);
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 0);
     hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
-    const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cin, Cout, 36, s);
+    const int rc = wino_multiply_all(V, U, Mp, g, Cin, Cout, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, Mp, y, bias, scale, shift, g, Cout, act, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
@@ -697,7 +854,7 @@ static int wino_bwd_data_impl(const float* dy, const LazyBn* lazy, const float* 
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 1);
     if (lazy) hipLaunchKernelGGL(wino_in_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, *lazy);
     else hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
-    const int rc = myolo_gemm_nn_batched(V, U, Mp, g.T, Cout, Cin, 36, s);
+    const int rc = wino_multiply_all(V, U, Mp, g, Cout, Cin, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_out_kernel, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, Mp, dx, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, g, Cin, MYOLO_ACT_NONE, (double*)nullptr);
@@ -712,7 +869,7 @@ static int wino_bwd_weight_impl(const float* x, const float* v_saved, const floa
     MYOLO_REQUIRE((Cin & 3) == 0 && (Cout & 3) == 0, "conv3x3_wino_bwd_weight: needs Cin %% 4 == 0 and Cout %% 4 == 0 (got %d, %d)", Cin, Cout);
     const TileGeom g = geom(N, H, W);
     const size_t ub = u_bytes(Cin, Cout), vb = v_saved ? 0 : plane_bytes(g, Cin), qb = plane_bytes(g, Cout);
-    const size_t pb = align256(myolo_gemm_tn_batched_ws_bytes(g.T, Cin, Cout, 36));
+    const size_t pb = align256(wino_tn_ws_bytes(g, Cin, Cout));
     MYOLO_NEED_WS(ub + vb + qb + pb);
     hipStream_t s = (hipStream_t)stream;
     float* dU = (float*)ws;
@@ -722,7 +879,7 @@ static int wino_bwd_weight_impl(const float* x, const float* v_saved, const floa
     if (!v_saved) hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     if (lazy) hipLaunchKernelGGL(wino_dy_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout, *lazy);
     else hipLaunchKernelGGL(wino_dy_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, Q, g, Cout, LazyBn{});
-    const int rc = myolo_gemm_tn_batched(v_saved ? v_saved : V, Q, dU, g.T, Cin, Cout, 36, part, pb, s);
+    const int rc = wino_tn_all(v_saved ? v_saved : V, Q, dU, g, Cin, Cout, part, pb, s);
     if (rc != MYOLO_OK) return rc;
     hipLaunchKernelGGL(wino_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
     MYOLO_CHECK_LAUNCH();

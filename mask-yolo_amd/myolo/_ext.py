@@ -104,6 +104,8 @@ def load():
     lib.myolo_workspace_bytes.restype = Z
     lib.myolo_conv3x3_wino_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_conv3x3_wino_ws_bytes.restype = Z
+    lib.myolo_wino_plane_elems.argtypes = [I, I, I, I]
+    lib.myolo_wino_plane_elems.restype = Z
     lib.myolo_deconv2x2s2_mask_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
     lib.myolo_wino_output_transform_bn_ws_bytes.argtypes = [I]
@@ -113,7 +115,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -168,6 +170,11 @@ def workspace_bytes(rows, cin, cout):
 def wino_ws_bytes(n, h, w, cin, cout, which):
     """scratch bytes of myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2)."""
     return int(load().myolo_conv3x3_wino_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(which)))
+
+
+def wino_plane_elems(n, h, w, c):
+    """floats in the 36 Winograd planes V (or M) of an [n,h,w,c] tensor."""
+    return int(load().myolo_wino_plane_elems(int(n), int(h), int(w), int(c)))
 
 
 def deconv_mask_ws_bytes(n, h, w, cin, cout, ncls):

@@ -167,7 +167,9 @@ def test_winograd_transforms_with_folded_batchnorm(N, H, W, C):
     V1, V2 = new(36, T, C), new(36, T, C)
     X.call("myolo_wino_input_transform", X.ptr(a), X.ptr(V1), N, H, W, C, st)
     X.call("myolo_wino_input_transform_affine", X.ptr(y_ref), X.ptr(sc), X.ptr(sh), 1, X.ptr(V2), N, H, W, C, st)
-    assert float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())
+    n = X.wino_plane_elems(N, H, W, C)                    # the planes' used prefix (mixed tiling: <= 36*T*C)
+    V1, V2 = V1.view(-1)[:n], V2.view(-1)[:n]
+    assert not bool(torch.isnan(V1).any()) and float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())
 
 
 @pytest.mark.parametrize("B,H,W,C,nb,crop", [(2, 28, 28, 256, 40, 14), (3, 7, 9, 16, 11, 5), (1, 16, 16, 64, 6, 8)])
@@ -184,7 +186,36 @@ def test_winograd_input_transform_fused_with_roialign(B, H, W, C, nb, crop):
     X.call("myolo_crop_and_resize_fwd", *a, X.ptr(x), B, H, W, C, nb, crop, crop, X.stream())
     X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V1), nb, crop, crop, C, X.stream())
     X.call("myolo_wino_input_transform_roialign", *a, X.ptr(V2), B, H, W, C, nb, crop, crop, X.stream())
+    n = X.wino_plane_elems(nb, crop, crop, C)
+    V1, V2 = V1.view(-1)[:n], V2.view(-1)[:n]
+    assert not bool(torch.isnan(V1).any())
     assert float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())      # fma contraction differs between the two kernels
+
+
+def test_winograd_mixed_tiling_counts_and_agrees_with_uniform_tiling():
+    """14 = 4+4+4+2: the last tile row / column uses F(2,3) embedded in F(4,3)'s point set, 484 point-tiles per image instead
+    of 576; same convolution as the all-F(4,3) tiling (option wino_no_mixed) to fp32 noise, forward and both gradients."""
+    assert X.wino_plane_elems(1, 14, 14, 1) == 484 and X.wino_plane_elems(1, 28, 28, 1) == 36 * 49
+    assert X.wino_plane_elems(1, 7, 9, 1) == 16 * 6 + 8 * 4 + 8 * 6 + 4 * 4            # 7 = 4+3 (not reduced), 9 = 4+4+1 (reduced)
+    with X.option("wino_no_mixed", 1):
+        assert X.wino_plane_elems(1, 14, 14, 1) == 576
+    rng = np.random.default_rng(3)
+    N, H, W, Cin, Cout = 6, 14, 14, 64, 32
+    x, w, b, dy = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout), rnd(rng, N, H, W, Cout)
+    wsb = torch.empty(max(X.wino_ws_bytes(N, H, W, Cin, Cout, k) for k in (0, 1, 2)) * 2, dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    wsa = (wsb.data_ptr(), wsb.numel())
+    res = []
+    for no_mixed in (0, 1):
+        with X.option("wino_no_mixed", no_mixed):
+            y, dx, dw = new(N, H, W, Cout), new(N, H, W, Cin), new(3, 3, Cin, Cout)
+            X.call("myolo_conv3x3_wino_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), None, None, X.ptr(y), N, H, W, Cin, Cout, 0, None, *wsa, X.stream())
+            X.call("myolo_conv3x3_wino_bwd_data", X.ptr(dt(dy)), X.ptr(dt(w)), X.ptr(dx), N, H, W, Cin, Cout, *wsa, X.stream())
+            X.call("myolo_conv3x3_wino_bwd_weight", X.ptr(dt(x)), None, X.ptr(dt(dy)), X.ptr(dw), N, H, W, Cin, Cout, *wsa, X.stream())
+            torch.cuda.synchronize()
+            res.append([t.cpu().numpy() for t in (y, dx, dw)])
+    for a, bb, name in zip(res[0], res[1], ("y", "dx", "dw")):
+        assert np.isfinite(a).all() and np.abs(a - bb).max() <= 2e-5 * np.abs(bb).max(), name
 
 
 def test_winograd_error_is_at_fp32_level():
