@@ -315,7 +315,7 @@ def bench_train(args, rank, world, local):
         kname = ("gemm_nn_fast<PLAIN> batched over the 36 Winograd points (multiply stage of the mask-head 3x3 convs; mixed F(4,3)/F(2,3) tiling: "
                  "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (ptiles, ptiles / float(args.batch * R)))
         kbytes = float(ptiles) * (256 + 256) * 4 + 36 * 256 * 256 * 4
-        pmc = "r1_pmc_wino_multiply.json"
+        pmc = "r2_pmc_wino_multiply.json"
     else:
         kflop, kms, kn = flop_direct, conv_ms, conv_n
         kname = "gemm_nn_fast<CONV3> (mask-head 3x3 conv fwd, M=%d K=2304 N=256)" % M

@@ -201,9 +201,11 @@ int myolo_shapes_batch(const int32_t* spec, int spec_stride, const double* ancho
 /* ---- inference post-processing: unmold_mask for all detections of one image (myolo_utils.py:883-912 as
  *      called from MaskYOLO.decode_masks model.py:1355-1389).  masks [N,mh,mw,C] post-sigmoid, detections [N,6]
  *      (x1,y1,x2,y2,score,class) normalised; full_masks [H,W,N] uint8 0/1 (class channel picked, order-1 resize to
- *      the clamped pixel window, threshold 0.5, paste). ---- */
+ *      the clamped pixel window, threshold 0.5, paste).  The resize is skimage.transform.resize(order=1, mode='constant',
+ *      cval=0, clip=True, anti_aliasing=False) as the reference's wrapper calls it (myolo_utils.py:433-447): zero border,
+ *      output clipped to the mask's value range.  ws: N * 4 bytes. ---- */
 int myolo_unmold_masks(const float* masks, const float* detections, uint8_t* full_masks,
-                       int N, int mh, int mw, int C, int H, int W, void* stream);
+                       int N, int mh, int mw, int C, int H, int W, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- final mask conv 1x1 + bias + sigmoid (myolo_mask model.py:713-714), C small ---- */
 int myolo_mask_head_out_fwd(const float* x, const float* w, const float* bias, float* p,

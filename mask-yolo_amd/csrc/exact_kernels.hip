@@ -330,8 +330,29 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a)
 // paste.  out[H][W][N] uint8 (the reference's np.stack(axis=-1) layout); lanes run along N so a wave writes
 // N contiguous bytes per pixel.
 // ---------------------------------------------------------------------------------------
+// skimage.transform.resize(..., clip=True) clips its output to the value range of the INPUT mask.  With the zero border of
+// mode='constant' that matters in exactly one case for the 0.5 threshold: a mask whose minimum is already >= 0.5 keeps its rim
+// (the fade towards 0 is clipped back up to the minimum).  allhigh[n] = 1 for such a detection (its class channel).
+__global__ __launch_bounds__(256) void unmold_allhigh_kernel(const float* __restrict__ masks, const float* __restrict__ det,
+                                                             int32_t* __restrict__ allhigh, int mh, int mw, int C)
+{
+    __shared__ int low;
+    const int n = blockIdx.x;
+    if (threadIdx.x == 0) low = 0;
+    __syncthreads();
+    const int cls = (int)det[(long long)n * 6 + 5];
+    const float* m = masks + (long long)n * mh * mw * C + cls;
+    int mine = 0;
+    for (int i = threadIdx.x; i < mh * mw; i += blockDim.x)
+        if (!(m[(long long)i * C] >= 0.5f)) mine = 1;
+    if (mine) low = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) allhigh[n] = low ? 0 : 1;
+}
+
 __global__ __launch_bounds__(256) void unmold_kernel(const float* __restrict__ masks, const float* __restrict__ det,
-                                                     uint8_t* __restrict__ out, int N, int mh, int mw, int C, int H, int W)
+                                                     const int32_t* __restrict__ allhigh, uint8_t* __restrict__ out, int N, int mh, int mw,
+                                                     int C, int H, int W)
 {
     const long long total = (long long)H * W * N;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,17 +372,20 @@ __global__ __launch_bounds__(256) void unmold_kernel(const float* __restrict__ m
             const float sy = (float)mh / (float)oh, sx = (float)mw / (float)ow;
             float fy = ((float)(y - y1) + 0.5f) * sy - 0.5f;
             float fx = ((float)(x - x1) + 0.5f) * sx - 0.5f;
-            fy = fminf(fmaxf(fy, 0.0f), (float)(mh - 1));
-            fx = fminf(fmaxf(fx, 0.0f), (float)(mw - 1));
+            // skimage.transform.resize(order=1, mode='constant', cval=0) as the reference calls it (myolo_utils.py:433-447, 903):
+            // samples outside the 28x28 mask read 0 (NOT the edge value), so an up-scaled mask fades to 0 over the outermost
+            // half source pixel -- pinned against scikit-image 0.18.3 in tests/golden/skimage_resize_fixture.npz
             const int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
-            const int yb = min(y0 + 1, mh - 1), xb = min(x0 + 1, mw - 1);
+            const int yb = y0 + 1, xb = x0 + 1;
             const float wy = fy - (float)y0, wx = fx - (float)x0;
             const float* m = masks + (long long)n * mh * mw * C + cls;
-            const float tl = m[((long long)y0 * mw + x0) * C], tr = m[((long long)y0 * mw + xb) * C];
-            const float bl = m[((long long)yb * mw + x0) * C], br = m[((long long)yb * mw + xb) * C];
+            const bool y0in = (unsigned)y0 < (unsigned)mh, ybin = (unsigned)yb < (unsigned)mh;
+            const bool x0in = (unsigned)x0 < (unsigned)mw, xbin = (unsigned)xb < (unsigned)mw;
+            const float tl = (y0in && x0in) ? m[((long long)y0 * mw + x0) * C] : 0.f, tr = (y0in && xbin) ? m[((long long)y0 * mw + xb) * C] : 0.f;
+            const float bl = (ybin && x0in) ? m[((long long)yb * mw + x0) * C] : 0.f, br = (ybin && xbin) ? m[((long long)yb * mw + xb) * C] : 0.f;
             const float top = tl + (tr - tl) * wx;
             const float bot = bl + (br - bl) * wx;
-            v = (top + (bot - top) * wy) >= 0.5f ? 1 : 0;
+            v = ((top + (bot - top) * wy) >= 0.5f || allhigh[n]) ? 1 : 0;        // clip=True: see unmold_allhigh_kernel
         }
         out[i] = v;
     }
@@ -544,14 +568,17 @@ int myolo_shapes_batch(const int32_t* spec, int spec_stride, const double* ancho
 }
 
 int myolo_unmold_masks(const float* masks, const float* detections, uint8_t* full_masks, int N, int mh, int mw, int C, int H,
-                       int W, void* stream)
+                       int W, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(masks && detections && full_masks && N > 0 && mh > 0 && mw > 0 && C > 0 && H > 0 && W > 0, "unmold_masks: bad arguments");
+    MYOLO_NEED_WS((size_t)N * sizeof(int32_t));
+    int32_t* allhigh = (int32_t*)ws;
+    hipLaunchKernelGGL(unmold_allhigh_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, masks, detections, allhigh, mh, mw, C);
     const long long total = (long long)H * W * N;
     long long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(unmold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, masks, detections, full_masks, N, mh,
-                       mw, C, H, W);
+    hipLaunchKernelGGL(unmold_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, masks, detections, allhigh, full_masks, N,
+                       mh, mw, C, H, W);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

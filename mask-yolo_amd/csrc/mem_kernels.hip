@@ -184,12 +184,18 @@ __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict
     const bool ok = FIN::PAIR ? ((int)blockIdx.x * 4 + (ol & 3)) < C : i < nvc;
     double s0 = 0, s1 = 0;
     if (ok) {
+        // 8 independent loads in flight per thread: the loop is pure load latency (a few hundred partial rows per thread-lane)
+        double s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
         int b = bl;
-        for (; b + 32 < nblk; b += 64) {
-            s0 += part[(long long)b * nvc + i];
-            s1 += part[(long long)(b + 32) * nvc + i];
+        for (; b + 224 < nblk; b += 256) {
+            const double* q = part + (long long)b * nvc + i;
+            const long long st = 32ll * nvc;
+            const double v0 = q[0], v1 = q[st], v2 = q[2 * st], v3 = q[3 * st], v4 = q[4 * st], v5 = q[5 * st], v6 = q[6 * st], v7 = q[7 * st];
+            s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
         }
-        if (b < nblk) s0 += part[(long long)b * nvc + i];
+        for (; b < nblk; b += 32) s0 += part[(long long)b * nvc + i];
+        s0 = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
+        s1 = 0;
     }
     red[bl][ol] = s0 + s1;
     __syncthreads();

@@ -46,7 +46,7 @@ SIGS = {
     "myolo_yolo_detections": [P, P, P, I, I, I, I, P],
     "myolo_yolo_loss": [P, P, P, P, P, F, F, F, F, F, P, P, I, I, I, I, I, P, Z, P],
     "myolo_shapes_batch": [P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, Z, P],
-    "myolo_unmold_masks": [P, P, P, I, I, I, I, I, I, P],
+    "myolo_unmold_masks": [P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_mask_targets": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_mask_head_out_fwd": [P, P, P, P, L, I, I, P],
     "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],

@@ -13,10 +13,11 @@ reference reads the base class from free functions, model.py:25); ``train`` uses
 the dataset unless ``max_samples`` is given (reference hard-codes 50/6, model.py:995,1002);
 ``detect`` keeps the NMB result (reference overrides it with [109,130], model.py:1306), returns ``bboxes`` in
 PIXELS of the input image (x by its width, y by its height; the reference hard-codes ``* 224``, model.py:1307) and
-does not mutate ``Config.BATCH_SIZE`` (model.py:1268); ``train`` runs the validation pass Keras' fit_generator runs
+does not mutate ``Config.BATCH_SIZE`` (model.py:1268); ``load_weights`` reads Keras ``.h5`` weight files with a built-in
+pure-Python HDF5 reader (no h5py in this image) as well as ``.npz``; ``train`` runs the validation pass Keras' fit_generator runs
 (model.py:1053-1054) and keeps the per-epoch numbers in ``self.history``; ``custom_callbacks`` (commented out in the
 reference, model.py:1037-1038) are honoured as plain callables ``cb(epoch, logs)``; checkpoints are ``.npz`` keyed by Keras layer names
-(h5py is not available); weights are cached by (path, mtime) instead of reloaded per call.
+(and Keras ``.h5`` files are read too); weights are cached by (path, mtime) instead of reloaded per call.
 """
 import datetime
 import os
@@ -91,17 +92,25 @@ class MaskYOLO(object):
 
     @staticmethod
     def _load_npz_into(net, filepath, by_name=False, exclude=None):
-        data = np.load(filepath)
-        sd = {}
-        for k in data.files:
-            layer = k.split("/")[0]
-            if exclude and layer in exclude:
-                continue
-            sd[k] = data[k]
+        """.npz keyed '<keras layer name>/<weight name>', or a Keras .h5 / .hdf5 weight file (keras_io.load_h5_state: the
+        reference's checkpoint format, model.py:1024-1027, read without h5py)."""
+        if str(filepath).lower().endswith((".h5", ".hdf5")):
+            from .keras_io import load_h5_state
+            sd = load_h5_state(filepath, exclude=exclude)
+        else:
+            data = np.load(filepath)
+            sd = {}
+            for k in data.files:
+                layer = k.split("/")[0]
+                if exclude and layer in exclude:
+                    continue
+                sd[k] = data[k]
         net.load_state_dict(sd, strict=not (by_name or exclude))
 
     def load_weights(self, filepath, by_name=False, exclude=None):
-        """model.py:1157-1196 with an .npz container keyed '<keras layer name>/<weight name>'."""
+        """model.py:1157-1196: Keras weight files (.h5, as the reference's ModelCheckpoint writes them) or the .npz container
+        keyed '<keras layer name>/<weight name>'.  by_name=True loads the layers present in the file and leaves the others;
+        exclude drops layers by name (and implies by_name, model.py:1181-1187)."""
         if exclude:
             by_name = True
         key = (os.path.abspath(filepath), os.path.getmtime(filepath), by_name, tuple(exclude or ()))
@@ -360,7 +369,9 @@ class MaskYOLO(object):
             return boxes, class_ids, scores, np.empty((H, W, 0))
         mh, mw, C = int(masks.shape[1]), int(masks.shape[2]), int(masks.shape[3])
         full = torch.empty(H, W, N, dtype=torch.uint8, device=det.device)
-        X.call("myolo_unmold_masks", X.ptr(masks.contiguous()), X.ptr(det.contiguous()), X.ptr(full), N, mh, mw, C, H, W, X.stream())
+        ws = torch.empty(N, dtype=torch.int32, device=det.device)
+        X.call("myolo_unmold_masks", X.ptr(masks.contiguous()), X.ptr(det.contiguous()), X.ptr(full), N, mh, mw, C, H, W,
+               ws.data_ptr(), ws.numel() * 4, X.stream())
         return boxes, class_ids, scores, full.cpu().numpy().astype(bool)
 
     def decode_masks(self, detections, myolo_mask, image_shape):

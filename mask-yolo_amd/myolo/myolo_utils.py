@@ -234,19 +234,23 @@ def NMB(boxes, class_ids, indices, image_shape, nms_threshold=0.3):
 
 
 def _resize_bilinear(mask, out_h, out_w):
-    """Order-1 resize with pixel-centre alignment and edge clamp, float32 (stands in for the un-vendored
-    skimage.transform.resize, myolo_utils.py:903; same definition as the GPU kernel myolo_unmold_masks)."""
+    """skimage.transform.resize(order=1, mode='constant', cval=0, anti_aliasing=False) as the reference's wrapper calls it
+    (myolo_utils.py:433-447, 903): pixel centres aligned, bilinear, samples outside the mask read 0.  float32; same definition
+    as the GPU kernel myolo_unmold_masks."""
     f = np.float32
     mask = np.asarray(mask, f)
     h, w = mask.shape
-    ys = np.clip((np.arange(out_h, dtype=f) + f(0.5)) * (f(h) / f(out_h)) - f(0.5), f(0), f(h - 1)).astype(f)
-    xs = np.clip((np.arange(out_w, dtype=f) + f(0.5)) * (f(w) / f(out_w)) - f(0.5), f(0), f(w - 1)).astype(f)
+    ys = ((np.arange(out_h, dtype=f) + f(0.5)) * (f(h) / f(out_h)) - f(0.5)).astype(f)
+    xs = ((np.arange(out_w, dtype=f) + f(0.5)) * (f(w) / f(out_w)) - f(0.5)).astype(f)
     y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
-    y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
     wy, wx = (ys - y0.astype(f))[:, None], (xs - x0.astype(f))[None, :]
-    top = mask[y0][:, x0] + (mask[y0][:, x1] - mask[y0][:, x0]) * wx
-    bot = mask[y1][:, x0] + (mask[y1][:, x1] - mask[y1][:, x0]) * wx
-    return (top + (bot - top) * wy).astype(f)
+    P = np.zeros((h + 2, w + 2), f)
+    P[1:-1, 1:-1] = mask
+    tl, tr = P[y0 + 1][:, x0 + 1], P[y0 + 1][:, x0 + 2]
+    bl, br = P[y0 + 2][:, x0 + 1], P[y0 + 2][:, x0 + 2]
+    top = tl + (tr - tl) * wx
+    bot = bl + (br - bl) * wx
+    return np.clip((top + (bot - top) * wy).astype(f), mask.min(), mask.max()).astype(f)      # clip=True
 
 
 def unmold_mask(mask, bbox, image_shape):

@@ -92,23 +92,28 @@ def box_to_pixels(bbox, image_shape):
 
 
 def resize_bilinear_f32(mask, out_h, out_w):
-    """order-1 resize, pixel centres aligned, edge clamp; every operation float32 in this order."""
+    """skimage.transform.resize(mask, (out_h, out_w), order=1, mode='constant', cval=0, clip=True, anti_aliasing=False) -- the
+    call the reference makes through its wrapper (myolo_utils.py:433-447, 903): pixel centres aligned
+    (src = (dst + 0.5) * in/out - 0.5), bilinear, and samples OUTSIDE the mask read cval = 0 (not the edge value), so an
+    up-scaled mask fades towards 0 over its outermost half source pixel -- and clip=True then clips the result to the input's
+    [min, max], which undoes that fade for a mask whose minimum is already above it.  Every operation float32 in this order (the HIP kernel
+    uses the same expressions); pinned against scikit-image 0.18.3 outputs in tests/golden/skimage_resize_fixture.npz."""
     mask = np.asarray(mask, F32)
     h, w = mask.shape
     sy, sx = F32(h) / F32(out_h), F32(w) / F32(out_w)
-    ys = (np.arange(out_h, dtype=F32) + F32(0.5)) * sy - F32(0.5)
-    xs = (np.arange(out_w, dtype=F32) + F32(0.5)) * sx - F32(0.5)
-    ys = np.minimum(np.maximum(ys, F32(0)), F32(h - 1))
-    xs = np.minimum(np.maximum(xs, F32(0)), F32(w - 1))
+    ys = ((np.arange(out_h, dtype=F32) + F32(0.5)) * sy - F32(0.5)).astype(F32)
+    xs = ((np.arange(out_w, dtype=F32) + F32(0.5)) * sx - F32(0.5)).astype(F32)
     y0, x0 = np.floor(ys).astype(np.int64), np.floor(xs).astype(np.int64)
-    y1, x1 = np.minimum(y0 + 1, h - 1), np.minimum(x0 + 1, w - 1)
     wy = (ys - y0.astype(F32))[:, None].astype(F32)
     wx = (xs - x0.astype(F32))[None, :].astype(F32)
-    tl, tr = mask[y0][:, x0], mask[y0][:, x1]
-    bl, br = mask[y1][:, x0], mask[y1][:, x1]
+    P = np.zeros((h + 2, w + 2), F32)                    # constant-0 border: index -1 -> 0, index h -> h + 1
+    P[1:-1, 1:-1] = mask
+    tl, tr = P[y0 + 1][:, x0 + 1], P[y0 + 1][:, x0 + 2]
+    bl, br = P[y0 + 2][:, x0 + 1], P[y0 + 2][:, x0 + 2]
     top = tl + (tr - tl) * wx
     bot = bl + (br - bl) * wx
-    return (top + (bot - top) * wy).astype(F32)
+    out = (top + (bot - top) * wy).astype(F32)
+    return np.clip(out, mask.min(), mask.max()).astype(F32)          # clip=True: to the value range of the input
 
 
 def unmold_mask(mask, bbox, image_shape):

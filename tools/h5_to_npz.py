@@ -2,8 +2,9 @@
 """Convert a reference Keras weight file (what model.py:1024-1027's ModelCheckpoint(save_weights_only=True) writes and
 model.py:1157-1196 load_weights reads) into the .npz container of myolo.model.MaskYOLO.load_weights, and back.
 
-  python tools/h5_to_npz.py mask_yolo_shapes_0005.h5 weights.npz          # needs h5py on the user's side
-  python tools/h5_to_npz.py --to-h5 weights.npz keras_weights.h5
+  python tools/h5_to_npz.py mask_yolo_shapes_0005.h5 weights.npz          # no h5py needed (myolo/h5lite.py)
+  python tools/h5_to_npz.py --to-h5 weights.npz keras_weights.h5          # writing needs h5py on the user's side
+(MaskYOLO.load_weights also takes the .h5 directly.)
 
 Keras weight-file schema (keras/engine/saving.py, Keras >= 2.0.8 as pinned by model.py:28):
   root.attrs['layer_names'] -> one group per layer; group.attrs['weight_names'] -> datasets named
@@ -11,64 +12,22 @@ Keras weight-file schema (keras/engine/saving.py, Keras >= 2.0.8 as pinned by mo
   weight_names are the inner layers' ('conv_dw_7/depthwise_kernel:0', ...).
 Array layouts are Keras' (HWIO conv kernels, [kh,kw,C,1] depthwise kernels, [kh,kw,Cout,Cin] Conv2DTranspose
 kernels); the only reshape is the depthwise kernel's trailing multiplier axis.  The mapping itself
-(`keras_weights_to_state` / `state_to_keras_weights`) has no h5py dependency and is unit-tested."""
+(`keras_weights_to_state` / `state_to_keras_weights`) lives in myolo/keras_io.py, has no h5py dependency and is unit-tested."""
 import argparse
 import sys
 
 import numpy as np
 
-NESTED_MODEL = "yolo_model"          # model.py:851-852
-INNER_OF_NESTED = ("conv_dw_%d", "conv_dw_%d_bn", "conv_pw_%d", "conv_pw_%d_bn")
+import os
 
-
-def keras_weights_to_state(named_arrays):
-    """{'<layer>/<weight>:0': array} (flattened over all layer groups) -> {'<layer>/<weight>': array} in the
-    myolo layout.  Unknown suffixes are kept; ':0' device suffixes are dropped."""
-    sd = {}
-    for name, arr in named_arrays.items():
-        key = name.split(":")[0]
-        parts = key.split("/")
-        if len(parts) > 2:               # 'yolo_model/conv_dw_7/depthwise_kernel' style (tf.keras variants)
-            key = "/".join(parts[-2:])
-        a = np.asarray(arr, np.float32)
-        if key.endswith("/depthwise_kernel") and a.ndim == 4:
-            assert a.shape[3] == 1, "depth multiplier must be 1 (%s has shape %s)" % (name, a.shape)
-            a = a[..., 0]
-        sd[key] = a
-    return sd
-
-
-def nested_layers(n_backbone_blocks=6, n_yolo_blocks=8):
-    names = []
-    for b in range(n_backbone_blocks + 1, n_backbone_blocks + n_yolo_blocks + 1):
-        names += [p % b for p in INNER_OF_NESTED]
-    return names + ["conv_23"]
-
-
-def state_to_keras_weights(sd):
-    """inverse mapping: {layer group name: [(weight name, array), ...]} with the reference's nesting."""
-    inner = set(nested_layers())
-    groups = {}
-    for key in sorted(sd):
-        layer, w = key.split("/")
-        a = np.asarray(sd[key], np.float32)
-        if w == "depthwise_kernel":
-            a = a[..., None]
-        groups.setdefault(NESTED_MODEL if layer in inner else layer, []).append(("%s/%s:0" % (layer, w), a))
-    return groups
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mask-yolo_amd"))
+from myolo.keras_io import (NESTED_MODEL, INNER_OF_NESTED, keras_weights_to_state, nested_layers,       # noqa: E402,F401
+                            state_to_keras_weights, read_keras_h5)
 
 
 def read_h5(path):
-    import h5py                                              # noqa: F401  (user-side dependency)
-    out = {}
-    with h5py.File(path, "r") as f:
-        root = f["model_weights"] if "model_weights" in f else f
-        for lname in root.attrs["layer_names"]:
-            g = root[lname.decode() if isinstance(lname, bytes) else lname]
-            for wname in g.attrs["weight_names"]:
-                wname = wname.decode() if isinstance(wname, bytes) else wname
-                out[wname] = np.asarray(g[wname])
-    return out
+    """every '<layer>/<weight>:0' array of a Keras weight file (pure-Python HDF5 reader, no h5py needed)"""
+    return read_keras_h5(path)[0]
 
 
 def write_h5(path, groups):
@@ -96,7 +55,7 @@ def main():
         else:
             np.savez(a.dst, **keras_weights_to_state(read_h5(a.src)))
     except ImportError:
-        sys.exit("h5py is required on the machine doing the conversion (it is not part of the MI355X image)")
+        sys.exit("writing .h5 needs h5py on the machine doing the conversion (it is not part of the MI355X image)")
 
 
 if __name__ == "__main__":
