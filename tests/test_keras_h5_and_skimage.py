@@ -123,8 +123,8 @@ def test_unmold_kernel_matches_scikit_image():
         det = np.array([[0.0, 0.0, (ow + 0.5) / W, (oh + 0.5) / H, 0.9, 1.0]], np.float32)     # window [0, ow) x [0, oh)
         full = torch.zeros(H, W, 1, dtype=torch.uint8, device="cuda")
         wsb = torch.empty(4, dtype=torch.int32, device="cuda")
-        X.call("myolo_unmold_masks", X.ptr(torch.as_tensor(masks).cuda()), X.ptr(torch.as_tensor(det).cuda()), X.ptr(full), 1, 28, 28, C, H, W,
-               wsb.data_ptr(), 16, X.stream())
+        mt, dtt = torch.as_tensor(masks).cuda(), torch.as_tensor(det).cuda()      # named: a temporary would be freed before the launch
+        X.call("myolo_unmold_masks", X.ptr(mt), X.ptr(dtt), X.ptr(full), 1, 28, 28, C, H, W, wsb.data_ptr(), 16, X.stream())
         got = full.cpu().numpy()[:, :, 0].astype(bool)
         assert not got[oh:, :].any() and not got[:, ow:].any()
         clear = np.abs(ref - 0.5) > 1e-5
