@@ -39,7 +39,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"wino_fused", &MyoloOptions::wino_fused}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"wino_fused", &MyoloOptions::wino_fused}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -614,12 +614,15 @@ struct OpConv1Dw {
 // holding the (TW-1)*S+3 input columns of each of the 3 rows in registers (each input quad is
 // loaded once per thread instead of up to 9 times).
 // ---------------------------------------------------------------------------------------
-template <int S, int TW>
+template <int S, int TW, int TH>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo)
 {
-    // grid: x = (w-tile, channel quad) pairs, y = output row, z = image: no 64-bit div/mod per thread
+    // grid: x = (w-tile, channel quad) pairs, y = group of TH output rows, z = image: no 64-bit div/mod per thread.
+    // The thread walks down the (TH-1)*S+3 input rows of its strip once (sliding window: every input row is loaded once per
+    // strip and feeds up to 3 output rows), so an input element is fetched (TH+2)/TH * (TW+2)/TW times in all instead of 4.5.
     constexpr int NC = (TW - 1) * S + 3;
+    constexpr int NR = (TH - 1) * S + 3;
     const int pt = (S == 1) ? 1 : 0, plft = (S == 1) ? 1 : 0;
     const int cq = C / 4;
     const int wtiles = (Wo + TW - 1) / TW;
@@ -627,34 +630,49 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     if (e >= (unsigned)(wtiles * cq)) return;
     const int wt = e / (unsigned)cq;
     const int c = (e - wt * cq) * 4;
-    const int oy = blockIdx.y, n = blockIdx.z;
+    const int oy0 = blockIdx.y * TH, n = blockIdx.z;
     const int ox0 = wt * TW;
     float4 wv[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = ld4g(w + k * C + c);
-    float4 acc[TW];
+    float4 acc[TH][TW];
 #pragma unroll
-    for (int j = 0; j < TW; ++j) acc[j] = f4zero();
+    for (int r = 0; r < TH; ++r)
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * S + ky - pt;
-        if (iy < 0 || iy >= H) continue;
-        const float* rowp = x + (((long long)n * H + iy) * W) * C + c;
+        for (int j = 0; j < TW; ++j) acc[r][j] = f4zero();
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+        const int iy = oy0 * S + ri - pt;
         float4 col[NC];
+        const bool rowin = iy >= 0 && iy < H;
+        const float* rowp = x + (((long long)n * H + (rowin ? iy : 0)) * W) * C + c;
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const int ix = ox0 * S + k - plft;
-            col[k] = (ix >= 0 && ix < W) ? ld4g(rowp + (long long)ix * C) : f4zero();
+            col[k] = (rowin && ix >= 0 && ix < W) ? ld4g(rowp + (long long)ix * C) : f4zero();
         }
 #pragma unroll
-        for (int j = 0; j < TW; ++j)
+        for (int ky = 0; ky < 3; ++ky) {
+            // input row ri feeds output row r with r*S + ky == ri
+            if ((ri - ky) >= 0 && ((ri - ky) % S) == 0 && (ri - ky) / S < TH) {
+                constexpr int dummy = 0; (void)dummy;
+                const int r = (ri - ky) / S;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) acc[j] = f4fma(col[j * S + kx], wv[ky * 3 + kx], acc[j]);
+                for (int j = 0; j < TW; ++j)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[r][j] = f4fma(col[j * S + kx], wv[ky * 3 + kx], acc[r][j]);
+            }
+        }
     }
-    float* yrow = y + (((long long)n * Ho + oy) * Wo) * C + c;
 #pragma unroll
-    for (int j = 0; j < TW; ++j)
-        if (ox0 + j < Wo) st4g(yrow + (long long)(ox0 + j) * C, acc[j]);
+    for (int r = 0; r < TH; ++r) {
+        const int oy = oy0 + r;
+        if (oy >= Ho) continue;
+        float* yrow = y + (((long long)n * Ho + oy) * Wo) * C + c;
+#pragma unroll
+        for (int j = 0; j < TW; ++j)
+            if (ox0 + j < Wo) st4g(yrow + (long long)(ox0 + j) * C, acc[r][j]);
+    }
 }
 
 // dx[iy,ix] = sum_{ky,kx} dy[(iy+pt-ky)/S, (ix+pl-kx)/S] * w[ky,kx]   (when divisible and in range)
@@ -1355,10 +1373,21 @@ int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y, int N, int H, 
     const int Ho = H / stride, Wo = W / stride;
     if (stride == 1) {
         const int per_row = ((Wo + 3) / 4) * (C / 4);
-        hipLaunchKernelGGL((dw_fwd_kernel<1, 4>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        // strips of 4 output rows where that still leaves >= ~1000 workgroups; the small late layers keep more, shorter strips
+        const long long wg4 = (long long)((per_row + 255) / 256) * ((Ho + 3) / 4) * N;
+        if (Ho >= 4 && wg4 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1)
+            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 4>), dim3((per_row + 255) / 256, (Ho + 3) / 4, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        else if (Ho >= 2 && !g_myolo_opt.dw_rows1)
+            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        else
+            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
     } else {
         const int per_row = ((Wo + 1) / 2) * (C / 4);
-        hipLaunchKernelGGL((dw_fwd_kernel<2, 2>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        const long long wg2 = (long long)((per_row + 255) / 256) * ((Ho + 1) / 2) * N;
+        if (Ho >= 2 && wg2 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1)
+            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+        else
+            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
     }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

@@ -127,6 +127,10 @@ def main():
         layers = [(112, 32, 1), (112, 64, 2), (56, 64, 1), (56, 128, 2), (28, 256, 1), (28, 256, 1), (28, 512, 2),
                   (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 2), (7, 1024, 1)]
         tot_ms, tot_b = 0.0, 0.0
+        if os.environ.get("KBENCH_DW_ROWS1"):
+            X.set_option("dw_rows1", 1)
+        if os.environ.get("KBENCH_DW_MIN_WG"):
+            X.set_option("dw_min_wg", int(os.environ["KBENCH_DW_MIN_WG"]))
         for H, Cc, s in layers:
             x, w = rn(32, H, H, Cc), rn(3, 3, Cc)
             y = torch.empty(32, H // s, H // s, Cc, device=dev)
