@@ -919,40 +919,91 @@ __global__ __launch_bounds__(256) void crop_bwd_grouped_lds_kernel(const float* 
     __syncthreads();
     float4 acc = f4zero();
     const float fy = (float)y, fx = (float)x;
-    for (int r = 0; r < R; ++r) {
-        const float4 bx = *reinterpret_cast<const float4*>(&sp[r * 8]);
-        const float4 q = *reinterpret_cast<const float4*>(&sp[r * 8 + 4]);      // y0, 1/sy, x0, 1/sx
-        int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
-        if (q.y != 0.f) {
-            const float a = (fy - 1.f - q.x) * q.y, cc = (fy + 1.f - q.x) * q.y;
-            pya = max(0, (int)floorf(fminf(a, cc)) - 2);
-            pyb = min(ch - 1, (int)ceilf(fmaxf(a, cc)) + 2);
-        } else if (fabsf(q.x - fy) > 1.5f) continue;
-        if (q.w != 0.f) {
-            const float a = (fx - 1.f - q.z) * q.w, cc = (fx + 1.f - q.z) * q.w;
-            pxa = max(0, (int)floorf(fminf(a, cc)) - 2);
-            pxb = min(cw - 1, (int)ceilf(fmaxf(a, cc)) + 2);
-        } else if (fabsf(q.z - fx) > 1.5f) continue;
-        if (pya > pyb || pxa > pxb) continue;
-        const long long bi = (long long)b * R + r;
-        for (int py = pya; py <= pyb; ++py) {
-            float iny;
-            if (!crop_coord(bx.x, bx.z, H, ch, py, iny)) continue;
-            const int ty = (int)floorf(iny), by = (int)ceilf(iny);
-            if (ty != y && by != y) continue;
-            const float ly = iny - (float)ty;
-            const float wyv = (ty == y ? (1.f - ly) : 0.f) + (by == y ? ly : 0.f);
-            for (int px = pxa; px <= pxb; ++px) {
-                float inx;
-                if (!crop_coord(bx.y, bx.w, W, cw, px, inx)) continue;
-                const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
-                if (lx != x && rx != x) continue;
-                const float lxw = inx - (float)lx;
-                const float wxv = (lx == x ? (1.f - lxw) : 0.f) + (rx == x ? lxw : 0.f);
-                const float wgt = wyv * wxv;
-                const float4 g = ld4g(dout + ((bi * ch + py) * cw + px) * C + c);
-                acc.x = fmaf(g.x, wgt, acc.x); acc.y = fmaf(g.y, wgt, acc.y);
-                acc.z = fmaf(g.z, wgt, acc.z); acc.w = fmaf(g.w, wgt, acc.w);
+    // A wave is ONE feature pixel (64 lanes = the 256 channels), so the candidate test of a box is the same in every lane:
+    // the lanes test 64 different boxes at once, a ballot collects the boxes whose sample window can touch this pixel, and only
+    // those are walked (ascending box order: the summation order, hence the result, does not depend on the lane assignment).
+    const int lane = threadIdx.x & 63;
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        const int rt = r0 + lane;
+        bool hit = false;
+        if (rt < R) {
+            const float4 q = *reinterpret_cast<const float4*>(&sp[rt * 8 + 4]);      // y0, 1/sy, x0, 1/sx
+            int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
+            hit = true;
+            if (q.y != 0.f) {
+                const float a = (fy - 1.f - q.x) * q.y, cc = (fy + 1.f - q.x) * q.y;
+                pya = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pyb = min(ch - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            } else if (fabsf(q.x - fy) > 1.5f) hit = false;
+            if (q.w != 0.f) {
+                const float a = (fx - 1.f - q.z) * q.w, cc = (fx + 1.f - q.z) * q.w;
+                pxa = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pxb = min(cw - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            } else if (fabsf(q.z - fx) > 1.5f) hit = false;
+            if (pya > pyb || pxa > pxb) hit = false;
+        }
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int r = r0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 bx = *reinterpret_cast<const float4*>(&sp[r * 8]);
+            const float4 q = *reinterpret_cast<const float4*>(&sp[r * 8 + 4]);
+            int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
+            if (q.y != 0.f) {
+                const float a = (fy - 1.f - q.x) * q.y, cc = (fy + 1.f - q.x) * q.y;
+                pya = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pyb = min(ch - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            }
+            if (q.w != 0.f) {
+                const float a = (fx - 1.f - q.z) * q.w, cc = (fx + 1.f - q.z) * q.w;
+                pxa = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pxb = min(cw - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            }
+            const long long bi = (long long)b * R + r;
+            // the candidate samples (py, px) of the window are tested one per lane; the ones that touch this pixel are then
+            // accumulated in ascending (py, px) order -- the order of the plain double loop, so results are bit-identical
+            const int wxn = pxb - pxa + 1;
+            const int ncand = (pyb - pya + 1) * wxn;
+            for (int k0 = 0; k0 < ncand; k0 += 64) {
+                const int k = k0 + lane;
+                float wgt = 0.f;
+                int off = 0;
+                bool use = false;
+                if (k < ncand) {
+                    const int py = pya + k / wxn, px = pxa + k % wxn;
+                    float iny, inx;
+                    if (crop_coord(bx.x, bx.z, H, ch, py, iny) && crop_coord(bx.y, bx.w, W, cw, px, inx)) {
+                        const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+                        const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+                        if ((ty == y || by == y) && (lx == x || rx == x)) {
+                            const float ly = iny - (float)ty, lxw = inx - (float)lx;
+                            const float wyv = (ty == y ? (1.f - ly) : 0.f) + (by == y ? ly : 0.f);
+                            const float wxv = (lx == x ? (1.f - lxw) : 0.f) + (rx == x ? lxw : 0.f);
+                            wgt = wyv * wxv;
+                            off = py * cw + px;
+                            use = true;
+                        }
+                    }
+                }
+                unsigned long long cm = __ballot(use);
+                while (cm) {                 // four samples per trip: their loads are in flight together, the sums stay in order
+                    float wg[4];
+                    float4 g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool any = cm != 0;
+                        const int src = any ? __builtin_ctzll(cm) : 0;
+                        cm &= cm - 1;                                   // 0 stays 0
+                        wg[u] = any ? __shfl(wgt, src, 64) : 0.f;
+                        const int o = __shfl(off, src, 64);
+                        g[u] = any ? ld4g(dout + (bi * ch * cw + o) * C + c) : f4zero();
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {                       // a padded slot adds +0 * 0: exact no-op
+                        acc.x = fmaf(g[u].x, wg[u], acc.x); acc.y = fmaf(g[u].y, wg[u], acc.y);
+                        acc.z = fmaf(g[u].z, wg[u], acc.z); acc.w = fmaf(g[u].w, wg[u], acc.w);
+                    }
+                }
             }
         }
     }
