@@ -1,6 +1,6 @@
 """
 ORACLE (test infrastructure, NOT product code) -- the whole Mask-YOLO training step and
-inference forward, composed from oracle/np_ops.py.  PARITY UNPINNED (see np_ops.py header).
+inference forward, composed from oracle/np_ops.py.  PARITY PARTLY PINNED (see np_ops.py header).
 
 Follows MaskYOLO.build model.py:787-941 (training branch :872-904, inference :922-936),
 mobilenet_graph :55-79, yolo_branch_graph :249-278, build_mask_graph :668-715,

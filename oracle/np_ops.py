@@ -2,11 +2,16 @@
 ORACLE (test infrastructure, NOT product code) -- numpy restatement of every
 arithmetic op on the Mask-YOLO forward/backward hot path.
 
-PARITY UNPINNED: the reference delegates all arithmetic to TensorFlow-1.x /
+PARITY PARTLY PINNED: the reference delegates all arithmetic to TensorFlow-1.x /
 Keras-2.x / keras_applications (un-vendored, un-pinned, not installable here;
 SURVEY.md section 8(c)) and has no tests, golden vectors or weights.  This file
-restates the documented behaviour of those ops; it is pinned only by the
-hand-derived known-answer tests in tests/test_oracle_kat.py and by agreement
+restates the documented behaviour of those ops -- never checked against TensorFlow
+itself.  It is pinned by vectors quoted from the dependencies' own test suites
+(tests/test_third_party_kats.py: TF crop_and_resize_op_test.cc, adam_test.py,
+fused_batch_norm x Keras' moving-variance factor, keras_applications padding,
+tf.round), by fixtures generated with the real scikit-image / h5py of this image's
+Anaconda Python (tests/golden/make_*_fixture.py: oracle/np_post.py's resize), by
+the hand-derived known-answer tests in tests/test_oracle_kat.py and by agreement
 with an independent torch-CPU autograd composition (oracle/torch_ref.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import

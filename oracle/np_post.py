@@ -1,9 +1,10 @@
 """
 ORACLE (test infrastructure, NOT product code) -- literal restatement of the reference's inference
-post-processing.  PARITY UNPINNED: `skimage.transform.resize` (used by
-unmold_mask, myolo_utils.py:903) is un-vendored and un-pinned; it is restated here as order-1 (bilinear)
-interpolation with pixel-centre alignment and edge clamping, evaluated in float32 in a fixed operation order so
-that the GPU kernel can reproduce the thresholded masks bit for bit.
+post-processing.  `skimage.transform.resize` (used by unmold_mask,
+myolo_utils.py:903, through the wrapper at :433-447) is PINNED: the restatement below (order-1 interpolation, pixel-centre
+alignment, zero border of mode='constant', clip=True to the input range, float32 in a fixed operation order so that the GPU
+kernel can reproduce the thresholded masks bit for bit) is checked against outputs of the real scikit-image 0.18.3 found in this
+image's Anaconda Python (tests/golden/make_skimage_fixture.py -> skimage_resize_fixture.npz).
 
 Follows: decode_one_yolo_output myolo_utils.py:36-85; NMB myolo_utils.py:88-113; bbox_iou / bbox_iou_2 /
 _interval_overlap myolo_utils.py:186-244; unmold_mask myolo_utils.py:883-912; MaskYOLO.decode_masks

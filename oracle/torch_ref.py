@@ -2,7 +2,7 @@
 ORACLE (test infrastructure, NOT product code) -- second, independent CPU composition of the
 Mask-YOLO training step in torch-CPU with *autograd* (no hand-written backward).  Used
 (1) to pin oracle/np_model.py's analytic backward, (2) as the fast CPU baseline that bench.py
-times on the GPU box's host cores ("cpu_baseline", kind "port").  PARITY UNPINNED (np_ops.py).
+times on the GPU box's host cores ("cpu_baseline", kind "port").  PARITY PARTLY PINNED (np_ops.py).
 
 Reference lines followed: same as oracle/np_model.py (model.py:38-79, 86-242, 249-278,
 385-387, 457-602, 668-754, 1062-1094).  Integer-valued pieces (decode -> targets) are taken

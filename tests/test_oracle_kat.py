@@ -3,7 +3,7 @@
 The reference has no tests, golden vectors or runnable kernels, so the
 oracle is pinned by (1) the hand-derived KATs below -- each states the closed form it checks --
 (2) agreement of its analytic backward with an independent torch-autograd composition in float64,
-(3) property tests.  PARITY UNPINNED against TensorFlow itself; see oracle/np_ops.py header."""
+(3) property tests.  Never checked against TensorFlow itself (not installable); third-party pins: tests/test_third_party_kats.py, tests/test_keras_h5_and_skimage.py."""
 import numpy as np
 from hypothesis import given, settings, strategies as st
 
