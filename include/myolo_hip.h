@@ -135,6 +135,13 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma,
                      float* dx, float* dgamma, float* dbeta,
                      int64_t M, int C, int act, int batch_stats, void* ws, size_t ws_bytes, void* stream);
 
+/* frozen BatchNormalization (training=False, model.py:696,702,708) + ReLU/ReLU6 backward from the POST-activation tensor
+ * a = act(gamma*xhat + beta): where the activation passes gradient xhat = (a - beta)/gamma, so the pre-BN tensor is not needed.
+ * dx = scale * dy * [act passes], dgamma = sum dz*xhat, dbeta = sum dz.  ws as bn_act_bwd. */
+int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const float* gamma, const float* beta, const float* scale,
+                                 float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act,
+                                 void* ws, size_t ws_bytes, void* stream);
+
 /* Exact-sparsity helpers for the mask head backward (build_mask_graph model.py:690-708: bn1 is the only
  * batch-statistics layer, so behind it only ROIs with a positive target carry non-zero gradient):
  * gather_groups: dst[i] = src[idx[i]] for groups of group_elems floats (one ROI's rows);

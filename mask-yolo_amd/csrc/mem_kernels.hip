@@ -415,6 +415,43 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     }
 }
 
+// Frozen BatchNorm (+ activation) backward from the POST-activation tensor a = act(gamma * xhat + beta): where the activation
+// passes gradient, xhat = (a - beta) / gamma, elsewhere dz = 0 -- the pre-BN tensor is not needed (the fused forward never
+// stores it; the compacted mask-head backward used to re-run the convolution to get it back).
+struct OpBnBwdPost {
+    static constexpr int NV = 2;
+    const float* dy;
+    const float* a;
+    const float* gamma;
+    const float* beta;
+    int C, act;
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const float4 g = ld4g(dy + r * C + c), v = ld4g(a + r * C + c);
+        const float4 ga = ld4g(gamma + c), be = ld4g(beta + c);
+        float dz, xh;
+        dz = g.x * actmask(v.x, act); xh = ga.x != 0.f ? (v.x - be.x) / ga.x : 0.f; acc[0].x += dz; acc[1].x = fmaf(dz, xh, acc[1].x);
+        dz = g.y * actmask(v.y, act); xh = ga.y != 0.f ? (v.y - be.y) / ga.y : 0.f; acc[0].y += dz; acc[1].y = fmaf(dz, xh, acc[1].y);
+        dz = g.z * actmask(v.z, act); xh = ga.z != 0.f ? (v.z - be.z) / ga.z : 0.f; acc[0].z += dz; acc[1].z = fmaf(dz, xh, acc[1].z);
+        dz = g.w * actmask(v.w, act); xh = ga.w != 0.f ? (v.w - be.w) / ga.w : 0.f; acc[0].w += dz; acc[1].w = fmaf(dz, xh, acc[1].w);
+    }
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_dx_post_kernel(const float* __restrict__ dy, const float* __restrict__ a,
+                                                             const float* __restrict__ scale, float* __restrict__ dx, long long nquads,
+                                                             int C, int act)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int cq = C / 4;
+    for (; i < nquads; i += stride) {
+        const int c = (int)(i % cq) * 4;
+        const float4 g = ld4g(dy + i * 4), v = ld4g(a + i * 4), sc = ld4g(scale + c);
+        st4g(dx + i * 4, make_float4(sc.x * g.x * actmask(v.x, act), sc.y * g.y * actmask(v.y, act), sc.z * g.z * actmask(v.z, act),
+                                     sc.w * g.w * actmask(v.w, act)));
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // group gather: dst[i] = src[idx[i]] for groups of `gq` float4 (one group = one ROI's rows)
 // ---------------------------------------------------------------------------------------
@@ -1331,6 +1368,26 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq,
                        C, act, batch_stats, 1.0f / (float)M);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const float* gamma, const float* beta, const float* scale,
+                                 float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act, void* ws, size_t ws_bytes,
+                                 void* stream)
+{
+    MYOLO_REQUIRE(dy && a_post && gamma && beta && scale && dx && dgamma && dbeta && M > 0 && (C & 3) == 0,
+                  "bn_act_bwd_frozen_post: bad arguments");
+    MYOLO_REQUIRE(act == MYOLO_ACT_RELU || act == MYOLO_ACT_RELU6, "bn_act_bwd_frozen_post: needs a ReLU / ReLU6 (the mask is read off the output)");
+    const size_t pb = col_ws_bytes(M, C, 2);
+    MYOLO_NEED_WS(align256(pb) + 2 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    hipStream_t s = (hipStream_t)stream;
+    OpBnBwdPost op{dy, a_post, gamma, beta, C, act};
+    run_colreduce(op, M, C, part, tot, s, FinBnBwd{dgamma, dbeta});
+    const long long nq = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_dx_post_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, a_post, scale, dx, nq, C, act);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

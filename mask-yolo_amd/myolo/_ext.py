@@ -37,6 +37,7 @@ SIGS = {
     "myolo_bn_frozen_coeffs": [P, P, P, P, P, P, I, P],
     "myolo_bn_apply_act": [P, P, P, P, L, I, I, P],
     "myolo_bn_act_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, Z, P],
+    "myolo_bn_act_bwd_frozen_post": [P, P, P, P, P, P, P, P, L, I, I, P, Z, P],
     "myolo_crop_and_resize_fwd": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_crop_and_resize_bwd_image": [P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_gather_groups": [P, P, P, I, L, P],

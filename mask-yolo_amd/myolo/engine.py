@@ -892,13 +892,19 @@ class Net(object):
             else:
                 xin = gather(src, q)
             if self.tape[bn][0] is None:
-                # the fused forward never wrote the pre-BN tensor: recompute it for the positive ROIs with the
-                # same kernel (same k order per output element -> the same fp32 values)
-                c_p = self._new(NP * q, MASK_FILTERS)
-                self.conv3x3_fwd(xin, cn, c_p, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
+                # the fused forward never wrote the pre-BN tensor.  bn2-4 are frozen affine maps followed by a ReLU, so their
+                # backward can be read off the POST-activation tensor, which the forward did keep for the positive ROIs (it is the
+                # next layer's input): mask = a > 0, xhat = (a - beta) / gamma there -- no convolution is re-run
+                a_post = a4_p if i == 4 else a_next
+                buf = self.bnbuf[bn]
+                dy = self._new(NP * q, MASK_FILTERS)
+                X.call("myolo_bn_act_bwd_frozen_post", X.ptr(da), X.ptr(a_post), X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]),
+                       X.ptr(buf[2]), X.ptr(dy), X.ptr(self.g[bn + "/gamma"]), X.ptr(self.g[bn + "/beta"]), NP * q, MASK_FILTERS,
+                       self.tape[bn][1], *self._wsargs(), X.stream())
             else:
                 c_p = gather(self.tape[bn][0], q)
-            dy = self.bn_act_bwd(bn, da, y_override=c_p)
+                dy = self.bn_act_bwd(bn, da, y_override=c_p)
+            a_next = xin                  # conv_i's input = post-activation of layer i-1
             self.conv3x3_bwd_weight(xin, None, dy, cn, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
             self.colsum(dy, self.g[cn + "/bias"])
             da = self._new(NP * q, MASK_FILTERS)

@@ -558,3 +558,25 @@ def test_bad_arguments_fail_loudly():
     with pytest.raises(RuntimeError):       # workspace too small
         x = dt(np.zeros((64, 64), np.float32))
         X.call("myolo_pwconv1x1_bwd_data", X.ptr(x), X.ptr(x), X.ptr(x), 64, 64, 64, None, 0, X.stream())
+
+
+def test_frozen_bn_backward_from_post_activation():
+    """bn2-4 of the mask head are frozen affine maps + ReLU (model.py:696,702,708): their backward read off the POST-activation
+    tensor (mask = a > 0, xhat = (a - beta) / gamma) equals the oracle's backward from the pre-BN tensor."""
+    rng = np.random.default_rng(21)
+    M, C = 5000, 64
+    x = rnd(rng, M, C)
+    g, b = (1 + 0.2 * rnd(rng, C)), rnd(rng, C, scale=0.3)
+    g[3] = -0.7                                                     # a negative gamma: xhat's sign must follow it
+    mm, mv = rnd(rng, C, scale=0.2), (0.5 + rng.random(C)).astype(np.float32)
+    da = rnd(rng, M, C)
+    y, cache = O.bn_infer(x, g, b, mm, mv)
+    a = O.relu(y)
+    rdx, rdg, rdb = O.bn_infer_bwd(cache, g, O.relu_bwd(a, da))
+    scale = (g / np.sqrt(mv.astype(np.float64) + 1e-3)).astype(np.float32)
+    dx, dg, db = new(M, C), new(C), new(C)
+    X.call("myolo_bn_act_bwd_frozen_post", X.ptr(dt(da)), X.ptr(dt(a)), X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(dt(scale)), X.ptr(dx), X.ptr(dg),
+           X.ptr(db), M, C, 1, *ws(), X.stream())
+    check(dx, rdx, 1e-5, "frozen bn dx from post-activation")
+    check(dg, rdg, 1e-4, "frozen bn dgamma from post-activation")
+    check(db, rdb, 1e-4, "frozen bn dbeta from post-activation")
