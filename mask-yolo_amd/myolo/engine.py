@@ -160,6 +160,12 @@ class Net(object):
         self._ws_active = self._ws_main
         self._yolo_stream = torch.cuda.Stream(device=self.dev)
         self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
+        # conv1's weight gradient (MFMA-bound, 2.7 ms, nothing downstream but the optimiser) on a third stream with its own
+        # scratch, underneath conv1's data gradient -> ROIAlign backward -> backbone backward (launch- / HBM-bound small kernels)
+        self._wgrad_stream = torch.cuda.Stream(device=self.dev)
+        self._ws_wgrad = Workspace(self.dev)
+        self.overlap_conv1_wgrad = True
+        self._wgrad_pending = False
         self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
@@ -927,10 +933,24 @@ class Net(object):
                    X.ptr(buf[3]), X.ptr(self.g["myolo_mask_bn1/gamma"]), X.ptr(self.g["myolo_mask_bn1/beta"]), X.ptr(kab[0]),
                    X.ptr(kab[1]), M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
             lazy = (X.ptr(c1), X.ptr(da), X.ptr(inv_d), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(kab[0]), X.ptr(kab[1]), act)
-            self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)))
-            X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
-                   MASK_FILTERS, *self._wsargs(), X.stream())
             self.g["myolo_mask_conv1/bias"].zero_()
+            if self.overlap_conv1_wgrad:
+                self._ws_wgrad.ensure(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2))
+                cur = torch.cuda.current_stream()
+                self._wgrad_stream.wait_stream(cur)
+                with torch.cuda.stream(self._wgrad_stream):
+                    X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps,
+                           cin, MASK_FILTERS, self._ws_wgrad.ptr, self._ws_wgrad.size, X.stream())
+                    if self.on_bucket_ready:          # every other gradient of the mask-head bucket was complete at the fork
+                        self.on_bucket_ready(2)
+                for t in (v1, c1, da, inv_d, kab):
+                    t.record_stream(self._wgrad_stream)
+                self._wgrad_pending = True
+                self.ws.ensure(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1))
+            else:
+                self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)))
+                X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
+                       MASK_FILTERS, *self._wsargs(), X.stream())
             X.call("myolo_conv3x3_wino_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, ps, ps, cin,
                    MASK_FILTERS, *self._wsargs(), X.stream())
         else:
@@ -943,9 +963,15 @@ class Net(object):
             self.conv3x3_bwd_data(dc1, "myolo_mask_conv1", dp0, NR, ps, ps, cin, MASK_FILTERS)
         dF = self._new(n * h * w, cf)
         X.call("myolo_roialign_bwd_grouped", X.ptr(dp0), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
-        if self.on_bucket_ready:
-            self.on_bucket_ready(2)
+        if self.on_bucket_ready and not self._wgrad_pending:
+            self.on_bucket_ready(2)       # (otherwise the bucket was released on the weight gradient's stream, behind that kernel)
         return dF
+
+    def join_conv1_wgrad(self):
+        """make the current stream wait for conv1's weight gradient (side stream)."""
+        if self._wgrad_pending:
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
+            self._wgrad_pending = False
 
     # ------------------------------------------------------------------ steps
     def to_device_batch(self, batch):
@@ -1023,6 +1049,7 @@ class Net(object):
             self.start_yolo_head_bwd(dyolo)
         dF = self.mask_head_bwd_sparse(dz, B, R) if self.sparse_mask_bwd else self.mask_head_bwd(dz)
         self.trunk_bwd(dF, dyolo)
+        self.join_conv1_wgrad()
         if self.sparse_mask_fwd:          # the positives' masks only, in positive order (see mask_head_fwd_positives)
             mm = None if pred is None else pred.view(-1, mh, mw, C)
         else:

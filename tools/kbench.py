@@ -40,6 +40,9 @@ def main():
     NR, ps, C = a.rois, 14, 256
     M = NR * ps * ps
     st = X.stream()
+    for opt in os.environ.get("KBENCH_OPTIONS", "").split(","):      # e.g. KBENCH_OPTIONS=gemm_no_glds=1,wino_no_mixed=1
+        if "=" in opt:
+            X.set_option(opt.split("=")[0], int(opt.split("=")[1]))
     if a.which in ("conv3x3_bf16_fwd", "deconv_bf16_fwd"):
         bf = torch.bfloat16
         x, b = rn(M, C).to(bf), rn(C)
