@@ -886,6 +886,89 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
         }
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight gradient of a THIN pointwise conv (Cin <= 64, Cout <= 128: conv_pw_1..3, 154 MB of activations for a 32x64 result):
+//   dW[Cin][Cout] = sum_m x[m][ci] * dy[m][co].
+// The 128x128-tile kernel above wastes 3/4 (or 15/16) of its tile on such a shape and runs at 0.5-0.8 TB/s.  Here one wave
+// owns the WHOLE Cin x Cout result as KT x NT MFMA 32x32 tiles and streams rows: the MFMA "k" index is the row m, so lane
+// (i = l&31, h = l>>5) needs x[m + h][32*kt + i] and dy[m + h][32*nt + i] -- contiguous 128-byte segments straight from global
+// memory, no LDS, no transposition.  Each wave takes every (gridDim.x*4)-th pair of rows; the four waves of a workgroup are summed
+// through LDS, the workgroups' partials by splitk_reduce (fixed order: bit-reproducible).
+// ------------------------------------------------------------------------------------------
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void pw_wgrad_thin(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
+                                                     long long M, int Cin, int Cout)
+{
+    __shared__ float red[4][32 * 32];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    f32x16 acc[KT][NT];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const long long nwaves = (long long)gridDim.x * 4;
+    const long long w0 = (long long)blockIdx.x * 4 + wave;
+    // rows in chunks of 2*RS per wave-iteration (RS MFMA steps of 2 rows): RS independent loads per operand tile in flight
+    constexpr int RS = (KT + NT <= 3) ? 8 : 4;
+    for (long long m0 = w0 * (2 * RS); m0 < M; m0 += nwaves * (2 * RS)) {
+        float xa[RS][KT], yb[RS][NT];
+#pragma unroll
+        for (int st = 0; st < RS; ++st) {
+            const long long m = m0 + 2 * st + half;
+            const bool ok = m < M;
+#pragma unroll
+            for (int a = 0; a < KT; ++a) xa[st][a] = ok ? x[m * Cin + 32 * a + l31] : 0.f;
+#pragma unroll
+            for (int b = 0; b < NT; ++b) yb[st][b] = ok ? dy[m * Cout + 32 * b + l31] : 0.f;
+        }
+#pragma unroll
+        for (int st = 0; st < RS; ++st)
+#pragma unroll
+            for (int a = 0; a < KT; ++a)
+#pragma unroll
+                for (int b = 0; b < NT; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[st][a], yb[st][b], acc[a][b], 0, 0, 0);
+    }
+    // sum the four waves tile by tile through LDS, then one coalesced store of the workgroup's partial
+    float* dst = part + (long long)blockIdx.x * Cin * Cout;
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[a][b][r];
+            __syncthreads();
+            for (int e = threadIdx.x; e < 1024; e += 256) {
+                const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+                dst[(long long)(32 * a + (e >> 5)) * Cout + 32 * b + (e & 31)] = v;
+            }
+        }
+}
+
+// out[i] = sum_s part[s][i] for SMALL n (a few thousand elements) and many splits: splitk_reduce would leave one short serial chain
+// per element.  Workgroup = 64 consecutive elements x 4 split lanes, 8 loads in flight per thread, fixed summation order.
+__global__ __launch_bounds__(256) void partial_sum_small(const float* __restrict__ part, float* __restrict__ out, int n, int splits)
+{
+    __shared__ float red[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (e < n) {
+        int k = sl;
+        for (; k + 28 < splits; k += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += part[(long long)(k + 4 * u) * n + e];
+        }
+        for (; k < splits; k += 4) s[0] += part[(long long)k * n + e];
+    }
+    red[sl][threadIdx.x & 63] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    __syncthreads();
+    if (sl == 0 && e < n) out[e] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 // out = sum over splits of part[split]; n4 = n/4 float4 elements.  Loads of 4 splits are issued together.
 __global__ __launch_bounds__(256) void splitk_reduce(const float* __restrict__ part, float* __restrict__ out, long long n, int splits)
 {
@@ -1202,6 +1285,25 @@ int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
                                int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && dy && dw && M > 0, "pwconv1x1_bwd_weight: bad arguments");
+    if ((Cin == 32 || Cin == 64) && (Cout == 64 || Cout == 128) && M >= 16384 && !g_myolo_opt.gemm_generic) {
+        // thin layer: one wave holds the whole result (pw_wgrad_thin)
+        const int nblk = g_myolo_opt.tune0 > 0 ? g_myolo_opt.tune0 : (M >= 300000 ? 512 : 256);     // measured: tools/pw_layers.py
+        const size_t need = (size_t)nblk * Cin * Cout * sizeof(float);
+        if (ws && need <= ws_bytes) {
+            hipStream_t s = (hipStream_t)stream;
+            float* part = (float*)ws;
+#define THIN(KT_, NT_) hipLaunchKernelGGL((pw_wgrad_thin<KT_, NT_>), dim3(nblk), dim3(256), 0, s, x, dy, part, (long long)M, Cin, Cout)
+            if (Cin == 32 && Cout == 64) THIN(1, 2);
+            else if (Cin == 32 && Cout == 128) THIN(1, 4);
+            else if (Cin == 64 && Cout == 64) THIN(2, 2);
+            else THIN(2, 4);
+#undef THIN
+            const int n = Cin * Cout;
+            hipLaunchKernelGGL(partial_sum_small, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, (const float*)part, dw, n, nblk);
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+    }
     GemmArgs a = {};
     a.A = x; a.B = dy; a.M = M; a.N = Cout; a.K = Cin; a.lda = Cin; a.ldb = Cout;
     int rc = launch_tn<AM_PLAIN>(a, dw, ws, ws_bytes, (hipStream_t)stream, "pwconv1x1_bwd_weight");

@@ -20,6 +20,7 @@ struct MyoloOptions {
     int bf16_no256;       // bf16 gemm: never the 256x256-tile kernel
     int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
     int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS
+    int tune0;            // scratch integer for kernel-tuning experiments (0 = off); never set by the product
     int dw_min_wg;        // depthwise forward: fewest workgroups for which the 4-row strip kernel is chosen (0 = default)
     int dw_rows1;         // depthwise forward: one output row per thread (no vertical strip)
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)

@@ -63,7 +63,8 @@ def rnd(rng, *shape, scale=1.0):
 
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,Cin,Cout,bias", [(300, 32, 64, False), (1568, 1024, 27, True), (130, 16, 16, True),
-                                             (4096, 64, 128, False), (257, 512, 1024, False)])
+                                             (4096, 64, 128, False), (257, 512, 1024, False),
+                                             (20003, 32, 64, False), (16391, 64, 128, False), (25088, 64, 64, False)])   # thin-layer weight gradient
 def test_pwconv1x1(M, Cin, Cout, bias):
     rng = np.random.default_rng(1)
     x, w = rnd(rng, M, Cin), rnd(rng, Cin, Cout, scale=0.1)
