@@ -10,6 +10,9 @@ import torch         # noqa: E402
 from myolo import _ext as X   # noqa: E402
 
 dev = "cuda:0"
+for opt in os.environ.get("KBENCH_OPTIONS", "").split(","):
+    if "=" in opt:
+        X.set_option(opt.split("=")[0], int(opt.split("=")[1]))
 C, ps = 256, 14
 NRh = 32 * 147 // 2
 n = X.wino_plane_elems(NRh, ps, ps, C)
