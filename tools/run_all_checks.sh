@@ -8,4 +8,4 @@ python -m pytest tests -x -q -m "not gpu"
 python -m pytest tests -x -q -m gpu
 python -c "import __graft_entry__ as g; g.smoke()"
 python bench.py --steps 10 --warmup 3
-python tools/bench_infer.py --batch 4
+python bench.py --config rice416-bf16 --steps 20
