@@ -227,7 +227,7 @@ def bench_train(args, rank, world, local):
     for i in range(args.warmup):
         net.train_step(dbs[i % nb], args.lr)
     # ---- the timed region: only the dominant kernel (and the conv op it belongs to) is bracketed with events
-    dom_tags = {"mask_conv3x3_fwd", "wino_multiply", "wino_fused"}
+    dom_tags = {"mask_conv3x3_fwd", "wino_multiply"}
     net.timed_tags = set(dom_tags)
     net.timings = {}
     elapsed, out = timed_steps(net, dbs, args.steps, args.lr, barrier)
@@ -237,7 +237,6 @@ def bench_train(args, rank, world, local):
     npos_mean = float(out["n_pos"].float().mean())          # positives per image in the last timed batch
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
     mul_ms, mul_n = net.kernel_ms("wino_multiply")
-    fus_ms, fus_n = net.kernel_ms("wino_fused")
     bucket_ms = reducer.bucket_ms() if world > 1 else None
 
     # ---- second pass (not part of `value`): per-launch timings of the kernels north_star names
@@ -305,12 +304,7 @@ def bench_train(args, rank, world, local):
     ptiles = X.wino_plane_elems(args.batch * R, ps, ps, 1)     # point-tiles: 36 per tile, fewer where the ragged edge uses F(2,3)
     wflop = 2.0 * ptiles * 256 * 256                          # one 256x256 product per point-tile
     traffic, traffic_src = None, None
-    if fus_n:
-        kflop, kms, kn = wflop, fus_ms, fus_n
-        kname = "wino_fused_kernel (Winograd F(4x4,3x3) conv in ONE kernel: input transform -> LDS, 36 MFMA GEMMs, output transform from registers; T=%d tiles, Cin=Cout=256)" % tiles_w
-        kbytes = 2.0 * M * 256 * 4 + 36 * 256 * 256 * 4
-        pmc = "r2_pmc_wino_fused.json"
-    elif mul_n:
+    if mul_n:
         kflop, kms, kn = wflop, mul_ms, mul_n
         kname = ("gemm_nn_fast<PLAIN> batched over the 36 Winograd points (multiply stage of the mask-head 3x3 convs; mixed F(4,3)/F(2,3) tiling: "
                  "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (ptiles, ptiles / float(args.batch * R)))

@@ -45,7 +45,7 @@ size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
 
 /* Tuning / ablation switches (process-wide ints, default 0 = shipped behaviour).  Names: "no_nt", "gemm_generic",
  * "no_splitk", "gemm_w256", "wino_nt", "wino_w256", "bf16_regstage", "bf16_no256", "bf16_force256", "crop_bwd_nolds",
- * "tune0", "dw_rows1", "dw_min_wg", "wino_no_mixed", "wino_fused".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
+ * "tune0", "dw_rows1", "dw_min_wg", "wino_no_mixed".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
  * One semantic switch: "bn_fused_tf_variance" (default 1) -- the BatchNormalization moving-variance update of bn_stats
  * restates Keras 2.2.x on TensorFlow 1.x's fused path (tf.nn.fused_batch_norm hands Keras the Bessel-corrected batch
  * variance, Keras multiplies by n/(n-(1+eps)) on top); 0 = Keras' factor on the biased variance (non-fused backend). */
@@ -297,6 +297,13 @@ int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int 
                                 void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W,
                                   int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
+/* The same convolution for 14x14 maps as ONE kernel (csrc/wino_fused.hip): input transform into LDS, the 36 products on MFMA,
+ * output transform from the accumulators -- neither V nor M reaches HBM.  Uniform F(4,3) tiling (576 point-tiles per image).
+ * Needs H = W = 14, Cin % 8 == 0, Cout % 64 == 0, act NONE | RELU; ws holds the re-arranged transformed filters. */
+size_t myolo_conv3x3_wino_fused_ws_bytes(int Cin, int Cout);
+int myolo_conv3x3_wino_fused_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
+                                 int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- bf16 inference path of the mask head (BASELINE.json configs[3]: Rice 416x416, bf16, inference-only) ----
  * Activations are bf16 (uint16_t bit patterns, NHWC), accumulation fp32 on v_mfma_f32_32x32x16_bf16.  All four

@@ -24,7 +24,6 @@ struct MyoloOptions {
     int dw_min_wg;        // depthwise forward: fewest workgroups for which the 4-row strip kernel is chosen (0 = default)
     int dw_rows1;         // depthwise forward: one output row per thread (no vertical strip)
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)
-    int wino_fused;       // 3x3 conv: fused Winograd kernel (transforms in LDS / registers), 1 = on where supported
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
     // 1 = Keras 2.2.x on TF-1.x through tf.nn.fused_batch_norm (Bessel-corrected batch variance, then Keras' n/(n-(1+eps)));
     // 0 = Keras' factor on the biased variance (non-fused backend path).

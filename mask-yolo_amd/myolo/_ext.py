@@ -51,6 +51,7 @@ SIGS = {
     "myolo_mask_targets": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_mask_head_out_fwd": [P, P, P, P, L, I, I, P],
     "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],
+    "myolo_conv3x3_wino_fused_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_deconv2x2s2_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
@@ -105,6 +106,8 @@ def load():
     lib.myolo_workspace_bytes.restype = Z
     lib.myolo_conv3x3_wino_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_conv3x3_wino_ws_bytes.restype = Z
+    lib.myolo_conv3x3_wino_fused_ws_bytes.argtypes = [I, I]
+    lib.myolo_conv3x3_wino_fused_ws_bytes.restype = Z
     lib.myolo_wino_plane_elems.argtypes = [I, I, I, I]
     lib.myolo_wino_plane_elems.restype = Z
     lib.myolo_deconv2x2s2_mask_ws_bytes.argtypes = [I, I, I, I, I, I]
@@ -116,7 +119,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_conv3x3_wino_fused_ws_bytes",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -171,6 +174,10 @@ def workspace_bytes(rows, cin, cout):
 def wino_ws_bytes(n, h, w, cin, cout, which):
     """scratch bytes of myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2)."""
     return int(load().myolo_conv3x3_wino_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(which)))
+
+
+def wino_fused_ws_bytes(cin, cout):
+    return int(load().myolo_conv3x3_wino_fused_ws_bytes(int(cin), int(cout)))
 
 
 def wino_plane_elems(n, h, w, c):

@@ -581,3 +581,24 @@ def test_frozen_bn_backward_from_post_activation():
     check(dx, rdx, 1e-5, "frozen bn dx from post-activation")
     check(dg, rdg, 1e-4, "frozen bn dgamma from post-activation")
     check(db, rdb, 1e-4, "frozen bn dbeta from post-activation")
+
+
+@pytest.mark.parametrize("N,Cin,Cout", [(2, 8, 64), (5, 64, 128), (3, 256, 256), (64, 256, 256)])
+def test_conv3x3_winograd_fused_kernel(N, Cin, Cout):
+    """the one-kernel Winograd conv (csrc/wino_fused.hip: transforms in LDS / registers, V and M never in HBM) against the
+    float64 oracle, with bias, folded-BN affine and ReLU; odd N exercises the half-empty last workgroup."""
+    rng = np.random.default_rng(31)
+    H = W = 14
+    x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout)
+    sc, sh = (1 + 0.1 * rnd(rng, Cout)), rnd(rng, Cout, scale=0.1)
+    wsb = torch.empty(X.wino_fused_ws_bytes(Cin, Cout), dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    ref = O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64)
+    y = new(N, H, W, Cout)
+    X.call("myolo_conv3x3_wino_fused_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), None, None, X.ptr(y), N, H, W, Cin, Cout, 0,
+           wsb.data_ptr(), wsb.numel(), X.stream())
+    check(y, ref, 1e-4, "fused wino fwd")
+    y2 = new(N, H, W, Cout)
+    X.call("myolo_conv3x3_wino_fused_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(sc)), X.ptr(dt(sh)), X.ptr(y2), N, H, W, Cin,
+           Cout, 1, wsb.data_ptr(), wsb.numel(), X.stream())
+    check(y2, np.maximum(ref * sc + sh, 0), 1e-4, "fused wino fwd affine relu")
