@@ -306,7 +306,7 @@ def bench_train(args, rank, world, local):
     traffic, traffic_src = None, None
     if mul_n:
         kflop, kms, kn = wflop, mul_ms, mul_n
-        kname = ("gemm_nn_fast<PLAIN> batched over the 36 Winograd points (multiply stage of the mask-head 3x3 convs; mixed F(4,3)/F(2,3) tiling: "
+        kname = ("wino_mm_kernel: ONE launch of the 36 per-point GEMMs V[q] * U[q] (multiply stage of the mask-head 3x3 convs; mixed F(4,3)/F(2,3) tiling: "
                  "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (ptiles, ptiles / float(args.batch * R)))
         kbytes = float(ptiles) * (256 + 256) * 4 + 36 * 256 * 256 * 4
         pmc = "r2_pmc_wino_multiply.json"
@@ -339,7 +339,7 @@ def bench_train(args, rank, world, local):
     roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
                 "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
-                "conv_op": {"algo": "winograd_f4x4_3x3_fused" if fus_n else ("winograd_f4x4_3x3" if mul_n else "direct"),
+                "conv_op": {"algo": "winograd_f4x4_3x3" if mul_n else "direct",
                             "avg_ms": conv_ms, "ops_timed": conv_n, "direct_conv_flop": flop_direct,
                             "direct_equivalent_tflops": flop_direct / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                             "winograd_flop_frac_of_peak": wflop / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if conv_ms > 0 else 0.0},

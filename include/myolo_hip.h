@@ -45,7 +45,7 @@ size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
 
 /* Tuning / ablation switches (process-wide ints, default 0 = shipped behaviour).  Names: "no_nt", "gemm_generic",
  * "no_splitk", "gemm_w256", "wino_nt", "wino_w256", "bf16_regstage", "bf16_no256", "bf16_force256", "crop_bwd_nolds",
- * "tune0", "dw_rows1", "dw_min_wg", "wino_no_mixed".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
+ * "tune0", "dw_rows1", "dw_min_wg", "wino_no_mixed", "wino_no_bt".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
  * One semantic switch: "bn_fused_tf_variance" (default 1) -- the BatchNormalization moving-variance update of bn_stats
  * restates Keras 2.2.x on TensorFlow 1.x's fused path (tf.nn.fused_batch_norm hands Keras the Bessel-corrected batch
  * variance, Keras multiplies by n/(n-(1+eps)) on top); 0 = Keras' factor on the biased variance (non-fused backend). */
@@ -254,8 +254,10 @@ size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int w
 size_t myolo_wino_plane_elems(int N, int H, int W, int C);
 int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
                            int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
-/* the forward's four stages, callable on their own: U [36][Cin][Cout] (flip=1: rotated, [36][Cout][Cin], for the data
- * gradient), V and M = 36 planes of myolo_wino_plane_elems(N,H,W,C) elements in total (a buffer of 36*T*C floats,
+/* the forward's four stages, callable on their own: U = 36 planes of Cin*Cout transformed filter taps (flip=1: of the rotated
+ * filter with the channel roles exchanged, for the data gradient: call the multiply with (Cout, Cin) then).  U is OPAQUE between
+ * myolo_wino_weight_transform and myolo_wino_multiply: the element order inside a plane is the one the multiply kernel chosen
+ * for (Cin, Cout) wants ([K][N], or [N][K] for csrc/wino_mm.hip when K % 16 == 0 and N % 256 == 0).  V and M = 36 planes of myolo_wino_plane_elems(N,H,W,C) elements in total (a buffer of 36*T*C floats,
  * T = N*ceil(H/4)*ceil(W/4), always suffices); planes are ordered by point group, see csrc/wino_kernels.hip */
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream);
 int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);

@@ -232,7 +232,8 @@ __global__ __launch_bounds__(256, 1) void wino_fused_fwd_kernel(WFArgs p)
         // ONE basic block per chunk, hand-interleaved: a 32x32x2 fp32 MFMA holds the matrix pipe for 64 cycles and a wave issues in
         // order, so everything else -- the input transform of chunk c+1 (36 LDS reads, two B^T passes, 36 LDS writes), the A-fragment
         // reads, the B-fragment loads of chunk c+1 and the raw image of chunk c+2 -- is cut into 72 small pieces, one behind each
-        // MFMA (sched_barrier(0) pins the order; left alone, the compiler runs the transform first and the MFMAs back to back).
+        // MFMA (sched_barrier(0) pins the memory operations; pure arithmetic and the MFMAs still float between them -- pinning those too with
+        // empty volatile asm statements was measured and changes nothing, see profiles/r2_notes.md).
         // The look-ahead of the last iterations is clamped to the last chunk (it lands in buffers nobody reads) instead of branching.
         const int cur = c & 1;
         const int c1 = min(c + 1, nchunk - 1), c2 = min(c + 2, nchunk - 1);
@@ -252,12 +253,7 @@ __global__ __launch_bounds__(256, 1) void wino_fused_fwd_kernel(WFArgs p)
             constexpr int pl = g >> 3, nh = (g >> 2) & 1, st = g & 3;
             const float av = st == 0 ? af[pl].x : st == 1 ? af[pl].y : st == 2 ? af[pl].z : af[pl].w;
             const float bv = st == 0 ? bq[pl][nh].x : st == 1 ? bq[pl][nh].y : st == 2 ? bq[pl][nh].z : bq[pl][nh].w;
-            // Pin the MFMA inside its gap: it has no memory effect, so instruction selection is free to float it over the
-            // sched_barriers (it ran MFMAs 4..8 back to back and everything of those gaps behind them).  An empty volatile asm on
-            // its A operand holds it below the previous barrier (one on the result would cost the hazard nops of a real reader).
-            float avp = av;
-            asm volatile("" : "+v"(avp));
-            acc[pl][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(avp, bv, acc[pl][nh], 0, 0, 0);
+            acc[pl][nh] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[pl][nh], 0, 0, 0);
             if constexpr (st == 3) bq[pl][nh] = *reinterpret_cast<const float4*>(un + (pl * 2 + nh) * 256);       // same registers, next chunk
             if constexpr ((g & 7) == 2 && pl < 8) af[pl + 1] = *reinterpret_cast<const float4*>(va + (pl + 1) * (WF_NT * WF_KC));
             if constexpr (g == 1) { rr[0] = *reinterpret_cast<const float4*>(xs0); rr[1] = *reinterpret_cast<const float4*>(xs0 + 4); }
@@ -267,16 +263,13 @@ __global__ __launch_bounds__(256, 1) void wino_fused_fwd_kernel(WFArgs p)
                 if constexpr (part == 0) {
 #pragma unroll
                     for (int i = 0; i < 6; ++i) d[i] = rbn[(i * WF_PW + j) * WF_RS];
-                } else if constexpr (part == 3) {        // (the asm keeps the arithmetic -- and the wait for the reads -- three gaps behind them)
-                    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+                } else if constexpr (part == 2) {
                     tmp[0][j] = 4.f * d[0] - 5.f * d[2] + d[4];
                     tmp[1][j] = d[3] + d[4] - 4.f * (d[1] + d[2]);
-                } else if constexpr (part == 4) {
-                    asm volatile("" : "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]));
+                } else if constexpr (part == 3) {
                     tmp[2][j] = 4.f * (d[1] - d[2]) - d[3] + d[4];
                     tmp[3][j] = 2.f * (d[3] - d[1]) - d[2] + d[4];
-                } else if constexpr (part == 5) {
-                    asm volatile("" : "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+                } else if constexpr (part == 4) {
                     tmp[4][j] = 2.f * (d[1] - d[3]) - d[2] + d[4];
                     tmp[5][j] = 4.f * d[1] - 5.f * d[3] + d[5];
                 }

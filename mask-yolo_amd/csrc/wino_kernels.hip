@@ -482,16 +482,23 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 
 // w [3,3,Ci,Co] -> U [36][Ci][Co]   (flip = 0), planes in q order (q_of(i, j))
 //                  U'[36][Co][Ci] of the 180-degree rotated filter with (ci,co) exchanged (flip = 1: data gradient)
-__global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int flip)
+// bt = 1: each plane transposed ([N][K] for the multiply's K x N operand: wino_mm_kernel reads both operands k-contiguous)
+__global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int flip, int bt)
 {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= Ci * Co) return;
-    const int ci = idx / Co, co = idx - ci * Co;
+    // block = a 16 x 16 patch of (ci, co); reads run along co (w's contiguous axis); planes whose contiguous axis is ci are
+    // written through an LDS transpose so both sides move 64-byte segments
+    __shared__ float tr[36][16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int ci0 = blockIdx.y * 16, co0 = blockIdx.x * 16;
+    const int ci = ci0 + ty, co = co0 + tx;
+    const bool ok = ci < Ci && co < Co;
+    const bool ci_major = (flip == bt);                   // plane [ci][co]; otherwise [co][ci]
     float g[3][3], tmp[6][3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx) * Ci + ci) * (long long)Co + co];
+        for (int kx = 0; kx < 3; ++kx)
+            g[ky][kx] = ok ? w[((flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx) * Ci + ci) * (long long)Co + co] : 0.f;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const float col[3] = {g[0][kx], g[1][kx], g[2][kx]};
@@ -501,13 +508,22 @@ __global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w
         for (int i = 0; i < 6; ++i) tmp[i][kx] = u[i];
     }
     const long long plane = (long long)Ci * Co;
-    const long long o = flip ? (long long)co * Ci + ci : (long long)ci * Co + co;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         float u[6];
         g3(tmp[i], u);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) U[q_of(i, j) * plane + o] = u[j];
+        for (int j = 0; j < 6; ++j) {
+            if (ci_major) { if (ok) U[q_of(i, j) * plane + (long long)ci * Co + co] = u[j]; }
+            else tr[q_of(i, j)][ty][tx] = u[j];
+        }
+    }
+    if (ci_major) return;
+    __syncthreads();
+    const int oci = ci0 + tx, oco = co0 + ty;             // thread (ty, tx) now owns (co = co0 + ty, ci = ci0 + tx)
+    if (oci < Ci && oco < Co) {
+#pragma unroll
+        for (int q = 0; q < 36; ++q) U[q * plane + (long long)oco * Ci + oci] = tr[q][tx][ty];
     }
 }
 
@@ -662,11 +678,21 @@ static int group_runs(const TileGeom& g, GroupRun out[4])
     return n;
 }
 
-// M[q] = V[q] * U[q] for the 36 points
+// M[q] = V[q] * U[q] for the 36 points (U planes [Cin][Cout], or transposed when myolo_gemm_nt_batched_ok(Cin, Cout): wino_w_kernel
+// and this function take the same decision from the same two numbers)
 static int wino_multiply_all(const float* V, const float* U, float* M, const TileGeom& g, int Cin, int Cout, hipStream_t s)
 {
     GroupRun runs[4];
     const int n = group_runs(g, runs);
+    if (myolo_gemm_nt_batched_ok(Cin, Cout)) {          // all runs in one launch (csrc/wino_mm.hip)
+        long long rows[4], ao[4], bo[4], co[4];
+        int nq[4];
+        for (int k = 0; k < n; ++k) {
+            rows[k] = runs[k].rows; nq[k] = runs[k].nq;
+            ao[k] = runs[k].row0 * Cin; bo[k] = (long long)runs[k].q0 * Cin * Cout; co[k] = runs[k].row0 * Cout;
+        }
+        return myolo_gemm_nt_batched_runs(V, U, M, n, rows, ao, bo, co, nq, Cin, Cout, s);
+    }
     for (int k = 0; k < n; ++k) {
         if (runs[k].rows <= 0) continue;
         const int rc = myolo_gemm_nn_batched(V + runs[k].row0 * Cin, U + (long long)runs[k].q0 * Cin * Cout, M + runs[k].row0 * Cout,
@@ -721,7 +747,8 @@ size_t myolo_wino_plane_elems(int N, int H, int W, int C) { return (size_t)geom(
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream)
 {
     MYOLO_REQUIRE(w && U && Cin > 0 && Cout > 0, "wino_weight_transform: bad arguments");
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, flip);
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, flip,
+                       (int)(flip ? myolo_gemm_nt_batched_ok(Cout, Cin) : myolo_gemm_nt_batched_ok(Cin, Cout)));
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -828,7 +855,7 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     float* U = (float*)ws;
     float* V = v_keep ? v_keep : (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 0);
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 0, (int)myolo_gemm_nt_batched_ok(Cin, Cout));
     hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = wino_multiply_all(V, U, Mp, g, Cin, Cout, s);
     if (rc != MYOLO_OK) return rc;
@@ -851,7 +878,7 @@ static int wino_bwd_data_impl(const float* dy, const LazyBn* lazy, const float* 
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, 1);
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 1, (int)myolo_gemm_nt_batched_ok(Cout, Cin));
     if (lazy) hipLaunchKernelGGL(wino_in_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, *lazy);
     else hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = wino_multiply_all(V, U, Mp, g, Cout, Cin, s);

@@ -1,0 +1,205 @@
+// Batched fp32 GEMM of the Winograd multiply stage with the SECOND operand stored transposed:
+//     C[z] (M x N) = A[z] (M x K) * Bt[z]^T,   A [M][K], Bt [N][K], C [M][N], all dense row-major, z = transform point.
+// (the 36 products per mask-head 3x3 conv, model.py:687-709; Bt = the transformed filters, which our own wino_w_kernel writes in
+// whichever layout the multiply wants.)
+//
+// Why another GEMM kernel: on gfx950 every non-MFMA instruction a SIMD issues costs the fp32 matrix pipe ~2-3 cycles, whoever
+// issues it (tools/mfma_valu_overlap.hip, profiles/r2_notes.md), and gemm_nn_fast's loop issues 41 of them per 32 MFMAs
+// (16 ds_read2_b32, 6 LDS writes, 4 buffer loads, ~15 VALU).  With BOTH operands k-contiguous in LDS a lane's four consecutive
+// k-steps are one ds_read_b128; a 32x32x2 MFMA only needs lanes 0-31 and 32-63 to hold two DIFFERENT k of the chunk, so the
+// k order is permuted: lanes 0-31 walk k = 0..7 of the 16-deep chunk, lanes 32-63 walk k = 8..15.  Tile 128 x 256 (A is read
+// once for all 256 output channels), 4 waves of 64 x 128 = 8 MFMA tiles:
+//     per 16-deep chunk and wave: 64 MFMAs, 12 ds_read_b128, 6 ds_write_b128, 6 buffer_load_dwordx4, one barrier.
+// LDS rows are padded to 20 floats: the 16 lanes of a ds_read_b128 phase (rows l .. l+15, same 16-byte slot) cover all 64
+// banks exactly once; the b128 writes (4 lanes per row) are conflict-free as well.
+// Pipeline: chunk c+1 is written to the other LDS buffer at the start of the second half of chunk c (its global loads were issued
+// one chunk earlier), one barrier, then the first-half fragments of chunk c+1 are read under the remaining MFMAs of chunk c;
+// the second-half fragments of a chunk are read under its first-half MFMAs.  No LDS read is waited for right after it is issued.
+#include "myolo_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define MM_BM 128
+#define MM_BN 256
+#define MM_BK 16
+#define MM_LD 20                     // padded LDS row (floats)
+#define MM_OOB 0x7fffff00u
+
+// one launch covers up to 4 "runs" of planes (groups of transform points whose planes have the same number of rows, see
+// group_runs() in wino_kernels.hip): separate launches would each end in a partial wave of workgroups.
+struct MMRun {
+    long long rows;        // M of every plane of the run
+    long long a_off;       // element offset of the run's first plane in A (planes M*K apart), likewise Bt (K*N apart) and C (M*N)
+    long long b_off;
+    long long c_off;
+    long long tile0;       // first flattened tile index of the run
+    int mtiles;            // ceil(rows / 128)
+    int nq;                // planes in the run
+};
+struct MMArgs {
+    const float* A;
+    const float* Bt;
+    float* C;
+    int K, N;
+    int nruns;
+    int nt;
+    MMRun run[4];
+};
+
+__device__ __forceinline__ float4 mm_bufld4(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mm_rsrc(const float* base, long long nbytes)
+{
+    if (nbytes < 0) nbytes = 0;
+    if (nbytes > 0x7ffffe00ll) nbytes = 0x7ffffe00ll;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(unsigned)nbytes, 0x00020000);
+}
+__device__ __forceinline__ float f4c(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
+
+__global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float As[2][MM_BM * MM_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][MM_BN * MM_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int ntn = p.N / MM_BN;
+    // workgroup b runs on XCD b % 8: give each XCD a contiguous run of tiles (consecutive tiles = consecutive row blocks of ONE
+    // plane: its 256 KB of filters stay in that XCD's L2)
+    long long bid;
+    {
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    int ri = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < p.nruns && bid >= p.run[k].tile0) ri = k;
+    const MMRun& R = p.run[ri];
+    const long long local = bid - R.tile0;
+    const long long per_plane = (long long)R.mtiles * ntn;
+    const int z = (int)(local / per_plane);
+    const long long rem = local - z * per_plane;
+    const int n0 = (int)(rem % ntn) * MM_BN;
+    const long long m0 = (rem / ntn) * MM_BM;
+    const long long M = R.rows;
+    const float* Ap = p.A + R.a_off + (long long)z * M * p.K;
+    const float* Bp = p.Bt + R.b_off + (long long)z * p.K * p.N;
+    float* Cp = p.C + R.c_off + (long long)z * M * p.N;
+    const long long mend = (m0 + MM_BM < M) ? m0 + MM_BM : M;
+    const __amdgpu_buffer_rsrc_t ra = mm_rsrc(Ap + m0 * p.K, (mend - m0) * p.K * 4);      // rows beyond M read 0
+    const __amdgpu_buffer_rsrc_t rb = mm_rsrc(Bp + (long long)n0 * p.K, (long long)MM_BN * p.K * 4);
+
+    // loader role: thread = (row r4 [+64 i], 16-byte slot kq) of the 16-deep chunk
+    const int r4 = tid >> 2, kq = (tid & 3) * 4;
+    const unsigned rowb = (unsigned)p.K * 4u;
+    unsigned goff = ((unsigned)r4 * (unsigned)p.K + (unsigned)kq) * 4u;      // advanced by 64 bytes per chunk
+    const int soff = r4 * MM_LD + kq;
+    float4 sa[2], sb[4];
+    auto gload = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) sa[i] = mm_bufld4(ra, goff + (unsigned)(64 * i) * rowb);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sb[i] = mm_bufld4(rb, goff + (unsigned)(64 * i) * rowb);
+        goff += MM_BK * 4u;
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&As[buf][soff + 64 * i * MM_LD]) = sa[i];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[buf][soff + 64 * i * MM_LD]) = sb[i];
+    };
+    // MFMA role: lane (l31, half) holds k = 8*half + 4*q + s of rows / columns l31 (+32 t, +32 u)
+    const int aoff = (wm * 64 + l31) * MM_LD + half * 8;
+    const int boff = (wn * 128 + l31) * MM_LD + half * 8;
+    float4 fa[2][2], fb[2][4];          // [q][tile]
+    auto fread = [&](int buf, int q) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) fa[q][t] = *reinterpret_cast<const float4*>(&As[buf][aoff + t * 32 * MM_LD + 4 * q]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fb[q][u] = *reinterpret_cast<const float4*>(&Bs[buf][boff + u * 32 * MM_LD + 4 * q]);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int nk = p.K / MM_BK;
+    gload();
+    sstore(0);
+    if (nk > 1) gload();
+    __syncthreads();
+    fread(0, 0);
+
+#define MM_STEP(q, s)                                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                      \
+        _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                  \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(fa[q][t], s), f4c(fb[q][u], s), acc[t][u], 0, 0, 0);
+
+    for (int c = 0; c < nk; ++c) {
+        const int cur = c & 1;
+        fread(cur, 1);                       // second-half fragments, used 32 MFMAs from now
+        MM_STEP(0, 0) MM_STEP(0, 1) MM_STEP(0, 2) MM_STEP(0, 3)
+        if (c + 1 < nk) sstore(cur ^ 1);     // chunk c+1 (loaded one chunk ago) -> the buffer whose last reader was chunk c-1
+        if (c + 2 < nk) gload();             // chunk c+2 into the same staging registers
+        MM_STEP(1, 0)
+        __syncthreads();
+        if (c + 1 < nk) fread(cur ^ 1, 0);   // first-half fragments of chunk c+1 under the rest of this chunk
+        MM_STEP(1, 1) MM_STEP(1, 2) MM_STEP(1, 3)
+    }
+#undef MM_STEP
+
+    // ---- epilogue: 128-byte row segments per 32 lanes ----
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= M) continue;
+            float* dst = Cp + row * p.N + n0 + wn * 128 + l31;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p.nt) __builtin_nontemporal_store(acc[t][u][r], dst + 32 * u);
+                else dst[32 * u] = acc[t][u][r];
+            }
+        }
+}
+
+/* whether the Winograd multiply of a (K = Cin, N = Cout) layer runs here (and the filters are therefore stored transposed) */
+bool myolo_gemm_nt_batched_ok(int K, int N) { return !g_myolo_opt.wino_no_bt && K >= MM_BK && (K % MM_BK) == 0 && (N % MM_BN) == 0; }
+
+/* For every run r < nruns and plane z < nq[r]:  C_r[z] (rows[r] x N) = A_r[z] (rows[r] x K) * Bt_r[z]^T, with
+ * A_r = A + a_off[r] (planes rows[r]*K elements apart), Bt_r = Bt + b_off[r] (K*N apart), C_r = C + c_off[r] (rows[r]*N apart).
+ * Needs myolo_gemm_nt_batched_ok(K, N) and 16-byte aligned operands; ONE launch. */
+int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nruns, const long long* rows, const long long* a_off,
+                               const long long* b_off, const long long* c_off, const int* nq, int K, int N, hipStream_t s)
+{
+    if (K < MM_BK || (K % MM_BK) || (N % MM_BN) || ((uintptr_t)A & 15) || ((uintptr_t)Bt & 15) || ((uintptr_t)C & 15) || nruns < 0 || nruns > 4) {
+        myolo_set_error("gemm_nt_batched_runs: needs K %% %d == 0, N %% %d == 0, <= 4 runs and 16-byte aligned operands", MM_BK, MM_BN);
+        return MYOLO_EINVAL;
+    }
+    MMArgs a{};
+    a.A = A; a.Bt = Bt; a.C = C; a.K = K; a.N = N; a.nt = g_myolo_opt.wino_nt ? 1 : 0;
+    long long tiles = 0;
+    for (int r = 0; r < nruns; ++r) {
+        if (rows[r] <= 0 || nq[r] <= 0) continue;
+        if ((a_off[r] | b_off[r] | c_off[r]) & 3) { myolo_set_error("gemm_nt_batched_runs: run offsets must be multiples of 4 elements"); return MYOLO_EINVAL; }
+        MMRun& R = a.run[a.nruns++];
+        R.rows = rows[r]; R.a_off = a_off[r]; R.b_off = b_off[r]; R.c_off = c_off[r]; R.nq = nq[r];
+        R.mtiles = (int)((rows[r] + MM_BM - 1) / MM_BM);
+        R.tile0 = tiles;
+        tiles += (long long)R.mtiles * (N / MM_BN) * nq[r];
+    }
+    if (tiles <= 0) return MYOLO_OK;
+    hipLaunchKernelGGL(wino_mm_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}

@@ -29,6 +29,10 @@ __global__ __launch_bounds__(256 * NW, 1) void k(float* out, int iters)
                 for (int i = 0; i < KV; ++i) v[i] = fmaf(v[i], 1.0001f, 0.5f);
 #pragma unroll
                 for (int i = 0; i < KL; ++i) l += lp[(g * KL + i) * 256];
+                if (KL < 0 && (g & 3) == 0) {
+#pragma unroll
+                    for (int i = 0; i < -KL; ++i) { const float4 q = *reinterpret_cast<const float4*>(lds + ((g / 4 * -KL + i) * 256 + threadIdx.x) * 4); l += q.x + q.w; }
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -43,6 +47,10 @@ __global__ __launch_bounds__(256 * NW, 1) void k(float* out, int iters)
             for (int i = 0; i < KV; ++i) v[i] = fmaf(v[i], 1.0001f, 0.5f);
 #pragma unroll
             for (int i = 0; i < KL; ++i) l += lp[(g * KL + i) * 256];
+            if (KL < 0 && (g & 3) == 0) {
+#pragma unroll
+                for (int i = 0; i < -KL; ++i) { const float4 q = *reinterpret_cast<const float4*>(lds + ((g / 4 * -KL + i) * 256 + threadIdx.x) * 4); l += q.x + q.w; }
+            }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -74,5 +82,7 @@ int main()
     run<0, 0, 0, 2>(out); run<4, 0, 0, 2>(out); run<8, 0, 0, 2>(out); run<12, 0, 0, 2>(out); run<4, 1, 0, 2>(out);
     run<4, 0, 2, 2>(out); run<8, 0, 2, 2>(out); run<12, 0, 2, 2>(out); run<8, 1, 2, 2>(out);
     run<0, 0, 0, 4>(out); run<8, 0, 0, 4>(out);
+    // LDS reads only: KL > 0 = ds_read_b32 per MFMA; KL < 0 = -KL ds_read_b128 per FOUR MFMAs (same bytes as KL b32 per MFMA)
+    run<0, 1, 0, 2>(out); run<0, -1, 0, 2>(out); run<0, 2, 0, 2>(out); run<0, -2, 0, 2>(out); run<0, -3, 0, 2>(out); run<1, 0, 0, 2>(out); run<2, 0, 0, 2>(out);
     return 0;
 }
