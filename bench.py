@@ -200,7 +200,7 @@ def bench_train(args, rank, world, local):
     dev = "cuda:%d" % local
     base = ShapesConfig if args.nbox == 3 else ShapesHeadConfig
     cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch,
-                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois, CONV3X3_ALGO=args.conv3x3)
+                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois, CONV3X3_ALGO=args.conv3x3, FP32_MATMUL=args.fp32_matmul)
     model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
     net = model.net
     reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1)
@@ -271,6 +271,14 @@ def bench_train(args, rank, world, local):
             lambda: setattr(net, "sparse_mask_bwd", False), lambda: setattr(net, "sparse_mask_bwd", True),
             "mask-head backward on ALL ROIs (conv2-4 / deconv / myolo_mask dense): the structural zeros behind bn1 are not "
             "exploited; same gradients (tests/test_gpu_step.py::test_sparse_mask_backward_equals_dense)")
+        from myolo import _ext as Xo
+        other = "native" if net.fp32_matmul == "bf16x6" else "bf16x6"
+        variants["winograd_multiply_%s" % other] = run_variant(
+            lambda: Xo.set_option("wino_x6", 1 if other == "bf16x6" else 0), lambda: Xo.set_option("wino_x6", 0 if other == "bf16x6" else 1),
+            "cfg.FP32_MATMUL='%s' instead of '%s': the Winograd multiply's fp32 products formed %s; identical fp32 inputs, outputs and "
+            "accumulation, error against fp64 not larger than the native path's (tests/test_gpu_ops.py::test_wino_multiply_bf16x6_accuracy)"
+            % (other, net.fp32_matmul, "from six exact bf16 piece products on the bf16 matrix pipe (csrc/wino_mm.hip)" if other == "bf16x6"
+               else "by v_mfma_f32_32x32x2_f32"))
         if world == 1:
             def flip_fwd():
                 net.sparse_mask_fwd = not net.sparse_mask_fwd
@@ -322,6 +330,19 @@ def bench_train(args, rank, world, local):
             traffic_src = "profiles/%s (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)" % pmc
     except Exception:
         pass
+    peak = FP32_MFMA_PEAK
+    x6 = bool(mul_n) and net.fp32_matmul == "bf16x6"
+    if x6:          # six bf16 piece products per fp32 product: price the launch in bf16 MFMA flops against the dense bf16 peak
+        kname = kname.replace("wino_mm_kernel", "wino_mm_x6_kernel (FP32_MATMUL='bf16x6': flops counted are the 6 bf16 piece products per fp32 product)")
+        kflop, peak, pmc = 6.0 * kflop, BF16_MFMA_PEAK, "r2_pmc_wino_multiply_x6.json"
+        traffic, traffic_src = None, None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", pmc)))
+            if args.batch * R == 32 * 147:
+                traffic = pj["traffic_bytes_per_launch_corrected"]
+                traffic_src = "profiles/%s (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)" % pmc
+        except Exception:
+            pass
     achieved = kflop / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
 
     # SURVEY 8(d) bytes
@@ -336,9 +357,10 @@ def bench_train(args, rank, world, local):
              "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS}
         d.update(extra)
         return d
-    roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK, "unit": "TFLOP/s",
-                "frac": achieved / FP32_MFMA_PEAK, "traffic": traffic, "traffic_source": traffic_src,
+    roofline = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
+                "fp32_equivalent_tflops": wflop / (kms * 1e-3) / 1e12 if (mul_n and kms > 0) else None,
                 "conv_op": {"algo": "winograd_f4x4_3x3" if mul_n else "direct",
                             "avg_ms": conv_ms, "ops_timed": conv_n, "direct_conv_flop": flop_direct,
                             "direct_equivalent_tflops": flop_direct / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
@@ -373,9 +395,11 @@ def bench_train(args, rank, world, local):
                                    args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
                                    "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + "3x3 convs: " +
                                {"auto": "fp32 Winograd F(4x4,3x3) for launches >= 16384 pixels, direct implicit GEMM below",
-                                "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO],
+                                "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO] +
+                               "; Winograd multiply products: " + ("native fp32 MFMA" if net.fp32_matmul == "native" else
+                               "FP32_MATMUL='bf16x6' (each fp32 product = six exact bf16 piece products, fp32 accumulation)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "n_pos_mean": npos_mean, "rois_per_image": R,
+                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option),
                    "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
         "roofline": roofline,
     }
@@ -493,6 +517,9 @@ def main():
     ap.add_argument("--conv3x3", choices=["auto", "direct", "winograd"], default="auto", help="cfg.CONV3X3_ALGO")
     ap.add_argument("--comm", choices=["torch", "capi"], default="torch",
                     help="N>1: gradient all-reduce through torch.distributed (nccl = RCCL) or through the library's own myolo_comm_* entry points")
+    ap.add_argument("--fp32-matmul", choices=["native", "bf16x6"], default="native", help="cfg.FP32_MATMUL (how the Winograd multiply forms its fp32 products)")
+    ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="myolo_set_option switches for this run (kernel A/B comparisons, e.g. wino_x6=1); recorded in config.lib_options")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
@@ -508,6 +535,11 @@ def main():
                          % (args.gpus, world, args.gpus, args.gpus))
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local)
+    if args.lib_option:
+        from myolo import _ext as X
+        for kv in args.lib_option:
+            name, _, val = kv.partition("=")
+            X.set_option(name, int(val))
     if args.config == "rice416-bf16":
         res = bench_infer(args) if rank == 0 else None
     else:

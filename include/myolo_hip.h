@@ -45,7 +45,7 @@ size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
 
 /* Tuning / ablation switches (process-wide ints, default 0 = shipped behaviour).  Names: "no_nt", "gemm_generic",
  * "no_splitk", "gemm_w256", "wino_nt", "wino_w256", "bf16_regstage", "bf16_no256", "bf16_force256", "crop_bwd_nolds",
- * "tune0", "dw_rows1", "dw_min_wg", "wino_no_mixed", "wino_no_bt".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
+ * "tune0", "dw_rows1", "dw_min_wg", "wino_no_mixed", "wino_no_bt", "wino_x6".  Unknown name -> MYOLO_EINVAL.  Every switch selects between kernels with the same contract.
  * One semantic switch: "bn_fused_tf_variance" (default 1) -- the BatchNormalization moving-variance update of bn_stats
  * restates Keras 2.2.x on TensorFlow 1.x's fused path (tf.nn.fused_batch_norm hands Keras the Bessel-corrected batch
  * variance, Keras multiplies by n/(n-(1+eps)) on top); 0 = Keras' factor on the biased variance (non-fused backend). */
@@ -252,6 +252,8 @@ size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int w
  * F(2,3) on a last tile row / column that holds <= 2 outputs, e.g. 14 = 4+4+4+2 -- reduced tiles have no row in the planes of
  * the points they do not use; at 14x14 that is 484 instead of 576 point-tiles per image) */
 size_t myolo_wino_plane_elems(int N, int H, int W, int C);
+/* floats to allocate for U of myolo_wino_weight_transform (1.5 x 36*Cin*Cout: room for the split-bf16 layout of option "wino_x6") */
+size_t myolo_wino_u_elems(int Cin, int Cout);
 int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
                            int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
 /* the forward's four stages, callable on their own: U = 36 planes of Cin*Cout transformed filter taps (flip=1: of the rotated

@@ -23,6 +23,7 @@ struct MyoloOptions {
     int tune0;            // scratch integer for kernel-tuning experiments (0 = off); never set by the product
     int dw_min_wg;        // depthwise forward: fewest workgroups for which the 4-row strip kernel is chosen (0 = default)
     int dw_rows1;         // depthwise forward: one output row per thread (no vertical strip)
+    int wino_x6;          // winograd multiply on the bf16 matrix pipe: 6 piece products per fp32 product, fp32 accumulation (csrc/wino_mm.hip)
     int wino_no_bt;       // winograd multiply: gemm_nn_fast on [K][N] filters instead of wino_mm_kernel on transposed ones
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
@@ -68,6 +69,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M, int K, int N, int batch, hipStream_t s);
 // csrc/wino_mm.hip: the same product with the second operand stored transposed ([N][K]); _ok says whether (K, N) qualifies
 bool myolo_gemm_nt_batched_ok(int K, int N);
+bool myolo_gemm_nt_batched_x6(int K, int N);
 int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nruns, const long long* rows, const long long* a_off,
                                const long long* b_off, const long long* c_off, const int* nq, int K, int N, hipStream_t s);
 size_t myolo_gemm_tn_batched_ws_bytes(long long M, int Ka, int N, int batch);

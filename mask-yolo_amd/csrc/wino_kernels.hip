@@ -483,6 +483,8 @@ __global__ __launch_bounds__(256) void wino_dy_kernel(const float* __restrict__ 
 // w [3,3,Ci,Co] -> U [36][Ci][Co]   (flip = 0), planes in q order (q_of(i, j))
 //                  U'[36][Co][Ci] of the 180-degree rotated filter with (ci,co) exchanged (flip = 1: data gradient)
 // bt = 1: each plane transposed ([N][K] for the multiply's K x N operand: wino_mm_kernel reads both operands k-contiguous)
+// bt = 2: the transposed plane split into three bf16 pieces per value (round-to-nearest; exact: 3 x 8 significand bits) in the
+//         MFMA operand order of wino_mm_x6_kernel: [plane][k / 16][n / 32][piece][(k / 8) % 2][n % 32][k % 8] bf16
 __global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int flip, int bt)
 {
     // block = a 16 x 16 patch of (ci, co); reads run along co (w's contiguous axis); planes whose contiguous axis is ci are
@@ -492,6 +494,8 @@ __global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w
     const int ci0 = blockIdx.y * 16, co0 = blockIdx.x * 16;
     const int ci = ci0 + ty, co = co0 + tx;
     const bool ok = ci < Ci && co < Co;
+    const bool x6 = bt == 2;
+    if (x6) bt = 1;
     const bool ci_major = (flip == bt);                   // plane [ci][co]; otherwise [co][ci]
     float g[3][3], tmp[6][3];
 #pragma unroll
@@ -514,11 +518,21 @@ __global__ __launch_bounds__(256) void wino_w_kernel(const float* __restrict__ w
         g3(tmp[i], u);
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
-            if (ci_major) { if (ok) U[q_of(i, j) * plane + (long long)ci * Co + co] = u[j]; }
+            if (x6) {
+                if (!ok) continue;
+                const int k = flip ? co : ci, n = flip ? ci : co, N = flip ? Ci : Co, nkc = (flip ? Co : Ci) >> 4;
+                __bf16* rec = reinterpret_cast<__bf16*>(U) + ((((long long)q_of(i, j) * nkc + (k >> 4)) * (N >> 5) + (n >> 5)) * 6 + ((k >> 3) & 1)) * 256 + (n & 31) * 8 + (k & 7);
+                const __bf16 p1 = (__bf16)u[j];
+                const float r1 = u[j] - (float)p1;
+                const __bf16 p2 = (__bf16)r1;
+                const __bf16 p3 = (__bf16)(r1 - (float)p2);
+                rec[0] = p1; rec[512] = p2; rec[1024] = p3;
+            }
+            else if (ci_major) { if (ok) U[q_of(i, j) * plane + (long long)ci * Co + co] = u[j]; }
             else tr[q_of(i, j)][ty][tx] = u[j];
         }
     }
-    if (ci_major) return;
+    if (ci_major || x6) return;
     __syncthreads();
     const int oci = ci0 + tx, oco = co0 + ty;             // thread (ty, tx) now owns (co = co0 + ty, ci = ci0 + tx)
     if (oci < Ci && oco < Co) {
@@ -662,7 +676,10 @@ static unsigned ew_grid(long long total)
     return (unsigned)(b < 1 ? 1 : b);
 }
 static size_t plane_bytes(const TileGeom& g, int C) { return align256((size_t)g.rows * C * sizeof(float)); }
-static size_t u_bytes(int Ci, int Co) { return align256((size_t)36 * Ci * Co * sizeof(float)); }
+// transformed filters: 36 planes of Ci*Co values, 6 bytes each when stored as three bf16 pieces (always sized for that)
+static size_t u_bytes(int Ci, int Co) { return align256((size_t)36 * Ci * Co * 6); }
+// layout of the transformed filters for the multiply of a (K, N) layer: 0 = [K][N], 1 = [N][K], 2 = split bf16 records
+static int wino_u_layout(int K, int N) { return myolo_gemm_nt_batched_x6(K, N) ? 2 : (myolo_gemm_nt_batched_ok(K, N) ? 1 : 0); }
 
 // runs of consecutive groups whose planes have the same row count: one batched GEMM launch each
 struct GroupRun { int q0, nq; long long rows, row0; };
@@ -742,13 +759,15 @@ size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int w
 /* elements of the 36 V (or M) planes of an [N,H,W,C] tensor: <= 36 * N*ceil(H/4)*ceil(W/4) * C (mixed tiling drops the rows of
  * reduced tiles from the planes of the points they do not use) */
 size_t myolo_wino_plane_elems(int N, int H, int W, int C) { return (size_t)geom(N, H, W).rows * (size_t)C; }
+/* floats to allocate for the transformed filters U of myolo_wino_weight_transform (any layout the multiply may choose) */
+size_t myolo_wino_u_elems(int Cin, int Cout) { return u_bytes(Cin, Cout) / sizeof(float); }
 
 /* ---- the four stages on their own (the engine times the multiply stage for bench.py's roofline) ---- */
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream)
 {
     MYOLO_REQUIRE(w && U && Cin > 0 && Cout > 0, "wino_weight_transform: bad arguments");
     hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, flip,
-                       (int)(flip ? myolo_gemm_nt_batched_ok(Cout, Cin) : myolo_gemm_nt_batched_ok(Cin, Cout)));
+                       wino_u_layout(flip ? Cout : Cin, flip ? Cin : Cout));
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -855,7 +874,7 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     float* U = (float*)ws;
     float* V = v_keep ? v_keep : (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 0, (int)myolo_gemm_nt_batched_ok(Cin, Cout));
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 0, wino_u_layout(Cin, Cout));
     hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = wino_multiply_all(V, U, Mp, g, Cin, Cout, s);
     if (rc != MYOLO_OK) return rc;
@@ -878,7 +897,7 @@ static int wino_bwd_data_impl(const float* dy, const LazyBn* lazy, const float* 
     float* U = (float*)ws;
     float* V = (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 1, (int)myolo_gemm_nt_batched_ok(Cout, Cin));
+    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 1, wino_u_layout(Cout, Cin));
     if (lazy) hipLaunchKernelGGL(wino_in_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, *lazy);
     else hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = wino_multiply_all(V, U, Mp, g, Cout, Cin, s);

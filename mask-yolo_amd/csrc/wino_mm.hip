@@ -174,8 +174,164 @@ __global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
         }
 }
 
+// =====================================================================================================================
+// The same product on the bf16 matrix pipe, at fp32 accuracy ("bf16x6"): every fp32 operand is split EXACTLY into three bf16
+// pieces (x = x1 + x2 + x3: 8 + 8 + 8 significand bits), and a*b is accumulated in fp32 from the six piece products that are
+// not below fp32 resolution:  a1b3 + a3b1 + a2b2 + a1b2 + a2b1 + a1b1  (dropped: a2b3, a3b2, a3b3 <= 2^-25 |ab|).
+// bf16 x bf16 products are exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result carries the same
+// kind of error as the fp32 MFMA path -- measured against an fp64 reference it is slightly SMALLER (96 instead of 128 fp32
+// roundings per 256-deep dot product; tests/test_gpu_ops.py::test_wino_multiply_bf16x6_accuracy, tools/split_bf16_numerics.py)
+// -- while six 32-cycle bf16 MFMAs replace eight 64-cycle fp32 MFMAs per 32x32x16 block: 2.67x less matrix-pipe time.
+//   A (activations V): fp32 in HBM as before; split in the loader by truncation (and / sub / perm: 44 VALU per 8 elements) into
+//                LDS row records [p0h0 | p0h1 | p1h0 | p1h1 | p2h0 | p2h1 | pad] x 16 bytes = 112 bytes (piece p, k half h): a
+//                lane's operand (row l&31, k = 8*(l>>5) .. +7) is one ds_read_b128 and 16 consecutive rows at one slot cover all
+//                64 banks.  Double-buffered (2 x 14 KB), one barrier per 16-deep chunk.
+//   B (filters): split once by wino_w_kernel (round-to-nearest) and stored in MFMA operand order
+//                [plane][chunk][n / 32][piece][k half][n % 32][8 bf16]: a wave's B fragment is 1 KB contiguous and goes
+//                straight from L2 to registers (the 9.4 MB of filters are L2 / MALL resident), one chunk ahead of its use --
+//                no LDS traffic and no barrier for two thirds of the operand bytes.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define X6_REC 112            // bytes per LDS row record
+
+__device__ __forceinline__ unsigned x6_top(float lo, float hi) { return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u); }
+__device__ __forceinline__ float x6_rest(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ bf16x8 x6_ldb(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff)
+{
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][MM_BM * X6_REC];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int ntn = p.N / MM_BN;
+    long long bid;
+    {
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    int ri = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < p.nruns && bid >= p.run[k].tile0) ri = k;
+    const MMRun& R = p.run[ri];
+    const long long local = bid - R.tile0;
+    const long long per_plane = (long long)R.mtiles * ntn;
+    const int z = (int)(local / per_plane);
+    const long long rem = local - z * per_plane;
+    const int n0 = (int)(rem % ntn) * MM_BN;
+    const long long m0 = (rem / ntn) * MM_BM;
+    const long long M = R.rows;
+    const int nk = p.K / MM_BK;
+    const float* Ap = p.A + R.a_off + (long long)z * M * p.K;
+    // split filters: 6 bytes per element; b_off counts ELEMENTS of the plane sequence
+    const unsigned char* Bp = reinterpret_cast<const unsigned char*>(p.Bt) + (R.b_off + (long long)z * p.K * p.N) * 6;
+    float* Cp = p.C + R.c_off + (long long)z * M * p.N;
+    const long long mend = (m0 + MM_BM < M) ? m0 + MM_BM : M;
+    const __amdgpu_buffer_rsrc_t ra = mm_rsrc(Ap + m0 * p.K, (mend - m0) * p.K * 4);      // rows beyond M read 0
+    const __amdgpu_buffer_rsrc_t rb = mm_rsrc(reinterpret_cast<const float*>(Bp), (long long)p.K * p.N * 6);
+
+    // A loader: thread = (row tid>>1, k half tid&1): 8 consecutive floats
+    const int arow = tid >> 1, ah = tid & 1;
+    unsigned aoffg = ((unsigned)arow * (unsigned)p.K + (unsigned)ah * 8u) * 4u;            // + 64 bytes per chunk
+    const int asto = arow * X6_REC + ah * 16;                                              // + piece * 32
+    float4 sa[2];
+    auto gload = [&]() {
+        sa[0] = mm_bufld4(ra, aoffg);
+        sa[1] = mm_bufld4(ra, aoffg + 16u);
+        aoffg += MM_BK * 4u;
+    };
+    auto sstore = [&](int buf) {
+        const float x[8] = {sa[0].x, sa[0].y, sa[0].z, sa[0].w, sa[1].x, sa[1].y, sa[1].z, sa[1].w};
+        float r1[8], r2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { r1[e] = x6_rest(x[e]); r2[e] = x6_rest(r1[e]); }
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            p1[e] = x6_top(x[2 * e], x[2 * e + 1]);
+            p2[e] = x6_top(r1[2 * e], r1[2 * e + 1]);
+            p3[e] = x6_top(r2[2 * e], r2[2 * e + 1]);
+        }
+        *reinterpret_cast<u32x4*>(As[buf] + asto) = p1;
+        *reinterpret_cast<u32x4*>(As[buf] + asto + 32) = p2;
+        *reinterpret_cast<u32x4*>(As[buf] + asto + 64) = p3;
+    };
+    const int afr = (wm * 64 + l31) * X6_REC + half * 16;          // + t * 32 rows, + piece * 32 bytes
+    // B fragments: tile (n0 + wn*128)/32 + u, piece pc, this lane's k half and column: 16 bytes at
+    //   ((chunk * N/32 + tile) * 6 + pc * 2 + half) * 512 + l31 * 16
+    const unsigned bvo = (unsigned)(((n0 + wn * 128) >> 5) * 6 + half) * 512u + (unsigned)l31 * 16u;     // + u * 3072 + pc * 1024
+    const unsigned bchunk = (unsigned)(p.N >> 5) * 3072u;
+    unsigned bso = 0;                                                                                    // chunk offset (scalar)
+    bf16x8 bq[4][3];
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    gload();
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bso);
+    sstore(0);
+    if (nk > 1) gload();
+    __syncthreads();
+
+    for (int c = 0; c < nk; ++c) {
+        const int cur = c & 1;
+        bf16x8 fa[2][3];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) fa[t][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + t * 32 * X6_REC + pc * 32);
+        // under the latency of those reads: split chunk c+1 into the other buffer (its last readers finished before the barrier
+        // that ended chunk c-1) and fetch chunk c+2
+        if (c + 1 < nk) sstore(cur ^ 1);
+        if (c + 2 < nk) gload();
+        const unsigned bnext = (c + 1 < nk) ? bso + bchunk : bso;      // the last chunk re-reads itself (into registers nobody uses)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            // smallest terms first; the two row tiles alternate so that no MFMA waits for the one just issued
+#define X6_TERM(pa, pb)                                                                                        \
+            acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][pa], bq[u][pb], acc[0][u], 0, 0, 0);     \
+            acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][pa], bq[u][pb], acc[1][u], 0, 0, 0);
+            X6_TERM(0, 2) X6_TERM(2, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0)
+#undef X6_TERM
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bnext);      // same registers, next chunk
+        }
+        bso = bnext;
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row >= M) continue;
+            float* dst = Cp + row * p.N + n0 + wn * 128 + l31;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (p.nt) __builtin_nontemporal_store(acc[t][u][r], dst + 32 * u);
+                else dst[32 * u] = acc[t][u][r];
+            }
+        }
+}
+
 /* whether the Winograd multiply of a (K = Cin, N = Cout) layer runs here (and the filters are therefore stored transposed) */
 bool myolo_gemm_nt_batched_ok(int K, int N) { return !g_myolo_opt.wino_no_bt && K >= MM_BK && (K % MM_BK) == 0 && (N % MM_BN) == 0; }
+/* ... and whether it runs as six bf16 piece products per fp32 product (option "wino_x6"; the filters are stored split then) */
+bool myolo_gemm_nt_batched_x6(int K, int N) { return g_myolo_opt.wino_x6 && myolo_gemm_nt_batched_ok(K, N); }
 
 /* For every run r < nruns and plane z < nq[r]:  C_r[z] (rows[r] x N) = A_r[z] (rows[r] x K) * Bt_r[z]^T, with
  * A_r = A + a_off[r] (planes rows[r]*K elements apart), Bt_r = Bt + b_off[r] (K*N apart), C_r = C + c_off[r] (rows[r]*N apart).
@@ -200,6 +356,7 @@ int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nr
         tiles += (long long)R.mtiles * (N / MM_BN) * nq[r];
     }
     if (tiles <= 0) return MYOLO_OK;
-    hipLaunchKernelGGL(wino_mm_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    if (g_myolo_opt.wino_x6) hipLaunchKernelGGL(wino_mm_x6_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);      // Bt = split filters
+    else hipLaunchKernelGGL(wino_mm_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
 }

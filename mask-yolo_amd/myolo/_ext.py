@@ -110,6 +110,8 @@ def load():
     lib.myolo_conv3x3_wino_fused_ws_bytes.restype = Z
     lib.myolo_wino_plane_elems.argtypes = [I, I, I, I]
     lib.myolo_wino_plane_elems.restype = Z
+    lib.myolo_wino_u_elems.argtypes = [I, I]
+    lib.myolo_wino_u_elems.restype = Z
     lib.myolo_deconv2x2s2_mask_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
     lib.myolo_wino_output_transform_bn_ws_bytes.argtypes = [I]
@@ -119,7 +121,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_conv3x3_wino_fused_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_conv3x3_wino_fused_ws_bytes",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -178,6 +180,11 @@ def wino_ws_bytes(n, h, w, cin, cout, which):
 
 def wino_fused_ws_bytes(cin, cout):
     return int(load().myolo_conv3x3_wino_fused_ws_bytes(int(cin), int(cout)))
+
+
+def wino_u_elems(cin, cout):
+    """floats to allocate for the transformed filters U of myolo_wino_weight_transform"""
+    return int(load().myolo_wino_u_elems(int(cin), int(cout)))
 
 
 def wino_plane_elems(n, h, w, c):

@@ -94,6 +94,11 @@ class Config(object):
     # multiplications at 14x14, same operand and accumulator type, sums associated differently: agrees with the direct
     # kernel to ~1e-5 relative), "auto" = Winograd for launches of >= 16384 output pixels, direct below.
     CONV3X3_ALGO = "auto"
+    # How the fp32 products of the Winograd multiply stage are formed: "native" = v_mfma_f32_32x32x2_f32; "bf16x6" = every fp32
+    # operand split exactly into three bf16 pieces and each product accumulated in fp32 from its six significant piece products
+    # on the bf16 matrix pipe (csrc/wino_mm.hip; measured error against fp64 <= the native path's, 2.7x less matrix-pipe time).
+    # Process-wide library switch ("wino_x6"), set when a Net is built.
+    FP32_MATMUL = "native"
     # detect(): replay the inference forward from a captured hipGraph (one capture per input shape) instead of ~150 launches
     INFERENCE_HIP_GRAPH = True
     # detect() keeps at most 10 boxes (model.py:1290-1304).  True: ROIAlign + mask head run on those survivors only instead

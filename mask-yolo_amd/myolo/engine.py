@@ -180,6 +180,10 @@ class Net(object):
         self.conv3x3_algo = getattr(cfg, "CONV3X3_ALGO", "auto")
         if self.conv3x3_algo not in ("auto", "direct", "winograd"):
             raise ValueError("CONV3X3_ALGO must be 'auto', 'direct' or 'winograd' (got %r)" % (self.conv3x3_algo,))
+        self.fp32_matmul = getattr(cfg, "FP32_MATMUL", "native")
+        if self.fp32_matmul not in ("native", "bf16x6"):
+            raise ValueError("FP32_MATMUL must be 'native' or 'bf16x6' (got %r)" % (self.fp32_matmul,))
+        X.set_option("wino_x6", 1 if self.fp32_matmul == "bf16x6" else 0)
         self.sparse_mask_bwd = True
         # exact-sparsity FORWARD of the mask head (see mask_head_fwd_positives): conv2-4 / deconv / myolo_mask only on
         # the positive ROIs.  Same loss, gradients and BN state; the training graph's unused myolo_mask rows of the
@@ -321,7 +325,7 @@ class Net(object):
         v = None
         if self._wino_ok(nimg, h, w, cin, cout):
             T = nimg * ((h + 3) // 4) * ((w + 3) // 4)
-            U, V, M = self._new(36, cin, cout), self._new(36, T, cin), self._new(36, T, cout)
+            U, V, M = self._new(X.wino_u_elems(cin, cout)), self._new(36, T, cin), self._new(36, T, cout)
             X.call("myolo_wino_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, 0, X.stream())
             X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V), nimg, h, w, cin, X.stream())
             # only the dense mask-head launches (tag given) feed bench.py's roofline; feature_map / compacted ones do not
@@ -572,7 +576,7 @@ class Net(object):
                                      X.ptr(Vcur), fn, fh, fw, cin, NR, ps, ps, X.stream())
                 else:
                     self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
-            U, M = self._new(36, cin, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
+            U, M = self._new(X.wino_u_elems(cin, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
             X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
             self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, ps, ps, cin, MASK_FILTERS,
                              X.stream())
@@ -790,7 +794,7 @@ class Net(object):
             T = NR * ((ps + 3) // 4) ** 2
             start, stop = self._timed("mask_conv3x3_fwd")
             start()
-            V, U, M = self._new(36, T, cf), self._new(36, cf, MASK_FILTERS), self._new(36, T, MASK_FILTERS)
+            V, U, M = self._new(36, T, cf), self._new(X.wino_u_elems(cf, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
             self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(V),
                              n, h, w, cf, NR, ps, ps, X.stream())        # ROIAlign fused into the input transform
             X.call("myolo_wino_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, 0, X.stream())

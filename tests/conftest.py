@@ -21,4 +21,14 @@ def _built_library():
     if not os.path.exists(lib) and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
         import __graft_entry__
         __graft_entry__.build()
+    # run the whole suite against an alternative kernel choice:  MYOLO_TEST_OPTIONS=wino_x6=1 python -m pytest tests -m gpu
+    opts = os.environ.get("MYOLO_TEST_OPTIONS", "")
+    if opts:
+        from myolo import _ext as X
+        for kv in opts.split(","):
+            name, _, val = kv.partition("=")
+            X.set_option(name.strip(), int(val))
+            if name.strip() == "wino_x6":          # a Net sets this switch from its config: make it the default there as well
+                from myolo import config as mcfg
+                mcfg.Config.FP32_MATMUL = "bf16x6" if int(val) else "native"
     yield

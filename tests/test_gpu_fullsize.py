@@ -102,7 +102,7 @@ def test_winograd_full_size_adjoint_agrees_with_direct_and_chain(gen):
     a1, ref = torch.empty(M, C, device=DEV), torch.empty(M, C, device=DEV)
     X.call("myolo_conv3x3_wino_fwd", X.ptr(x), X.ptr(w), X.ptr(bias), None, None, X.ptr(a1), NR, PS, PS, C, C, 1, None, *wsa, X.stream())
     X.call("myolo_conv3x3_wino_fwd", X.ptr(a1), X.ptr(w2), X.ptr(zero), None, None, X.ptr(ref), NR, PS, PS, C, C, 0, None, *wsa, X.stream())
-    U, U2 = torch.empty(36, C, C, device=DEV), torch.empty(36, C, C, device=DEV)
+    U, U2 = torch.empty(X.wino_u_elems(C, C), device=DEV), torch.empty(X.wino_u_elems(C, C), device=DEV)
     V1, Mp, V2 = (torch.empty(36, T, C, device=DEV) for _ in range(3))
     flags = torch.zeros(NR, dtype=torch.int32, device=DEV)
     flags[::7] = 1

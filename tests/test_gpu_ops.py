@@ -583,6 +583,37 @@ def test_frozen_bn_backward_from_post_activation():
     check(db, rdb, 1e-4, "frozen bn dbeta from post-activation")
 
 
+def test_wino_multiply_bf16x6_accuracy():
+    """cfg.FP32_MATMUL='bf16x6' (library switch wino_x6, csrc/wino_mm.hip): the multiply stage V[q] * U[q] with every fp32 operand
+    split exactly into three bf16 pieces and six piece products per fp32 product on the bf16 matrix pipe, against an fp64
+    reference of the SAME fp32 operands -- beside the native fp32 MFMA kernel.  The split path must not be less accurate."""
+    NR, HW, C = 24, 16, 256                      # 16x16 maps: every plane has NR*16 rows (no reduced tiles), one launch of 36 GEMMs
+    T = NR * 16
+    gen = torch.Generator(device="cpu").manual_seed(11)
+    V = (torch.randn(36, T, C, generator=gen) * 3.0).to(DEV)
+    V[0, :8, :8] = torch.tensor(float.fromhex("0x1.fffffep+0"))            # all 24 significand bits set: the split must be exact
+    w = (torch.randn(3, 3, C, C, generator=gen) * 0.05).to(DEV)
+    st = X.stream()
+    with X.option("wino_x6", 0), X.option("wino_no_bt", 1):               # [36][K][N] fp32: the operand values themselves
+        Unat = torch.empty(X.wino_u_elems(C, C), device=DEV)
+        X.call("myolo_wino_weight_transform", X.ptr(w), X.ptr(Unat), C, C, 0, st)
+    ref = torch.bmm(V.double(), Unat[:36 * C * C].view(36, C, C).double())
+    scale = float(ref.abs().max())
+    err = {}
+    for x6 in (0, 1):
+        with X.option("wino_x6", x6):
+            U = torch.empty(X.wino_u_elems(C, C), device=DEV)
+            M = torch.full((36, T, C), float("nan"), device=DEV)
+            X.call("myolo_wino_weight_transform", X.ptr(w), X.ptr(U), C, C, 0, st)
+            X.call("myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, HW, HW, C, C, st)
+        e = (M.double() - ref).abs()
+        err[x6] = (float(e.max()) / scale, float((e ** 2).mean().sqrt()) / scale)
+    print("multiply stage vs fp64, relative to max|ref|: native fp32 MFMA max %.3e rms %.3e | bf16x6 max %.3e rms %.3e" % (err[0] + err[1]))
+    assert err[0][0] < 2e-6 and err[1][0] < 2e-6                           # both are fp32-level (K = 256 accumulation)
+    assert err[1][1] <= 1.05 * err[0][1] and err[1][0] <= 1.25 * err[0][0], err
+
+
+
 @pytest.mark.parametrize("N,Cin,Cout", [(2, 8, 64), (5, 64, 128), (3, 256, 256), (64, 256, 256)])
 def test_conv3x3_winograd_fused_kernel(N, Cin, Cout):
     """the one-kernel Winograd conv (csrc/wino_fused.hip: transforms in LDS / registers, V and M never in HBM) against the
