@@ -1401,7 +1401,8 @@ extern "C" {
 
 size_t myolo_deconv2x2s2_mask_ws_bytes(int N, int H, int W, int Cin, int Cout, int ncls)
 {
-    return align256((size_t)4 * Cin * Cout * sizeof(float)) +
+    // (transposed filters, or their three-bf16-piece split: 6 bytes per value) + the partial logits of the column slabs
+    return align256((size_t)4 * Cin * Cout * 6) +
            (size_t)(Cout / BN) * 2 * 4 * N * H * W * ncls * sizeof(float);
 }
 
@@ -1411,9 +1412,18 @@ int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias
     MYOLO_REQUIRE(x && w && bias && w2 && b2 && p_out && N > 0 && H > 0 && W > 0, "deconv2x2s2_mask_fwd: bad arguments");
     MYOLO_REQUIRE(Cout % BN == 0 && Cin % BK == 0 && (Cin & 3) == 0 && ncls >= 1 && ncls <= 4,
                   "deconv2x2s2_mask_fwd: needs Cout %% %d == 0, Cin %% %d == 0, 1 <= classes <= 4 (got %d, %d, %d)", BN, BK, Cout, Cin, ncls);
-    const size_t wb = align256((size_t)4 * Cin * Cout * sizeof(float));
+    const size_t wb = align256((size_t)4 * Cin * Cout * 6);
     MYOLO_NEED_WS(myolo_deconv2x2s2_mask_ws_bytes(N, H, W, Cin, Cout, ncls));
     hipStream_t s = (hipStream_t)stream;
+    MYOLO_REQUIRE(((uintptr_t)x & 15) == 0, "deconv2x2s2_mask_fwd: x must be 16-byte aligned");
+    if (myolo_deconv_mask_x6_ok(Cin, Cout)) {          // option "wino_x6": six bf16 piece products per fp32 product (csrc/wino_mm.hip)
+        float* part = (float*)((char*)ws + wb);
+        const int rc = myolo_deconv_mask_x6(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s);
+        if (rc != MYOLO_OK) return rc;
+        myolo_launch_deconv_mask_finish(part, b2, p_out, 4ll * N * H * W, ncls, Cout / 128, s);      // a wave covers 128 channels there
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     launch_transpose(w, (float*)ws, 4 * Cout, Cin, 1, 0, s);     // ws[ci][(ky,kx,co)]
     GemmArgs a = {};
     a.A = x; a.B = (const float*)ws; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
