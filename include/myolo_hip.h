@@ -79,8 +79,9 @@ int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw,
                                int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- pointwise Conv2D 1x1 (conv_pw_N, conv_23 model.py:271) : y[M,Cout] = x[M,Cin] w[Cin,Cout] (+bias) ---- */
+/* fwd: ws may be NULL (ws_bytes 0); with scratch of >= 8*M*Cout*4 bytes the small deep layers run split-K (same result up to summation order) */
 int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
-                        int64_t M, int Cin, int Cout, void* stream);
+                        int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
                              int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,

@@ -1084,7 +1084,7 @@ static int launch_transpose(const float* in, float* out, int R, int C, int nz, i
 }
 
 template <int AMODE, int EPI>
-static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, size_t sk_ws_bytes = 0)
+static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, size_t sk_ws_bytes = 0, long long sk_max_tiles = 512)
 {
     const long long tiles = cdiv64(a.M, BM) * ((a.N + BN - 1) / BN);
     if (tiles <= 0) return MYOLO_OK;
@@ -1097,7 +1097,7 @@ static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, si
         // whole chip works on it; a lone 128x128 tile with K = 2304 takes ~185 us however few tiles there are
         const int nk = a.K / BK;
         int splits = 1;
-        if (sk_ws && tiles < 512 && nk >= 16 && (a.N & 3) == 0 && (EPI == EP_PLAIN ? (a.ldc & 3) == 0 : (a.Co & 3) == 0) &&
+        if (sk_ws && tiles < sk_max_tiles && nk >= 16 && (a.N & 3) == 0 && (EPI == EP_PLAIN ? (a.ldc & 3) == 0 : (a.Co & 3) == 0) &&
             !g_myolo_opt.no_splitk) {
             splits = (int)(1024 / tiles);
             if (splits > nk / 8) splits = nk / 8;
@@ -1254,13 +1254,16 @@ size_t myolo_workspace_bytes(int64_t rows, int cin, int cout)
 }
 
 int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
-                        int64_t M, int Cin, int Cout, void* stream)
+                        int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && w && y && M > 0 && Cin > 0 && Cout > 0, "pwconv1x1_fwd: bad arguments");
     GemmArgs a = {};
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = M; a.N = Cout; a.K = Cin;
     a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = MYOLO_ACT_NONE;
-    launch_nn<AM_PLAIN, EP_PLAIN>(a, (hipStream_t)stream);
+    // ws (optional): split-K partials for the 14x14 / 7x7 layers, whose few output tiles and long K loop (a serial chain of
+    // load -> LDS -> MFMA steps) would leave most of the chip idle
+    // (measured, tools/pw_layers.py: 7x7 layers 83 -> 52 us and 77 -> 30 us; the 14x14 layers' 196 tiles are better left alone)
+    launch_nn<AM_PLAIN, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes, 128);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -22,7 +22,7 @@ SIGS = {
     "myolo_dwconv3x3_fwd": [P, P, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_bwd_data": [P, P, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
-    "myolo_pwconv1x1_fwd": [P, P, P, P, L, I, I, P],
+    "myolo_pwconv1x1_fwd": [P, P, P, P, L, I, I, P, Z, P],
     "myolo_pwconv1x1_bwd_data": [P, P, P, L, I, I, P, Z, P],
     "myolo_pwconv1x1_bwd_weight": [P, P, P, L, I, I, P, Z, P],
     "myolo_conv3x3_fwd": [P, P, P, P, I, I, I, I, I, P, Z, P],

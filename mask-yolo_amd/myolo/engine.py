@@ -372,7 +372,7 @@ class Net(object):
         Co = self.p[pwn + "/kernel"].shape[3]
         y2 = self._new(N * Ho * Wo, Co)
         self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), None, X.ptr(y2), N * Ho * Wo, C, Co,
-                         X.stream())
+                         *self._wsargs(), X.stream())
         ap = self.bn_act_fwd(pwn + "_bn", y2, ACT_RELU6, train)
         self.tape["blk%d" % bid] = (a, shape, stride, ad)
         return ap, (N, Ho, Wo, Co)
@@ -421,7 +421,7 @@ class Net(object):
         D = cfg.N_BOX * (5 + cfg.NUM_CLASSES)
         yo = self._new(n2 * h2 * w2, D)
         X.call("myolo_pwconv1x1_fwd", X.ptr(a), X.ptr(self.p["conv_23/kernel"]), X.ptr(self.p["conv_23/bias"]), X.ptr(yo),
-               n2 * h2 * w2, c2, D, X.stream())
+               n2 * h2 * w2, c2, D, *self._wsargs(), X.stream())
         self.tape["trunk"] = (C4, c4shape, a, shape)
         return Fm, (n, h, w, Cf), yo
 

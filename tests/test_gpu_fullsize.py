@@ -141,7 +141,7 @@ def test_pointwise_adjoint_backbone_shapes(gen, H, Cin, Cout):
     Mm = B * H * H
     x, w, dy = rn(gen, Mm, Cin), rn(gen, Cin, Cout, scale=0.05), rn(gen, Mm, Cout)
     y, dx, dw = torch.empty(Mm, Cout, device=DEV), torch.empty(Mm, Cin, device=DEV), torch.empty(Cin, Cout, device=DEV)
-    X.call("myolo_pwconv1x1_fwd", X.ptr(x), X.ptr(w), None, X.ptr(y), Mm, Cin, Cout, X.stream())
+    X.call("myolo_pwconv1x1_fwd", X.ptr(x), X.ptr(w), None, X.ptr(y), Mm, Cin, Cout, None, 0, X.stream())
     X.call("myolo_pwconv1x1_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx), Mm, Cin, Cout, *ws(), X.stream())
     X.call("myolo_pwconv1x1_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), Mm, Cin, Cout, *ws(), X.stream())
     a = dot(dy, y)

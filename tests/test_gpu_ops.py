@@ -62,7 +62,9 @@ def rnd(rng, *shape, scale=1.0):
 
 
 # ----------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,Cin,Cout,bias", [(300, 32, 64, False), (1568, 1024, 27, True), (130, 16, 16, True),
+@pytest.mark.parametrize("M,Cin,Cout,bias", [(300, 32, 64, False), (1568, 1024, 27, True), (130, 16, 16, True), (1568, 1024, 24, True),
+                                             (6272, 512, 512, False),                                        # split-K forward
+
                                              (4096, 64, 128, False), (257, 512, 1024, False),
                                              (20003, 32, 64, False), (16391, 64, 128, False), (25088, 64, 64, False)])   # thin-layer weight gradient
 def test_pwconv1x1(M, Cin, Cout, bias):
@@ -71,7 +73,7 @@ def test_pwconv1x1(M, Cin, Cout, bias):
     b = rnd(rng, Cout) if bias else None
     dy = rnd(rng, M, Cout)
     y = new(M, Cout)
-    X.call("myolo_pwconv1x1_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)) if bias else None, X.ptr(y), M, Cin, Cout, X.stream())
+    X.call("myolo_pwconv1x1_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)) if bias else None, X.ptr(y), M, Cin, Cout, *ws(), X.stream())
     ref = x.astype(np.float64) @ w + (b if bias else 0)
     check(y, ref, what="pw fwd")
     dx, dw = new(M, Cin), new(Cin, Cout)

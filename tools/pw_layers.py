@@ -24,7 +24,7 @@ for kind in (("fwd", "bwd_data", "bwd_weight") if not ONLY else (ONLY,)):
         dx, dw = torch.empty(M, c, device=dev), torch.empty(c, co, device=dev)
         st = X.stream()
         if kind == "fwd":
-            fn = lambda: X.call("myolo_pwconv1x1_fwd", X.ptr(x), X.ptr(w), None, X.ptr(y), M, c, co, st)
+            fn = lambda: X.call("myolo_pwconv1x1_fwd", X.ptr(x), X.ptr(w), None, X.ptr(y), M, c, co, ws.data_ptr(), ws.numel(), st)
         elif kind == "bwd_data":
             fn = lambda: X.call("myolo_pwconv1x1_bwd_data", X.ptr(y), X.ptr(w), X.ptr(dx), M, c, co, ws.data_ptr(), ws.numel(), st)
         else:
