@@ -293,48 +293,68 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     sstore(0);
     if (nk > 1) gload();
     __syncthreads();
+    bf16x8 fa[2][3];
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) fa[0][pc] = *reinterpret_cast<const bf16x8*>(As[0] + afr + pc * 32);
 
+    // One barrier per chunk, and no LDS read is waited for right behind its issue:
+    //   u = 0, 1: row tile 1's fragments of THIS chunk are read first thing (used six MFMAs later: each column tile runs row tile 0's
+    //             six terms, then row tile 1's); chunk c+1, in registers since the previous chunk, is split into the other buffer
+    //             in two slices behind these column tiles' MFMAs (that buffer's last readers finished before the previous barrier);
+    //   u = 2:    barrier;
+    //   u = 3:    row tile 0's fragments of chunk c+1 are read into the (now dead) registers of this chunk's.
+    // The B fragments of chunk c+1 replace each column tile's registers as soon as its MFMAs are issued.
     for (int c = 0; c < nk; ++c) {
         const int cur = c & 1;
-        bf16x8 fa[2][3];
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int pc = 0; pc < 3; ++pc) fa[t][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + t * 32 * X6_REC + pc * 32);
-        // chunk c+1 (in registers since the previous chunk) is split into the other buffer in four slices, one behind each column
-        // tile's MFMAs, so that the matrix pipe never sees a long run of VALU work from this wave (the buffer's last readers
-        // finished before the barrier that ended chunk c-1)
         const bool more = c + 1 < nk;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) fa[1][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + 32 * X6_REC + pc * 32);
         const float x[8] = {sa[0].x, sa[0].y, sa[0].z, sa[0].w, sa[1].x, sa[1].y, sa[1].z, sa[1].w};
         u32x4 p1, p2, p3;
         if (c + 2 < nk) gload();                                        // chunk c+2 (x[] holds copies of chunk c+1)
         const unsigned bnext = more ? bso + bchunk : bso;               // the last chunk re-reads itself (into registers nobody uses)
+        bf16x8 fn0, fn1, fn2;                                           // row tile 0 of chunk c+1
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            // smallest terms first; the two row tiles alternate so that no MFMA waits for the one just issued
-#define X6_TERM(pa, pb)                                                                                        \
-            acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][pa], bq[u][pb], acc[0][u], 0, 0, 0);     \
-            acc[1][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][pa], bq[u][pb], acc[1][u], 0, 0, 0);
-            X6_TERM(0, 2) X6_TERM(2, 0) X6_TERM(1, 1) X6_TERM(0, 1) X6_TERM(1, 0) X6_TERM(0, 0)
-#undef X6_TERM
+            // smallest terms first
+#define X6_TILE(t)                                                                                                 \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][2], acc[t][u], 0, 0, 0);           \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][2], bq[u][0], acc[t][u], 0, 0, 0);           \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][1], acc[t][u], 0, 0, 0);           \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][1], acc[t][u], 0, 0, 0);           \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][0], acc[t][u], 0, 0, 0);           \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][0], acc[t][u], 0, 0, 0);
+            X6_TILE(0)
+            X6_TILE(1)
+#undef X6_TILE
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bnext);      // same registers, next chunk
-            {
-                const float a0 = x[2 * u], a1 = x[2 * u + 1];
-                const float b0 = x6_rest(a0), b1 = x6_rest(a1);
-                p1[u] = x6_top(a0, a1);
-                p2[u] = x6_top(b0, b1);
-                p3[u] = x6_top(x6_rest(b0), x6_rest(b1));
+            if (u < 2) {
+#pragma unroll
+                for (int e = 2 * u; e < 2 * u + 2; ++e) {
+                    const float a0 = x[2 * e], a1 = x[2 * e + 1];
+                    const float b0 = x6_rest(a0), b1 = x6_rest(a1);
+                    p1[e] = x6_top(a0, a1);
+                    p2[e] = x6_top(b0, b1);
+                    p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
+                }
+                if (u == 1 && more) {
+                    *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto) = p1;
+                    *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 32) = p2;
+                    *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 64) = p3;
+                }
+            } else if (u == 2) {
+                __syncthreads();
+                if (more) {
+                    fn0 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr);
+                    fn1 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 32);
+                    fn2 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 64);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto) = p1;
-            *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 32) = p2;
-            *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 64) = p3;
-        }
+        if (more) { fa[0][0] = fn0; fa[0][1] = fn1; fa[0][2] = fn2; }
         bso = bnext;
-        __syncthreads();
     }
 
     if constexpr (EPI == X6_EP_DECONV_MASK) {
