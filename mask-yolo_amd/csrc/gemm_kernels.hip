@@ -1419,9 +1419,9 @@ int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias
     MYOLO_NEED_WS(myolo_deconv2x2s2_mask_ws_bytes(N, H, W, Cin, Cout, ncls));
     hipStream_t s = (hipStream_t)stream;
     MYOLO_REQUIRE(((uintptr_t)x & 15) == 0, "deconv2x2s2_mask_fwd: x must be 16-byte aligned");
-    if (myolo_deconv_mask_x6_ok(Cin, Cout)) {          // option "wino_x6": six bf16 piece products per fp32 product (csrc/wino_mm.hip)
+    if (myolo_deconv_mask_mm_ok(Cin, Cout)) {          // csrc/wino_mm.hip: 128x256 tiles, b128 fragments; bf16x6 with option "wino_x6"
         float* part = (float*)((char*)ws + wb);
-        const int rc = myolo_deconv_mask_x6(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s);
+        const int rc = myolo_deconv_mask_mm(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s);
         if (rc != MYOLO_OK) return rc;
         myolo_launch_deconv_mask_finish(part, b2, p_out, 4ll * N * H * W, ncls, Cout / 128, s);      // a wave covers 128 channels there
         MYOLO_CHECK_LAUNCH();

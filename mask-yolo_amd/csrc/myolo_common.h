@@ -70,9 +70,9 @@ int myolo_gemm_nn_batched(const float* A, const float* B, float* C, long long M,
 // csrc/wino_mm.hip: the same product with the second operand stored transposed ([N][K]); _ok says whether (K, N) qualifies
 bool myolo_gemm_nt_batched_ok(int K, int N);
 bool myolo_gemm_nt_batched_x6(int K, int N);
-bool myolo_deconv_mask_x6_ok(int Cin, int Cout);
-size_t myolo_deconv_mask_x6_split_bytes(int Cin, int Cout);
-int myolo_deconv_mask_x6(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
+bool myolo_deconv_mask_mm_ok(int Cin, int Cout);
+size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout);
+int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
                          long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s);
 int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nruns, const long long* rows, const long long* a_off,
                                const long long* b_off, const long long* c_off, const int* nq, int K, int N, hipStream_t s);

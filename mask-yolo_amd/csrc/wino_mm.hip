@@ -44,7 +44,7 @@ struct MMArgs {
     int K, N;
     int nruns;
     int nt;
-    // X6_EP_DECONV_MASK only (csrc/gemm_kernels.hip EP_DECONV_MASK, model.py:711-714): columns = (tap, co) of a 2x2 / s2 deconv
+    // MM_EP_DECONV_MASK only (csrc/gemm_kernels.hip EP_DECONV_MASK, model.py:711-714): columns = (tap, co) of a 2x2 / s2 deconv
     const float* bias;     // [Co]
     const float* w2;       // [Co][ncls]: the 1x1 mask conv
     float* part;           // [Co/128 slabs][4*M pixels][ncls] partial logits
@@ -65,6 +65,69 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mm_rsrc(const float* base, lon
 }
 __device__ __forceinline__ float f4c(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
+enum { MM_EP_PLAIN = 0, MM_EP_DECONV_MASK = 1 };
+
+// Epilogue of the fused deconv + ReLU + 1x1 mask conv (model.py:711-714; csrc/gemm_kernels.hip EP_DECONV_MASK for 4 column tiles per
+// wave), shared by the fp32 and the bf16x6 kernel: both hold the 128 x 256 tile as 4 waves x (2 x 4) 32x32 accumulator tiles.
+__device__ __forceinline__ void mm_deconv_mask_epilogue(const MMArgs& p, const f32x16 (&acc)[2][4], long long m0, long long M, int n0,
+                                                        int wm, int wn, int half, int l31)
+{
+        // relu(deconv + bias) times the 1x1 mask conv, never writing the [N,2H,2W,Co] tensor: this tile is 128 input pixels x the
+        // 256 channels starting at n0 of ONE tap (Co % 256 == 0).  Per class each lane forms its 32 row slots' products for its 4
+        // columns, then a reduce-scatter butterfly over the 32 lanes of its half leaves lane l the sum of row slot l over the
+        // wave's 128 columns; the Co/128 column slabs are summed in fixed order by deconv_mask_finish (deterministic).
+        const int tap = n0 / p.Co;
+        const int cbase = n0 - tap * p.Co + wn * 128 + l31;
+        float cbm[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cbm[u] = p.bias[cbase + 32 * u];
+        const long long hw = (long long)p.H * p.W;
+        const int rr = l31 & 15;          // after the butterfly lane l31 owns row slot rr of the 32-row block l31 >> 4
+        const long long row = m0 + wm * 64 + (l31 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+        float* dst = nullptr;
+        if (row < M) {
+            const long long n_img = row / hw;
+            const int rem2 = (int)(row - n_img * hw);
+            const int y = rem2 / p.W, x = rem2 - y * p.W;
+            const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
+            const int slab = (cbase - l31) >> 7;
+            dst = p.part + ((long long)slab * 4 * M + pix) * p.ncls;
+        }
+#pragma unroll 1
+        for (int c = 0; c < p.ncls; ++c) {
+            float wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wv[u] = p.w2[(cbase + 32 * u) * p.ncls + c];
+            float outv = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float cur[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    float v = fmaxf(acc[t][0][j] + cbm[0], 0.f) * wv[0];
+                    v = fmaf(fmaxf(acc[t][1][j] + cbm[1], 0.f), wv[1], v);
+                    v = fmaf(fmaxf(acc[t][2][j] + cbm[2], 0.f), wv[2], v);
+                    cur[j] = fmaf(fmaxf(acc[t][3][j] + cbm[3], 0.f), wv[3], v);
+                }
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int m = 1 << st;
+                    const bool bit = (l31 >> st) & 1;
+#pragma unroll
+                    for (int ii = 0; ii < (8 >> st); ++ii) {
+                        const float a = cur[2 * ii], b = cur[2 * ii + 1];
+                        const float keep = bit ? b : a, send = bit ? a : b;
+                        cur[ii] = keep + __shfl_xor(send, m, 64);
+                    }
+                }
+                const float tot = cur[0] + __shfl_xor(cur[0], 16, 64);
+                if ((l31 >> 4) == t) outv = tot;
+            }
+            if (dst) dst[c] = outv;
+        }
+}
+
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
 {
     __shared__ __attribute__((aligned(16))) float As[2][MM_BM * MM_LD];
@@ -163,6 +226,10 @@ __global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
     }
 #undef MM_STEP
 
+    if constexpr (EPI == MM_EP_DECONV_MASK) {
+        mm_deconv_mask_epilogue(p, acc, m0, M, n0, wm, wn, half, l31);
+        return;
+    }
     // ---- epilogue: 128-byte row segments per 32 lanes ----
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -205,8 +272,6 @@ __device__ __forceinline__ bf16x8 x6_ldb(__amdgpu_buffer_rsrc_t r, unsigned voff
     u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
     return __builtin_bit_cast(bf16x8, v);
 }
-
-enum { X6_EP_PLAIN = 0, X6_EP_DECONV_MASK = 1 };
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
@@ -357,60 +422,8 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         bso = bnext;
     }
 
-    if constexpr (EPI == X6_EP_DECONV_MASK) {
-        // relu(deconv + bias) times the 1x1 mask conv, never writing the [N,2H,2W,Co] tensor: this tile is 128 input pixels x the
-        // 256 channels starting at n0 of ONE tap (Co % 256 == 0).  Per class each lane forms its 32 row slots' products for its 4
-        // columns, then a reduce-scatter butterfly over the 32 lanes of its half leaves lane l the sum of row slot l over the
-        // wave's 128 columns; the Co/128 column slabs are summed in fixed order by deconv_mask_finish (deterministic).
-        const int tap = n0 / p.Co;
-        const int cbase = n0 - tap * p.Co + wn * 128 + l31;
-        float cbm[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cbm[u] = p.bias[cbase + 32 * u];
-        const long long hw = (long long)p.H * p.W;
-        const int rr = l31 & 15;          // after the butterfly lane l31 owns row slot rr of the 32-row block l31 >> 4
-        const long long row = m0 + wm * 64 + (l31 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
-        float* dst = nullptr;
-        if (row < M) {
-            const long long n_img = row / hw;
-            const int rem2 = (int)(row - n_img * hw);
-            const int y = rem2 / p.W, x = rem2 - y * p.W;
-            const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
-            const int slab = (cbase - l31) >> 7;
-            dst = p.part + ((long long)slab * 4 * M + pix) * p.ncls;
-        }
-#pragma unroll 1
-        for (int c = 0; c < p.ncls; ++c) {
-            float wv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) wv[u] = p.w2[(cbase + 32 * u) * p.ncls + c];
-            float outv = 0.f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float cur[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    float v = fmaxf(acc[t][0][j] + cbm[0], 0.f) * wv[0];
-                    v = fmaf(fmaxf(acc[t][1][j] + cbm[1], 0.f), wv[1], v);
-                    v = fmaf(fmaxf(acc[t][2][j] + cbm[2], 0.f), wv[2], v);
-                    cur[j] = fmaf(fmaxf(acc[t][3][j] + cbm[3], 0.f), wv[3], v);
-                }
-#pragma unroll
-                for (int st = 0; st < 4; ++st) {
-                    const int m = 1 << st;
-                    const bool bit = (l31 >> st) & 1;
-#pragma unroll
-                    for (int ii = 0; ii < (8 >> st); ++ii) {
-                        const float a = cur[2 * ii], b = cur[2 * ii + 1];
-                        const float keep = bit ? b : a, send = bit ? a : b;
-                        cur[ii] = keep + __shfl_xor(send, m, 64);
-                    }
-                }
-                const float tot = cur[0] + __shfl_xor(cur[0], 16, 64);
-                if ((l31 >> 4) == t) outv = tot;
-            }
-            if (dst) dst[c] = outv;
-        }
+    if constexpr (EPI == MM_EP_DECONV_MASK) {
+        mm_deconv_mask_epilogue(p, acc, m0, M, n0, wm, wn, half, l31);
         return;
     }
 #pragma unroll
@@ -456,8 +469,8 @@ int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nr
         tiles += (long long)R.mtiles * (N / MM_BN) * nq[r];
     }
     if (tiles <= 0) return MYOLO_OK;
-    if (g_myolo_opt.wino_x6) hipLaunchKernelGGL(wino_mm_x6_kernel<X6_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);      // Bt = split filters
-    else hipLaunchKernelGGL(wino_mm_kernel, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    if (g_myolo_opt.wino_x6) hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);      // Bt = split filters
+    else hipLaunchKernelGGL(wino_mm_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
 }
 
@@ -477,25 +490,32 @@ __global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restric
     rec[0] = p1; rec[512] = p2; rec[1024] = p3;
 }
 
-bool myolo_deconv_mask_x6_ok(int Cin, int Cout) { return g_myolo_opt.wino_x6 && (Cin % MM_BK) == 0 && Cin >= MM_BK && (Cout % MM_BN) == 0; }
-size_t myolo_deconv_mask_x6_split_bytes(int Cin, int Cout) { return align256((size_t)4 * Cin * Cout * 6); }
+/* whether the fused deconv + ReLU + 1x1 mask conv GEMM (csrc/gemm_kernels.hip: myolo_deconv2x2s2_mask_fwd) runs on these kernels */
+bool myolo_deconv_mask_mm_ok(int Cin, int Cout) { return !g_myolo_opt.wino_no_bt && (Cin % MM_BK) == 0 && Cin >= MM_BK && (Cout % MM_BN) == 0; }
+size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout) { return align256((size_t)4 * Cin * Cout * 6); }
 
-/* The fused deconv + ReLU + 1x1 mask conv GEMM (csrc/gemm_kernels.hip: myolo_deconv2x2s2_mask_fwd) with six bf16 piece products
- * per fp32 product: x [M][Cin] fp32, w [2,2,Cout,Cin] (Keras Conv2DTranspose: for tap (ky,kx), w[tap][co][ci] = B[ci][tap*Cout+co]),
- * split = scratch of myolo_deconv_mask_x6_split_bytes, part = [Cout/128][4*M][ncls] partial logits. */
-int myolo_deconv_mask_x6(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
+/* x [M][Cin] fp32, w [2,2,Cout,Cin] (Keras Conv2DTranspose: for tap (ky,kx), w[tap][co][ci] = B[ci][tap*Cout+co], i.e. w IS the
+ * transposed operand [N][K] the fp32 kernel wants), split = scratch of myolo_deconv_mask_mm_split_bytes (bf16x6 only),
+ * part = [Cout/128][4*M][ncls] partial logits.  Option "wino_x6": six bf16 piece products per fp32 product. */
+int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
                          long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s)
 {
     const int K = Cin, N = 4 * Cout;
-    const long long total = (long long)K * N;
-    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N);
     MMArgs a{};
-    a.A = x; a.Bt = (const float*)split; a.C = nullptr; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
+    a.A = x; a.C = nullptr; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
     a.bias = bias; a.w2 = w2; a.part = part; a.H = H; a.W = W; a.Co = Cout; a.ncls = ncls;
     MMRun& R = a.run[0];
     R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
     R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
     const long long tiles = (long long)R.mtiles * (N / MM_BN);
-    hipLaunchKernelGGL(wino_mm_x6_kernel<X6_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    if (g_myolo_opt.wino_x6) {
+        const long long total = (long long)K * N;
+        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N);
+        a.Bt = (const float*)split;
+        hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    } else {
+        a.Bt = w;
+        hipLaunchKernelGGL(wino_mm_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    }
     return MYOLO_OK;
 }
