@@ -25,7 +25,7 @@ extern "C" void myolo_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* myolo_last_error_string(void) { return g_err; }
-extern "C" int myolo_version(void) { return 200; }
+extern "C" int myolo_version(void) { return 210; }
 
 // ---------------------------------------------------------------------------------------
 // tuning switches (myolo_set_option): plain process-wide ints, no environment reads anywhere
