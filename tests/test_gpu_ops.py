@@ -102,11 +102,16 @@ def test_conv3x3(N, H, W, Cin, Cout):
     check(db, rdb, what="colsum")
 
 
+@pytest.mark.parametrize("x6", [0, 1])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 32, 64), (2, 7, 9, 16, 48), (1, 28, 28, 128, 256), (5, 14, 14, 256, 256),
-                                            (2, 16, 12, 64, 32), (40, 14, 14, 256, 256)])
-def test_conv3x3_winograd(N, H, W, Cin, Cout):
+                                            (2, 16, 12, 64, 32), (40, 14, 14, 256, 256), (3, 14, 14, 256, 512), (2, 14, 14, 16, 256)])
+def test_conv3x3_winograd(N, H, W, Cin, Cout, x6, request):
     """Winograd F(4x4,3x3) form of the same three operators, same oracle, same 1e-3 bound (ragged tiles: 14 = 3.5 tiles,
-    7x9, and exact multiples of 4)."""
+    7x9, and exact multiples of 4); x6 = 1: the multiply forms its fp32 products from six bf16 piece products (csrc/wino_mm.hip)
+    wherever that kernel applies (K % 16 == 0, N % 256 == 0: forward of the 256/512-column cases, data gradient of the 256-row ones)."""
+    opt = X.option("wino_x6", x6)
+    opt.__enter__()
+    request.addfinalizer(lambda: opt.__exit__(None, None, None))
     rng = np.random.default_rng(2)
     x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout)
     dy = rnd(rng, N, H, W, Cout)
@@ -260,8 +265,13 @@ def test_deconv2x2s2(N, H, W, Cin, Cout):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,C", [(3, 14, 14, 256, 256, 4), (5, 14, 14, 256, 256, 2), (2, 5, 7, 32, 128, 1), (37, 14, 14, 64, 128, 3)])
-def test_deconv_mask_fused(N, H, W, Cin, Cout, C):
-    """deconv + ReLU + 1x1 + sigmoid in one pass == oracle, and == the two-kernel path up to summation order."""
+@pytest.mark.parametrize("x6", [0, 1])
+def test_deconv_mask_fused(N, H, W, Cin, Cout, C, x6, request):
+    """deconv + ReLU + 1x1 + sigmoid in one pass == oracle, and == the two-kernel path up to summation order (x6 = 1: with the
+    fp32 products formed from six bf16 piece products where csrc/wino_mm.hip applies, Cout % 256 == 0)."""
+    opt = X.option("wino_x6", x6)
+    opt.__enter__()
+    request.addfinalizer(lambda: opt.__exit__(None, None, None))
     rng = np.random.default_rng(4)
     x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 2, 2, Cout, Cin, scale=0.05), rnd(rng, Cout)
     w2, b2 = rnd(rng, Cout, C, scale=0.1), rnd(rng, C)

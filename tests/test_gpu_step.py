@@ -264,6 +264,29 @@ def test_positives_only_forward_equals_full_forward():
             assert np.abs(s1[k] - s0[k]).max() <= 1e-5 * max(1.0, np.abs(s0[k]).max()), k
 
 
+def test_fp32_matmul_bf16x6_step_matches_native():
+    """cfg.FP32_MATMUL='bf16x6' (six exact bf16 piece products per fp32 product in the Winograd multiply and the fused deconv GEMM,
+    csrc/wino_mm.hip) against the native fp32 MFMA step on the same batch and weights: everything upstream of the mask head is
+    bit-identical, losses agree to 1e-6, predicted masks to 1e-5, and both satisfy the oracle bound of test_train_step_config1."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    outs = []
+    for mm in ("native", "bf16x6"):
+        c = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4, FP32_MATMUL=mm)
+        model = MaskYOLO(mode="training", config=c)
+        model.load_state_dict(P)
+        assert model.net.fp32_matmul == mm
+        outs.append(model.train_on_batch(batch, learning_rate=0.0))
+    o0, o1 = outs
+    assert np.array_equal(o0["yolo_output"], o1["yolo_output"]) and np.array_equal(o0["output_rois"], o1["output_rois"])
+    assert np.array_equal(o0["target_class_ids"], o1["target_class_ids"]) and np.array_equal(o0["n_pos"], o1["n_pos"])
+    for k in ("yolo_sum_loss", "mask_loss", "loss"):
+        assert abs(o0[k] - o1[k]) <= 1e-6 * max(1.0, abs(o0[k])), (k, o0[k], o1[k])
+    assert np.abs(o0["myolo_mask"] - o1["myolo_mask"]).max() < 1e-5
+    assert np.abs(o1["myolo_mask"] - ref["myolo_mask"]).max() <= 1e-3            # the oracle bound (north_star: activations within 1e-3)
+    from myolo import _ext as X
+    X.set_option("wino_x6", 0)
+
+
 def test_positives_only_forward_without_positives():
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     b2 = [a.copy() for a in batch]
