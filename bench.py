@@ -200,7 +200,8 @@ def bench_train(args, rank, world, local):
     dev = "cuda:%d" % local
     base = ShapesConfig if args.nbox == 3 else ShapesHeadConfig
     cfg = make_config(base, IMAGE_SHAPE=[args.size, args.size, 3], ALPHA=args.alpha, BATCH_SIZE=args.batch,
-                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois, CONV3X3_ALGO=args.conv3x3, FP32_MATMUL=args.fp32_matmul)
+                      TRAIN_MASK_HEAD_ROIS=args.mask_head_rois, CONV3X3_ALGO=args.conv3x3, FP32_MATMUL=args.fp32_matmul,
+                      **({"WINOGRAD_TILES": args.wino_tiles} if args.wino_tiles else {}))
     model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
     net = model.net
     reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1)
@@ -312,11 +313,17 @@ def bench_train(args, rank, world, local):
     ptiles = X.wino_plane_elems(args.batch * R, ps, ps, 1)     # point-tiles: 36 per tile, fewer where the ragged edge uses F(2,3)
     wflop = 2.0 * ptiles * 256 * 256                          # one 256x256 product per point-tile
     traffic, traffic_src = None, None
+    t63 = bool(mul_n) and net.wino_tiles == "f63" and X.wino63_ok(ps, ps, 256, 256)
+    if t63:          # conv1 keeps 484 point-tiles per ROI, conv2-4 run on 400: the four timed launches of a step average to
+        ptiles = (ptiles + 3 * 400 * args.batch * R) / 4.0
+        wflop = 2.0 * ptiles * 256 * 256
     if mul_n:
         kflop, kms, kn = wflop, mul_ms, mul_n
-        kname = ("wino_mm_kernel: ONE launch of the 36 per-point GEMMs V[q] * U[q] (multiply stage of the mask-head 3x3 convs; mixed F(4,3)/F(2,3) tiling: "
-                 "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (ptiles, ptiles / float(args.batch * R)))
-        kbytes = float(ptiles) * (256 + 256) * 4 + 36 * 256 * 256 * 4
+        kname = ("wino_mm_kernel: ONE launch of the per-point GEMMs V[q] * U[q] (multiply stage of the mask-head 3x3 convs; %s: "
+                 "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (
+                     "conv1 on the F(4,3)/F(2,3) tiling (484 per ROI, 36 planes), conv2-4 on the F(6,3)/F(4,3) tiling (400 per ROI, 64 planes); "
+                     "average over the four launches of a step" if t63 else "mixed F(4,3)/F(2,3) tiling", ptiles, ptiles / float(args.batch * R)))
+        kbytes = float(ptiles) * (256 + 256) * 4 + (36 + 3 * 64 if t63 else 4 * 36) / 4.0 * 256 * 256 * 4
         pmc = "r2_pmc_wino_multiply.json"
     else:
         kflop, kms, kn = flop_direct, conv_ms, conv_n
@@ -328,6 +335,11 @@ def bench_train(args, rank, world, local):
         if args.batch * R == 32 * 147:        # the counters were collected at exactly this shape
             traffic = pj["traffic_bytes_per_launch_corrected"]
             traffic_src = "profiles/%s (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)" % pmc
+            if t63:
+                p63 = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_wino63_multiply.json")))
+                traffic = (traffic + 3 * p63["traffic_bytes_per_launch_corrected"]) / 4.0
+                traffic_src = ("average over a step's four launches of profiles/%s (conv1) and 3 x profiles/r2_pmc_wino63_multiply.json (conv2-4); "
+                               "separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run" % pmc)
     except Exception:
         pass
     peak = FP32_MFMA_PEAK
@@ -338,7 +350,7 @@ def bench_train(args, rank, world, local):
         traffic, traffic_src = None, None
         try:
             pj = json.load(open(os.path.join(ROOT, "profiles", pmc)))
-            if args.batch * R == 32 * 147:
+            if args.batch * R == 32 * 147 and not t63:          # (not collected for bf16x6 on the F(6,3) tiling)
                 traffic = pj["traffic_bytes_per_launch_corrected"]
                 traffic_src = "profiles/%s (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)" % pmc
         except Exception:
@@ -388,7 +400,7 @@ def bench_train(args, rank, world, local):
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
+        "config": {"winograd_tiles": net.wino_tiles, "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
                                "(fwd+bwd+Adam%s); mask head FORWARD on %s ROIs; mask-head BACKWARD behind bn1 (conv2-4, deconv, myolo_mask) on "
                                "the positive ROIs only -- exact: bn2-4 are frozen and the loss reads positives only, so the other ROIs' "
                                "gradients are structural zeros (dense-backward time in variants.dense_mask_backward); " % (
@@ -518,6 +530,7 @@ def main():
     ap.add_argument("--comm", choices=["torch", "capi"], default="torch",
                     help="N>1: gradient all-reduce through torch.distributed (nccl = RCCL) or through the library's own myolo_comm_* entry points")
     ap.add_argument("--fp32-matmul", choices=["native", "bf16x6"], default="native", help="cfg.FP32_MATMUL (how the Winograd multiply forms its fp32 products)")
+    ap.add_argument("--wino-tiles", choices=["f43", "f63"], default=None, help="cfg.WINOGRAD_TILES (default: the config's)")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="myolo_set_option switches for this run (kernel A/B comparisons, e.g. wino_x6=1); recorded in config.lib_options")
     args = ap.parse_args()

@@ -303,6 +303,26 @@ int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int 
 int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W,
                                   int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- F(6,3)/F(4,3) tiling for 14x14 maps (csrc/wino63_kernels.hip): 14 = 6+4+4 per direction, 400 point-tiles per image in 64 planes
+ * (the F(4,3) tiles use the 36 planes of the points they share with F(6,3)).  Stages as above; V / M buffers hold
+ * myolo_wino63_plane_elems floats, U myolo_wino63_u_elems (opaque).  Needs myolo_wino63_ok(H, W, Cin, Cout):
+ * H = W = 14, channels multiples of 64, Cin % 16 == 0, Cout % 256 == 0.  The reference op: the conv2-4 / bn / ReLU stages of
+ * build_mask_graph (model.py:693-709). ---- */
+int    myolo_wino63_ok(int H, int W, int Cin, int Cout);
+size_t myolo_wino63_plane_elems(int N, int C);
+size_t myolo_wino63_u_elems(int Cin, int Cout);
+int myolo_wino63_weight_transform(const float* w, float* U, int Cin, int Cout, void* stream);
+int myolo_wino63_multiply(const float* V, const float* U, float* M, int N, int Cin, int Cout, void* stream);
+/* x [N,14,14,C] -> act(x*scale + shift) (scale NULL: identity) -> V; the activation also goes to y (NULL: nowhere) where flags[img] != 0
+ * (flags NULL: everywhere) */
+int myolo_wino63_input_transform(const float* x, const float* scale, const float* shift, int act, float* y, const int32_t* flags, float* V,
+                                 int N, int C, void* stream);
+/* layer boundary in one kernel: M_i -> act((A^T m A + bias)*scale + shift) -> V_{i+1}; y / flags as above */
+int myolo_wino63_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
+                                        const int32_t* flags, float* Vn, int N, int C, int act, void* stream);
+int myolo_wino63_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y, int N, int C, int act,
+                                  void* stream);
+
 /* The same convolution for 14x14 maps as ONE kernel (csrc/wino_fused.hip): input transform into LDS, the 36 products on MFMA,
  * output transform from the accumulators -- neither V nor M reaches HBM.  Uniform F(4,3) tiling (576 point-tiles per image).
  * Needs H = W = 14, Cin % 8 == 0, Cout % 64 == 0, act NONE | RELU; ws holds the re-arranged transformed filters. */

@@ -1,0 +1,374 @@
+// Winograd with F(6x6,3x3) tiles for the 14x14 maps of the mask head (myolo_mask_conv2-4, model.py:693-709), fp32.
+//
+// 14 = 6 + 4 + 4: per direction one F(6,3) tile (8 interpolation points {0, 1, -1, 2, -2, 1/2, -1/2, inf}) and two F(4,3) tiles,
+// whose 6 points {0, 1, -1, 2, -2, inf} are a SUBSET S6 of those 8.  The Cook-Toom filter transform of F(4,3) differs from the
+// F(6,3) one on S6 only by a per-point factor rho = (x^2 - 1/4) = (-1/4, 3/4, 3/4, 15/4, 15/4, 1), which is folded into the data
+// transform of the F(4,3) tiles -- so ONE set of 64 transformed filters (G8 g G8^T) serves all nine tiles of an image, an F(4,3)
+// direction simply has no row in the planes of the two points it does not use (the construction of wino_kernels.hip's
+// F(2,3)-in-F(4,3) tiling, one level up).  An image costs (8 + 6 + 6)^2 = 400 point-tiles instead of 484 (F(4,3)/F(2,3) tiling) or
+// 576 (uniform F(4,3)): 17.4 % fewer multiplications and 17.4 % smaller V / M planes than wino_kernels.hip.  Exact in exact
+// arithmetic (tools/wino63_numerics.py: 7e-14 in fp64); in fp32 its error against a float64 convolution is 1.2-1.5x the F(4,3)
+// tiling's (max 9e-6, rms 6e-7 of the output maximum at K = 256; only one tile in nine is F(6,3) in both directions).
+//
+// Planes: 64 planes of [rows][C], ordered by who uses them (i = vertical point, j = horizontal point, C2 = {1/2, -1/2}):
+//   g0  i, j in S6      36 planes, 9 rows per image (every tile)                row = img*9 + ty*3 + tx
+//   g1  i in S6, j in C2 12 planes, 3 rows per image (tiles of tile column 0)   row = img*3 + ty
+//   g2  i in C2, j in S6 12 planes, 3 rows per image (tiles of tile row 0)      row = img*3 + tx
+//   g3  i, j in C2        4 planes, 1 row  per image (tile (0,0))               row = img
+// -> three runs of equal-height planes (36, 24, 4) for the one-launch batched GEMM of csrc/wino_mm.hip.
+//
+// The layer boundary (output transform + bias + folded-BN affine + ReLU -> 14x14x64 activation tile in LDS -> input transform) is
+// one kernel: workgroup = (image, 64-channel slice), nine waves = the nine tiles (so a wave's tile class is uniform and every
+// transform is straight-line code), lane = channel: every global access is 256 contiguous bytes.
+#include "myolo_common.h"
+
+#define W63_HW 14
+#define W63_CS 64            // channels per workgroup
+#define W63_TILES 9
+
+__host__ __device__ constexpr int w63_s6(int p) { return p == 7 ? 5 : p; }        // index of point p inside S6 (p != 5, 6)
+// plane of transform point (i, j), 0 <= i, j < 8 in the order {0, 1, -1, 2, -2, 1/2, -1/2, inf}
+__host__ __device__ constexpr int w63_q(int i, int j)
+{
+    const bool ci = (i == 5 || i == 6), cj = (j == 5 || j == 6);
+    return !ci ? (!cj ? w63_s6(i) * 6 + w63_s6(j) : 36 + w63_s6(i) * 2 + (j - 5)) : (!cj ? 48 + (i - 5) * 6 + w63_s6(j) : 60 + (i - 5) * 2 + (j - 5));
+}
+__host__ __device__ constexpr int w63_grp(int i, int j) { return ((i == 5 || i == 6) ? 2 : 0) + ((j == 5 || j == 6) ? 1 : 0); }
+__host__ __device__ constexpr int w63_qfirst(int g) { return g == 0 ? 0 : g == 1 ? 36 : g == 2 ? 48 : 60; }
+
+// ---- one-dimensional transforms.  CLS = 6: F(6,3) (8 points, patch of 8, 6 outputs); CLS = 4: F(4,3) on S6 with rho folded in ----
+template <int CLS>
+__device__ __forceinline__ void w63_bt(const float d[8], float t[8])
+{
+    if (CLS == 6) {
+        const float e0 = d[2] + d[6] - 4.25f * d[4], o0 = d[1] + d[5] - 4.25f * d[3];
+        const float e1 = 0.25f * d[2] - 1.25f * d[4] + d[6], o1 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+        const float e2 = 4.f * d[2] - 5.f * d[4] + d[6], o2 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+        t[0] = (d[6] - d[0]) + 5.25f * (d[2] - d[4]);
+        t[1] = e0 + o0;
+        t[2] = e0 - o0;
+        t[3] = e1 + o1;
+        t[4] = e1 - o1;
+        t[5] = e2 + o2;
+        t[6] = e2 - o2;
+        t[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+    } else {            // rho .* (B6^T d), patch d[0..5]
+        t[0] = -d[0] + 1.25f * d[2] - 0.25f * d[4];
+        t[1] = 0.75f * (d[3] + d[4] - 4.f * (d[1] + d[2]));
+        t[2] = 0.75f * (4.f * (d[1] - d[2]) - d[3] + d[4]);
+        t[3] = 3.75f * (2.f * (d[3] - d[1]) - d[2] + d[4]);
+        t[4] = 3.75f * (2.f * (d[1] - d[3]) - d[2] + d[4]);
+        t[5] = 0.f;
+        t[6] = 0.f;
+        t[7] = 4.f * d[1] - 5.f * d[3] + d[5];
+    }
+}
+template <int CLS>
+__device__ __forceinline__ void w63_at(const float m[8], float y[6])
+{
+    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    if (CLS == 6) {
+        const float s56 = m[5] + m[6], d56 = m[5] - m[6];
+        y[0] = m[0] + s12 + s34 + s56;
+        y[1] = d12 + 2.f * d34 + 0.5f * d56;
+        y[2] = s12 + 4.f * s34 + 0.25f * s56;
+        y[3] = d12 + 8.f * d34 + 0.125f * d56;
+        y[4] = s12 + 16.f * s34 + 0.0625f * s56;
+        y[5] = d12 + 32.f * d34 + 0.03125f * d56 + m[7];
+    } else {
+        y[0] = m[0] + s12 + s34;
+        y[1] = d12 + 2.f * d34;
+        y[2] = s12 + 4.f * s34;
+        y[3] = d12 + 8.f * d34 + m[7];
+        y[4] = 0.f;
+        y[5] = 0.f;
+    }
+}
+// G8 (8x3) on a 3-vector
+__device__ __forceinline__ void w63_g(const float g[3], float u[8])
+{
+    u[0] = -g[0];
+    u[1] = -(2.f / 9.f) * (g[0] + g[1] + g[2]);
+    u[2] = -(2.f / 9.f) * (g[0] - g[1] + g[2]);
+    u[3] = g[0] * (1.f / 90.f) + g[1] * (1.f / 45.f) + g[2] * (2.f / 45.f);
+    u[4] = g[0] * (1.f / 90.f) - g[1] * (1.f / 45.f) + g[2] * (2.f / 45.f);
+    u[5] = g[0] * (32.f / 45.f) + g[1] * (16.f / 45.f) + g[2] * (8.f / 45.f);
+    u[6] = g[0] * (32.f / 45.f) - g[1] * (16.f / 45.f) + g[2] * (8.f / 45.f);
+    u[7] = g[2];
+}
+
+struct W63Planes {
+    long long base[4];       // element offset of (this tile's row, this lane's channel) in the first plane of each group
+    long long stride[4];     // plane stride of the group (elements)
+};
+__device__ __forceinline__ W63Planes w63_planes(long long NR, long long img, int ty, int tx, int C, int c)
+{
+    W63Planes p;
+    const long long r0 = 9 * NR, r1 = 3 * NR;
+    p.stride[0] = r0 * C; p.stride[1] = r1 * C; p.stride[2] = r1 * C; p.stride[3] = NR * C;
+    p.base[0] = (img * 9 + ty * 3 + tx) * C + c;
+    p.base[1] = 36 * r0 * C + (img * 3 + ty) * C + c;
+    p.base[2] = (36 * r0 + 12 * r1) * C + (img * 3 + tx) * C + c;
+    p.base[3] = (36 * r0 + 24 * r1) * C + img * C + c;
+    return p;
+}
+#define W63_ADDR(pl, i, j) ((pl).base[w63_grp(i, j)] + (long long)(w63_q(i, j) - w63_qfirst(w63_grp(i, j))) * (pl).stride[w63_grp(i, j)])
+template <int CLS>
+__device__ __forceinline__ constexpr bool w63_used(int p) { return CLS == 6 || (p != 5 && p != 6); }
+
+struct W63Args {
+    const float* src;        // FROM_M: M planes;  FROM_ACT: activation [NR,14,14,C]
+    float* Vn;               // TO_V: the next conv's V planes
+    float* y;                // activation out [NR,14,14,C] or NULL
+    const int32_t* flags;    // y is written where flags[img] != 0 (NULL: everywhere)
+    const float* bias;       // FROM_M: added before the affine (NULL: 0)
+    const float* scale;      // per-channel affine (NULL: identity)
+    const float* shift;
+    long long NR;
+    int C, act;
+};
+
+__device__ __forceinline__ float w63_act(float v, int act)
+{
+    if (act == MYOLO_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MYOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+// output transform of one tile (class CY x CX) from its M values + bias/affine/activation -> LDS tile (and y)
+template <int CY, int CX>
+__device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& pl, float* act_lds, int oy, int ox, int lane, long long img, int c,
+                                            bool wr)
+{
+    constexpr int MY = CY, MX = CX;                  // outputs per direction
+    float tmp[6][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (!w63_used<CX>(j)) continue;
+        float m[8], r[6];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m[i] = w63_used<CY>(i) ? a.src[W63_ADDR(pl, i, j)] : 0.f;
+        w63_at<CY>(m, r);
+#pragma unroll
+        for (int i = 0; i < MY; ++i) tmp[i][j] = r[i];
+    }
+    const float b = a.bias ? a.bias[c] : 0.f;
+    const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
+    float* ybase = wr ? a.y + (img * W63_HW * W63_HW) * a.C + c : nullptr;
+#pragma unroll
+    for (int i = 0; i < MY; ++i) {
+        float r[6];
+        w63_at<CX>(tmp[i], r);
+#pragma unroll
+        for (int j = 0; j < MX; ++j) {
+            const float v = w63_act(fmaf(r[j] + b, sc, sh), a.act);
+            const int pix = (oy + i) * W63_HW + ox + j;
+            act_lds[pix * W63_CS + lane] = v;
+            if (wr) ybase[(long long)pix * a.C] = v;
+        }
+    }
+}
+
+// input transform of one tile (class CY x CX) from the LDS activation tile -> V planes
+template <int CY, int CX>
+__device__ __forceinline__ void w63_back_v(const W63Args& a, const W63Planes& pl, const float* act_lds, int py0, int px0, int lane)
+{
+    constexpr int NY = CY + 2, NX = CX + 2;          // patch size per direction
+    float tmp[8][8];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) {
+        float d[8], r[8];
+        const int xx = px0 + j;
+        const bool xin = (unsigned)xx < (unsigned)W63_HW;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int yy = py0 + i;
+            d[i] = (i < NY && xin && (unsigned)yy < (unsigned)W63_HW) ? act_lds[(yy * W63_HW + xx) * W63_CS + lane] : 0.f;
+        }
+        w63_bt<CY>(d, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i][j] = r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (!w63_used<CY>(i)) continue;
+        float d[8], r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = j < NX ? tmp[i][j] : 0.f;
+        w63_bt<CX>(d, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w63_used<CX>(j)) a.Vn[W63_ADDR(pl, i, j)] = r[j];
+    }
+}
+
+enum { W63_FROM_M = 0, W63_FROM_ACT = 1 };
+enum { W63_TO_V = 0, W63_TO_NONE = 1 };
+
+template <int FRONT, int BACK>
+__global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float act_lds[];         // [14][14][64]
+    const long long img = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.y * W63_CS + lane;
+    const int ty = wave / 3, tx = wave - ty * 3;
+    const W63Planes pl = w63_planes(a.NR, img, ty, tx, a.C, c);
+    const bool wr = a.y && (!a.flags || a.flags[img] != 0);
+    if (FRONT == W63_FROM_M) {
+        const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;           // output origin: 0, 6, 10
+        if (ty == 0) { if (tx == 0) w63_front_m<6, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr); else w63_front_m<6, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr); }
+        else         { if (tx == 0) w63_front_m<4, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr); else w63_front_m<4, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr); }
+    } else {
+        const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
+        const float* xb = a.src + (img * W63_HW * W63_HW) * a.C + c;
+        float* yb = wr ? a.y + (img * W63_HW * W63_HW) * a.C + c : nullptr;
+        for (int p0 = wave; p0 < W63_HW * W63_HW; p0 += 4 * W63_TILES) {             // 4 loads in flight per lane
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const int pix = p0 + k * W63_TILES; v[k] = pix < W63_HW * W63_HW ? xb[(long long)pix * a.C] : 0.f; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int pix = p0 + k * W63_TILES;
+                if (pix >= W63_HW * W63_HW) continue;
+                const float t = w63_act(fmaf(v[k], sc, sh), a.act);
+                act_lds[pix * W63_CS + lane] = t;
+                if (wr) yb[(long long)pix * a.C] = t;
+            }
+        }
+    }
+    if (BACK == W63_TO_NONE) return;
+    __syncthreads();
+    const int py0 = ty == 0 ? -1 : 1 + 4 * ty, px0 = tx == 0 ? -1 : 1 + 4 * tx;           // patch origin: -1, 5, 9
+    if (ty == 0) { if (tx == 0) w63_back_v<6, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<6, 4>(a, pl, act_lds, py0, px0, lane); }
+    else         { if (tx == 0) w63_back_v<4, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<4, 4>(a, pl, act_lds, py0, px0, lane); }
+}
+
+// w [3,3,Ci,Co] -> 64 planes U[q] = (G8 g G8^T)[i][j] in w63_q order; layout per plane: 0 = [Ci][Co], 1 = [Co][Ci] (transposed for
+// wino_mm_kernel), 2 = the split-bf16 operand order of wino_mm_x6_kernel (see wino_kernels.hip: wino_w_kernel)
+__global__ __launch_bounds__(256) void wino63_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int layout)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ci * Co) return;
+    // consecutive threads walk the contiguous axis of the destination (co for layout 0, ci otherwise)
+    const int ci = layout == 0 ? idx / Co : idx % Ci, co = layout == 0 ? idx % Co : idx / Ci;
+    float g[3][3], tmp[8][3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((ky * 3 + kx) * Ci + ci) * (long long)Co + co];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+        const float col[3] = {g[0][kx], g[1][kx], g[2][kx]};
+        float u[8];
+        w63_g(col, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i][kx] = u[i];
+    }
+    const long long plane = (long long)Ci * Co;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float u[8];
+        w63_g(tmp[i], u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int q = w63_q(i, j);
+            if (layout == 0) U[q * plane + (long long)ci * Co + co] = u[j];
+            else if (layout == 1) U[q * plane + (long long)co * Ci + ci] = u[j];
+            else {
+                const int k = ci, n = co, nkc = Ci >> 4;
+                __bf16* rec = reinterpret_cast<__bf16*>(U) + ((((long long)q * nkc + (k >> 4)) * (Co >> 5) + (n >> 5)) * 6 + ((k >> 3) & 1)) * 256 + (n & 31) * 8 + (k & 7);
+                const __bf16 p1 = (__bf16)u[j];
+                const float r1 = u[j] - (float)p1;
+                const __bf16 p2 = (__bf16)r1;
+                rec[0] = p1; rec[512] = p2; rec[1024] = (__bf16)(r1 - (float)p2);
+            }
+        }
+    }
+}
+
+static int w63_layout(int K, int N) { return myolo_gemm_nt_batched_x6(K, N) ? 2 : 1; }
+
+template <int FRONT, int BACK>
+static int w63_launch(const W63Args& a, hipStream_t s)
+{
+    static bool attr_set = false;
+    const size_t lds = (size_t)W63_HW * W63_HW * W63_CS * sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wino63_boundary_kernel<FRONT, BACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wino63_boundary_kernel<FRONT, BACK>), dim3((unsigned)a.NR, a.C / W63_CS), dim3(W63_TILES * 64), lds, s, a);
+    return MYOLO_OK;
+}
+
+extern "C" {
+
+/* whether the F(6,3)/F(4,3) tiling is available for a conv: 14x14 maps, Cin and Cout handled by the one-launch multiply */
+int myolo_wino63_ok(int H, int W, int Cin, int Cout)
+{
+    return H == W63_HW && W == W63_HW && (Cin % W63_CS) == 0 && (Cout % W63_CS) == 0 && myolo_gemm_nt_batched_ok(Cin, Cout) ? 1 : 0;
+}
+/* elements of the 64 V (or M) planes of an [N,14,14,C] tensor: 400 point-tiles per image */
+size_t myolo_wino63_plane_elems(int N, int C) { return (size_t)400 * (size_t)N * (size_t)C; }
+/* floats to allocate for the transformed filters (64 planes, 6 bytes per value in the split-bf16 layout) */
+size_t myolo_wino63_u_elems(int Cin, int Cout) { return align256((size_t)64 * Cin * Cout * 6) / sizeof(float); }
+
+int myolo_wino63_weight_transform(const float* w, float* U, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(w && U && myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "wino63_weight_transform: needs Cin, Cout multiples of 64 with Cin %% 16 == 0, Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
+    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, w63_layout(Cin, Cout));
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* M[q] = V[q] * U[q] for the 64 points: one launch over the three runs of equal-height planes (csrc/wino_mm.hip) */
+int myolo_wino63_multiply(const float* V, const float* U, float* M, int N, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(V && U && M && N > 0 && myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "wino63_multiply: bad arguments");
+    const long long NR = N;
+    const long long rows[3] = {9 * NR, 3 * NR, NR};
+    const int nq[3] = {36, 24, 4};
+    const long long prow[3] = {0, 36 * 9 * NR, 36 * 9 * NR + 24 * 3 * NR};       // first row of each run, counted over all planes
+    const long long pq[3] = {0, 36, 60};
+    long long ao[3], bo[3], co[3];
+    for (int k = 0; k < 3; ++k) { ao[k] = prow[k] * Cin; bo[k] = pq[k] * (long long)Cin * Cout; co[k] = prow[k] * Cout; }
+    const int rc = myolo_gemm_nt_batched_runs(V, U, M, 3, rows, ao, bo, co, nq, Cin, Cout, (hipStream_t)stream);
+    if (rc != MYOLO_OK) return rc;
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* x [N,14,14,C] -> act(x * scale + shift) (scale NULL: identity) -> V; the activation is also written to y where flags allow */
+int myolo_wino63_input_transform(const float* x, const float* scale, const float* shift, int act, float* y, const int32_t* flags, float* V,
+                                 int N, int C, void* stream)
+{
+    MYOLO_REQUIRE(x && V && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_input_transform: bad arguments (C %% 64 == 0)");
+    W63Args a{x, V, y, flags, nullptr, scale, shift, N, C, act};
+    w63_launch<W63_FROM_ACT, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* layer boundary: M_i -> act((A^T m A + bias) * scale + shift) -> V_{i+1}; y (NULL: never) written where flags[img] != 0 (NULL: always) */
+int myolo_wino63_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
+                                        const int32_t* flags, float* Vn, int N, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && Vn && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_input_transform: bad arguments (C %% 64 == 0)");
+    W63Args a{M, Vn, y, flags, bias, scale, shift, N, C, act};
+    w63_launch<W63_FROM_M, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino63_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y, int N, int C, int act,
+                                  void* stream)
+{
+    MYOLO_REQUIRE(M && y && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_transform: bad arguments (C %% 64 == 0)");
+    W63Args a{M, nullptr, y, nullptr, bias, scale, shift, N, C, act};
+    w63_launch<W63_FROM_M, W63_TO_NONE>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,11 @@ SIGS = {
     "myolo_mask_targets": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],
     "myolo_mask_head_out_fwd": [P, P, P, P, L, I, I, P],
     "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],
+    "myolo_wino63_weight_transform": [P, P, I, I, P],
+    "myolo_wino63_multiply": [P, P, P, I, I, I, P],
+    "myolo_wino63_input_transform": [P, P, P, I, P, P, P, I, I, P],
+    "myolo_wino63_output_input_transform": [P, P, P, P, P, P, P, I, I, I, P],
+    "myolo_wino63_output_transform": [P, P, P, P, P, I, I, I, P],
     "myolo_conv3x3_wino_fused_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
@@ -112,6 +117,12 @@ def load():
     lib.myolo_wino_plane_elems.restype = Z
     lib.myolo_wino_u_elems.argtypes = [I, I]
     lib.myolo_wino_u_elems.restype = Z
+    lib.myolo_wino63_u_elems.argtypes = [I, I]
+    lib.myolo_wino63_u_elems.restype = Z
+    lib.myolo_wino63_plane_elems.argtypes = [I, I]
+    lib.myolo_wino63_plane_elems.restype = Z
+    lib.myolo_wino63_ok.argtypes = [I, I, I, I]
+    lib.myolo_wino63_ok.restype = I
     lib.myolo_deconv2x2s2_mask_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
     lib.myolo_wino_output_transform_bn_ws_bytes.argtypes = [I]
@@ -121,7 +132,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_conv3x3_wino_fused_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_conv3x3_wino_fused_ws_bytes",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -185,6 +196,18 @@ def wino_fused_ws_bytes(cin, cout):
 def wino_u_elems(cin, cout):
     """floats to allocate for the transformed filters U of myolo_wino_weight_transform"""
     return int(load().myolo_wino_u_elems(int(cin), int(cout)))
+
+
+def wino63_ok(h, w, cin, cout):
+    return bool(load().myolo_wino63_ok(int(h), int(w), int(cin), int(cout)))
+
+
+def wino63_u_elems(cin, cout):
+    return int(load().myolo_wino63_u_elems(int(cin), int(cout)))
+
+
+def wino63_plane_elems(n, c):
+    return int(load().myolo_wino63_plane_elems(int(n), int(c)))
 
 
 def wino_plane_elems(n, h, w, c):

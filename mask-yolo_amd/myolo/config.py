@@ -99,6 +99,10 @@ class Config(object):
     # on the bf16 matrix pipe (csrc/wino_mm.hip; measured error against fp64 <= the native path's, 2.7x less matrix-pipe time).
     # Process-wide library switch ("wino_x6"), set when a Net is built.
     FP32_MATMUL = "native"
+    # Tiling of the Winograd convs on the 14x14 mask-head maps: "f43" = F(4,3) with F(2,3) on the ragged last tile row / column
+    # (14 = 4+4+4+2: 484 point-tiles per ROI); "f63" = conv2-4 with one F(6,3) and two F(4,3) tiles per direction (14 = 6+4+4: 400
+    # point-tiles, 17 % fewer multiplications and plane bytes; fp32 error 1.2-1.5x the f43 tiling's, csrc/wino63_kernels.hip).
+    WINOGRAD_TILES = "f63"
     # detect(): replay the inference forward from a captured hipGraph (one capture per input shape) instead of ~150 launches
     INFERENCE_HIP_GRAPH = True
     # detect() keeps at most 10 boxes (model.py:1290-1304).  True: ROIAlign + mask head run on those survivors only instead

@@ -180,6 +180,9 @@ class Net(object):
         self.conv3x3_algo = getattr(cfg, "CONV3X3_ALGO", "auto")
         if self.conv3x3_algo not in ("auto", "direct", "winograd"):
             raise ValueError("CONV3X3_ALGO must be 'auto', 'direct' or 'winograd' (got %r)" % (self.conv3x3_algo,))
+        self.wino_tiles = getattr(cfg, "WINOGRAD_TILES", "f43")
+        if self.wino_tiles not in ("f43", "f63"):
+            raise ValueError("WINOGRAD_TILES must be 'f43' or 'f63' (got %r)" % (self.wino_tiles,))
         self.fp32_matmul = getattr(cfg, "FP32_MATMUL", "native")
         if self.fp32_matmul not in ("native", "bf16x6"):
             raise ValueError("FP32_MATMUL must be 'native' or 'bf16x6' (got %r)" % (self.fp32_matmul,))
@@ -558,28 +561,44 @@ class Net(object):
 
     def _mask_convs_winograd_chain(self, x, convs, NR, ps, cin, train, pos_flags, roi=None):
         """myolo_mask_conv1-4 (+bn, ReLU) as a chain of Winograd stages; appends each conv's input to `convs` (an input the
-        forward never materialised is recorded as ("lazy_bn", pre-BN tensor, bn layer)).  Returns conv4's activation."""
+        forward never materialised is recorded as ("lazy_bn", pre-BN tensor, bn layer)).  Returns conv4's activation.
+        cfg.WINOGRAD_TILES = "f63": conv2-4 (whose inputs and outputs are MASK_FILTERS wide 14x14 maps) use the F(6,3)/F(4,3)
+        tiling of csrc/wino63_kernels.hip (400 instead of 484 point-tiles per ROI); conv1 keeps the F(4,3)/F(2,3) tiling (its input
+        transform is fused with ROIAlign and its V planes feed the weight gradient)."""
         q = ps * ps
         Vcur = None
+        t63 = self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, MASK_FILTERS)
         for i in range(1, 5):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             batch_stats = train and i == 1
             fold = not batch_stats
+            use63 = t63 and i >= 2                     # this conv's V / M planes are in the F(6,3) layout
+            next63 = t63 and i + 1 >= 2 and i < 4      # ... and so are the next conv's
             T = NR * ((ps + 3) // 4) ** 2
             start, stop = self._timed("mask_conv3x3_fwd")
             start()
             if Vcur is None:
-                Vcur = self._new(36, T, cin)
-                if x is None:                         # conv1: crops sampled from the feature map on the fly (roi)
-                    Fm, boxes, bind, fn, fh, fw = roi
-                    self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind),
-                                     X.ptr(Vcur), fn, fh, fw, cin, NR, ps, ps, X.stream())
+                if use63:
+                    Vcur = self._new(X.wino63_plane_elems(NR, cin))
+                    self._call_timed("wino_in", "myolo_wino63_input_transform", X.ptr(x), None, None, ACT_NONE, None, None, X.ptr(Vcur),
+                                     NR, cin, X.stream())
                 else:
-                    self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
-            U, M = self._new(X.wino_u_elems(cin, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
-            X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
-            self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, ps, ps, cin, MASK_FILTERS,
-                             X.stream())
+                    Vcur = self._new(36, T, cin)
+                    if x is None:                         # conv1: crops sampled from the feature map on the fly (roi)
+                        Fm, boxes, bind, fn, fh, fw = roi
+                        self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind),
+                                         X.ptr(Vcur), fn, fh, fw, cin, NR, ps, ps, X.stream())
+                    else:
+                        self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
+            if use63:
+                U, M = self._new(X.wino63_u_elems(cin, MASK_FILTERS)), self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
+                X.call("myolo_wino63_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, X.stream())
+                self._call_timed("wino_multiply", "myolo_wino63_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, cin, MASK_FILTERS, X.stream())
+            else:
+                U, M = self._new(X.wino_u_elems(cin, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
+                X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
+                self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, ps, ps, cin, MASK_FILTERS,
+                                 X.stream())
             if i == 1 and train:
                 self.tape["conv1_V"] = Vcur          # reused by conv1's weight gradient
             convs.append(x)                          # for i >= 3 in training: valid only in the rows of flagged ROIs
@@ -590,20 +609,30 @@ class Net(object):
                        X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
                        X.ptr(buf[2]), X.ptr(buf[3]), MASK_FILTERS, X.stream())
                 self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
-            if fold and i < 4:
+            if fold and i < 4 and use63 == next63:
                 ykeep = self._new(NR * q, MASK_FILTERS) if train else None
-                Vn = self._new(36, T, MASK_FILTERS)
-                self._call_timed("wino_out_in", "myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
-                                 X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS,
-                                 ACT_RELU, X.stream())
+                if use63:
+                    Vn = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
+                    self._call_timed("wino_out_in", "myolo_wino63_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
+                                     X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, MASK_FILTERS,
+                                     ACT_RELU, X.stream())
+                else:
+                    Vn = self._new(36, T, MASK_FILTERS)
+                    self._call_timed("wino_out_in", "myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
+                                     X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS,
+                                     ACT_RELU, X.stream())
                 x, Vcur = ykeep, Vn
             else:
                 y = self._new(NR * q, MASK_FILTERS)
                 if fold:
-                    X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps,
-                           MASK_FILTERS, ACT_RELU, X.stream())
+                    if use63:
+                        X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, MASK_FILTERS,
+                               ACT_RELU, X.stream())
+                    else:
+                        X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps,
+                               MASK_FILTERS, ACT_RELU, X.stream())
                     x = y
-                    Vcur = None
+                    Vcur = None                      # (a tiling change at this boundary: the next conv transforms y itself)
                 elif 256 % (MASK_FILTERS // 4) == 0 and i < 4:
                     # training-mode BN behind this conv (bn1): its statistics come out of the output transform, and its
                     # apply + ReLU go into the next conv's input transform -- the normalised activation is never written
@@ -614,9 +643,14 @@ class Net(object):
                            X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
                            *self._wsargs(), X.stream())
                     self.tape[bn] = (y, ACT_RELU, True)
-                    Vcur = self._new(36, T, MASK_FILTERS)
-                    X.call("myolo_wino_input_transform_affine", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, X.ptr(Vcur),
-                           NR, ps, ps, MASK_FILTERS, X.stream())
+                    if next63:
+                        Vcur = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
+                        X.call("myolo_wino63_input_transform", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, None, None, X.ptr(Vcur),
+                               NR, MASK_FILTERS, X.stream())
+                    else:
+                        Vcur = self._new(36, T, MASK_FILTERS)
+                        X.call("myolo_wino_input_transform_affine", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, X.ptr(Vcur),
+                               NR, ps, ps, MASK_FILTERS, X.stream())
                     x = ("lazy_bn", y, bn)
                 else:
                     X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), None, None, X.ptr(y), NR, ps, ps, MASK_FILTERS,

@@ -27,6 +27,10 @@ def _built_library():
         from myolo import _ext as X
         for kv in opts.split(","):
             name, _, val = kv.partition("=")
+            if name.strip() == "wino_tiles":       # a config default, not a library switch:  MYOLO_TEST_OPTIONS=wino_tiles=f63
+                from myolo import config as mcfg
+                mcfg.Config.WINOGRAD_TILES = val.strip()
+                continue
             X.set_option(name.strip(), int(val))
             if name.strip() == "wino_x6":          # a Net sets this switch from its config: make it the default there as well
                 from myolo import config as mcfg

@@ -645,3 +645,63 @@ def test_conv3x3_winograd_fused_kernel(N, Cin, Cout):
     X.call("myolo_conv3x3_wino_fused_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(sc)), X.ptr(dt(sh)), X.ptr(y2), N, H, W, Cin,
            Cout, 1, wsb.data_ptr(), wsb.numel(), X.stream())
     check(y2, np.maximum(ref * sc + sh, 0), 1e-4, "fused wino fwd affine relu")
+
+
+@pytest.mark.parametrize("x6", [0, 1])
+@pytest.mark.parametrize("N,Cin,Cout", [(3, 256, 256), (37, 64, 256), (2, 128, 512)])
+def test_winograd_f63_tiling(N, Cin, Cout, x6, request):
+    """csrc/wino63_kernels.hip: 14 = 6+4+4, one F(6,3) and two F(4,3) tiles per direction sharing one set of 64 transformed filters
+    (400 point-tiles per image).  (a) input transform (with a folded affine + ReLU) -> multiply -> output transform == the float64
+    oracle convolution at the suite's 1e-3 bound and within 3x the F(4,3) tiling's own error; (b) the one-kernel layer boundary ==
+    output transform followed by input transform, and writes the activation for flagged images only."""
+    opt = X.option("wino_x6", x6)
+    opt.__enter__()
+    request.addfinalizer(lambda: opt.__exit__(None, None, None))
+    assert X.wino63_ok(14, 14, Cin, Cout) and not X.wino63_ok(16, 16, Cin, Cout) and not X.wino63_ok(14, 14, Cin, 128)
+    rng = np.random.default_rng(9)
+    H = W = 14
+    xin = rnd(rng, N, H, W, Cin)
+    sc, sh = (1 + 0.1 * rnd(rng, Cin)), rnd(rng, Cin, scale=0.1)
+    w, b = rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout)
+    st = X.stream()
+    V = torch.full((X.wino63_plane_elems(N, Cin),), float("nan"), device=DEV)
+    U = torch.empty(X.wino63_u_elems(Cin, Cout), device=DEV)
+    M = torch.full((X.wino63_plane_elems(N, Cout),), float("nan"), device=DEV)
+    ya = new(N, H, W, Cin)
+    xin_t, sc_t, sh_t, w_t, b_t = dt(xin), dt(sc), dt(sh), dt(w), dt(b)
+    X.call("myolo_wino63_input_transform", X.ptr(xin_t), X.ptr(sc_t), X.ptr(sh_t), 1, X.ptr(ya), None, X.ptr(V), N, Cin, st)
+    X.call("myolo_wino63_weight_transform", X.ptr(w_t), X.ptr(U), Cin, Cout, st)
+    X.call("myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(M), N, Cin, Cout, st)
+    y = new(N, H, W, Cout)
+    X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(b_t), None, None, X.ptr(y), N, Cout, 0, st)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(V).any()) and not bool(torch.isnan(M).any()), "every plane row must be written"
+    a0 = ya.cpu().numpy()                                                       # what the input transform formed on load (one fma)
+    assert np.abs(a0 - np.maximum(xin * sc + sh, 0)).max() < 1e-6
+    ref = O.conv2d(a0, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64)
+    check(y, ref, what="F(6,3)/F(4,3) conv")
+    e63 = float(np.abs(y.cpu().numpy() - ref).max() / np.abs(ref).max())
+    wsb = torch.empty(X.wino_ws_bytes(N, H, W, Cin, Cout, 0), dtype=torch.uint8, device=DEV)
+    y43 = new(N, H, W, Cout)
+    a0_t = dt(a0)
+    X.call("myolo_conv3x3_wino_fwd", X.ptr(a0_t), X.ptr(w_t), X.ptr(b_t), None, None, X.ptr(y43), N, H, W, Cin, Cout, 0, None,
+           wsb.data_ptr(), wsb.numel(), st)
+    e43 = float(np.abs(y43.cpu().numpy() - ref).max() / np.abs(ref).max())
+    print("max error / max|y|: F(6,3)/F(4,3) tiling %.3e, F(4,3)/F(2,3) tiling %.3e" % (e63, e43))
+    assert e63 < 5e-5 and e63 < 3.0 * e43 + 2e-6
+    # (b) layer boundary: M -> relu((A^T m A + bias) * s2 + t2) -> V2, in one kernel == output transform, then input transform
+    if Cout % 64 == 0 and X.wino63_ok(14, 14, Cout, 256):
+        s2, t2 = dt(1 + 0.1 * rnd(rng, Cout)), dt(rnd(rng, Cout, scale=0.1))
+        flags = torch.zeros(N, dtype=torch.int32, device=DEV)
+        flags[::2] = 1
+        yk = torch.full((N, H, W, Cout), float("nan"), device=DEV)
+        V2 = torch.full((X.wino63_plane_elems(N, Cout),), float("nan"), device=DEV)
+        X.call("myolo_wino63_output_input_transform", X.ptr(M), X.ptr(b_t), X.ptr(s2), X.ptr(t2), X.ptr(yk), X.ptr(flags), X.ptr(V2), N, Cout, 1, st)
+        y2 = new(N, H, W, Cout)
+        X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(b_t), X.ptr(s2), X.ptr(t2), X.ptr(y2), N, Cout, 1, st)
+        V3 = torch.full((X.wino63_plane_elems(N, Cout),), float("nan"), device=DEV)
+        X.call("myolo_wino63_input_transform", X.ptr(y2), None, None, 0, None, None, X.ptr(V3), N, Cout, st)
+        torch.cuda.synchronize()
+        assert torch.equal(V2, V3), "fused boundary differs from output transform + input transform"
+        assert torch.equal(yk[::2], y2[::2]) and bool(torch.isnan(yk[1::2]).all()), "activation must be written for flagged images only"
+

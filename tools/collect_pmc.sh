@@ -18,7 +18,9 @@ for x6 in 0 1; do
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/cal_$c -o p -- python tools/kbench.py roialign_fwd --iters 3 > /dev/null 2>&1
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/w63_$c -o p -- python tools/kbench.py wino63_fwd --iters 3 > /dev/null 2>&1
 done
+rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/w63_sq -o p -- python tools/kbench.py wino63_fwd --iters 3 > /dev/null 2>&1
 python - "$OUT" "$TAG" <<'PY'
 import csv, collections, json, sys
 sys.path[:0] = [".", "mask-yolo_amd"]
@@ -70,5 +72,34 @@ for x6, mmk, fname in ((0, "wino_mm_kernel", "%s_pmc_wino_multiply.json"), (1, "
     w["correction"] = "2 x FETCH_SIZE (gfx950 counts 128-B requests at 64 B; see calibration_crop_fwd) + WRITE_SIZE, KB -> bytes"
     json.dump(w, open(("%s/" + fname) % (out, tag), "w"), indent=1)
     print(json.dumps(m, indent=1)[:1200])
+# the same multiply kernel on the F(6,3)/F(4,3) tiling (400 point-tiles per ROI, 64 planes in three runs)
+p63 = 400 * NR
+w = {"op": "myolo_wino63_* NR=4704 14x14 256->256 (tools/kbench.py wino63_fwd): %d point-tiles (400 per ROI)" % p63, "multiply": {}}
+m = w["multiply"]
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    v, ns, nops = per_op("w63_" + c, "wino_mm_kernel")
+    m[c + "_KB_per_op"] = v.get(c); m["avg_ns_per_op"] = ns; m["ops"] = nops
+m["traffic_bytes_per_launch_corrected"] = 1024.0 * (2 * m["FETCH_SIZE_KB_per_op"] + m["WRITE_SIZE_KB_per_op"])
+m["algorithmic_bytes"] = float(p63) * 512 * 4 + 64 * 256 * 256 * 4
+m["algorithmic_flop_fp32"] = 2.0 * p63 * 256 * 256
+v, ns, nops = per_op("w63_sq", "wino_mm_kernel")
+m["sq_per_op"] = v
+if "GRBM_GUI_ACTIVE" in v:
+    cyc = v["GRBM_GUI_ACTIVE"] / 8
+    m["effective_clock_GHz"] = cyc / ns
+    m["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
+    m["mfma_busy_cycles_minimum"] = m["algorithmic_flop_fp32"] / 4096 * 64
+for kname, key in (("wino63_boundary_kernel<1, 0>", "input_transform"), ("wino63_boundary_kernel<0, 1>", "output_transform")):
+    e = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        try:
+            v, ns, nops = per_op("w63_" + c, kname)
+            e[c + "_KB_per_op"] = v.get(c); e["avg_ns_per_op"] = ns
+        except Exception:
+            pass
+    w[key] = e
+w["traffic_bytes_per_launch_corrected"] = m["traffic_bytes_per_launch_corrected"]
+json.dump(w, open("%s/%s_pmc_wino63_multiply.json" % (out, tag), "w"), indent=1)
+print(json.dumps(m, indent=1)[:900])
 PY
-rm -rf $OUT/wino0_* $OUT/wino1_* $OUT/cal_FETCH_SIZE $OUT/cal_WRITE_SIZE
+rm -rf $OUT/wino0_* $OUT/wino1_* $OUT/cal_FETCH_SIZE $OUT/cal_WRITE_SIZE $OUT/w63_*

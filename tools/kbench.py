@@ -64,6 +64,20 @@ def main():
         flop = 2.0 * M * 9 * C * C
         wfl = 2.0 * 576 * NR * C * C
         print("wino_fused_fwd NR=%d: %.3f ms  %.1f direct-equivalent TFLOP/s; Winograd FLOPs (576 point-tiles/ROI) %.1f TFLOP/s = %.1f%% of 157.3" % (NR, ms, flop / ms / 1e9, wfl / ms / 1e9, wfl / ms / 1e9 / 1.573))
+    elif a.which == "wino63_fwd":
+        # the F(6,3)/F(4,3) tiling (csrc/wino63_kernels.hip): input transform -> one-launch multiply -> output transform
+        x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
+        V, Mp = torch.empty(X.wino63_plane_elems(NR, C), device=dev), torch.empty(X.wino63_plane_elems(NR, C), device=dev)
+        U = torch.empty(X.wino63_u_elems(C, C), device=dev)
+
+        def fn():
+            X.call("myolo_wino63_weight_transform", X.ptr(w), X.ptr(U), C, C, st)
+            X.call("myolo_wino63_input_transform", X.ptr(x), None, None, 0, None, None, X.ptr(V), NR, C, st)
+            X.call("myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(Mp), NR, C, C, st)
+            X.call("myolo_wino63_output_transform", X.ptr(Mp), X.ptr(b), None, None, X.ptr(y), NR, C, 0, st)
+        ms = timeit(fn, a.iters)
+        flop = 2.0 * M * 9 * C * C
+        print("wino63_fwd M=%d: %.3f ms  %.1f direct-equivalent TFLOP/s (direct-conv FLOPs / time)" % (M, ms, flop / ms / 1e9))
     elif a.which.startswith("wino"):
         x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
         T = NR * 16
