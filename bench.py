@@ -373,7 +373,7 @@ def bench_train(args, rank, world, local):
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
                 "fp32_equivalent_tflops": wflop / (kms * 1e-3) / 1e12 if (mul_n and kms > 0) else None,
-                "conv_op": {"algo": "winograd_f4x4_3x3" if mul_n else "direct",
+                "conv_op": {"algo": ("winograd: conv1 F(4,3)/F(2,3) tiling, conv2-4 F(6,3)/F(4,3) tiling (average of the four ops)" if t63 else "winograd_f4x4_3x3") if mul_n else "direct",
                             "avg_ms": conv_ms, "ops_timed": conv_n, "direct_conv_flop": flop_direct,
                             "direct_equivalent_tflops": flop_direct / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                             "winograd_flop_frac_of_peak": wflop / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if conv_ms > 0 else 0.0},
@@ -389,9 +389,9 @@ def bench_train(args, rank, world, local):
                               "achieved_gbs": pwb / (pw_ms * 1e-3) / 1e9 if pw_ms > 0 else 0.0,
                               "frac_of_hbm_peak": pwb / (pw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pw_ms > 0 else 0.0}}
     if mul_n and woi_n:
-        vbytes = float(ptiles) * 256 * 4
+        vbytes = float(400 * args.batch * R if t63 else ptiles) * 256 * 4          # the timed boundary launches are all on the conv2-4 tiling
         roofline["hbm_stages"] = ([hbm_obj("wino_in_kernel (input transform: activation -> V)", float(M) * 256 * 4 + vbytes, win_ms)] if win_n else []) + [
-            hbm_obj("wino_out_in_kernel (layer boundary M_i -> V_{i+1} through LDS)", 2 * vbytes, woi_ms)]
+            hbm_obj("%s (layer boundary M_i -> V_{i+1} through LDS)" % ("wino63_boundary_kernel<FROM_M, TO_V>" if t63 else "wino_out_in_kernel"), 2 * vbytes, woi_ms)]
     res = {
         "metric": "images/sec fwd+bwd, %dx%d Shapes batch %d, at %d MI355X" % (args.size, args.size, args.batch, world),
         "value": args.batch * world * args.steps / elapsed,

@@ -322,6 +322,11 @@ int myolo_wino63_output_input_transform(const float* M, const float* bias, const
                                         const int32_t* flags, float* Vn, int N, int C, int act, void* stream);
 int myolo_wino63_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y, int N, int C, int act,
                                   void* stream);
+/* myolo_conv3x3_wino_bwd_data_lazybn on this tiling (same operands; needs myolo_wino63_ok(14, 14, Cout, Cin)) */
+size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout);
+int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
+                                 const float* ka, const float* kb, int act, const float* w, float* dx, int N, int Cin, int Cout, void* ws,
+                                 size_t ws_bytes, void* stream);
 
 /* The same convolution for 14x14 maps as ONE kernel (csrc/wino_fused.hip): input transform into LDS, the 36 products on MFMA,
  * output transform from the accumulators -- neither V nor M reaches HBM.  Uniform F(4,3) tiling (576 point-tiles per image).

@@ -126,6 +126,12 @@ struct W63Args {
     const float* shift;
     long long NR;
     int C, act;
+    // FROM_LAZY (data gradient behind a training-mode BatchNorm with a row-sparse upstream gradient, see wino_kernels.hip LazyBn):
+    // src = the BN's input x, the operand is  scale * (dyc * [act passes](scale*x + shift)) + (ka + kb*x),  dyc compact per image
+    const float* dyc;        // [n_pos images][14*14][C]
+    const int32_t* inv;      // [NR] compact slot of an image or -1
+    const float* ka;
+    const float* kb;
 };
 
 __device__ __forceinline__ float w63_act(float v, int act)
@@ -202,7 +208,7 @@ __device__ __forceinline__ void w63_back_v(const W63Args& a, const W63Planes& pl
     }
 }
 
-enum { W63_FROM_M = 0, W63_FROM_ACT = 1 };
+enum { W63_FROM_M = 0, W63_FROM_ACT = 1, W63_FROM_LAZY = 2 };
 enum { W63_TO_V = 0, W63_TO_NONE = 1 };
 
 template <int FRONT, int BACK>
@@ -223,15 +229,33 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
         const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
         const float* xb = a.src + (img * W63_HW * W63_HW) * a.C + c;
         float* yb = wr ? a.y + (img * W63_HW * W63_HW) * a.C + c : nullptr;
+        float ka = 0.f, kb = 0.f;
+        const float* gb = nullptr;
+        if (FRONT == W63_FROM_LAZY) {
+            ka = a.ka[c]; kb = a.kb[c];
+            const int slot = a.inv[img];
+            if (slot >= 0) gb = a.dyc + ((long long)slot * W63_HW * W63_HW) * a.C + c;
+        }
         for (int p0 = wave; p0 < W63_HW * W63_HW; p0 += 4 * W63_TILES) {             // 4 loads in flight per lane
-            float v[4];
+            float v[4], gq[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { const int pix = p0 + k * W63_TILES; v[k] = pix < W63_HW * W63_HW ? xb[(long long)pix * a.C] : 0.f; }
+            for (int k = 0; k < 4; ++k) {
+                const int pix = p0 + k * W63_TILES;
+                v[k] = pix < W63_HW * W63_HW ? xb[(long long)pix * a.C] : 0.f;
+                gq[k] = (FRONT == W63_FROM_LAZY && gb && pix < W63_HW * W63_HW) ? gb[(long long)pix * a.C] : 0.f;
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int pix = p0 + k * W63_TILES;
                 if (pix >= W63_HW * W63_HW) continue;
-                const float t = w63_act(fmaf(v[k], sc, sh), a.act);
+                float t;
+                if (FRONT == W63_FROM_LAZY) {
+                    const float z = fmaf(v[k], sc, sh);
+                    const float pass = a.act == MYOLO_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : a.act == MYOLO_ACT_RELU6 ? ((z > 0.f && z < 6.f) ? 1.f : 0.f) : 1.f;
+                    t = fmaf(sc, gq[k] * pass, fmaf(kb, v[k], ka));
+                } else {
+                    t = w63_act(fmaf(v[k], sc, sh), a.act);
+                }
                 act_lds[pix * W63_CS + lane] = t;
                 if (wr) yb[(long long)pix * a.C] = t;
             }
@@ -246,17 +270,20 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
 
 // w [3,3,Ci,Co] -> 64 planes U[q] = (G8 g G8^T)[i][j] in w63_q order; layout per plane: 0 = [Ci][Co], 1 = [Co][Ci] (transposed for
 // wino_mm_kernel), 2 = the split-bf16 operand order of wino_mm_x6_kernel (see wino_kernels.hip: wino_w_kernel)
-__global__ __launch_bounds__(256) void wino63_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int layout)
+__global__ __launch_bounds__(256) void wino63_w_kernel(const float* __restrict__ w, float* __restrict__ U, int Ci, int Co, int layout, int flip)
 {
+    // flip = 1: the 180-degree rotated filter with (ci, co) exchanged (data gradient): the multiply's K = Co, N = Ci then
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= Ci * Co) return;
-    // consecutive threads walk the contiguous axis of the destination (co for layout 0, ci otherwise)
-    const int ci = layout == 0 ? idx / Co : idx % Ci, co = layout == 0 ? idx % Co : idx / Ci;
+    // consecutive threads walk the contiguous axis of the destination: the multiply's k for layouts 1 and 2
+    const bool ci_fast = layout != 0 && !flip;
+    const int ci = ci_fast ? idx % Ci : idx / Co, co = ci_fast ? idx / Ci : idx % Co;
+    const int K = flip ? Co : Ci, N = flip ? Ci : Co, k = flip ? co : ci, n = flip ? ci : co;
     float g[3][3], tmp[8][3];
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((ky * 3 + kx) * Ci + ci) * (long long)Co + co];
+        for (int kx = 0; kx < 3; ++kx) g[ky][kx] = w[((flip ? (2 - ky) * 3 + (2 - kx) : ky * 3 + kx) * Ci + ci) * (long long)Co + co];
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
         const float col[3] = {g[0][kx], g[1][kx], g[2][kx]};
@@ -273,11 +300,11 @@ __global__ __launch_bounds__(256) void wino63_w_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int q = w63_q(i, j);
-            if (layout == 0) U[q * plane + (long long)ci * Co + co] = u[j];
-            else if (layout == 1) U[q * plane + (long long)co * Ci + ci] = u[j];
+            if (layout == 0) U[q * plane + (long long)k * N + n] = u[j];
+            else if (layout == 1) U[q * plane + (long long)n * K + k] = u[j];
             else {
-                const int k = ci, n = co, nkc = Ci >> 4;
-                __bf16* rec = reinterpret_cast<__bf16*>(U) + ((((long long)q * nkc + (k >> 4)) * (Co >> 5) + (n >> 5)) * 6 + ((k >> 3) & 1)) * 256 + (n & 31) * 8 + (k & 7);
+                const int nkc = K >> 4;
+                __bf16* rec = reinterpret_cast<__bf16*>(U) + ((((long long)q * nkc + (k >> 4)) * (N >> 5) + (n >> 5)) * 6 + ((k >> 3) & 1)) * 256 + (n & 31) * 8 + (k & 7);
                 const __bf16 p1 = (__bf16)u[j];
                 const float r1 = u[j] - (float)p1;
                 const __bf16 p2 = (__bf16)r1;
@@ -317,7 +344,7 @@ size_t myolo_wino63_u_elems(int Cin, int Cout) { return align256((size_t)64 * Ci
 int myolo_wino63_weight_transform(const float* w, float* U, int Cin, int Cout, void* stream)
 {
     MYOLO_REQUIRE(w && U && myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "wino63_weight_transform: needs Cin, Cout multiples of 64 with Cin %% 16 == 0, Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
-    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, w63_layout(Cin, Cout));
+    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, U, Cin, Cout, w63_layout(Cin, Cout), 0);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -367,6 +394,38 @@ int myolo_wino63_output_transform(const float* M, const float* bias, const float
     MYOLO_REQUIRE(M && y && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_transform: bad arguments (C %% 64 == 0)");
     W63Args a{M, nullptr, y, nullptr, bias, scale, shift, N, C, act};
     w63_launch<W63_FROM_M, W63_TO_NONE>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout)
+{
+    return align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)) + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)) +
+           align256(myolo_wino63_plane_elems(N, Cin) * sizeof(float));
+}
+
+/* Data gradient of a 3x3 / s1 / SAME conv on 14x14 maps behind a training-mode BatchNorm + activation with a row-sparse upstream
+ * gradient -- myolo_conv3x3_wino_bwd_data_lazybn (bn1 / conv1 of the mask head, model.py:687-690) on the F(6,3)/F(4,3) tiling:
+ * y_pre is the BN's input (= the conv's output), dy_compact / inv / ka / kb as produced by myolo_bn_bwd_rowsparse_coeffs; the dense
+ * gradient is formed while the transform loads y_pre and never written.  Needs myolo_wino63_ok(14, 14, Cout, Cin). */
+int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
+                                 const float* ka, const float* kb, int act, const float* w, float* dx, int N, int Cin, int Cout, void* ws,
+                                 size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(y_pre && inv && scale && shift && ka && kb && w && dx && N > 0, "wino63_bwd_data_lazybn: bad arguments");
+    MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cout, Cin), "wino63_bwd_data_lazybn: unsupported channel counts (%d -> %d)", Cin, Cout);
+    MYOLO_NEED_WS(myolo_wino63_bwd_data_ws_bytes(N, Cin, Cout));
+    hipStream_t s = (hipStream_t)stream;
+    float* U = (float*)ws;
+    float* V = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
+    float* Mp = (float*)((char*)V + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)));
+    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, w63_layout(Cout, Cin), 1);
+    W63Args a{y_pre, V, nullptr, nullptr, nullptr, scale, shift, N, Cout, act, dy_compact, inv, ka, kb};
+    w63_launch<W63_FROM_LAZY, W63_TO_V>(a, s);
+    const int rc = myolo_wino63_multiply(V, U, Mp, N, Cout, Cin, stream);
+    if (rc != MYOLO_OK) return rc;
+    W63Args b{Mp, nullptr, dx, nullptr, nullptr, nullptr, nullptr, N, Cin, MYOLO_ACT_NONE};
+    w63_launch<W63_FROM_M, W63_TO_NONE>(b, s);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -989,8 +989,13 @@ class Net(object):
                 self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)))
                 X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
                        MASK_FILTERS, *self._wsargs(), X.stream())
-            X.call("myolo_conv3x3_wino_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, ps, ps, cin,
-                   MASK_FILTERS, *self._wsargs(), X.stream())
+            if self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, cin):
+                self.ws.ensure(X.wino63_bwd_data_ws_bytes(NR, cin, MASK_FILTERS))
+                X.call("myolo_wino63_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, cin, MASK_FILTERS,
+                       *self._wsargs(), X.stream())
+            else:
+                X.call("myolo_conv3x3_wino_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, ps, ps, cin,
+                       MASK_FILTERS, *self._wsargs(), X.stream())
         else:
             dc1 = self._new(M1, MASK_FILTERS)
             X.call("myolo_bn_act_bwd_rowsparse", X.ptr(da), X.ptr(c1), X.ptr(idx_d), X.ptr(inv_d), X.ptr(buf[0]), X.ptr(buf[1]),
