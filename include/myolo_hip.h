@@ -322,6 +322,19 @@ int myolo_wino63_output_input_transform(const float* M, const float* bias, const
                                         const int32_t* flags, float* Vn, int N, int C, int act, void* stream);
 int myolo_wino63_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y, int N, int C, int act,
                                   void* stream);
+/* conv1 of the mask head on this tiling: ROIAlign fused into the input transform (myolo_wino_input_transform_roialign), the output
+ * transform that also yields the training-mode BatchNorm statistics (myolo_wino_output_transform_bn_stats), and the weight gradient
+ * from the kept V planes and the lazily formed output gradient (myolo_conv3x3_wino_bwd_weight_lazybn) */
+int myolo_wino63_input_transform_roialign(const float* feature, const float* boxes, const int32_t* box_ind, float* V, int B, int FH, int FW,
+                                          int C, int nb, void* stream);
+size_t myolo_wino63_output_transform_bn_ws_bytes(int N, int C);
+int myolo_wino63_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int C, const float* gamma, const float* beta,
+                                           float* mean, float* var, float* scale, float* shift, float* moving_mean, float* moving_var,
+                                           void* ws, size_t ws_bytes, void* stream);
+size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout);
+int myolo_wino63_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
+                                   const float* shift, const float* ka, const float* kb, int act, float* dw, int N, int Cin, int Cout,
+                                   void* ws, size_t ws_bytes, void* stream);
 /* myolo_conv3x3_wino_bwd_data_lazybn on this tiling (same operands; needs myolo_wino63_ok(14, 14, Cout, Cin)) */
 size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout);
 int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,

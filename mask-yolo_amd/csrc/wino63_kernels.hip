@@ -97,6 +97,36 @@ __device__ __forceinline__ void w63_g(const float g[3], float u[8])
     u[7] = g[2];
 }
 
+// A (8x6 / 6x4): the adjoint of w63_at -- Q = A dY A^T of the weight gradient
+template <int CLS>
+__device__ __forceinline__ void w63_a(const float d[6], float q[8])
+{
+    if (CLS == 6) {
+        const float e = d[0] + d[2] + d[4], o = d[1] + d[3] + d[5];
+        const float e2 = d[0] + 4.f * d[2] + 16.f * d[4], o2 = 2.f * d[1] + 8.f * d[3] + 32.f * d[5];
+        const float eh = d[0] + 0.25f * d[2] + 0.0625f * d[4], oh = 0.5f * d[1] + 0.125f * d[3] + 0.03125f * d[5];
+        q[0] = d[0];
+        q[1] = e + o;  q[2] = e - o;
+        q[3] = e2 + o2; q[4] = e2 - o2;
+        q[5] = eh + oh; q[6] = eh - oh;
+        q[7] = d[5];
+    } else {
+        const float e = d[0] + d[2], o = d[1] + d[3], e2 = d[0] + 4.f * d[2], o2 = 2.f * d[1] + 8.f * d[3];
+        q[0] = d[0];
+        q[1] = e + o;  q[2] = e - o;
+        q[3] = e2 + o2; q[4] = e2 - o2;
+        q[5] = 0.f; q[6] = 0.f;
+        q[7] = d[3];
+    }
+}
+// G8^T (3x8) on an 8-vector
+__device__ __forceinline__ void w63_gt(const float d[8], float w[3])
+{
+    w[0] = -d[0] - (2.f / 9.f) * (d[1] + d[2]) + (1.f / 90.f) * (d[3] + d[4]) + (32.f / 45.f) * (d[5] + d[6]);
+    w[1] = (2.f / 9.f) * (d[2] - d[1]) + (1.f / 45.f) * (d[3] - d[4]) + (16.f / 45.f) * (d[5] - d[6]);
+    w[2] = -(2.f / 9.f) * (d[1] + d[2]) + (2.f / 45.f) * (d[3] + d[4]) + (8.f / 45.f) * (d[5] + d[6]) + d[7];
+}
+
 struct W63Planes {
     long long base[4];       // element offset of (this tile's row, this lane's channel) in the first plane of each group
     long long stride[4];     // plane stride of the group (elements)
@@ -132,6 +162,12 @@ struct W63Args {
     const int32_t* inv;      // [NR] compact slot of an image or -1
     const float* ka;
     const float* kb;
+    // FROM_CROP (ROIAlign fused into the input transform, tf.image.crop_and_resize model.py:385-387): src = feature map [B,FH,FW,C]
+    const float* boxes;      // [NR][4] y1, x1, y2, x2 (normalised)
+    const int32_t* bind;     // [NR] image of each box
+    int FH, FW;
+    // FROM_M with BatchNorm statistics: per-image partial sums [NR][2*C] (sum | sum of squares) of the values written to y
+    double* stats;
 };
 
 __device__ __forceinline__ float w63_act(float v, int act)
@@ -144,7 +180,7 @@ __device__ __forceinline__ float w63_act(float v, int act)
 // output transform of one tile (class CY x CX) from its M values + bias/affine/activation -> LDS tile (and y)
 template <int CY, int CX>
 __device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& pl, float* act_lds, int oy, int ox, int lane, long long img, int c,
-                                            bool wr)
+                                            bool wr, float& s1, float& s2)
 {
     constexpr int MY = CY, MX = CX;                  // outputs per direction
     float tmp[6][8];
@@ -171,6 +207,8 @@ __device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& p
             const int pix = (oy + i) * W63_HW + ox + j;
             act_lds[pix * W63_CS + lane] = v;
             if (wr) ybase[(long long)pix * a.C] = v;
+            s1 += v;
+            s2 = fmaf(v, v, s2);
         }
     }
 }
@@ -208,8 +246,55 @@ __device__ __forceinline__ void w63_back_v(const W63Args& a, const W63Planes& pl
     }
 }
 
-enum { W63_FROM_M = 0, W63_FROM_ACT = 1, W63_FROM_LAZY = 2 };
-enum { W63_TO_V = 0, W63_TO_NONE = 1 };
+// Q = A dY A^T of one tile (class CY x CX) from the LDS tile (holding dY) -> Q planes
+template <int CY, int CX>
+__device__ __forceinline__ void w63_back_q(const W63Args& a, const W63Planes& pl, const float* act_lds, int oy, int ox, int lane)
+{
+    constexpr int MY = CY, MX = CX;
+    float tmp[8][6];
+#pragma unroll
+    for (int j = 0; j < MX; ++j) {
+        float d[6], r[8];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) d[i] = i < MY ? act_lds[((oy + i) * W63_HW + ox + j) * W63_CS + lane] : 0.f;
+        w63_a<CY>(d, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i][j] = r[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (!w63_used<CY>(i)) continue;
+        float d[6], r[8];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) d[j] = j < MX ? tmp[i][j] : 0.f;
+        w63_a<CX>(d, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w63_used<CX>(j)) a.Vn[W63_ADDR(pl, i, j)] = r[j];
+    }
+}
+
+struct W63CropAxis { int lo, hi; float w; bool ok; };
+// same float expressions as crop_fwd_kernel / wino_in_crop_kernel (csrc/wino_kernels.hip)
+__device__ __forceinline__ W63CropAxis w63_crop_axis(float b0, float b1, int size, int crop, int idx)
+{
+    W63CropAxis a;
+    a.ok = true;
+    float in;
+    if (crop > 1) {
+        const float scale = (b1 - b0) * (float)(size - 1) / (float)(crop - 1);
+        in = b0 * (float)(size - 1) + (float)idx * scale;
+    } else {
+        in = 0.5f * (b0 + b1) * (float)(size - 1);
+    }
+    if (in < 0.f || in > (float)(size - 1)) a.ok = false;      // extrapolation value 0
+    a.lo = (int)floorf(in); a.hi = (int)ceilf(in); a.w = in - (float)a.lo;
+    if (!a.ok) { a.lo = 0; a.hi = 0; a.w = 0.f; }
+    return a;
+}
+
+enum { W63_FROM_M = 0, W63_FROM_ACT = 1, W63_FROM_LAZY = 2, W63_FROM_CROP = 3 };
+enum { W63_TO_V = 0, W63_TO_NONE = 1, W63_TO_Q = 2 };
 
 template <int FRONT, int BACK>
 __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
@@ -223,8 +308,49 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
     const bool wr = a.y && (!a.flags || a.flags[img] != 0);
     if (FRONT == W63_FROM_M) {
         const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;           // output origin: 0, 6, 10
-        if (ty == 0) { if (tx == 0) w63_front_m<6, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr); else w63_front_m<6, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr); }
-        else         { if (tx == 0) w63_front_m<4, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr); else w63_front_m<4, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr); }
+        float s1 = 0.f, s2 = 0.f;
+        if (ty == 0) { if (tx == 0) w63_front_m<6, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); else w63_front_m<6, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); }
+        else         { if (tx == 0) w63_front_m<4, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); else w63_front_m<4, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); }
+        if (a.stats) {         // BatchNorm statistics of this image's 196 x 64 values: the nine tiles' partial sums, added in tile order
+            __shared__ float red[2][W63_TILES][W63_CS];
+            red[0][wave][lane] = s1; red[1][wave][lane] = s2;
+            __syncthreads();
+            if (wave == 0) {
+                double t1 = 0, t2 = 0;
+#pragma unroll
+                for (int k = 0; k < W63_TILES; ++k) { t1 += (double)red[0][k][lane]; t2 += (double)red[1][k][lane]; }
+                double* dst = a.stats + img * 2 * a.C;
+                dst[c] = t1;
+                dst[a.C + c] = t2;
+            }
+        }
+    } else if (FRONT == W63_FROM_CROP) {
+        const float* bxp = a.boxes + img * 4;
+        const float by1 = bxp[0], bx1 = bxp[1], by2 = bxp[2], bx2 = bxp[3];
+        const float* fb = a.src + (long long)a.bind[img] * a.FH * a.FW * a.C + c;
+        for (int p0 = wave; p0 < W63_HW * W63_HW; p0 += 2 * W63_TILES) {               // 2 pixels x 4 corners in flight per lane
+            float tl[2], tr[2], bl[2], br[2], wx[2], wy[2];
+            bool ok[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int pix = min(p0 + k * W63_TILES, W63_HW * W63_HW - 1);
+                const int py = pix / W63_HW, px = pix - py * W63_HW;
+                const W63CropAxis ay = w63_crop_axis(by1, by2, a.FH, W63_HW, py), ax = w63_crop_axis(bx1, bx2, a.FW, W63_HW, px);
+                ok[k] = ay.ok && ax.ok; wx[k] = ax.w; wy[k] = ay.w;
+                tl[k] = fb[((long long)ay.lo * a.FW + ax.lo) * a.C];
+                tr[k] = fb[((long long)ay.lo * a.FW + ax.hi) * a.C];
+                bl[k] = fb[((long long)ay.hi * a.FW + ax.lo) * a.C];
+                br[k] = fb[((long long)ay.hi * a.FW + ax.hi) * a.C];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int pix = p0 + k * W63_TILES;
+                if (pix >= W63_HW * W63_HW) continue;
+                const float top = tl[k] + (tr[k] - tl[k]) * wx[k], bot = bl[k] + (br[k] - bl[k]) * wx[k];
+                const float o = top + (bot - top) * wy[k];
+                act_lds[pix * W63_CS + lane] = ok[k] ? o : 0.f;
+            }
+        }
     } else {
         const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
         const float* xb = a.src + (img * W63_HW * W63_HW) * a.C + c;
@@ -263,9 +389,40 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
     }
     if (BACK == W63_TO_NONE) return;
     __syncthreads();
+    if (BACK == W63_TO_Q) {
+        const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;
+        if (ty == 0) { if (tx == 0) w63_back_q<6, 6>(a, pl, act_lds, oy, ox, lane); else w63_back_q<6, 4>(a, pl, act_lds, oy, ox, lane); }
+        else         { if (tx == 0) w63_back_q<4, 6>(a, pl, act_lds, oy, ox, lane); else w63_back_q<4, 4>(a, pl, act_lds, oy, ox, lane); }
+        return;
+    }
     const int py0 = ty == 0 ? -1 : 1 + 4 * ty, px0 = tx == 0 ? -1 : 1 + 4 * tx;           // patch origin: -1, 5, 9
     if (ty == 0) { if (tx == 0) w63_back_v<6, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<6, 4>(a, pl, act_lds, py0, px0, lane); }
     else         { if (tx == 0) w63_back_v<4, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<4, 4>(a, pl, act_lds, py0, px0, lane); }
+}
+
+// dU [64][Ci][Co] -> dw [3,3,Ci,Co] = G8^T dU G8
+__global__ __launch_bounds__(256) void wino63_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Ci, int Co)
+{
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= Ci * Co) return;
+    const long long plane = (long long)Ci * Co;
+    float tmp[3][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float col[8], r[3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) col[i] = dU[w63_q(i, j) * plane + idx];
+        w63_gt(col, r);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) tmp[k][j] = r[k];
+    }
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        float r[3];
+        w63_gt(tmp[ky], r);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) dw[(ky * 3 + kx) * plane + idx] = r[kx];
+    }
 }
 
 // w [3,3,Ci,Co] -> 64 planes U[q] = (G8 g G8^T)[i][j] in w63_q order; layout per plane: 0 = [Ci][Co], 1 = [Co][Ci] (transposed for
@@ -394,6 +551,85 @@ int myolo_wino63_output_transform(const float* M, const float* bias, const float
     MYOLO_REQUIRE(M && y && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_transform: bad arguments (C %% 64 == 0)");
     W63Args a{M, nullptr, y, nullptr, bias, scale, shift, N, C, act};
     w63_launch<W63_FROM_M, W63_TO_NONE>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* ROIAlign fused into the input transform (myolo_wino_input_transform_roialign on this tiling): V straight from the feature map
+ * [B,FH,FW,C] for nb boxes (y1,x1,y2,x2) / box_ind, crop 14x14; the crops are never written */
+int myolo_wino63_input_transform_roialign(const float* feature, const float* boxes, const int32_t* box_ind, float* V, int B, int FH, int FW,
+                                          int C, int nb, void* stream)
+{
+    MYOLO_REQUIRE(feature && boxes && box_ind && V && B > 0 && FH > 0 && FW > 0 && nb > 0 && (C % W63_CS) == 0,
+                  "wino63_input_transform_roialign: bad arguments (C %% 64 == 0)");
+    W63Args a{};
+    a.src = feature; a.Vn = V; a.NR = nb; a.C = C; a.act = MYOLO_ACT_NONE; a.boxes = boxes; a.bind = box_ind; a.FH = FH; a.FW = FW;
+    w63_launch<W63_FROM_CROP, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+size_t myolo_wino63_output_transform_bn_ws_bytes(int N, int C) { return align256((size_t)N * 2 * C * sizeof(double)) + 2 * C * sizeof(double); }
+
+/* conv + bias -> y, and the training-mode BatchNorm statistics of y in the same pass (myolo_wino_output_transform_bn_stats on this
+ * tiling; model.py:690): mean / var / folded scale, shift and the moving averages, exactly as myolo_bn_stats */
+int myolo_wino63_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int C, const float* gamma, const float* beta,
+                                           float* mean, float* var, float* scale, float* shift, float* moving_mean, float* moving_var,
+                                           void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(M && y && gamma && beta && mean && var && scale && shift && N > 0 && (C % W63_CS) == 0, "wino63_output_transform_bn_stats: bad arguments");
+    MYOLO_NEED_WS(myolo_wino63_output_transform_bn_ws_bytes(N, C));
+    hipStream_t s = (hipStream_t)stream;
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256((size_t)N * 2 * C * sizeof(double)));
+    W63Args a{};
+    a.src = M; a.y = y; a.bias = bias; a.NR = N; a.C = C; a.act = MYOLO_ACT_NONE; a.stats = part;
+    w63_launch<W63_FROM_M, W63_TO_NONE>(a, s);
+    myolo_bn_stats_from_partials(part, tot, N, C, (double)N * W63_HW * W63_HW, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+static const long long* w63_run_rows(long long NR, long long rows[3]) { rows[0] = 9 * NR; rows[1] = 3 * NR; rows[2] = NR; return rows; }
+
+size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout)
+{
+    long long rows[3];
+    w63_run_rows(N, rows);
+    const int nq[3] = {36, 24, 4};
+    size_t pb = 0;
+    for (int k = 0; k < 3; ++k) { const size_t b = myolo_gemm_tn_batched_ws_bytes(rows[k], Cin, Cout, nq[k]); if (b > pb) pb = b; }
+    return align256((size_t)64 * Cin * Cout * sizeof(float)) + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)) + align256(pb);
+}
+
+/* Weight gradient of the same conv from the V planes kept by the forward (v_saved: myolo_wino63_input_transform[_roialign]) and the
+ * lazily formed gradient of the conv's output (see myolo_wino63_bwd_data_lazybn): dU[q] = V[q]^T (A dY A^T)[q], dw = G8^T dU G8 */
+int myolo_wino63_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
+                                   const float* shift, const float* ka, const float* kb, int act, float* dw, int N, int Cin, int Cout,
+                                   void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(v_saved && y_pre && inv && scale && shift && ka && kb && dw && N > 0, "wino63_bwd_weight_lazybn: bad arguments");
+    MYOLO_REQUIRE((Cin % W63_CS) == 0 && (Cout % W63_CS) == 0, "wino63_bwd_weight_lazybn: channels must be multiples of 64 (got %d, %d)", Cin, Cout);
+    MYOLO_NEED_WS(myolo_wino63_bwd_weight_ws_bytes(N, Cin, Cout));
+    hipStream_t s = (hipStream_t)stream;
+    float* dU = (float*)ws;
+    float* Q = (float*)((char*)ws + align256((size_t)64 * Cin * Cout * sizeof(float)));
+    void* part = (char*)Q + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float));
+    const size_t part_bytes = ws_bytes - (size_t)((char*)part - (char*)ws);
+    W63Args a{};
+    a.src = y_pre; a.Vn = Q; a.scale = scale; a.shift = shift; a.NR = N; a.C = Cout; a.act = act; a.dyc = dy_compact; a.inv = inv; a.ka = ka; a.kb = kb;
+    w63_launch<W63_FROM_LAZY, W63_TO_Q>(a, s);
+    long long rows[3];
+    w63_run_rows(N, rows);
+    const int nq[3] = {36, 24, 4};
+    const long long prow[3] = {0, 36 * rows[0], 36 * rows[0] + 24 * rows[1]};
+    const long long pq[3] = {0, 36, 60};
+    for (int k = 0; k < 3; ++k) {
+        const int rc = myolo_gemm_tn_batched(v_saved + prow[k] * Cin, Q + prow[k] * Cout, dU + pq[k] * (long long)Cin * Cout, rows[k], Cin, Cout,
+                                             nq[k], part, part_bytes, s);
+        if (rc != MYOLO_OK) return rc;
+    }
+    hipLaunchKernelGGL(wino63_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

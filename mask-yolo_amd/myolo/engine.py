@@ -568,20 +568,27 @@ class Net(object):
         q = ps * ps
         Vcur = None
         t63 = self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, MASK_FILTERS)
+        # conv1 too, when its backward has the matching kernels (the lazy-BN gradients of the sparse backward) or there is none
+        c1_63 = t63 and X.wino63_ok(ps, ps, cin, MASK_FILTERS) and (not train or (self.lazy_bn1_bwd and self.sparse_mask_bwd))
         for i in range(1, 5):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             batch_stats = train and i == 1
             fold = not batch_stats
-            use63 = t63 and i >= 2                     # this conv's V / M planes are in the F(6,3) layout
-            next63 = t63 and i + 1 >= 2 and i < 4      # ... and so are the next conv's
+            use63 = t63 and (i >= 2 or c1_63)          # this conv's V / M planes are in the F(6,3) layout
+            next63 = t63 and i < 4                     # ... and so are the next conv's
             T = NR * ((ps + 3) // 4) ** 2
             start, stop = self._timed("mask_conv3x3_fwd")
             start()
             if Vcur is None:
                 if use63:
                     Vcur = self._new(X.wino63_plane_elems(NR, cin))
-                    self._call_timed("wino_in", "myolo_wino63_input_transform", X.ptr(x), None, None, ACT_NONE, None, None, X.ptr(Vcur),
-                                     NR, cin, X.stream())
+                    if x is None:                         # conv1: crops sampled from the feature map on the fly (roi)
+                        Fm, boxes, bind, fn, fh, fw = roi
+                        self._call_timed("roialign_fwd", "myolo_wino63_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind),
+                                         X.ptr(Vcur), fn, fh, fw, cin, NR, X.stream())
+                    else:
+                        self._call_timed("wino_in", "myolo_wino63_input_transform", X.ptr(x), None, None, ACT_NONE, None, None, X.ptr(Vcur),
+                                         NR, cin, X.stream())
                 else:
                     Vcur = self._new(36, T, cin)
                     if x is None:                         # conv1: crops sampled from the feature map on the fly (roi)
@@ -601,6 +608,7 @@ class Net(object):
                                  X.stream())
             if i == 1 and train:
                 self.tape["conv1_V"] = Vcur          # reused by conv1's weight gradient
+                self.tape["conv1_V_fmt"] = "f63" if use63 else "f43"
             convs.append(x)                          # for i >= 3 in training: valid only in the rows of flagged ROIs
             bias = self.p[cn + "/bias"]
             buf = self.bnbuf[bn]
@@ -637,11 +645,18 @@ class Net(object):
                     # training-mode BN behind this conv (bn1): its statistics come out of the output transform, and its
                     # apply + ReLU go into the next conv's input transform -- the normalised activation is never written
                     # (the sparse backward re-applies it to the positive ROIs' rows)
-                    self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
-                    X.call("myolo_wino_output_transform_bn_stats", X.ptr(M), X.ptr(bias), X.ptr(y), NR, ps, ps, MASK_FILTERS,
-                           X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
-                           X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
-                           *self._wsargs(), X.stream())
+                    if use63:
+                        self.ws.ensure(X.wino63_out_bn_ws_bytes(NR, MASK_FILTERS))
+                        X.call("myolo_wino63_output_transform_bn_stats", X.ptr(M), X.ptr(bias), X.ptr(y), NR, MASK_FILTERS,
+                               X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
+                               X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+                               *self._wsargs(), X.stream())
+                    else:
+                        self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
+                        X.call("myolo_wino_output_transform_bn_stats", X.ptr(M), X.ptr(bias), X.ptr(y), NR, ps, ps, MASK_FILTERS,
+                               X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
+                               X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]),
+                               *self._wsargs(), X.stream())
                     self.tape[bn] = (y, ACT_RELU, True)
                     if next63:
                         Vcur = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
@@ -972,13 +987,22 @@ class Net(object):
                    X.ptr(kab[1]), M1, MASK_FILTERS, NP, q, act, *self._wsargs(), X.stream())
             lazy = (X.ptr(c1), X.ptr(da), X.ptr(inv_d), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(kab[0]), X.ptr(kab[1]), act)
             self.g["myolo_mask_conv1/bias"].zero_()
+            v63 = self.tape.pop("conv1_V_fmt", "f43") == "f63"      # the layout the forward left conv1's V planes in
+
+            def conv1_wgrad(wsp, wsz):
+                if v63:
+                    X.call("myolo_wino63_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, cin, MASK_FILTERS,
+                           wsp, wsz, X.stream())
+                else:
+                    X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps,
+                           cin, MASK_FILTERS, wsp, wsz, X.stream())
+            wg_bytes = X.wino63_bwd_weight_ws_bytes(NR, cin, MASK_FILTERS) if v63 else X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)
             if self.overlap_conv1_wgrad:
-                self._ws_wgrad.ensure(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2))
+                self._ws_wgrad.ensure(wg_bytes)
                 cur = torch.cuda.current_stream()
                 self._wgrad_stream.wait_stream(cur)
                 with torch.cuda.stream(self._wgrad_stream):
-                    X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps,
-                           cin, MASK_FILTERS, self._ws_wgrad.ptr, self._ws_wgrad.size, X.stream())
+                    conv1_wgrad(self._ws_wgrad.ptr, self._ws_wgrad.size)
                     if self.on_bucket_ready:          # every other gradient of the mask-head bucket was complete at the fork
                         self.on_bucket_ready(2)
                 for t in (v1, c1, da, inv_d, kab):
@@ -986,9 +1010,8 @@ class Net(object):
                 self._wgrad_pending = True
                 self.ws.ensure(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1))
             else:
-                self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)))
-                X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps, cin,
-                       MASK_FILTERS, *self._wsargs(), X.stream())
+                self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), wg_bytes))
+                conv1_wgrad(*self._wsargs())
             if self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, cin):
                 self.ws.ensure(X.wino63_bwd_data_ws_bytes(NR, cin, MASK_FILTERS))
                 X.call("myolo_wino63_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, cin, MASK_FILTERS,

@@ -705,3 +705,76 @@ def test_winograd_f63_tiling(N, Cin, Cout, x6, request):
         assert torch.equal(V2, V3), "fused boundary differs from output transform + input transform"
         assert torch.equal(yk[::2], y2[::2]) and bool(torch.isnan(yk[1::2]).all()), "activation must be written for flagged images only"
 
+
+def test_winograd_f63_conv1_pieces():
+    """conv1 of the mask head on the F(6,3)/F(4,3) tiling: (a) ROIAlign fused into the input transform == crop_and_resize followed by
+    the plain input transform, bit for bit (same sampling expressions, same transform code); (b) the output transform that also
+    yields the training-mode BatchNorm statistics == plain output transform + myolo_bn_stats; (c) the weight gradient from the kept V
+    planes and a lazily formed output gradient == the F(4,3) kernel's on the same operands; (d) likewise the data gradient."""
+    rng = np.random.default_rng(12)
+    B, FH, FW, C, nb, Co = 2, 28, 28, 256, 21, 256
+    st = X.stream()
+    img, boxes = rnd(rng, B, FH, FW, C), _boxes(rng, nb)
+    boxes[0] = [-0.2, 0.1, 0.7, 1.3]
+    bind = rng.integers(0, B, nb).astype(np.int32)
+    img_t, boxes_t, bind_t = dt(img), dt(boxes), dt(bind)
+    a = (X.ptr(img_t), X.ptr(boxes_t), X.ptr(bind_t))
+    x = new(nb, 14, 14, C)
+    n63 = X.wino63_plane_elems(nb, C)
+    V1, V2 = torch.full((n63,), float("nan"), device=DEV), torch.full((n63,), float("nan"), device=DEV)
+    X.call("myolo_crop_and_resize_fwd", *a, X.ptr(x), B, FH, FW, C, nb, 14, 14, st)
+    X.call("myolo_wino63_input_transform", X.ptr(x), None, None, 0, None, None, X.ptr(V1), nb, C, st)
+    X.call("myolo_wino63_input_transform_roialign", *a, X.ptr(V2), B, FH, FW, C, nb, st)
+    torch.cuda.synchronize()
+    assert not bool(torch.isnan(V2).any()) and float((V1 - V2).abs().max()) <= 1e-5 * float(V1.abs().max())
+    # (b) conv + BN statistics
+    w, b = rnd(rng, 3, 3, C, Co, scale=0.05), rnd(rng, Co)
+    w_t, b_t = dt(w), dt(b)
+    U = torch.empty(X.wino63_u_elems(C, Co), device=DEV)
+    M = torch.empty(X.wino63_plane_elems(nb, Co), device=DEV)
+    X.call("myolo_wino63_weight_transform", X.ptr(w_t), X.ptr(U), C, Co, st)
+    X.call("myolo_wino63_multiply", X.ptr(V2), X.ptr(U), X.ptr(M), nb, C, Co, st)
+    gamma, beta = dt(1 + 0.1 * rnd(rng, Co)), dt(rnd(rng, Co, scale=0.1))
+    outs = []
+    for fused in (True, False):
+        y = new(nb, 14, 14, Co)
+        mean, var, sc, sh = new(Co), new(Co), new(Co), new(Co)
+        mm, mv = torch.zeros(Co, device=DEV), torch.ones(Co, device=DEV)
+        if fused:
+            wsb = torch.empty(X.wino63_out_bn_ws_bytes(nb, Co), dtype=torch.uint8, device=DEV)
+            X.call("myolo_wino63_output_transform_bn_stats", X.ptr(M), X.ptr(b_t), X.ptr(y), nb, Co, X.ptr(gamma), X.ptr(beta), X.ptr(mean),
+                   X.ptr(var), X.ptr(sc), X.ptr(sh), X.ptr(mm), X.ptr(mv), wsb.data_ptr(), wsb.numel(), st)
+        else:
+            X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(b_t), None, None, X.ptr(y), nb, Co, 0, st)
+            X.call("myolo_bn_stats", X.ptr(y), X.ptr(gamma), X.ptr(beta), X.ptr(mean), X.ptr(var), X.ptr(sc), X.ptr(sh), X.ptr(mm), X.ptr(mv),
+                   nb * 196, Co, *ws(), st)
+        torch.cuda.synchronize()
+        outs.append([t.clone() for t in (y, mean, var, sc, sh, mm, mv)])
+    assert torch.equal(outs[0][0], outs[1][0])
+    for t0, t1 in zip(outs[0][1:], outs[1][1:]):
+        assert float((t0 - t1).abs().max()) <= 2e-6 * max(1.0, float(t1.abs().max()))
+    y_pre, sc, sh = outs[0][0], outs[0][3], outs[0][4]
+    # (c), (d): gradients behind that BN with a row-sparse upstream gradient, against the F(4,3) kernels on the same operands
+    npos = 5
+    inv = np.full(nb, -1, np.int32)
+    inv[[1, 4, 7, 8, 20]] = np.arange(npos)
+    inv_t = dt(inv)
+    dyc = dt(rnd(rng, npos, 196, Co))
+    ka, kb = dt(rnd(rng, Co, scale=0.01)), dt(rnd(rng, Co, scale=0.01))
+    lazy = (X.ptr(y_pre), X.ptr(dyc), X.ptr(inv_t), X.ptr(sc), X.ptr(sh), X.ptr(ka), X.ptr(kb), 1)
+    T = nb * 16
+    V43 = new(36, T, C)
+    X.call("myolo_wino_input_transform_roialign", *a, X.ptr(V43), B, FH, FW, C, nb, 14, 14, st)
+    wsz = max(X.wino_ws_bytes(nb, 14, 14, C, Co, k) for k in (1, 2)) + X.wino63_bwd_weight_ws_bytes(nb, C, Co) + X.wino63_bwd_data_ws_bytes(nb, C, Co)
+    wsb = torch.empty(wsz, dtype=torch.uint8, device=DEV)
+    wsa = (wsb.data_ptr(), wsb.numel())
+    dw43, dw63, dx43, dx63 = new(3, 3, C, Co), new(3, 3, C, Co), new(nb, 14, 14, C), new(nb, 14, 14, C)
+    X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(V43), *lazy, X.ptr(dw43), nb, 14, 14, C, Co, *wsa, st)
+    X.call("myolo_wino63_bwd_weight_lazybn", X.ptr(V2), *lazy, X.ptr(dw63), nb, C, Co, *wsa, st)
+    X.call("myolo_conv3x3_wino_bwd_data_lazybn", *lazy, X.ptr(w_t), X.ptr(dx43), nb, 14, 14, C, Co, *wsa, st)
+    X.call("myolo_wino63_bwd_data_lazybn", *lazy, X.ptr(w_t), X.ptr(dx63), nb, C, Co, *wsa, st)
+    torch.cuda.synchronize()
+    for got, want, what in ((dw63, dw43, "dw"), (dx63, dx43, "dx")):
+        err = float((got - want).abs().max()) / float(want.abs().max())
+        assert err < 1e-4, (what, err)
+

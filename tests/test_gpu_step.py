@@ -352,9 +352,13 @@ def test_lazy_bn1_backward_equals_materialised():
     path that materialises it, to fp32 rounding (same formula, evaluated inside another kernel); conv1's bias gradient is the
     analytic 0 instead of rounding noise."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    # the same forward on both sides: with WINOGRAD_TILES='f63' the lazy backward also moves conv1's FORWARD to the F(6,3) tiling
+    # (engine._mask_convs_winograd_chain), which would compare two forwards; the F(6,3) forms of the two lazy gradients are checked
+    # against the F(4,3) ones on identical operands in tests/test_gpu_ops.py::test_winograd_f63_conv1_pieces
+    c43 = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4, WINOGRAD_TILES="f43")
     grads = []
     for lazy in (False, True):
-        model = MaskYOLO(mode="training", config=cfg)
+        model = MaskYOLO(mode="training", config=c43)
         model.load_state_dict(P)
         model.net.lazy_bn1_bwd = lazy
         model.train_on_batch(batch, learning_rate=0.0)
