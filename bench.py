@@ -314,16 +314,18 @@ def bench_train(args, rank, world, local):
     wflop = 2.0 * ptiles * 256 * 256                          # one 256x256 product per point-tile
     traffic, traffic_src = None, None
     t63 = bool(mul_n) and net.wino_tiles == "f63" and X.wino63_ok(ps, ps, 256, 256)
-    if t63:          # conv1 keeps 484 point-tiles per ROI, conv2-4 run on 400: the four timed launches of a step average to
-        ptiles = (ptiles + 3 * 400 * args.batch * R) / 4.0
+    c1_63 = t63 and net.lazy_bn1_bwd and net.sparse_mask_bwd          # engine._mask_convs_winograd_chain: conv1 on that tiling too
+    if t63:          # 400 point-tiles per ROI (484 for conv1 where it stays on the F(4,3)/F(2,3) tiling): the four timed launches average to
+        ptiles = (400 * args.batch * R if c1_63 else (ptiles + 3 * 400 * args.batch * R) / 4.0)
         wflop = 2.0 * ptiles * 256 * 256
     if mul_n:
         kflop, kms, kn = wflop, mul_ms, mul_n
         kname = ("wino_mm_kernel: ONE launch of the per-point GEMMs V[q] * U[q] (multiply stage of the mask-head 3x3 convs; %s: "
                  "%d point-tiles = %.1f per ROI instead of 576, K=256 N=256)" % (
-                     "conv1 on the F(4,3)/F(2,3) tiling (484 per ROI, 36 planes), conv2-4 on the F(6,3)/F(4,3) tiling (400 per ROI, 64 planes); "
-                     "average over the four launches of a step" if t63 else "mixed F(4,3)/F(2,3) tiling", ptiles, ptiles / float(args.batch * R)))
-        kbytes = float(ptiles) * (256 + 256) * 4 + (36 + 3 * 64 if t63 else 4 * 36) / 4.0 * 256 * 256 * 4
+                     ("F(6,3)/F(4,3) tiling, 14 = 6+4+4: 64 planes" if c1_63 else
+                      "conv1 on the F(4,3)/F(2,3) tiling (484 per ROI, 36 planes), conv2-4 on the F(6,3)/F(4,3) tiling (400 per ROI, 64 planes); "
+                      "average over the four launches of a step") if t63 else "mixed F(4,3)/F(2,3) tiling", ptiles, ptiles / float(args.batch * R)))
+        kbytes = float(ptiles) * (256 + 256) * 4 + ((4 * 64 if c1_63 else 36 + 3 * 64) if t63 else 4 * 36) / 4.0 * 256 * 256 * 4
         pmc = "r2_pmc_wino_multiply.json"
     else:
         kflop, kms, kn = flop_direct, conv_ms, conv_n
@@ -337,9 +339,13 @@ def bench_train(args, rank, world, local):
             traffic_src = "profiles/%s (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)" % pmc
             if t63:
                 p63 = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_wino63_multiply.json")))
-                traffic = (traffic + 3 * p63["traffic_bytes_per_launch_corrected"]) / 4.0
-                traffic_src = ("average over a step's four launches of profiles/%s (conv1) and 3 x profiles/r2_pmc_wino63_multiply.json (conv2-4); "
-                               "separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run" % pmc)
+                if c1_63:
+                    traffic = p63["traffic_bytes_per_launch_corrected"]
+                    traffic_src = "profiles/r2_pmc_wino63_multiply.json (separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run)"
+                else:
+                    traffic = (traffic + 3 * p63["traffic_bytes_per_launch_corrected"]) / 4.0
+                    traffic_src = ("average over a step's four launches of profiles/%s (conv1) and 3 x profiles/r2_pmc_wino63_multiply.json (conv2-4); "
+                                   "separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE; not re-measured in this run" % pmc)
     except Exception:
         pass
     peak = FP32_MFMA_PEAK
@@ -373,7 +379,7 @@ def bench_train(args, rank, world, local):
                 "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes": kbytes, "algorithmic_flop": kflop, "launches_timed": kn, "avg_launch_ms": kms,
                 "fp32_equivalent_tflops": wflop / (kms * 1e-3) / 1e12 if (mul_n and kms > 0) else None,
-                "conv_op": {"algo": ("winograd: conv1 F(4,3)/F(2,3) tiling, conv2-4 F(6,3)/F(4,3) tiling (average of the four ops)" if t63 else "winograd_f4x4_3x3") if mul_n else "direct",
+                "conv_op": {"algo": (("winograd F(6,3)/F(4,3) tiling" if c1_63 else "winograd: conv1 F(4,3)/F(2,3) tiling, conv2-4 F(6,3)/F(4,3) tiling (average of the four ops)") if t63 else "winograd_f4x4_3x3") if mul_n else "direct",
                             "avg_ms": conv_ms, "ops_timed": conv_n, "direct_conv_flop": flop_direct,
                             "direct_equivalent_tflops": flop_direct / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                             "winograd_flop_frac_of_peak": wflop / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if conv_ms > 0 else 0.0},

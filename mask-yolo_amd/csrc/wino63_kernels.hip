@@ -325,30 +325,40 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
             }
         }
     } else if (FRONT == W63_FROM_CROP) {
+        // lane = (pixel lane >> 4 of a group of four, channel quad lane & 15): every corner read is 16 bytes per lane, 4 x 256 B per wave
         const float* bxp = a.boxes + img * 4;
         const float by1 = bxp[0], bx1 = bxp[1], by2 = bxp[2], bx2 = bxp[3];
-        const float* fb = a.src + (long long)a.bind[img] * a.FH * a.FW * a.C + c;
-        for (int p0 = wave; p0 < W63_HW * W63_HW; p0 += 2 * W63_TILES) {               // 2 pixels x 4 corners in flight per lane
-            float tl[2], tr[2], bl[2], br[2], wx[2], wy[2];
-            bool ok[2];
+        const int cq = (lane & 15) * 4;
+        const float* fb = a.src + (long long)a.bind[img] * a.FH * a.FW * a.C + blockIdx.y * W63_CS + cq;
+        constexpr int NP = 3;                                                          // pixels (x 4 corners) in flight per lane
+        constexpr int STEP = 4 * W63_TILES;                                            // pixels per pass of the workgroup
+        for (int p0 = wave * 4 + (lane >> 4); p0 < W63_HW * W63_HW; p0 += NP * STEP) {
+            float4 tl[NP], tr[NP], bl[NP], br[NP];
+            float wx[NP], wy[NP];
+            bool ok[NP];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int pix = min(p0 + k * W63_TILES, W63_HW * W63_HW - 1);
+            for (int k = 0; k < NP; ++k) {
+                const int pix = min(p0 + k * STEP, W63_HW * W63_HW - 1);
                 const int py = pix / W63_HW, px = pix - py * W63_HW;
                 const W63CropAxis ay = w63_crop_axis(by1, by2, a.FH, W63_HW, py), ax = w63_crop_axis(bx1, bx2, a.FW, W63_HW, px);
                 ok[k] = ay.ok && ax.ok; wx[k] = ax.w; wy[k] = ay.w;
-                tl[k] = fb[((long long)ay.lo * a.FW + ax.lo) * a.C];
-                tr[k] = fb[((long long)ay.lo * a.FW + ax.hi) * a.C];
-                bl[k] = fb[((long long)ay.hi * a.FW + ax.lo) * a.C];
-                br[k] = fb[((long long)ay.hi * a.FW + ax.hi) * a.C];
+                tl[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.lo * a.FW + ax.lo) * a.C);
+                tr[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.lo * a.FW + ax.hi) * a.C);
+                bl[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.hi * a.FW + ax.lo) * a.C);
+                br[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.hi * a.FW + ax.hi) * a.C);
             }
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int pix = p0 + k * W63_TILES;
+            for (int k = 0; k < NP; ++k) {
+                const int pix = p0 + k * STEP;
                 if (pix >= W63_HW * W63_HW) continue;
-                const float top = tl[k] + (tr[k] - tl[k]) * wx[k], bot = bl[k] + (br[k] - bl[k]) * wx[k];
-                const float o = top + (bot - top) * wy[k];
-                act_lds[pix * W63_CS + lane] = ok[k] ? o : 0.f;
+                float4 o;
+                float top, bot;
+                top = tl[k].x + (tr[k].x - tl[k].x) * wx[k]; bot = bl[k].x + (br[k].x - bl[k].x) * wx[k]; o.x = top + (bot - top) * wy[k];
+                top = tl[k].y + (tr[k].y - tl[k].y) * wx[k]; bot = bl[k].y + (br[k].y - bl[k].y) * wx[k]; o.y = top + (bot - top) * wy[k];
+                top = tl[k].z + (tr[k].z - tl[k].z) * wx[k]; bot = bl[k].z + (br[k].z - bl[k].z) * wx[k]; o.z = top + (bot - top) * wy[k];
+                top = tl[k].w + (tr[k].w - tl[k].w) * wx[k]; bot = bl[k].w + (br[k].w - bl[k].w) * wx[k]; o.w = top + (bot - top) * wy[k];
+                if (!ok[k]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&act_lds[pix * W63_CS + cq]) = o;
             }
         }
     } else {
