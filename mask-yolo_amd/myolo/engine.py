@@ -569,7 +569,8 @@ class Net(object):
         Vcur = None
         t63 = self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, MASK_FILTERS)
         # conv1 too, when its backward has the matching kernels (the lazy-BN gradients of the sparse backward) or there is none
-        c1_63 = t63 and X.wino63_ok(ps, ps, cin, MASK_FILTERS) and (not train or (self.lazy_bn1_bwd and self.sparse_mask_bwd))
+        c1_63 = (t63 and X.wino63_ok(ps, ps, cin, MASK_FILTERS) and X.wino63_ok(ps, ps, MASK_FILTERS, cin)
+                 and (not train or (self.lazy_bn1_bwd and self.sparse_mask_bwd)))
         for i in range(1, 5):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             batch_stats = train and i == 1
@@ -843,16 +844,30 @@ class Net(object):
             T = NR * ((ps + 3) // 4) ** 2
             start, stop = self._timed("mask_conv3x3_fwd")
             start()
-            V, U, M = self._new(36, T, cf), self._new(X.wino_u_elems(cf, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
-            self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(V),
-                             n, h, w, cf, NR, ps, ps, X.stream())        # ROIAlign fused into the input transform
-            X.call("myolo_wino_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, 0, X.stream())
-            self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, ps, ps, cf, MASK_FILTERS, X.stream())
-            self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
-            X.call("myolo_wino_output_transform_bn_stats", X.ptr(M), X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, ps, ps,
-                   MASK_FILTERS, X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
-                   X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]), *self._wsargs(),
-                   X.stream())
+            bn_args = (X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]),
+                       X.ptr(buf[3]), X.ptr(self.s[bn + "/moving_mean"]), X.ptr(self.s[bn + "/moving_variance"]))
+            c1_63 = (self.wino_tiles == "f63" and X.wino63_ok(ps, ps, cf, MASK_FILTERS) and X.wino63_ok(ps, ps, MASK_FILTERS, cf)
+                     and self.lazy_bn1_bwd and self.sparse_mask_bwd)
+            if c1_63:          # the F(6,3)/F(4,3) tiling, as in _mask_convs_winograd_chain
+                V, U, M = (self._new(X.wino63_plane_elems(NR, cf)), self._new(X.wino63_u_elems(cf, MASK_FILTERS)),
+                           self._new(X.wino63_plane_elems(NR, MASK_FILTERS)))
+                self._call_timed("roialign_fwd", "myolo_wino63_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(V),
+                                 n, h, w, cf, NR, X.stream())
+                X.call("myolo_wino63_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, X.stream())
+                self._call_timed("wino_multiply", "myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, cf, MASK_FILTERS, X.stream())
+                self.ws.ensure(X.wino63_out_bn_ws_bytes(NR, MASK_FILTERS))
+                X.call("myolo_wino63_output_transform_bn_stats", X.ptr(M), X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, MASK_FILTERS,
+                       *bn_args, *self._wsargs(), X.stream())
+            else:
+                V, U, M = self._new(36, T, cf), self._new(X.wino_u_elems(cf, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
+                self._call_timed("roialign_fwd", "myolo_wino_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(V),
+                                 n, h, w, cf, NR, ps, ps, X.stream())        # ROIAlign fused into the input transform
+                X.call("myolo_wino_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, 0, X.stream())
+                self._call_timed("wino_multiply", "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, ps, ps, cf, MASK_FILTERS, X.stream())
+                self.ws.ensure(X.wino_out_bn_ws_bytes(MASK_FILTERS))
+                X.call("myolo_wino_output_transform_bn_stats", X.ptr(M), X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, ps, ps,
+                       MASK_FILTERS, *bn_args, *self._wsargs(), X.stream())
+            self.tape["conv1_V_fmt"] = "f63" if c1_63 else "f43"
             stop()
             self.tape["conv1_V"] = V
         else:
