@@ -335,6 +335,13 @@ size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout);
 int myolo_wino63_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
                                    const float* shift, const float* ka, const float* kb, int act, float* dw, int N, int Cin, int Cout,
                                    void* ws, size_t ws_bytes, void* stream);
+/* the three conv operators as single calls, mirroring myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2 for the scratch size) */
+size_t myolo_conv3x3_wino63_ws_bytes(int N, int Cin, int Cout, int which);
+int myolo_conv3x3_wino63_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int N,
+                             int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_wino63_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int myolo_conv3x3_wino63_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int Cin, int Cout, void* ws,
+                                    size_t ws_bytes, void* stream);
 /* myolo_conv3x3_wino_bwd_data_lazybn on this tiling (same operands; needs myolo_wino63_ok(14, 14, Cout, Cin)) */
 size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout);
 int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,

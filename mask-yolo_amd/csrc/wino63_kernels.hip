@@ -602,6 +602,27 @@ int myolo_wino63_output_transform_bn_stats(const float* M, const float* bias, fl
 
 static const long long* w63_run_rows(long long NR, long long rows[3]) { rows[0] = 9 * NR; rows[1] = 3 * NR; rows[2] = NR; return rows; }
 
+}  // extern "C"
+
+// dU[q] = V[q]^T Q[q] per run of equal-height planes, then dw = G8^T dU G8
+static int w63_tn_and_dw(const float* V, const float* Q, float* dU, float* dw, int N, int Cin, int Cout, void* part, size_t part_bytes, hipStream_t s)
+{
+    long long rows[3];
+    w63_run_rows(N, rows);
+    const int nq[3] = {36, 24, 4};
+    const long long prow[3] = {0, 36 * rows[0], 36 * rows[0] + 24 * rows[1]};
+    const long long pq[3] = {0, 36, 60};
+    for (int k = 0; k < 3; ++k) {
+        const int rc = myolo_gemm_tn_batched(V + prow[k] * Cin, Q + prow[k] * Cout, dU + pq[k] * (long long)Cin * Cout, rows[k], Cin, Cout, nq[k],
+                                             part, part_bytes, s);
+        if (rc != MYOLO_OK) return rc;
+    }
+    hipLaunchKernelGGL(wino63_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
+    return MYOLO_OK;
+}
+
+extern "C" {
+
 size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout)
 {
     long long rows[3];
@@ -629,17 +650,8 @@ int myolo_wino63_bwd_weight_lazybn(const float* v_saved, const float* y_pre, con
     W63Args a{};
     a.src = y_pre; a.Vn = Q; a.scale = scale; a.shift = shift; a.NR = N; a.C = Cout; a.act = act; a.dyc = dy_compact; a.inv = inv; a.ka = ka; a.kb = kb;
     w63_launch<W63_FROM_LAZY, W63_TO_Q>(a, s);
-    long long rows[3];
-    w63_run_rows(N, rows);
-    const int nq[3] = {36, 24, 4};
-    const long long prow[3] = {0, 36 * rows[0], 36 * rows[0] + 24 * rows[1]};
-    const long long pq[3] = {0, 36, 60};
-    for (int k = 0; k < 3; ++k) {
-        const int rc = myolo_gemm_tn_batched(v_saved + prow[k] * Cin, Q + prow[k] * Cout, dU + pq[k] * (long long)Cin * Cout, rows[k], Cin, Cout,
-                                             nq[k], part, part_bytes, s);
-        if (rc != MYOLO_OK) return rc;
-    }
-    hipLaunchKernelGGL(wino63_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
+    const int rc = w63_tn_and_dw(v_saved, Q, dU, dw, N, Cin, Cout, part, part_bytes, s);
+    if (rc != MYOLO_OK) return rc;
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -672,6 +684,77 @@ int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, co
     if (rc != MYOLO_OK) return rc;
     W63Args b{Mp, nullptr, dx, nullptr, nullptr, nullptr, nullptr, N, Cin, MYOLO_ACT_NONE};
     w63_launch<W63_FROM_M, W63_TO_NONE>(b, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* ---- the three conv operators on this tiling with the signatures of myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (14x14 maps only) ---- */
+size_t myolo_conv3x3_wino63_ws_bytes(int N, int Cin, int Cout, int which)
+{
+    const size_t ub = align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float));
+    const size_t vi = align256(myolo_wino63_plane_elems(N, Cin) * sizeof(float)), vo = align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float));
+    if (which == 0 || which == 1) return ub + vi + vo;                              // U, V, M
+    return myolo_wino63_bwd_weight_ws_bytes(N, Cin, Cout) + vi;                     // dU, Q, partials (+ V when it was not kept)
+}
+
+/* y = act((conv3x3_same(x, w) + bias) * scale + shift); v_keep (optional) receives the transformed input for the weight gradient.
+ * Needs myolo_wino63_ok(14, 14, Cin, Cout). */
+int myolo_conv3x3_wino63_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int N,
+                             int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && N > 0 && !scale == !shift, "conv3x3_wino63_fwd: bad arguments");
+    MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "conv3x3_wino63_fwd: unsupported channel counts (%d -> %d)", Cin, Cout);
+    MYOLO_NEED_WS(myolo_conv3x3_wino63_ws_bytes(N, Cin, Cout, 0));
+    float* U = (float*)ws;
+    float* V = v_keep ? v_keep : (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
+    float* Mp = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)) + align256(myolo_wino63_plane_elems(N, Cin) * sizeof(float)));
+    int rc = myolo_wino63_weight_transform(w, U, Cin, Cout, stream);
+    if (rc == MYOLO_OK) rc = myolo_wino63_input_transform(x, nullptr, nullptr, MYOLO_ACT_NONE, nullptr, nullptr, V, N, Cin, stream);
+    if (rc == MYOLO_OK) rc = myolo_wino63_multiply(V, U, Mp, N, Cin, Cout, stream);
+    if (rc == MYOLO_OK) rc = myolo_wino63_output_transform(Mp, bias, scale, shift, y, N, Cout, act, stream);
+    return rc;
+}
+
+/* dx = conv3x3_same(dy, rot180(w)^T): needs myolo_wino63_ok(14, 14, Cout, Cin) */
+int myolo_conv3x3_wino63_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && w && dx && N > 0, "conv3x3_wino63_bwd_data: bad arguments");
+    MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cout, Cin), "conv3x3_wino63_bwd_data: unsupported channel counts (%d -> %d)", Cin, Cout);
+    MYOLO_NEED_WS(myolo_conv3x3_wino63_ws_bytes(N, Cin, Cout, 1));
+    hipStream_t s = (hipStream_t)stream;
+    float* U = (float*)ws;
+    float* V = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
+    float* Mp = (float*)((char*)V + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)));
+    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, w63_layout(Cout, Cin), 1);
+    int rc = myolo_wino63_input_transform(dy, nullptr, nullptr, MYOLO_ACT_NONE, nullptr, nullptr, V, N, Cout, stream);
+    if (rc == MYOLO_OK) rc = myolo_wino63_multiply(V, U, Mp, N, Cout, Cin, stream);
+    if (rc == MYOLO_OK) rc = myolo_wino63_output_transform(Mp, nullptr, nullptr, nullptr, dx, N, Cin, MYOLO_ACT_NONE, stream);
+    return rc;
+}
+
+/* dw = sum over pixels of x (x) dy; the forward's transformed input may be passed instead of x (v_saved).  Channels multiples of 64. */
+int myolo_conv3x3_wino63_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int Cin, int Cout, void* ws,
+                                    size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE((x || v_saved) && dy && dw && N > 0, "conv3x3_wino63_bwd_weight: bad arguments");
+    MYOLO_REQUIRE((Cin % W63_CS) == 0 && (Cout % W63_CS) == 0, "conv3x3_wino63_bwd_weight: channels must be multiples of 64 (got %d, %d)", Cin, Cout);
+    MYOLO_NEED_WS(myolo_conv3x3_wino63_ws_bytes(N, Cin, Cout, 2));
+    hipStream_t s = (hipStream_t)stream;
+    float* dU = (float*)ws;
+    float* Q = (float*)((char*)ws + align256((size_t)64 * Cin * Cout * sizeof(float)));
+    char* after_q = (char*)Q + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float));
+    float* V = (float*)after_q;
+    void* part = v_saved ? (void*)after_q : (void*)(after_q + align256(myolo_wino63_plane_elems(N, Cin) * sizeof(float)));
+    const size_t part_bytes = ws_bytes - (size_t)((char*)part - (char*)ws);
+    if (!v_saved) {
+        const int rc = myolo_wino63_input_transform(x, nullptr, nullptr, MYOLO_ACT_NONE, nullptr, nullptr, V, N, Cin, stream);
+        if (rc != MYOLO_OK) return rc;
+    }
+    W63Args a{};
+    a.src = dy; a.Vn = Q; a.NR = N; a.C = Cout; a.act = MYOLO_ACT_NONE;
+    w63_launch<W63_FROM_ACT, W63_TO_Q>(a, s);
+    const int rc = w63_tn_and_dw(v_saved ? v_saved : V, Q, dU, dw, N, Cin, Cout, part, part_bytes, s);
+    if (rc != MYOLO_OK) return rc;
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -59,6 +59,9 @@ SIGS = {
     "myolo_wino63_input_transform_roialign": [P, P, P, P, I, I, I, I, I, P],
     "myolo_wino63_output_transform_bn_stats": [P, P, P, I, I, P, P, P, P, P, P, P, P, P, Z, P],
     "myolo_wino63_bwd_weight_lazybn": [P, P, P, P, P, P, P, P, I, P, I, I, I, P, Z, P],
+    "myolo_conv3x3_wino63_fwd": [P, P, P, P, P, P, I, I, I, I, P, P, Z, P],
+    "myolo_conv3x3_wino63_bwd_data": [P, P, P, I, I, I, P, Z, P],
+    "myolo_conv3x3_wino63_bwd_weight": [P, P, P, P, I, I, I, P, Z, P],
     "myolo_wino63_bwd_data_lazybn": [P, P, P, P, P, P, P, I, P, P, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_fused_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
@@ -127,6 +130,8 @@ def load():
     lib.myolo_wino63_plane_elems.restype = Z
     lib.myolo_wino63_bwd_data_ws_bytes.argtypes = [I, I, I]
     lib.myolo_wino63_bwd_data_ws_bytes.restype = Z
+    lib.myolo_conv3x3_wino63_ws_bytes.argtypes = [I, I, I, I]
+    lib.myolo_conv3x3_wino63_ws_bytes.restype = Z
     lib.myolo_wino63_bwd_weight_ws_bytes.argtypes = [I, I, I]
     lib.myolo_wino63_bwd_weight_ws_bytes.restype = Z
     lib.myolo_wino63_output_transform_bn_ws_bytes.argtypes = [I, I]
@@ -142,7 +147,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino_fused_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_conv3x3_wino_fused_ws_bytes",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -210,6 +215,11 @@ def wino_u_elems(cin, cout):
 
 def wino63_ok(h, w, cin, cout):
     return bool(load().myolo_wino63_ok(int(h), int(w), int(cin), int(cout)))
+
+
+def wino63_ws_bytes(n, cin, cout, which):
+    """scratch bytes of myolo_conv3x3_wino63_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2)."""
+    return int(load().myolo_conv3x3_wino63_ws_bytes(int(n), int(cin), int(cout), int(which)))
 
 
 def wino63_bwd_weight_ws_bytes(n, cin, cout):

@@ -307,6 +307,10 @@ class Net(object):
             return fits
         return fits and nimg * h * w >= WINO_MIN_ROWS
 
+    def _wino63(self, h, w, cin, cout):
+        """the F(6,3)/F(4,3) tiling applies to this conv (cfg.WINOGRAD_TILES='f63', 14x14 maps, channel counts the one-launch multiply takes)"""
+        return self.wino_tiles == "f63" and X.wino63_ok(h, w, cin, cout)
+
     def _timed(self, tag):
         """(start, stop) closures bracketing a multi-launch op with HIP events on the launch stream, if `tag` is measured."""
         if tag is None or tag not in self.timed_tags:
@@ -326,7 +330,16 @@ class Net(object):
         start, stop = self._timed(tag)
         start()
         v = None
-        if self._wino_ok(nimg, h, w, cin, cout):
+        if self._wino_ok(nimg, h, w, cin, cout) and not keep_v and self._wino63(h, w, cin, cout):
+            # F(6,3)/F(4,3) tiling of a 14x14 map (csrc/wino63_kernels.hip); a kept V stays in the F(4,3) layout its consumer expects
+            U = self._new(X.wino63_u_elems(cin, cout))
+            V, M = self._new(X.wino63_plane_elems(nimg, cin)), self._new(X.wino63_plane_elems(nimg, cout))
+            X.call("myolo_wino63_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, X.stream())
+            X.call("myolo_wino63_input_transform", X.ptr(x), None, None, ACT_NONE, None, None, X.ptr(V), nimg, cin, X.stream())
+            self._call_timed("wino_multiply" if tag == "mask_conv3x3_fwd" else None, "myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(M),
+                             nimg, cin, cout, X.stream())
+            X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(bias), X.ptr(scale), X.ptr(shift), X.ptr(y), nimg, cout, act, X.stream())
+        elif self._wino_ok(nimg, h, w, cin, cout):
             T = nimg * ((h + 3) // 4) * ((w + 3) // 4)
             U, V, M = self._new(X.wino_u_elems(cin, cout)), self._new(36, T, cin), self._new(36, T, cout)
             X.call("myolo_wino_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, 0, X.stream())
@@ -347,7 +360,10 @@ class Net(object):
 
     def conv3x3_bwd_weight(self, x, v_saved, dy, layer, nimg, h, w, cin, cout):
         dw = self.g[layer + "/kernel"]
-        if self._wino_ok(nimg, h, w, cin, cout):
+        if self._wino_ok(nimg, h, w, cin, cout) and v_saved is None and self._wino63(h, w, cin, cout):
+            self.ws.ensure(X.wino63_ws_bytes(nimg, cin, cout, 2))
+            X.call("myolo_conv3x3_wino63_bwd_weight", X.ptr(x), None, X.ptr(dy), X.ptr(dw), nimg, cin, cout, *self._wsargs(), X.stream())
+        elif self._wino_ok(nimg, h, w, cin, cout):
             self.ws.ensure(X.wino_ws_bytes(nimg, h, w, cin, cout, 2))
             X.call("myolo_conv3x3_wino_bwd_weight", None if v_saved is not None else X.ptr(x), X.ptr(v_saved), X.ptr(dy), X.ptr(dw),
                    nimg, h, w, cin, cout, *self._wsargs(), X.stream())
@@ -355,7 +371,11 @@ class Net(object):
             X.call("myolo_conv3x3_bwd_weight", X.ptr(x), X.ptr(dy), X.ptr(dw), nimg, h, w, cin, cout, *self._wsargs(), X.stream())
 
     def conv3x3_bwd_data(self, dy, layer, dx, nimg, h, w, cin, cout):
-        if self._wino_ok(nimg, h, w, cout, cin):
+        if self._wino_ok(nimg, h, w, cout, cin) and self._wino63(h, w, cout, cin):
+            self.ws.ensure(X.wino63_ws_bytes(nimg, cin, cout, 1))
+            X.call("myolo_conv3x3_wino63_bwd_data", X.ptr(dy), X.ptr(self.p[layer + "/kernel"]), X.ptr(dx), nimg, cin, cout,
+                   *self._wsargs(), X.stream())
+        elif self._wino_ok(nimg, h, w, cout, cin):
             self.ws.ensure(X.wino_ws_bytes(nimg, h, w, cin, cout, 1))
             X.call("myolo_conv3x3_wino_bwd_data", X.ptr(dy), X.ptr(self.p[layer + "/kernel"]), X.ptr(dx), nimg, h, w, cin, cout,
                    *self._wsargs(), X.stream())

@@ -778,3 +778,30 @@ def test_winograd_f63_conv1_pieces():
         err = float((got - want).abs().max()) / float(want.abs().max())
         assert err < 1e-4, (what, err)
 
+
+@pytest.mark.parametrize("N,Cin,Cout", [(11, 256, 256), (3, 64, 256)])
+def test_winograd_f63_conv_operators(N, Cin, Cout):
+    """myolo_conv3x3_wino63_{fwd,bwd_data,bwd_weight}: the three operators as single calls on the F(6,3)/F(4,3) tiling, against the
+    float64 oracle at the suite's 1e-3 bound (the compacted mask-head backward at realistic positive counts runs through them)."""
+    rng = np.random.default_rng(21)
+    H = W = 14
+    x, w, b, dy = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout), rnd(rng, N, H, W, Cout)
+    wsb = torch.empty(max(X.wino63_ws_bytes(N, Cin, Cout, k) for k in (0, 1, 2)), dtype=torch.uint8, device=DEV)
+    wsa = (wsb.data_ptr(), wsb.numel())
+    st = X.stream()
+    x_t, w_t, b_t, dy_t = dt(x), dt(w), dt(b), dt(dy)
+    y, vk = new(N, H, W, Cout), torch.empty(X.wino63_plane_elems(N, Cin), device=DEV)
+    X.call("myolo_conv3x3_wino63_fwd", X.ptr(x_t), X.ptr(w_t), X.ptr(b_t), None, None, X.ptr(y), N, Cin, Cout, 0, X.ptr(vk), *wsa, st)
+    ref = O.conv2d(x, w, pads=(1, 1, 1, 1), bias=b, acc=np.float64)
+    check(y, ref, what="wino63 fwd")
+    rdx, rdw, rdb = O.conv2d_bwd(x, w, dy, pads=(1, 1, 1, 1), acc=np.float64)
+    dw, dw2 = new(3, 3, Cin, Cout), new(3, 3, Cin, Cout)
+    X.call("myolo_conv3x3_wino63_bwd_weight", None, X.ptr(vk), X.ptr(dy_t), X.ptr(dw), N, Cin, Cout, *wsa, st)
+    check(dw, rdw, what="wino63 dw (saved V)")
+    X.call("myolo_conv3x3_wino63_bwd_weight", X.ptr(x_t), None, X.ptr(dy_t), X.ptr(dw2), N, Cin, Cout, *wsa, st)
+    check(dw2, rdw, what="wino63 dw (from x)")
+    if X.wino63_ok(14, 14, Cout, Cin):
+        dx = new(N, H, W, Cin)
+        X.call("myolo_conv3x3_wino63_bwd_data", X.ptr(dy_t), X.ptr(w_t), X.ptr(dx), N, Cin, Cout, *wsa, st)
+        check(dx, rdx, what="wino63 dx")
+
