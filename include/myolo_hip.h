@@ -131,6 +131,10 @@ int myolo_bn_frozen_coeffs(const float* gamma, const float* beta, const float* m
                            const float* moving_var, float* scale, float* shift, int C, void* stream);
 int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, float* y,
                        int64_t M, int C, int act, void* stream);
+/* frozen BatchNorm + activation in one launch: myolo_bn_frozen_coeffs followed by myolo_bn_apply_act (same results; scale / shift are
+ * written as well); needs C/4 to divide 256 */
+int myolo_bn_frozen_apply_act(const float* x, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                              float* scale, float* shift, float* y, int64_t M, int C, int act, void* stream);
 int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma,
                      const float* mean, const float* var, const float* scale, const float* shift,
                      float* dx, float* dgamma, float* dbeta,

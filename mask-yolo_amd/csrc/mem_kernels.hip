@@ -331,6 +331,41 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     }
 }
 
+// frozen BatchNorm (moving statistics) + activation in ONE launch: bn_frozen_kernel's coefficients are formed by every thread for
+// its own channel quad (constant over its grid-stride loop: the stride is a multiple of 256 and C/4 divides 256) and written out by
+// the first workgroup, then bn_apply_kernel's loop.  Same expressions, same results as the two-kernel form.
+__global__ __launch_bounds__(256) void bn_frozen_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ mm,
+                                                              const float* __restrict__ mv, float* __restrict__ scale,
+                                                              float* __restrict__ shift, float* __restrict__ y, long long nquads, int C, int act)
+{
+    const bool nt = nquads > (4ll << 20);
+    const int cq = C / 4;
+    const int c = (int)(threadIdx.x % cq) * 4;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float rstd = (float)(1.0 / sqrt((double)mv[c + k] + (double)BN_EPS_F));
+        sc[k] = gamma[c + k] * rstd;
+        sh[k] = beta[c + k] - mm[c + k] * sc[k];
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < cq) {
+        st4g(scale + c, make_float4(sc[0], sc[1], sc[2], sc[3]));
+        st4g(shift + c, make_float4(sh[0], sh[1], sh[2], sh[3]));
+    }
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (; i < nquads; i += stride) {
+        const float4 v = ld4g(x + i * 4);
+        float4 o;
+        o.x = actf(fmaf(v.x, sc[0], sh[0]), act);
+        o.y = actf(fmaf(v.y, sc[1], sh[1]), act);
+        o.z = actf(fmaf(v.z, sc[2], sh[2]), act);
+        o.w = actf(fmaf(v.w, sc[3], sh[3]), act);
+        if (nt) st4g_nt(y + i * 4, o); else st4g(y + i * 4, o);
+    }
+}
+
 // backward pass 1: dbeta = sum dz, dgamma = sum dz*xhat, with dz = dy * actmask(x*scale+shift)
 struct OpBnBwd {
     static constexpr int NV = 2;
@@ -1347,6 +1382,18 @@ int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, f
     MYOLO_REQUIRE(x && scale && shift && y && M > 0 && (C & 3) == 0, "bn_apply_act: bad arguments");
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(nq)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, nq, C, act);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_bn_frozen_apply_act(const float* x, const float* gamma, const float* beta, const float* moving_mean, const float* moving_var,
+                              float* scale, float* shift, float* y, int64_t M, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(x && gamma && beta && moving_mean && moving_var && scale && shift && y && M > 0, "bn_frozen_apply_act: bad arguments");
+    MYOLO_REQUIRE((C & 3) == 0 && C >= 4 && 256 % (C / 4) == 0, "bn_frozen_apply_act: C/4 must divide 256 (got C=%d)", C);
+    const long long nq = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_frozen_apply_kernel, dim3(ew_blocks(nq)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, moving_mean,
+                       moving_var, scale, shift, y, nq, C, act);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -35,6 +35,7 @@ SIGS = {
     "myolo_colsum": [P, P, L, I, P, Z, P],
     "myolo_bn_stats": [P, P, P, P, P, P, P, P, P, L, I, P, Z, P],
     "myolo_bn_frozen_coeffs": [P, P, P, P, P, P, I, P],
+    "myolo_bn_frozen_apply_act": [P, P, P, P, P, P, P, P, L, I, I, P],
     "myolo_bn_apply_act": [P, P, P, P, L, I, I, P],
     "myolo_bn_act_bwd": [P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, Z, P],
     "myolo_bn_act_bwd_frozen_post": [P, P, P, P, P, P, P, P, L, I, I, P, Z, P],

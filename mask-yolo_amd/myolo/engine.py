@@ -167,6 +167,7 @@ class Net(object):
         self.overlap_conv1_wgrad = True
         self._wgrad_pending = False
         self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
+        self.fused_frozen_bn = True       # bn_act_fwd on moving statistics: one launch instead of coefficients + apply
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
         self.adam_t = 0
@@ -265,6 +266,13 @@ class Net(object):
                    X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift),
                    X.ptr(self.s[name + "/moving_mean"]), X.ptr(self.s[name + "/moving_variance"]),
                    M, C, *self._wsargs(), X.stream())
+        elif self.fused_frozen_bn and C % 4 == 0 and 256 % (C // 4) == 0:       # frozen BN: coefficients + apply + activation in one launch
+            a = self._new(M, C)
+            X.call("myolo_bn_frozen_apply_act", X.ptr(y), X.ptr(self.p[name + "/gamma"]), X.ptr(self.p[name + "/beta"]),
+                   X.ptr(self.s[name + "/moving_mean"]), X.ptr(self.s[name + "/moving_variance"]), X.ptr(scale), X.ptr(shift), X.ptr(a),
+                   M, C, act, X.stream())
+            self.tape[name] = (y, act, batch_stats)
+            return a
         else:
             X.call("myolo_bn_frozen_coeffs", X.ptr(self.p[name + "/gamma"]), X.ptr(self.p[name + "/beta"]),
                    X.ptr(self.s[name + "/moving_mean"]), X.ptr(self.s[name + "/moving_variance"]),

@@ -805,3 +805,19 @@ def test_winograd_f63_conv_operators(N, Cin, Cout):
         X.call("myolo_conv3x3_wino63_bwd_data", X.ptr(dy_t), X.ptr(w_t), X.ptr(dx), N, Cin, Cout, *wsa, st)
         check(dx, rdx, what="wino63 dx")
 
+
+@pytest.mark.parametrize("M,C,act", [(1000, 32, 2), (37, 1024, 1), (196 * 5, 256, 1), (64, 4, 0)])
+def test_bn_frozen_apply_act_equals_coeffs_then_apply(M, C, act):
+    """the one-launch frozen BatchNorm + activation == myolo_bn_frozen_coeffs followed by myolo_bn_apply_act, bit for bit"""
+    rng = np.random.default_rng(5)
+    x = dt(rnd(rng, M, C))
+    gamma, beta, mm, mv = dt(1 + 0.1 * rnd(rng, C)), dt(rnd(rng, C, scale=0.1)), dt(rnd(rng, C, scale=0.2)), dt(np.abs(rnd(rng, C)) + 0.1)
+    st = X.stream()
+    sc1, sh1, y1 = new(C), new(C), new(M, C)
+    X.call("myolo_bn_frozen_coeffs", X.ptr(gamma), X.ptr(beta), X.ptr(mm), X.ptr(mv), X.ptr(sc1), X.ptr(sh1), C, st)
+    X.call("myolo_bn_apply_act", X.ptr(x), X.ptr(sc1), X.ptr(sh1), X.ptr(y1), M, C, act, st)
+    sc2, sh2, y2 = new(C), new(C), new(M, C)
+    X.call("myolo_bn_frozen_apply_act", X.ptr(x), X.ptr(gamma), X.ptr(beta), X.ptr(mm), X.ptr(mv), X.ptr(sc2), X.ptr(sh2), X.ptr(y2), M, C, act, st)
+    torch.cuda.synchronize()
+    assert torch.equal(sc1, sc2) and torch.equal(sh1, sh2) and torch.equal(y1, y2)
+
