@@ -225,6 +225,13 @@ def bench_train(args, rank, world, local):
             return float(t.item())
         return x
 
+    if args.force_pos > 0:
+        def force_hook(proposals, db, k=args.force_pos):
+            gt = db["gt_boxes"].to(torch.float32)                       # [B,T,4] px, x1 y1 x2 y2
+            H, W = float(cfg.IMAGE_SHAPE[0]), float(cfg.IMAGE_SHAPE[1])
+            norm = (gt - torch.tensor([0., 0., 1., 1.], device=gt.device)) / torch.tensor([W - 1, H - 1, W - 1, H - 1], device=gt.device)
+            proposals[:, :k, :] = norm[:, :1, :].expand(-1, k, -1)
+        net.proposals_hook = force_hook
     for i in range(args.warmup):
         net.train_step(dbs[i % nb], args.lr)
     # ---- the timed region: only the dominant kernel (and the conv op it belongs to) is bracketed with events
@@ -417,7 +424,7 @@ def bench_train(args, rank, world, local):
                                "; Winograd multiply products: " + ("native fp32 MFMA" if net.fp32_matmul == "native" else
                                "FP32_MATMUL='bf16x6' (each fp32 product = six exact bf16 piece products, fp32 accumulation)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option),
+                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "forced_positives": args.force_pos,
                    "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
         "roofline": roofline,
     }
@@ -544,6 +551,9 @@ def main():
                     help="N>1: gradient all-reduce through torch.distributed (nccl = RCCL) or through the library's own myolo_comm_* entry points")
     ap.add_argument("--fp32-matmul", choices=["native", "bf16x6"], default="native", help="cfg.FP32_MATMUL (how the Winograd multiply forms its fp32 products)")
     ap.add_argument("--wino-tiles", choices=["f43", "f63"], default=None, help="cfg.WINOGRAD_TILES (default: the config's)")
+    ap.add_argument("--force-pos", type=int, default=0, metavar="K",
+                    help="replace the first K proposals of every image by a ground-truth box for the WHOLE run (the n_pos sweep's hook): the step "
+                         "at the positive counts a trained net produces; recorded in config.forced_positives")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="myolo_set_option switches for this run (kernel A/B comparisons, e.g. wino_x6=1); recorded in config.lib_options")
     args = ap.parse_args()
