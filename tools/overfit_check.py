@@ -2,7 +2,7 @@
 """End-to-end learning check (no oracle involved): overfit ONE fixed batch of 8 Shapes images with the training step, then
 run detect() on those images with the trained weights.  Expected on an MI355X (25 s): the mask loss falls from 0.69 to about
 0.01, every detection has the class of a ground-truth instance and its pasted mask overlaps that instance with IoU > 0.8.
-  python tools/overfit_check.py [WINOGRAD_TILES=f43|f63] [FP32_MATMUL=native|bf16x6]       (config overrides; default: the config's)
+  python tools/overfit_check.py [WINOGRAD_TILES=f43|f63] [FP32_MATMUL=native|bf16x6] [SEED=n]       (config overrides; default: the config's)
 """
 import sys
 import os
@@ -15,11 +15,12 @@ from myolo.shapes import make_shapes_samples
 from myolo.myolo_utils import BatchGenerator
 B = 8
 over = dict(a.split("=", 1) for a in sys.argv[1:])
+SEED = int(over.pop("SEED", 1))                # weight-init seed
 cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], BATCH_SIZE=B, **over)
 print("WINOGRAD_TILES=%s FP32_MATMUL=%s" % (cfg.WINOGRAD_TILES, cfg.FP32_MATMUL))
 samples = make_shapes_samples(B, cfg)
 batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
-m = MaskYOLO(mode="training", config=cfg, seed=1)
+m = MaskYOLO(mode="training", config=cfg, seed=SEED)
 m.set_trainable(".*"); m.compile(1e-3, 0.9)
 db = m.net.to_device_batch(batch)
 for i in range(1500):
