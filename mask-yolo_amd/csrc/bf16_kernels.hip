@@ -432,6 +432,49 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds(Bf16Args p)
     }
 }
 
+#define W2_ROW 136           // bytes per row of a wave's private 128 x 64 bf16 staging block (128 + 8)
+
+// ---- EP_PLAIN of the 256 x 256 kernels: bias + activation, each wave transposes its 128 x 64 block through its own LDS region ----
+__device__ __forceinline__ void epi_plain_256(f32x16 (&acc)[4][2], const Bf16Args& p, unsigned char* lds, long long m0, int n0)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int half = lane >> 5, l31 = lane & 31;
+    unsigned char* Ws = lds + wave * 128 * W2_ROW;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = u * 32 + 8 * g + 4 * half;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + wn * 64 + nl + e;
+                    float b = 0.f;
+                    if (p.bias && n < p.N) b = p.bias[n];
+                    v[e] = acc[t][u][4 * g + e] + b;
+                    if (p.act == MYOLO_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+                }
+                uint2 pk;
+                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
+                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                *reinterpret_cast<uint2*>(Ws + (t * 32 + l31) * W2_ROW + nl * 2) = pk;
+            }
+    __syncthreads();
+#pragma unroll 4
+    for (int it = 0; it < 32; ++it) {                  // 128 rows x 16 chunks of 8 B per wave / 64 lanes
+        const int idx = it * 64 + lane;
+        const int row = idx >> 4, cq = idx & 15;
+        const long long m = m0 + wm * 128 + row;
+        const int n = n0 + wn * 64 + cq * 4;
+        if (m >= p.M || n >= p.N) continue;
+        const uint2 pk = *reinterpret_cast<const uint2*>(Ws + row * W2_ROW + cq * 8);
+        *reinterpret_cast<uint2*>(p.C + m * p.N + n) = pk;
+    }
+}
+
 // ---- 256 x 256 x 64 tiles, 8 waves (2 x 4, each 128 x 64 = 4 x 2 MFMA blocks), same LDS-DMA fill and swizzle ----
 // One workgroup per CU (128 KB of LDS for the two buffers): per k step a wave reads 6 fragments for 8 MFMAs (0.75 per
 // MFMA against 1.0 in the 128^2 kernel) and the A tile is fetched once for all 256 output channels.  Used for the big
@@ -439,7 +482,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds(Bf16Args p)
 // EPI PLAIN (each wave transposes its own 128 x 64 block through a private LDS region) and EPI DECONV_MASK.
 #define T2M 256
 #define T2N 256
-#define W2_ROW 136           // bytes per row of a wave's private 128 x 64 bf16 staging block (128 + 8)
 
 template <int AMODE, int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
@@ -506,49 +548,95 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
 
     const int nk = p.K / TBK;
     int tap = 0, c0 = 0;
-    auto fill = [&](int kt, int b) {
-        unsigned ashift, abit;
-        if (AMODE == AM_PLAIN) { ashift = (unsigned)(kt * TBK) * 2u; abit = 0; }
+    unsigned f_ashift = 0, f_abit = 0, f_bshift = 0;
+    auto fill_begin = [&](int kt) {              // operand offsets of k tile kt (CONV3: tap and channel block of the implicit im2col)
+        if (AMODE == AM_PLAIN) { f_ashift = (unsigned)(kt * TBK) * 2u; f_abit = 0; }
         else {
             const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
-            ashift = (unsigned)((((ty - 1) * p.W + (tx - 1)) * p.Cc + c0) * 2);
-            abit = (unsigned)tap;
+            f_ashift = (unsigned)((((ty - 1) * p.W + (tx - 1)) * p.Cc + c0) * 2);
+            f_abit = (unsigned)tap;
             c0 += TBK;
             if (c0 == p.Cc) { c0 = 0; ++tap; }
         }
-        const unsigned bshift = (unsigned)(kt * TBK) * 2u;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned ao = ((amask[j] >> abit) & 1u) ? arow[j] + ashift : OOB_OFF;
-            const unsigned bo = brow[j] == OOB_OFF ? OOB_OFF : brow[j] + bshift;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)&buf[b][0][(wave * 32 + j * 8) * 128], 16, (int)ao, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)&buf[b][1][(wave * 32 + j * 8) * 128], 16, (int)bo, 0, 0, 0);
-        }
+        f_bshift = (unsigned)(kt * TBK) * 2u;
+    };
+    auto fill_piece = [&](int j, int b, bool live) {        // 8 rows of A and 8 rows of B per wave and piece, straight into LDS
+        // (live == false, past the last k tile: out-of-range offsets, the DMA writes zeros nobody reads -- keeps the loop body branch-free,
+        //  which the instruction-group scheduling below needs)
+        const unsigned ao = (live && ((amask[j] >> f_abit) & 1u)) ? arow[j] + f_ashift : OOB_OFF;
+        const unsigned bo = (!live || brow[j] == OOB_OFF) ? OOB_OFF : brow[j] + f_bshift;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)&buf[b][0][(wave * 32 + j * 8) * 128], 16, (int)ao, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)&buf[b][1][(wave * 32 + j * 8) * 128], 16, (int)bo, 0, 0, 0);
     };
 
     const int half = lane >> 5, l31 = lane & 31;
     const unsigned rsw = (unsigned)((l31 >> 1) & 7);
-    if (nk > 0) fill(0, 0);
+    if (nk > 0) {
+        fill_begin(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fill_piece(j, 0, true);
+    }
     __syncthreads();
+    // The loop is scheduled by hand (sched_group_barrier): a wave's MFMAs issue back to back and every LDS read / LDS-DMA piece sits in
+    // the 32-cycle shadow of one of them.  Fragments are double-buffered in registers (the six ds_read_b128 of k step ks+1 ride on the
+    // MFMAs of step ks, in the order the next step consumes them); the eight LDS-DMA pieces of the next k tile ride on steps 0 and 1, so
+    // they have two steps to land; the last step issues two MFMAs, waits for the DMA, passes the barrier and reads the next tile's first
+    // fragments under its remaining six MFMAs.  (The compiler's own schedule put the 8 DMA pieces in one block and waited on each group of
+    // reads in front of its MFMAs: 979 TFLOP/s.)
+    bf16x8 fa[2][4], fb[2][2];
+    auto rd = [&](int b, int ks, int slot) {
+        const unsigned char* Ab = &buf[b][0][(wm * 128 + l31) * 128];
+        const unsigned char* Bb = &buf[b][1][(wn * 64 + l31) * 128];
+        const unsigned co = (((unsigned)(ks * 2 + half)) ^ rsw) * 16u;
+        fb[slot][0] = *reinterpret_cast<const bf16x8*>(Bb + co);
+        fa[slot][0] = *reinterpret_cast<const bf16x8*>(Ab + co);
+        fb[slot][1] = *reinterpret_cast<const bf16x8*>(Bb + 32 * 128 + co);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) fa[slot][t] = *reinterpret_cast<const bf16x8*>(Ab + t * 32 * 128 + co);
+    };
+    auto mma = [&](int sl, int t0, int t1) {
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[sl][u], fa[sl][t], acc[t][u], 0, 0, 0);
+    };
     int cur = 0;
+    if (nk > 0) rd(0, 0, 0);
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) fill(kt + 1, cur ^ 1);
-        const unsigned char* Ab = &buf[cur][0][(wm * 128 + l31) * 128];
-        const unsigned char* Bb = &buf[cur][1][(wn * 64 + l31) * 128];
+        const bool more = kt + 1 < nk;
+        fill_begin(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < TBK / 16; ++ks) {
-            const unsigned co = (((unsigned)(ks * 2 + half)) ^ rsw) * 16u;
-            bf16x8 af[4], bfr[2];
+            const int sl = ks & 1;
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < TBK / 16) {
+                rd(cur, ks + 1, sl ^ 1);
+                if (ks < 2) { fill_piece(2 * ks, cur ^ 1, more); fill_piece(2 * ks + 1, cur ^ 1, more); }
+                mma(sl, 0, 4);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const bf16x8*>(Ab + t * 32 * 128 + co);
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks < 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (ks < 2) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+            } else {
+                mma(sl, 0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                rd(cur ^ 1, 0, sl ^ 1);         // (past the last k tile: stale bytes, never used)
+                mma(sl, 1, 4);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) bfr[u] = *reinterpret_cast<const bf16x8*>(Bb + u * 32 * 128 + co);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[u], af[t], acc[t][u], 0, 0, 0);
+                for (int i = 0; i < 6; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
         }
-        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
     }
 
@@ -599,40 +687,210 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
         }
         return;
     }
-    // ---- EP_PLAIN: bias + activation, each wave transposes its 128 x 64 block through its own LDS region ----
-    unsigned char* Ws = lds + wave * 128 * W2_ROW;
+    epi_plain_256(acc, p, lds, m0, n0);
+}
+
+// ---- 3x3 / s1 / SAME conv as an implicit GEMM whose A operand is fetched ONCE per channel block -------------------------------
+// gemm_bf16_256<AM_CONV3> re-fetches the 256 activation rows of its tile from L2 for each of the nine taps; with the weight tile that
+// is 64 KB of L2 -> LDS traffic per k tile, and the kernel turned out to be bound by exactly that traffic (a timing-only experiment
+// that skipped the A fetch on eight of the nine taps ran 20 % faster).  Here the k loop is (channel block) x (tap): the 256 + 2(W+1)
+// rows a tile can touch are put in LDS once per 64-channel block, and the nine taps read their fragments from that block at a row
+// offset -- the im2col happens in the LDS address.  Pixels whose tap falls outside the image read a row of zeros kept at the end of
+// LDS.  Per k tile only the weight tile (32 KB) crosses L2 -> LDS, plus 1/9 of the 40 KB activation block.
+//   LDS: two activation blocks of C3_AROWS rows x 128 B (same XOR swizzle as above, keyed by the block row), two weight tiles, zero row.
+#define C3_AROWS 320                     // >= 256 + 2 (W + 1): W <= 31
+#define C3_LDS (2 * C3_AROWS * 128 + 2 * T2N * 128 + 128)
+
+__global__ __launch_bounds__(512, 1) void conv3_bf16_256(Bf16Args p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char lds[C3_LDS];
+    unsigned char* const abuf = lds;                               // [2][C3_AROWS * 128]
+    unsigned char* const bbuf = lds + 2 * C3_AROWS * 128;          // [2][T2N * 128]
+    const unsigned zoff = 2 * C3_AROWS * 128 + 2 * T2N * 128;      // the zero row
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntn = p.N / T2N;
+    long long bid;
+    {
+        const long long nwg = gridDim.x, orig = blockIdx.x;
+        const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tn = (int)(bid % ntn);
+    const long long m0 = (bid / ntn) * T2M;
+    const int n0 = tn * T2N;
+    const int hw = p.H * p.W;
+    const int halo = p.W + 1, arows = T2M + 2 * halo;
+
+    long long base_row = m0 - halo; if (base_row < 0) base_row = 0;
+    long long end_row = m0 + T2M + halo; if (end_row > p.M) end_row = p.M;
+    const __amdgpu_buffer_rsrc_t ra = mk_rsrc(p.A + base_row * p.Cc, (end_row - base_row) * p.Cc * 2);
+    const __amdgpu_buffer_rsrc_t rb = mk_rsrc(p.Wt, (long long)p.N * p.K * 2);
+
+    if (tid < 32) *reinterpret_cast<unsigned*>(lds + zoff + tid * 4) = 0u;
+
+    // activation block: 40 pieces of 8 rows (piece q = wave + 8 i), block row r holds input row m0 - halo + r
+    unsigned aoff[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int prow = (wave + 8 * i) * 8 + (lane >> 3);
+        const unsigned chunk = (unsigned)((lane & 7) ^ ((prow >> 1) & 7));
+        const long long g = m0 - halo + prow;
+        aoff[i] = (prow < arows && g >= 0 && g < p.M) ? (unsigned)((g - base_row) * p.Cc) * 2u + chunk * 16u : OOB_OFF;
+    }
+    unsigned brow[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lrow = wave * 32 + j * 8 + (lane >> 3);
+        const unsigned chunk = (unsigned)((lane & 7) ^ ((lrow >> 1) & 7));
+        brow[j] = (unsigned)((long long)(n0 + lrow) * p.K) * 2u + chunk * 16u;
+    }
+    auto a_piece = [&](int i, int cb, int b, bool live) {
+        const unsigned ao = (live && aoff[i] != OOB_OFF) ? aoff[i] + (unsigned)cb * 128u : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(abuf + b * (C3_AROWS * 128) + (wave + 8 * i) * 1024), 16, (int)ao, 0, 0, 0);
+    };
+    auto b_piece = [&](int j, int tap, int cb, int b, bool live) {
+        const unsigned bo = live ? brow[j] + (unsigned)(tap * p.Cc + cb * TBK) * 2u : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(bbuf + b * (T2N * 128) + (wave * 32 + j * 8) * 128), 16, (int)bo, 0, 0, 0);
+    };
+
+    // this lane's four output pixels (rows wm*128 + 32 t + l31 of the tile) and, per pixel, which of the nine taps stay inside the image
+    const int half = lane >> 5, l31 = lane & 31;
+    unsigned mask9[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long long m = m0 + wm * 128 + t * 32 + l31;
+        unsigned mk = 0;
+        if (m < p.M) {
+            const int rem = (int)(m % hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+#pragma unroll
+            for (int tp = 0; tp < 9; ++tp) {
+                const int ty = tp / 3, tx = tp - ty * 3;
+                if ((unsigned)(y + ty - 1) < (unsigned)p.H && (unsigned)(x + tx - 1) < (unsigned)p.W) mk |= 1u << tp;
+            }
+        }
+        mask9[t] = mk;
+    }
+    const int prow0 = wm * 128 + l31 + halo;                       // block row of pixel t = 0 at the centre tap; + 32 t, + tap shift
+    const unsigned rswB = (unsigned)((l31 >> 1) & 7);
+    const unsigned cB = (unsigned)(wn * 64 + l31) * 128u;
+
+    f32x16 acc[4][2];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int nl = u * 32 + 8 * g + 4 * half;
-                float v[4];
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    const int ncb = p.Cc / TBK;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + wn * 64 + nl + e;
-                    float b = 0.f;
-                    if (p.bias && n < p.N) b = p.bias[n];
-                    v[e] = acc[t][u][4 * g + e] + b;
-                    if (p.act == MYOLO_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
-                }
-                uint2 pk;
-                pk.x = (unsigned)f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-                pk.y = (unsigned)f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-                *reinterpret_cast<uint2*>(Ws + (t * 32 + l31) * W2_ROW + nl * 2) = pk;
-            }
+    for (int i = 0; i < 5; ++i) a_piece(i, 0, 0, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_piece(j, 0, 0, 0, true);
     __syncthreads();
-#pragma unroll 4
-    for (int it = 0; it < 32; ++it) {                  // 128 rows x 16 chunks of 8 B per wave / 64 lanes
-        const int idx = it * 64 + lane;
-        const int row = idx >> 4, cq = idx & 15;
-        const long long m = m0 + wm * 128 + row;
-        const int n = n0 + wn * 64 + cq * 4;
-        if (m >= p.M || n >= p.N) continue;
-        const uint2 pk = *reinterpret_cast<const uint2*>(Ws + row * W2_ROW + cq * 8);
-        *reinterpret_cast<uint2*>(p.C + m * p.N + n) = pk;
+    b_piece(0, 1, 0, 1, true);                       // k tile 1 (tap 1 of block 0): first half of its weight tile
+    b_piece(1, 1, 0, 1, true);
+
+    // fragment addresses of one tap: LDS byte address of this lane's row in the activation block (or the zero row) per pixel, and the
+    // swizzle term of that row (32 t and the tap shift change (row >> 1) & 7 the same way for all four pixels)
+    unsigned arow[4], arsw = 0;
+    auto tap_addr = [&](int tap, int b) {
+        const int ty = tap / 3, tx = tap - ty * 3;
+        int pr = prow0 + (ty - 1) * p.W + (tx - 1);
+        asm volatile("" : "+v"(pr));                  // no per-(tap, k step) address table in registers (it would be spilled)
+        arsw = (unsigned)((pr >> 1) & 7) << 4;
+        const unsigned base = (unsigned)(b * (C3_AROWS * 128)) + (unsigned)pr * 128u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            unsigned mk = mask9[t];
+            asm volatile("" : "+v"(mk));              // likewise for the 36 (pixel, tap) tests
+            arow[t] = ((mk >> tap) & 1u) ? base + (unsigned)t * 4096u : zoff;
+        }
+    };
+    bf16x8 fa[2][4], fb[2][2];
+    auto rd = [&](int bb, int ks, int slot) {
+        const unsigned c16 = (unsigned)(ks * 2 + half) << 4;
+        const unsigned char* Bb = bbuf + bb * (T2N * 128) + cB + ((c16 >> 4) ^ rswB) * 16u;
+        const unsigned xa = c16 ^ arsw;
+        fb[slot][0] = *reinterpret_cast<const bf16x8*>(Bb);
+        fa[slot][0] = *reinterpret_cast<const bf16x8*>(lds + arow[0] + xa);
+        fb[slot][1] = *reinterpret_cast<const bf16x8*>(Bb + 32 * 128);
+#pragma unroll
+        for (int t = 1; t < 4; ++t) fa[slot][t] = *reinterpret_cast<const bf16x8*>(lds + arow[t] + xa);
+    };
+    auto mma = [&](int sl, int t0, int t1) {
+#pragma unroll
+        for (int t = t0; t < t1; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[sl][u], fa[sl][t], acc[t][u], 0, 0, 0);
+    };
+
+    // Schedule of k tile t = (cb, tap), everything in the shadow of an MFMA (see gemm_bf16_256):
+    //   step 0   : fragments of step 1; second half of the weight tile of t+1; for taps 0..4 one piece of the next activation block
+    //   step 1, 2: fragments of steps 2, 3
+    //   step 3   : next tap's row addresses; two MFMAs; wait for the DMA; barrier (weight tile t+1 complete, tile t's buffer free);
+    //              first fragments of t+1 and the first half of the weight tile of t+2 under the remaining six MFMAs
+    // so every LDS-DMA piece has three to four steps (of 8 MFMAs x 2 waves per SIMD) to land.
+    tap_addr(0, 0);
+    rd(0, 0, 0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        const int pa = cb & 1;                       // activation block buffer; weight tile buffer = (cb + tap) & 1 (nine taps: parity flips)
+        const bool more_cb = cb + 1 < ncb;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int bcur = (cb + tap) & 1;
+            const bool last_tap = tap == 8;
+            const bool more1 = tap < 8 || more_cb, more2 = tap < 7 || more_cb;          // k tiles t+1, t+2 exist
+            const int tap1 = tap < 8 ? tap + 1 : 0, cb1 = tap < 8 ? cb : cb + 1;
+            const int tap2 = tap < 7 ? tap + 2 : tap - 7, cb2 = tap < 7 ? cb : cb + 1;
+#pragma unroll
+            for (int ks = 0; ks < TBK / 16; ++ks) {
+                const int sl = ks & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (ks + 1 < TBK / 16) {
+                    rd(bcur, ks + 1, sl ^ 1);
+                    if (ks == 0) {
+                        b_piece(2, tap1, cb1, bcur ^ 1, more1);
+                        b_piece(3, tap1, cb1, bcur ^ 1, more1);
+                        if (tap < 5) a_piece(tap, cb + 1, pa ^ 1, more_cb);
+                    }
+                    mma(sl, 0, 4);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (ks == 0 && i == 5 && tap < 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                } else {
+                    tap_addr(tap1, last_tap ? pa ^ 1 : pa);          // the current tap's last fragments were read in step 2
+                    mma(sl, 0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __syncthreads();
+                    __builtin_amdgcn_sched_barrier(0);
+                    rd(bcur ^ 1, 0, sl ^ 1);                         // (past the last k tile: stale bytes, never used)
+                    b_piece(0, tap2, cb2, bcur, more2);
+                    b_piece(1, tap2, cb2, bcur, more2);
+                    mma(sl, 1, 4);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
+    __syncthreads();
+    epi_plain_256(acc, p, lds, m0, n0);
 }
 
 // ROIAlign (crop_and_resize) with fp32 feature map in, bf16 out -- same coordinate arithmetic as crop_fwd_kernel
@@ -760,7 +1018,10 @@ static void launch_bf16(const Bf16Args& a, hipStream_t s)
         const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
         const long long tiles256 = cdiv64(a.M, T2M) * ((a.N + T2N - 1) / T2N);
         if (!no256 && !regstage && (a.N % T2N) == 0 && (tiles256 >= 1536 || force256)) {
-            hipLaunchKernelGGL((gemm_bf16_256<AMODE, EP_PLAIN>), dim3((unsigned)tiles256), dim3(512), 0, s, a);
+            if (AMODE == AM_CONV3 && a.W + 1 <= (C3_AROWS - T2M) / 2 && !g_myolo_opt.bf16_no_c3)
+                hipLaunchKernelGGL(conv3_bf16_256, dim3((unsigned)tiles256), dim3(512), 0, s, a);
+            else
+                hipLaunchKernelGGL((gemm_bf16_256<AMODE, EP_PLAIN>), dim3((unsigned)tiles256), dim3(512), 0, s, a);
             return;
         }
     }
