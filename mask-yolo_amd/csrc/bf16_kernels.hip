@@ -791,8 +791,8 @@ __global__ __launch_bounds__(512, 1) void conv3_bf16_256(Bf16Args p)
 #pragma unroll
     for (int j = 0; j < 4; ++j) b_piece(j, 0, 0, 0, true);
     __syncthreads();
-    b_piece(0, 1, 0, 1, true);                       // k tile 1 (tap 1 of block 0): first half of its weight tile
-    b_piece(1, 1, 0, 1, true);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b_piece(j, 1, 0, 1, true);         // k tile 1 (tap 1 of block 0)
 
     // fragment addresses of one tap: LDS byte address of this lane's row in the activation block (or the zero row) per pixel, and the
     // swizzle term of that row (32 t and the tap shift change (row >> 1) & 7 the same way for all four pixels)
@@ -829,11 +829,12 @@ __global__ __launch_bounds__(512, 1) void conv3_bf16_256(Bf16Args p)
     };
 
     // Schedule of k tile t = (cb, tap), everything in the shadow of an MFMA (see gemm_bf16_256):
-    //   step 0   : fragments of step 1; second half of the weight tile of t+1; for taps 0..4 one piece of the next activation block
+    //   step 0   : fragments of step 1; for taps 0..4 one piece of the next activation block
     //   step 1, 2: fragments of steps 2, 3
-    //   step 3   : next tap's row addresses; two MFMAs; wait for the DMA; barrier (weight tile t+1 complete, tile t's buffer free);
-    //              first fragments of t+1 and the first half of the weight tile of t+2 under the remaining six MFMAs
-    // so every LDS-DMA piece has three to four steps (of 8 MFMAs x 2 waves per SIMD) to land.
+    //   step 3   : next tap's row addresses; two MFMAs; wait for the weight tile of t+1; barrier (tile t's buffer is free now);
+    //              first fragments of t+1 and the whole weight tile of t+2 (four pieces) under the remaining six MFMAs
+    // A weight piece (L2) has four steps (of 8 MFMAs x 2 waves per SIMD) to land.  The activation piece (HBM) is the youngest VMEM
+    // operation at its tile's barrier, which therefore waits with vmcnt(1) and leaves it in flight until the next tile's barrier.
     tap_addr(0, 0);
     rd(0, 0, 0);
     for (int cb = 0; cb < ncb; ++cb) {
@@ -843,8 +844,8 @@ __global__ __launch_bounds__(512, 1) void conv3_bf16_256(Bf16Args p)
         for (int tap = 0; tap < 9; ++tap) {
             const int bcur = (cb + tap) & 1;
             const bool last_tap = tap == 8;
-            const bool more1 = tap < 8 || more_cb, more2 = tap < 7 || more_cb;          // k tiles t+1, t+2 exist
-            const int tap1 = tap < 8 ? tap + 1 : 0, cb1 = tap < 8 ? cb : cb + 1;
+            const bool more2 = tap < 7 || more_cb;                                       // k tile t+2 exists
+            const int tap1 = tap < 8 ? tap + 1 : 0;
             const int tap2 = tap < 7 ? tap + 2 : tap - 7, cb2 = tap < 7 ? cb : cb + 1;
 #pragma unroll
             for (int ks = 0; ks < TBK / 16; ++ks) {
@@ -852,37 +853,33 @@ __global__ __launch_bounds__(512, 1) void conv3_bf16_256(Bf16Args p)
                 __builtin_amdgcn_sched_barrier(0);
                 if (ks + 1 < TBK / 16) {
                     rd(bcur, ks + 1, sl ^ 1);
-                    if (ks == 0) {
-                        b_piece(2, tap1, cb1, bcur ^ 1, more1);
-                        b_piece(3, tap1, cb1, bcur ^ 1, more1);
-                        if (tap < 5) a_piece(tap, cb + 1, pa ^ 1, more_cb);
-                    }
+                    if (ks == 0 && tap < 5) a_piece(tap, cb + 1, pa ^ 1, more_cb);
                     mma(sl, 0, 4);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (ks == 0 && i == 5 && tap < 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    if (ks == 0 && tap < 5) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (ks == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 } else {
                     tap_addr(tap1, last_tap ? pa ^ 1 : pa);          // the current tap's last fragments were read in step 2
                     mma(sl, 0, 1);
                     __builtin_amdgcn_sched_barrier(0);
-                    __syncthreads();
+                    // s_waitcnt vmcnt(tap < 5 ? 1 : 0) lgkmcnt(0) [gfx9 encoding: vmcnt simm[3:0], expcnt simm[6:4] = 7 (no wait), lgkmcnt simm[11:8]]
+                    if (tap < 5) __builtin_amdgcn_s_waitcnt(0x0071); else __builtin_amdgcn_s_waitcnt(0x0070);
+                    __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     rd(bcur ^ 1, 0, sl ^ 1);                         // (past the last k tile: stale bytes, never used)
-                    b_piece(0, tap2, cb2, bcur, more2);
-                    b_piece(1, tap2, cb2, bcur, more2);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) b_piece(j, tap2, cb2, bcur, more2);
                     mma(sl, 1, 4);
 #pragma unroll
                     for (int i = 0; i < 6; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                        if (i >= 4) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        if (i >= 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     }
                 }
             }
