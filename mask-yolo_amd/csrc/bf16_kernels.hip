@@ -23,6 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define LDSROW 72            // bf16 elements per LDS row (64 + 8 pad = 144 bytes)
 #define OOB_OFF 0x7fffff00u
 
+template <int V> struct IntC { static constexpr int value = V; };
 enum { AM_PLAIN = 0, AM_CONV3 = 1 };
 enum { EP_PLAIN = 0, EP_DECONV = 1, EP_DECONV_MASK = 2 };
 
@@ -331,46 +332,53 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_glds(Bf16Args p)
         // 128 columns are 128 of the Co channels of ONE tap (Co % 128 == 0); column slabs are summed by the finish kernel.
         const int tap = n0 / p.Co;
         const int cbase = n0 - tap * p.Co + wn * 64;
-        float ps[2][4];
+        auto epi = [&](auto ncc) {
+            constexpr int NC = decltype(ncc)::value;           // classes this instance accumulates; p.ncls <= NC (no per-element class tests)
+            float ps[2][NC];
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) ps[t][c] = 0.f;
+                for (int c = 0; c < NC; ++c) ps[t][c] = 0.f;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
+                for (int g = 0; g < 4; ++g)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int co = cbase + u * 32 + 8 * g + 4 * half + e;
-                    const float b = p.bias ? p.bias[co] : 0.f;
-                    const float v0 = fmaxf(acc[0][u][4 * g + e] + b, 0.f), v1 = fmaxf(acc[1][u][4 * g + e] + b, 0.f);
+                    for (int e = 0; e < 4; ++e) {
+                        const int co = cbase + u * 32 + 8 * g + 4 * half + e;
+                        const float b = p.bias ? p.bias[co] : 0.f;
+                        const float v0 = fmaxf(acc[0][u][4 * g + e] + b, 0.f), v1 = fmaxf(acc[1][u][4 * g + e] + b, 0.f);
+                        const float* w2r = p.w2 + co * p.ncls;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float wv = c < p.ncls ? p.w2[co * p.ncls + c] : 0.f;
-                        ps[0][c] = fmaf(v0, wv, ps[0][c]);
-                        ps[1][c] = fmaf(v1, wv, ps[1][c]);
+                        for (int c = 0; c < NC; ++c) {
+                            const float wv = (NC == 1 || c < p.ncls) ? w2r[c < p.ncls ? c : 0] : 0.f;
+                            ps[0][c] = fmaf(v0, wv, ps[0][c]);
+                            ps[1][c] = fmaf(v1, wv, ps[1][c]);
+                        }
                     }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
+            if (half == 0) {
+                const int slab = ((n0 - tap * p.Co) / TBN) * 2 + wn;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const long long row = m0 + wm * 64 + t * 32 + l31;
+                    if (row >= p.M) continue;
+                    const long long n_img = row / hw;
+                    const int rem = (int)(row - n_img * hw);
+                    const int y = rem / p.W, x = rem - y * p.W;
+                    const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
+                    float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) if (c < p.ncls) dst[c] = ps[t][c];
                 }
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
-        if (half == 0) {
-            const int slab = ((n0 - tap * p.Co) / TBN) * 2 + wn;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const long long row = m0 + wm * 64 + t * 32 + l31;
-                if (row >= p.M) continue;
-                const long long n_img = row / hw;
-                const int rem = (int)(row - n_img * hw);
-                const int y = rem / p.W, x = rem - y * p.W;
-                const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
-                float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < p.ncls) dst[c] = ps[t][c];
             }
-        }
+        };
+        if (p.ncls == 1) epi(IntC<1>{});
+        else if (p.ncls == 2) epi(IntC<2>{});
+        else epi(IntC<4>{});
         return;
     }
     // ---- epilogue: bias + activation, pack 4 channels, transpose through LDS, row-contiguous stores ----
@@ -483,7 +491,12 @@ __device__ __forceinline__ void epi_plain_256(f32x16 (&acc)[4][2], const Bf16Arg
 #define T2M 256
 #define T2N 256
 
-template <int AMODE, int EPI>
+// LOOPN (EP_DECONV_MASK, ablation switch bf16_loopn): one workgroup per 256 rows walks ALL column blocks (the four taps of the transposed
+// conv) in one software-pipelined loop, the previous tap's epilogue running while the next tap's tiles arrive.  Measured 0.89 ms against
+// 0.85 ms for a workgroup per (row tile, tap) at M = 921984: the fused op was slow (1.30 ms) because of its epilogue -- per-element class
+// tests and table loads that spilled -- not because of operand latency; with the epilogue specialised on the class count both forms run
+// at about the same speed and the simpler grid stays the default.
+template <int AMODE, int EPI, bool LOOPN = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char lds[8 * 128 * W2_ROW > 2 * 2 * T2M * 128 ? 8 * 128 * W2_ROW : 2 * 2 * T2M * 128];
@@ -498,8 +511,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
         const long long q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int tn = (int)(bid % ntn);
-    const long long m0 = (bid / ntn) * T2M;
+    const int tn = LOOPN ? 0 : (int)(bid % ntn);
+    const long long m0 = (LOOPN ? bid : bid / ntn) * T2M;
     const int n0 = tn * T2N;
     const long long hw = (long long)p.H * p.W;
 
@@ -512,6 +525,19 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
     }
     const __amdgpu_buffer_rsrc_t ra = mk_rsrc(p.A + base_row * row_elems, (end_row - base_row) * row_elems * 2);
     const __amdgpu_buffer_rsrc_t rb = mk_rsrc(p.Wt, (long long)p.N * p.K * 2);
+
+    // EP_DECONV_MASK: {deconv bias, 1x1 mask-conv weights of up to four classes} of the tile's 256 output channels, in LDS before the
+    // main loop (the epilogue used to fetch them from global memory element by element, with the accumulators pinning every register)
+    __shared__ float4 etab[EPI == EP_DECONV_MASK ? (LOOPN ? 512 : T2N) : 1];
+    __shared__ float etab3[EPI == EP_DECONV_MASK ? (LOOPN ? 512 : T2N) : 1];
+    if constexpr (EPI == EP_DECONV_MASK) {
+        if (tid < (LOOPN ? p.Co : T2N)) {                        // LOOPN: all Co (<= 512) channels, indexed by channel
+            const int co = LOOPN ? tid : n0 % p.Co + tid;
+            const float* w2r = p.w2 + (long long)co * p.ncls;
+            etab[tid] = make_float4(p.bias ? p.bias[co] : 0.f, w2r[0], p.ncls > 1 ? w2r[1] : 0.f, p.ncls > 2 ? w2r[2] : 0.f);
+            etab3[tid] = p.ncls > 3 ? w2r[3] : 0.f;
+        }
+    }
 
     unsigned arow[4], brow[4], amask[4];
 #pragma unroll
@@ -550,6 +576,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
     int tap = 0, c0 = 0;
     unsigned f_ashift = 0, f_abit = 0, f_bshift = 0;
     auto fill_begin = [&](int kt) {              // operand offsets of k tile kt (CONV3: tap and channel block of the implicit im2col)
+        int tnf = 0;
+        if (LOOPN) { tnf = kt / nk; kt -= tnf * nk; }
         if (AMODE == AM_PLAIN) { f_ashift = (unsigned)(kt * TBK) * 2u; f_abit = 0; }
         else {
             const int ty = (tap * 11) >> 5, tx = tap - ty * 3;
@@ -558,7 +586,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
             c0 += TBK;
             if (c0 == p.Cc) { c0 = 0; ++tap; }
         }
-        f_bshift = (unsigned)(kt * TBK) * 2u;
+        f_bshift = (unsigned)(kt * TBK) * 2u + (unsigned)tnf * (unsigned)(T2N * p.K * 2);
     };
     auto fill_piece = [&](int j, int b, bool live) {        // 8 rows of A and 8 rows of B per wave and piece, straight into LDS
         // (live == false, past the last k tile: out-of-range offsets, the DMA writes zeros nobody reads -- keeps the loop body branch-free,
@@ -583,6 +611,67 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
     // they have two steps to land; the last step issues two MFMAs, waits for the DMA, passes the barrier and reads the next tile's first
     // fragments under its remaining six MFMAs.  (The compiler's own schedule put the 8 DMA pieces in one block and waited on each group of
     // reads in front of its MFMAs: 979 TFLOP/s.)
+    // EP_DECONV_MASK epilogue of one 256-column block (columns nb .. nb+255 = 256 channels of ONE tap): deconv + bias + ReLU and the 1x1
+    // mask conv.  A lane owns one pixel per t and 32 of the wave's 64 channels, so the channel sum is almost entirely in registers; the
+    // two halves meet with one shuffle.  The 64-column slabs are summed by the finish kernel.  Two pixels (t) at a time keep the
+    // partial sums in 8 registers.
+    auto mask_epilogue_nc = [&](auto ncc, int nb) {
+        constexpr int NC = decltype(ncc)::value;                       // classes this instance accumulates (2 or 4); p.ncls <= NC
+        const int tap2 = nb / p.Co;
+        const int c0w = nb - tap2 * p.Co + wn * 64;                    // first channel of the wave's 64
+        const int tb = LOOPN ? c0w : wn * 64;                          // its row in the {bias, w} table
+#pragma unroll
+        for (int tp = 0; tp < 2; ++tp) {
+            float ps[2][NC];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ps[t][c] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int cl = tb + u * 32 + 8 * g + 4 * half + e;
+                        asm volatile("" : "+v"(cl));            // re-read the table in the second pass instead of holding 160 registers of it
+                        const float4 bw = etab[cl];
+                        float w3 = 0.f;
+                        if constexpr (NC > 3) w3 = etab3[cl];
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const float v = fmaxf(acc[2 * tp + t][u][4 * g + e] + bw.x, 0.f);
+                            ps[t][0] = fmaf(v, bw.y, ps[t][0]);
+                            ps[t][1] = fmaf(v, bw.z, ps[t][1]);
+                            if constexpr (NC > 2) ps[t][2] = fmaf(v, bw.w, ps[t][2]);
+                            if constexpr (NC > 3) ps[t][3] = fmaf(v, w3, ps[t][3]);
+                        }
+                    }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
+            if (half == 0) {
+                const int slab = c0w / 64;                                 // 64-column slabs: Co/64 of them per tap
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const long long row = m0 + wm * 128 + (2 * tp + t) * 32 + l31;
+                    if (row >= p.M) continue;
+                    const long long n_img = row / hw;
+                    const int rem = (int)(row - n_img * hw);
+                    const int y = rem / p.W, x = rem - y * p.W;
+                    const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap2 >> 1)) * 2 * p.W + 2 * x + (tap2 & 1);
+                    float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) if (c < p.ncls) dst[c] = ps[t][c];
+                }
+            }
+        }
+    };
+    auto mask_epilogue = [&](int nb) {
+        if (p.ncls <= 2) mask_epilogue_nc(IntC<2>{}, nb);
+        else mask_epilogue_nc(IntC<4>{}, nb);
+    };
     bf16x8 fa[2][4], fb[2][2];
     auto rd = [&](int b, int ks, int slot) {
         const unsigned char* Ab = &buf[b][0][(wm * 128 + l31) * 128];
@@ -602,8 +691,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
     };
     int cur = 0;
     if (nk > 0) rd(0, 0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
+    const int nk_all = LOOPN ? nk * ntn : nk;
+    for (int kt = 0; kt < nk_all; ++kt) {
+        const bool more = kt + 1 < nk_all;
         fill_begin(kt + 1);
 #pragma unroll
         for (int ks = 0; ks < TBK / 16; ++ks) {
@@ -638,53 +728,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
         }
         __builtin_amdgcn_sched_barrier(0);
         cur ^= 1;
+        if constexpr (LOOPN) {
+            const int kk = kt + 1;
+            if (kk % nk == 0) {                       // a column block is complete: its epilogue, then the accumulators start over
+                mask_epilogue((kk / nk - 1) * T2N);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+            }
+        }
     }
 
     if constexpr (EPI == EP_DECONV_MASK) {
-        const int tap2 = n0 / p.Co;
-        const int cbase = n0 - tap2 * p.Co + wn * 64;
-        float ps[4][4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ps[t][c] = 0.f;
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int co = cbase + u * 32 + 8 * g + 4 * half + e;
-                    const float b = p.bias ? p.bias[co] : 0.f;
-                    float wv[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) wv[c] = c < p.ncls ? p.w2[co * p.ncls + c] : 0.f;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const float v = fmaxf(acc[t][u][4 * g + e] + b, 0.f);
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) ps[t][c] = fmaf(v, wv[c], ps[t][c]);
-                    }
-                }
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
-        if (half == 0) {
-            const int slab = ((n0 - tap2 * p.Co) / 64) + wn;          // 64-column slabs: Co/64 of them per tap
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const long long row = m0 + wm * 128 + t * 32 + l31;
-                if (row >= p.M) continue;
-                const long long n_img = row / hw;
-                const int rem = (int)(row - n_img * hw);
-                const int y = rem / p.W, x = rem - y * p.W;
-                const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap2 >> 1)) * 2 * p.W + 2 * x + (tap2 & 1);
-                float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) if (c < p.ncls) dst[c] = ps[t][c];
-            }
-        }
+        if constexpr (!LOOPN) mask_epilogue(n0);
         return;
     }
     epi_plain_256(acc, p, lds, m0, n0);
@@ -1069,7 +1128,11 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
     const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
     const long long tiles256 = cdiv64(M, T2M) * (a.N / T2N);
     const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
-    if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256))       // same Cout/64 column slabs in both kernels
+    if (!no256 && (Cout % T2N) == 0 && Cout <= 512 && g_myolo_opt.bf16_loopn && (tiles256 >= 1536 || force256))
+        // ablation: one workgroup per 256 rows, all four taps in one pipelined loop (measured 0.89 ms against 0.85 ms for a workgroup per
+        // (row tile, tap); same Cout/64 column slabs in all three kernels)
+        hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, true>), dim3((unsigned)cdiv64(M, T2M)), dim3(512), 0, (hipStream_t)stream, a);
+    else if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256))
         hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL((gemm_bf16_glds<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);

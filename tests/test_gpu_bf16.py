@@ -146,7 +146,7 @@ def test_deconv2x2s2_bf16(N, H, W, Cin, Cout):
     check_bf16(from_bf16(y), ref, "deconv bf16")
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout,C", [(3, 14, 14, 256, 256, 2), (2, 5, 7, 64, 128, 4), (9, 14, 14, 128, 256, 1)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,C", [(3, 14, 14, 256, 256, 2), (2, 5, 7, 64, 128, 4), (9, 14, 14, 128, 256, 1), (2, 14, 14, 256, 256, 3), (2, 6, 5, 64, 512, 4)])
 def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C):
     """fused deconv + ReLU + 1x1 + sigmoid from bf16 activations: the deconv output stays in fp32 registers (it is never
     rounded to bf16, unlike the two-kernel path), so the result sits within fp32 summation noise of the float64 oracle."""
@@ -163,13 +163,14 @@ def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C):
     d = O.relu(O.deconv2x2s2(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)))
     ref = 1 / (1 + np.exp(-(d.reshape(-1, Cout) @ w2 + b2))).reshape(N, 2 * H, 2 * W, C)
     assert np.abs(p.cpu().numpy() - ref).max() < 1e-5
-    if Cout % 256 == 0:          # the 256x256-tile kernel forced onto this small shape
-        with X.option("bf16_force256", 1):
-            p2 = torch.full((N, 2 * H, 2 * W, C), float("nan"), device=DEV)
-            X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)),
-                   X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p2), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())
-            torch.cuda.synchronize()
-        assert np.abs(p2.cpu().numpy() - ref).max() < 1e-5
+    if Cout % 256 == 0:          # the 256x256-tile kernel forced onto this small shape: a workgroup per (row tile, tap), and the all-taps loop
+        for loopn in (0, 1):
+            with X.option("bf16_force256", 1), X.option("bf16_loopn", loopn):
+                p2 = torch.full((N, 2 * H, 2 * W, C), float("nan"), device=DEV)
+                X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)),
+                       X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p2), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())
+                torch.cuda.synchronize()
+            assert np.abs(p2.cpu().numpy() - ref).max() < 1e-5, loopn
 
 
 def _boxes(rng, nb):

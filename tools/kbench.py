@@ -56,6 +56,18 @@ def main():
             fn = lambda: X.call("myolo_deconv2x2s2_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(b), X.ptr(y), NR, ps, ps, C, C, 1, st)   # noqa: E731
         ms = timeit(fn, a.iters)
         print("%s M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500 bf16 dense)" % (a.which, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0))
+    elif a.which == "deconv_mask_bf16_fwd":
+        # bf16 deconv 2x2/s2 + ReLU + 1x1 mask conv + sigmoid in one GEMM launch (+ the slab-sum finish), ncls classes
+        bf = torch.bfloat16
+        ncls = 2                                           # RiceConfig: background + rice
+        x, b = rn(M, C).to(bf), rn(C)
+        wt = (rn(4 * C, C) * 0.02).to(bf)
+        w2, b2, pp = rn(C, ncls) * 0.1, rn(ncls), torch.empty(4 * M, ncls, device=dev)
+        wsw = torch.empty((C // 128) * 2 * 4 * M * ncls * 4, dtype=torch.uint8, device=dev)
+        fn = lambda: X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(b), X.ptr(w2), X.ptr(b2), X.ptr(pp), NR, ps, ps, C, C, ncls, wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        flop = 2.0 * M * C * 4 * C
+        print("deconv_mask_bf16_fwd (ncls=%d) M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500 bf16 dense)" % (ncls, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0))
     elif a.which == "wino_fused_fwd":
         x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
         wsw = torch.empty(X.wino_fused_ws_bytes(C, C), dtype=torch.uint8, device=dev)
