@@ -73,6 +73,11 @@ int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw,
  *      (keras_applications _depthwise_conv_block, model.py:19,68-77,256-268) ---- */
 int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y,
                         int N, int H, int W, int C, int stride, void* stream);
+/* inference: act(dwconv(x) * scale + shift) in one launch: the frozen BatchNorm after the depthwise conv folded into its epilogue
+ * (scale / shift from myolo_bn_frozen_coeffs[_batched]); bit-identical to myolo_dwconv3x3_fwd + myolo_bn_apply_act
+ * (keras_applications mobilenet _depthwise_conv_block with BatchNormalization in inference mode) */
+int myolo_dwconv3x3_affine_act_fwd(const float* x, const float* w, const float* scale, const float* shift, int act, float* y,
+                                   int N, int H, int W, int C, int stride, void* stream);
 int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx,
                              int N, int H, int W, int C, int stride, void* stream);
 int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw,
@@ -82,6 +87,10 @@ int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw,
 /* fwd: ws may be NULL (ws_bytes 0); with scratch of >= 8*M*Cout*4 bytes the small deep layers run split-K (same result up to summation order) */
 int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
                         int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+/* inference: act((x w) * scale + shift) in one launch (the affine in the GEMM / split-K epilogue), bit-identical to
+ * myolo_pwconv1x1_fwd + myolo_bn_apply_act; act: MYOLO_ACT_NONE | RELU | RELU6 */
+int myolo_pwconv1x1_affine_act_fwd(const float* x, const float* w, const float* scale, const float* shift, int act, float* y,
+                                   int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
                              int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
@@ -129,6 +138,10 @@ int myolo_bn_stats(const float* x, const float* gamma, const float* beta,
                    int64_t M, int C, void* ws, size_t ws_bytes, void* stream);
 int myolo_bn_frozen_coeffs(const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, float* scale, float* shift, int C, void* stream);
+/* the same coefficients for many layers in one launch: table [nlayers][6] int64 (device) = element offsets of gamma, beta into params,
+ * of the moving mean, moving variance into stats, of the layer's output into coeffs (scale[C] then shift[C]), and C */
+int myolo_bn_frozen_coeffs_batched(const float* params, const float* stats, const int64_t* table, int nlayers, float* coeffs,
+                                   void* stream);
 int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, float* y,
                        int64_t M, int C, int act, void* stream);
 /* frozen BatchNorm + activation in one launch: myolo_bn_frozen_coeffs followed by myolo_bn_apply_act (same results; scale / shift are

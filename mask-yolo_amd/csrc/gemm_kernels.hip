@@ -53,6 +53,18 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// per-column affine of the epilogue (a folded frozen BatchNorm): 1 / 0 when none is given
+__device__ __forceinline__ void col_affine(const GemmArgs& p, int col, float& cs, float& ct)
+{
+    cs = p.scale ? p.scale[col] : 1.f;
+    ct = p.scale ? p.shift[col] : 0.f;
+}
+__device__ __forceinline__ float gemm_act(float v, int act)
+{
+    if (act == MYOLO_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MYOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
 
 // ------------------------------------------------------------------------------------------
 template <int AMODE, int EPI>
@@ -226,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nn(GemmArgs p)
                 float v = acc[t][u][r];
                 if (EPI == EP_PLAIN) {
                     if (p.bias) v += p.bias[col];
-                    if (p.scale) v = fmaf(v, p.scale[col], p.shift[col]);
-                    if (p.act == MYOLO_ACT_RELU) v = fmaxf(v, 0.f);
+                    if (p.scale) { float cs, ct; col_affine(p, col, cs, ct); v = fmaf(v, cs, ct); }
+                    v = gemm_act(v, p.act);
                     p.C[rowoff + col] = v;
                 } else {
                     const int tap = col / p.Co, co = col - tap * p.Co;
@@ -691,10 +703,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         ccol[u] = colc;
         if (EPI == EP_DECONV) { ctap[u] = colc / p.Co; ccol[u] = colc - ctap[u] * p.Co; }
         cb[u] = p.bias ? p.bias[ccol[u]] : 0.f;
-        cs[u] = p.scale ? p.scale[colc] : 1.f;
-        ct[u] = p.scale ? p.shift[colc] : 0.f;
+        col_affine(p, colc, cs[u], ct[u]);
     }
-    const bool relu = p.act == MYOLO_ACT_RELU;
+    const int act = p.act;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -713,8 +724,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
 #pragma unroll
             for (int u = 0; u < WNT; ++u) {
                 if (!cok[u]) continue;
-                float v = fmaf(acc[t][u][r] + cb[u], cs[u], ct[u]);
-                if (relu) v = fmaxf(v, 0.f);
+                float v = gemm_act(fmaf(acc[t][u][r] + cb[u], cs[u], ct[u]), act);
                 float* dst = (EPI == EP_PLAIN) ? p.C + rowoff + ccol[u]
                                                : p.C + (rowoff + (long long)(ctap[u] >> 1) * 2 * p.W + (ctap[u] & 1)) * p.Co + ccol[u];
                 if (p.nt) __builtin_nontemporal_store(v, dst);
@@ -1025,8 +1035,8 @@ __global__ __launch_bounds__(256) void splitk_epilogue(GemmArgs p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (p.bias) v[e] += p.bias[cc + e];
-            if (p.scale) v[e] = fmaf(v[e], p.scale[col + e], p.shift[col + e]);
-            if (p.act == MYOLO_ACT_RELU) v[e] = fmaxf(v[e], 0.f);
+            if (p.scale) { float cs, ct; col_affine(p, col + e, cs, ct); v[e] = fmaf(v[e], cs, ct); }
+            v[e] = gemm_act(v[e], p.act);
         }
         float* dst;
         if (EPI == EP_PLAIN) {
@@ -1263,6 +1273,22 @@ int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float
     // ws (optional): split-K partials for the 14x14 / 7x7 layers, whose few output tiles and long K loop (a serial chain of
     // load -> LDS -> MFMA steps) would leave most of the chip idle
     // (measured, tools/pw_layers.py: 7x7 layers 83 -> 52 us and 77 -> 30 us; the 14x14 layers' 196 tiles are better left alone)
+    launch_nn<AM_PLAIN, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes, 128);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* inference: y = act((x @ w) * scale + shift) in one launch -- the frozen BatchNorm after a pointwise conv, folded (scale / shift from
+ * myolo_bn_frozen_coeffs[_batched]); equals myolo_pwconv1x1_fwd followed by myolo_bn_apply_act bit for bit (model.py:68-76 with the
+ * BatchNormalization layers in inference mode) */
+int myolo_pwconv1x1_affine_act_fwd(const float* x, const float* w, const float* scale, const float* shift, int act, float* y,
+                                   int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && scale && shift && M > 0 && Cin > 0 && Cout > 0, "pwconv1x1_affine_act_fwd: bad arguments");
+    GemmArgs a = {};
+    a.A = x; a.B = w; a.C = y; a.M = M; a.N = Cout; a.K = Cin;
+    a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = act;
+    a.scale = scale; a.shift = shift;
     launch_nn<AM_PLAIN, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes, 128);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

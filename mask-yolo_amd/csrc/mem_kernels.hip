@@ -25,7 +25,7 @@ extern "C" void myolo_set_error(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* myolo_last_error_string(void) { return g_err; }
-extern "C" int myolo_version(void) { return 210; }
+extern "C" int myolo_version(void) { return 211; }
 
 // ---------------------------------------------------------------------------------------
 // tuning switches (myolo_set_option): plain process-wide ints, no environment reads anywhere
@@ -308,6 +308,26 @@ __global__ void bn_frozen_kernel(const float* gamma, const float* beta, const fl
     const float sc = gamma[c] * rstd;
     scale[c] = sc;
     shift[c] = beta[c] - mm[c] * sc;
+}
+
+// one workgroup per layer; table row = {gamma, beta offsets into params; mean, variance offsets into stats; output offset; C}
+__global__ __launch_bounds__(256) void bn_frozen_batched_kernel(const float* __restrict__ params, const float* __restrict__ stats,
+                                                                const long long* __restrict__ table, float* __restrict__ coeffs)
+{
+    const long long* t = table + 6ll * blockIdx.x;
+    const float* gamma = params + t[0];
+    const float* beta = params + t[1];
+    const float* mm = stats + t[2];
+    const float* mv = stats + t[3];
+    const int C = (int)t[5];
+    float* scale = coeffs + t[4];
+    float* shift = scale + C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float rstd = (float)(1.0 / sqrt((double)mv[c] + (double)BN_EPS_F));
+        const float sc = gamma[c] * rstd;
+        scale[c] = sc;
+        shift[c] = beta[c] - mm[c] * sc;
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
@@ -686,9 +706,11 @@ struct OpConv1Dw {
 // holding the (TW-1)*S+3 input columns of each of the 3 rows in registers (each input quad is
 // loaded once per thread instead of up to 9 times).
 // ---------------------------------------------------------------------------------------
+struct DwAffine { const float* scale; const float* shift; int act; };   // scale == nullptr: none
+
 template <int S, int TW, int TH>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo)
+                                                     float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, DwAffine af)
 {
     // grid: x = (w-tile, channel quad) pairs, y = group of TH output rows, z = image: no 64-bit div/mod per thread.
     // The thread walks down the (TH-1)*S+3 input rows of its strip once (sliding window: every input row is loaded once per
@@ -736,6 +758,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
             }
         }
     }
+    // inference: the folded frozen BatchNorm + activation on the way out (same fma as bn_apply_kernel: bit-identical to the two-launch form)
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
+    if (af.scale) { sc = ld4g(af.scale + c); sh = ld4g(af.shift + c); }
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
         const int oy = oy0 + r;
@@ -743,7 +768,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
         float* yrow = y + (((long long)n * Ho + oy) * Wo) * C + c;
 #pragma unroll
         for (int j = 0; j < TW; ++j)
-            if (ox0 + j < Wo) st4g(yrow + (long long)(ox0 + j) * C, acc[r][j]);
+            if (ox0 + j < Wo) {
+                float4 o = acc[r][j];
+                if (af.scale) {
+                    o.x = actf(fmaf(o.x, sc.x, sh.x), af.act); o.y = actf(fmaf(o.y, sc.y, sh.y), af.act);
+                    o.z = actf(fmaf(o.z, sc.z, sh.z), af.act); o.w = actf(fmaf(o.w, sc.w, sh.w), af.act);
+                }
+                st4g(yrow + (long long)(ox0 + j) * C, o);
+            }
     }
 }
 
@@ -1376,6 +1408,17 @@ int myolo_bn_frozen_coeffs(const float* gamma, const float* beta, const float* m
     return MYOLO_OK;
 }
 
+/* scale / shift of MANY frozen BatchNorm layers in one launch (an inference forward folds them into its conv epilogues).
+ * table [nlayers][6] int64 on the device: element offsets of gamma, beta (into params), moving mean, moving variance (into stats), of the
+ * layer's 2*C outputs (into coeffs: scale then shift), and C.  Same expressions as myolo_bn_frozen_coeffs. */
+int myolo_bn_frozen_coeffs_batched(const float* params, const float* stats, const int64_t* table, int nlayers, float* coeffs, void* stream)
+{
+    MYOLO_REQUIRE(params && stats && table && coeffs && nlayers > 0, "bn_frozen_coeffs_batched: bad arguments");
+    hipLaunchKernelGGL(bn_frozen_batched_kernel, dim3(nlayers), dim3(256), 0, (hipStream_t)stream, params, stats, (const long long*)table, coeffs);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
 int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, float* y, int64_t M, int C, int act,
                        void* stream)
 {
@@ -1520,10 +1563,10 @@ int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, in
     return MYOLO_OK;
 }
 
-int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, void* stream)
+static int dw_fwd_launch(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, DwAffine af, void* stream)
 {
-    MYOLO_REQUIRE(x && w && y && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_fwd: bad arguments");
-    MYOLO_REQUIRE(stride == 1 || ((H & 1) == 0 && (W & 1) == 0), "dwconv3x3_fwd: stride 2 needs even H, W");
+    MYOLO_REQUIRE(x && w && y && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3[_affine_act]_fwd: bad arguments");
+    MYOLO_REQUIRE(stride == 1 || ((H & 1) == 0 && (W & 1) == 0), "dwconv3x3[_affine_act]_fwd: stride 2 needs even H, W");
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / stride, Wo = W / stride;
     if (stride == 1) {
@@ -1531,21 +1574,35 @@ int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y, int N, int H, 
         // strips of 4 output rows where that still leaves >= ~1000 workgroups; the small late layers keep more, shorter strips
         const long long wg4 = (long long)((per_row + 255) / 256) * ((Ho + 3) / 4) * N;
         if (Ho >= 4 && wg4 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1)
-            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 4>), dim3((per_row + 255) / 256, (Ho + 3) / 4, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 4>), dim3((per_row + 255) / 256, (Ho + 3) / 4, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
         else if (Ho >= 2 && !g_myolo_opt.dw_rows1)
-            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
         else
-            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
     } else {
         const int per_row = ((Wo + 1) / 2) * (C / 4);
         const long long wg2 = (long long)((per_row + 255) / 256) * ((Ho + 1) / 2) * N;
         if (Ho >= 2 && wg2 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1)
-            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
         else
-            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo);
+            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
     }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
+}
+
+int myolo_dwconv3x3_fwd(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, void* stream)
+{
+    return dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream);
+}
+
+/* inference: y = act(dwconv3x3(x) * scale + shift) in one launch -- the frozen BatchNorm after a depthwise conv, folded; equals
+ * myolo_dwconv3x3_fwd followed by myolo_bn_apply_act bit for bit (model.py:57-66 with the BatchNormalization layers in inference mode) */
+int myolo_dwconv3x3_affine_act_fwd(const float* x, const float* w, const float* scale, const float* shift, int act, float* y,
+                                   int N, int H, int W, int C, int stride, void* stream)
+{
+    MYOLO_REQUIRE(scale && shift, "dwconv3x3_affine_act_fwd: bad arguments");
+    return dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{scale, shift, act}, stream);
 }
 
 int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, void* stream)

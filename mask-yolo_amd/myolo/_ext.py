@@ -20,9 +20,12 @@ SIGS = {
     "myolo_conv3x3s2_c3_fwd": [P, P, P, I, I, I, I, P],
     "myolo_conv3x3s2_c3_bwd_weight": [P, P, P, I, I, I, I, P, Z, P],
     "myolo_dwconv3x3_fwd": [P, P, P, I, I, I, I, I, P],
+    "myolo_dwconv3x3_affine_act_fwd": [P, P, P, P, I, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_bwd_data": [P, P, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_pwconv1x1_fwd": [P, P, P, P, L, I, I, P, Z, P],
+    "myolo_pwconv1x1_affine_act_fwd": [P, P, P, P, I, P, L, I, I, P, Z, P],
+    "myolo_bn_frozen_coeffs_batched": [P, P, P, I, P, P],
     "myolo_pwconv1x1_bwd_data": [P, P, P, L, I, I, P, Z, P],
     "myolo_pwconv1x1_bwd_weight": [P, P, P, L, I, I, P, Z, P],
     "myolo_conv3x3_fwd": [P, P, P, P, I, I, I, I, I, P, Z, P],

@@ -168,6 +168,8 @@ class Net(object):
         self._wgrad_pending = False
         self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
         self.fused_frozen_bn = True       # bn_act_fwd on moving statistics: one launch instead of coefficients + apply
+        self.fold_frozen_bn = True        # train=False forwards: that BatchNorm + ReLU6 in the epilogue of the depthwise / pointwise conv
+        self._fz_table = None
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
         self.adam_t = 0
@@ -391,11 +393,46 @@ class Net(object):
             X.call("myolo_conv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[layer + "/kernel"]), X.ptr(dx), nimg, h, w, cin, cout,
                    *self._wsargs(), X.stream())
 
+    def _frozen_affine_all(self):
+        """scale / shift of every depthwise / pointwise BatchNorm on its moving statistics, ONE launch (the weights may have changed since
+        the last forward, so this runs at the start of each train=False trunk forward)."""
+        if self._fz_table is None:
+            rows, off = [], 0
+            self._fz_slot = {}
+            for name in sorted(k[:-len("/gamma")] for k in self.pslots if k.endswith("_bn/gamma") and (k.startswith("conv_dw_") or k.startswith("conv_pw_"))):
+                C = int(self.p[name + "/gamma"].numel())
+                rows.append([self.pslots[name + "/gamma"][0], self.pslots[name + "/beta"][0], self.sslots[name + "/moving_mean"][0],
+                             self.sslots[name + "/moving_variance"][0], off, C])
+                self._fz_slot[name] = (off, C)
+                off += 2 * C
+            self._fz_table = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+            self._fz_coeffs = torch.empty(off, dtype=torch.float32, device=self.dev)
+        X.call("myolo_bn_frozen_coeffs_batched", X.ptr(self.flat_p), X.ptr(self.flat_s), self._fz_table.data_ptr(), int(self._fz_table.shape[0]),
+               X.ptr(self._fz_coeffs), X.stream())
+
+    def _frozen_affine(self, name):
+        off, C = self._fz_slot[name]
+        base = self._fz_coeffs.data_ptr()
+        return base + 4 * off, base + 4 * (off + C)
+
     def dw_block_fwd(self, bid, a, shape, stride, train):
         """a [N*H*W, C] activation, shape=(N,H,W,C).  Returns (activation, new shape)."""
         N, H, W, C = shape
         Ho, Wo = H // stride, W // stride
         dwn, pwn = "conv_dw_%d" % bid, "conv_pw_%d" % bid
+        if not train and self.fold_frozen_bn:
+            # inference: BatchNorm on moving statistics + ReLU6 in the epilogue of the conv that feeds it (two launches per block, not four;
+            # bit-identical to the unfolded sequence; nothing is taped -- there is no backward through a train=False forward)
+            sc, sh = self._frozen_affine(dwn + "_bn")
+            ad = self._new(N * Ho * Wo, C)
+            self._call_timed("dw%d_fwd" % bid, "myolo_dwconv3x3_affine_act_fwd", X.ptr(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), sc, sh,
+                             ACT_RELU6, X.ptr(ad), N, H, W, C, stride, X.stream())
+            Co = self.p[pwn + "/kernel"].shape[3]
+            sc, sh = self._frozen_affine(pwn + "_bn")
+            ap = self._new(N * Ho * Wo, Co)
+            self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_affine_act_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), sc, sh,
+                             ACT_RELU6, X.ptr(ap), N * Ho * Wo, C, Co, *self._wsargs(), X.stream())
+            return ap, (N, Ho, Wo, Co)
         y = self._new(N * Ho * Wo, C)
         self._call_timed("dw%d_fwd" % bid, "myolo_dwconv3x3_fwd", X.ptr(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(y),
                          N, H, W, C, stride, X.stream())
@@ -431,6 +468,8 @@ class Net(object):
         cfg = self.cfg
         N, H, W, _ = images.shape
         C0 = self.p["conv1/kernel"].shape[3]
+        if not train and self.fold_frozen_bn:
+            self._frozen_affine_all()
         y = self._new(N * (H // 2) * (W // 2), C0)
         X.call("myolo_conv3x3s2_c3_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), X.ptr(y), N, H, W, C0, X.stream())
         a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)

@@ -107,7 +107,8 @@ def test_conv3x3_bf16(N, H, W, Cin, Cout):
     check_bf16(from_bf16(y), O.conv2d(x, w, pads=(1, 1, 1, 1), acc=np.float64), "conv3x3 bf16 linear")
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 64, 256), (7, 14, 14, 256, 256), (2, 7, 9, 128, 512), (1, 5, 31, 128, 256), (2, 3, 33, 64, 256)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 64, 256), (7, 14, 14, 256, 256), (2, 7, 9, 128, 512), (1, 5, 31, 128, 256), (2, 3, 33, 64, 256),
+                                             (336, 14, 14, 64, 256)])    # 258 tiles of 256 rows: more workgroups than CUs
 def test_conv3x3_bf16_256_tile_kernel(N, H, W, Cin, Cout):
     """the 256x256-tile kernel (normally chosen for launches of >= 1536 such tiles) forced onto small, ragged shapes: same
     oracle bound as the 128x128 kernel, and the two agree to the last bf16 step."""

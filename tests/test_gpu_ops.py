@@ -821,3 +821,58 @@ def test_bn_frozen_apply_act_equals_coeffs_then_apply(M, C, act):
     torch.cuda.synchronize()
     assert torch.equal(sc1, sc2) and torch.equal(sh1, sh2) and torch.equal(y1, y2)
 
+
+def _frozen_bn(rng, C):
+    return dt(1 + 0.1 * rnd(rng, C)), dt(rnd(rng, C, scale=0.1)), dt(rnd(rng, C, scale=0.2)), dt(np.abs(rnd(rng, C)) + 0.1)
+
+
+@pytest.mark.parametrize("M,Cin,Cout,act", [(4 * 26 * 26, 128, 256, 2),     # the MFMA fast path
+                                            (2 * 7 * 7, 512, 1024, 2),      # few tiles, long K: split-K with the affine in its epilogue
+                                            (300, 24, 40, 1), (77, 32, 64, 0)])   # the generic kernel's shapes; ReLU; no activation
+def test_pwconv1x1_affine_act_fwd_equals_conv_then_frozen_bn(M, Cin, Cout, act):
+    """inference fold (model.py:68-76 with BatchNormalization in inference mode): the pointwise conv with the frozen BatchNorm's affine and
+    the activation in its epilogue == myolo_pwconv1x1_fwd, then myolo_bn_apply_act, bit for bit; the coefficients come from the batched
+    kernel (one launch for many layers), which must equal myolo_bn_frozen_coeffs"""
+    rng = np.random.default_rng(8)
+    x, w = dt(rnd(rng, M, Cin)), dt(rnd(rng, 1, 1, Cin, Cout, scale=0.1))
+    gamma, beta, mm, mv = _frozen_bn(rng, Cout)
+    ws = torch.empty(8 * M * Cout * 4 + 4096, dtype=torch.uint8, device=DEV)
+    st = X.stream()
+    y0, y1, y2, sc, sh = new(M, Cout), new(M, Cout), new(M, Cout), new(Cout), new(Cout)
+    X.call("myolo_pwconv1x1_fwd", X.ptr(x), X.ptr(w), None, X.ptr(y0), M, Cin, Cout, ws.data_ptr(), ws.numel(), st)
+    X.call("myolo_bn_frozen_coeffs", X.ptr(gamma), X.ptr(beta), X.ptr(mm), X.ptr(mv), X.ptr(sc), X.ptr(sh), Cout, st)
+    X.call("myolo_bn_apply_act", X.ptr(y0), X.ptr(sc), X.ptr(sh), X.ptr(y1), M, Cout, act, st)
+    # two "layers" in one batched launch: this one and a dummy of 8 channels in front of it
+    params = torch.cat([torch.ones(8, device=DEV), torch.zeros(8, device=DEV), gamma, beta])
+    stats = torch.cat([torch.zeros(8, device=DEV), torch.ones(8, device=DEV), mm, mv])
+    table = torch.tensor([[0, 8, 0, 8, 0, 8], [16, 16 + Cout, 16, 16 + Cout, 16, Cout]], dtype=torch.int64, device=DEV)
+    co = new(16 + 2 * Cout)
+    X.call("myolo_bn_frozen_coeffs_batched", X.ptr(params), X.ptr(stats), table.data_ptr(), 2, X.ptr(co), st)
+    X.call("myolo_pwconv1x1_affine_act_fwd", X.ptr(x), X.ptr(w), co.data_ptr() + 64, co.data_ptr() + 64 + 4 * Cout, act, X.ptr(y2), M, Cin, Cout,
+           ws.data_ptr(), ws.numel(), st)
+    torch.cuda.synchronize()
+    assert torch.equal(co[16:16 + Cout], sc) and torch.equal(co[16 + Cout:], sh)
+    assert torch.equal(y1, y2)
+    g, b_, m_, v_ = (t.cpu().numpy().astype(np.float64) for t in (gamma, beta, mm, mv))
+    ref = x.cpu().numpy().astype(np.float64) @ w.cpu().numpy().reshape(Cin, Cout).astype(np.float64)
+    ref = ref * (g / np.sqrt(v_ + 1e-3)) + (b_ - m_ * g / np.sqrt(v_ + 1e-3))
+    ref = np.clip(ref, 0, 6) if act == 2 else (np.maximum(ref, 0) if act == 1 else ref)
+    assert np.abs(y2.cpu().numpy() - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 52, 52, 128, 1), (2, 52, 52, 128, 2), (3, 13, 13, 512, 1), (1, 6, 10, 8, 2), (1, 3, 5, 4, 1)])
+def test_dwconv3x3_affine_act_fwd_equals_conv_then_frozen_bn(N, H, W, C, stride):
+    """the depthwise half of the same fold: myolo_dwconv3x3_affine_act_fwd == myolo_dwconv3x3_fwd + myolo_bn_apply_act, bit for bit"""
+    rng = np.random.default_rng(9)
+    x, w = dt(rnd(rng, N, H, W, C)), dt(rnd(rng, 3, 3, C, 1, scale=0.3))
+    gamma, beta, mm, mv = _frozen_bn(rng, C)
+    Ho, Wo = H // stride, W // stride
+    st = X.stream()
+    y0, y1, y2, sc, sh = new(N, Ho, Wo, C), new(N, Ho, Wo, C), new(N, Ho, Wo, C), new(C), new(C)
+    X.call("myolo_dwconv3x3_fwd", X.ptr(x), X.ptr(w), X.ptr(y0), N, H, W, C, stride, st)
+    X.call("myolo_bn_frozen_coeffs", X.ptr(gamma), X.ptr(beta), X.ptr(mm), X.ptr(mv), X.ptr(sc), X.ptr(sh), C, st)
+    X.call("myolo_bn_apply_act", X.ptr(y0), X.ptr(sc), X.ptr(sh), X.ptr(y1), N * Ho * Wo, C, 2, st)
+    X.call("myolo_dwconv3x3_affine_act_fwd", X.ptr(x), X.ptr(w), X.ptr(sc), X.ptr(sh), 2, X.ptr(y2), N, H, W, C, stride, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+

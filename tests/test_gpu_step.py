@@ -501,6 +501,23 @@ def test_inference_hip_graph_replay_equals_eager_and_sees_weight_updates():
     assert len(net._graphs) == 1
 
 
+def test_inference_folded_frozen_bn_equals_unfolded():
+    """Net.fold_frozen_bn (BatchNorm on moving statistics + ReLU6 in the epilogue of the depthwise / pointwise conv in train=False
+    forwards) changes the launch count, not one bit of the outputs."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=2)
+    P = np_model.init_params(cfg, seed=3, bias_scale=0.05)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+    x = torch.as_tensor(np.random.default_rng(9).random((2, 128, 128, 3), dtype=np.float32), device=net.dev)
+    assert net.fold_frozen_bn
+    a = [t.clone() for t in net.predict(x)]
+    net.fold_frozen_bn = False
+    b = [t.clone() for t in net.predict(x)]
+    net.fold_frozen_bn = True
+    assert all(torch.equal(u, v) for u, v in zip(a, b))
+
+
 def test_detect_masks_for_selected_only_matches_full_detect():
     """cfg.DETECT_MASKS_FOR_SELECTED_ONLY: the mask head on the <= 10 surviving boxes gives the detect() output of the
     all-box graph (boxes, classes, scores identical; pasted masks equal except where a probability sits within 1e-4 of 0.5)."""
