@@ -1263,6 +1263,51 @@ size_t myolo_workspace_bytes(int64_t rows, int cin, int cout)
     return align256(m > c ? m : c) + align256(c) + (size_t)(1 << 20);
 }
 
+}  // extern "C"
+
+// ---- pointwise conv with a handful of output columns (conv_23: 1024 -> N_BOX*(5+classes) = 35 or 40; model.py:271) ----
+// Neither MFMA kernel takes an N that is not a multiple of 4, and the generic one walks K = 1024 serially in a few workgroups (138 us for
+// 676 x 1024 x 35).  Here a workgroup owns four rows, a lane is an output column, each of the four waves takes a quarter of K and the
+// partial sums meet in LDS: x is read once (16-byte broadcast loads), w once per workgroup from L2.
+__global__ __launch_bounds__(256) void pw_skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long long M, int K, int N)
+{
+    __shared__ float red[4][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * 4;
+    const int kq = K >> 2, k0 = wave * kq;
+    const int col = lane < N ? lane : 0;
+    const float* xr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xr[r] = x + (r0 + r < M ? r0 + r : M - 1) * (long long)K + k0;
+    const float* wp = w + (long long)k0 * N + col;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int k = 0; k < kq; k += 4) {
+        const float w0 = wp[(long long)k * N], w1 = wp[(long long)(k + 1) * N], w2 = wp[(long long)(k + 2) * N], w3 = wp[(long long)(k + 3) * N];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float4 xv = ld4(xr[r] + k);
+            acc[r] = fmaf(xv.x, w0, acc[r]);
+            acc[r] = fmaf(xv.y, w1, acc[r]);
+            acc[r] = fmaf(xv.z, w2, acc[r]);
+            acc[r] = fmaf(xv.w, w3, acc[r]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    // wave r finishes row r
+    const long long row = r0 + wave;
+    if (row < M && lane < N) {
+        float v = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+        if (bias) v += bias[lane];
+        y[row * N + lane] = v;
+    }
+}
+
+extern "C" {
+
 int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
                         int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
@@ -1270,6 +1315,11 @@ int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float
     GemmArgs a = {};
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = M; a.N = Cout; a.K = Cin;
     a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = MYOLO_ACT_NONE;
+    if (Cout <= 64 && (Cout & 3) != 0 && (Cin & 15) == 0 && ((uintptr_t)x & 15) == 0 && !g_myolo_opt.gemm_generic) {
+        hipLaunchKernelGGL(pw_skinny_fwd_kernel, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (long long)M, Cin, Cout);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     // ws (optional): split-K partials for the 14x14 / 7x7 layers, whose few output tiles and long K loop (a serial chain of
     // load -> LDS -> MFMA steps) would leave most of the chip idle
     // (measured, tools/pw_layers.py: 7x7 layers 83 -> 52 us and 77 -> 30 us; the 14x14 layers' 196 tiles are better left alone)

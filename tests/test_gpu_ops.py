@@ -64,6 +64,7 @@ def rnd(rng, *shape, scale=1.0):
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,Cin,Cout,bias", [(300, 32, 64, False), (1568, 1024, 27, True), (130, 16, 16, True), (1568, 1024, 24, True),
                                              (6272, 512, 512, False),                                        # split-K forward
+                                             (676, 1024, 35, True), (1571, 1024, 35, False), (10, 16, 63, True),    # pw_skinny_fwd_kernel (conv_23)
 
                                              (4096, 64, 128, False), (257, 512, 1024, False),
                                              (20003, 32, 64, False), (16391, 64, 128, False), (25088, 64, 64, False)])   # thin-layer weight gradient
