@@ -1168,9 +1168,22 @@ class Net(object):
         w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
         yterms = self._new(8)
         dyolo = self._new(yo.shape[0], yo.shape[1])
-        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
-               X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
-               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+        def yolo_loss():
+            X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+                   X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
+                   float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+        if self.overlap_yolo_bwd:
+            # the loss kernel (one workgroup row per image, ~0.17 ms) only feeds the YOLO head's backward, which runs on the side stream:
+            # launch it there too (side scratch buffer), under the mask head's forward, instead of in front of it
+            self._yolo_stream.wait_stream(torch.cuda.current_stream())
+            self._ws_active = self._ws_side
+            try:
+                with torch.cuda.stream(self._yolo_stream):
+                    yolo_loss()
+            finally:
+                self._ws_active = self._ws_main
+        else:
+            yolo_loss()
         if self.sparse_mask_fwd:
             if not self.sparse_mask_bwd:
                 raise RuntimeError("TRAIN_MASK_HEAD_ROIS='positives' needs the sparse backward (sparse_mask_bwd=True)")
