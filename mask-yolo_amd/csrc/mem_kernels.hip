@@ -102,8 +102,12 @@ static ColGeom col_geom(long long M, int C)
 {
     ColGeom g;
     const int q = C / 4;
+    // at most 64 channel quads per workgroup (wide layers are split over blockIdx.y) and at least 32 rows per row slab: a slab's
+    // partial sums are 2 C doubles, so 8-row slabs of a 1024-channel layer wrote (and the finish kernel re-read) as many bytes of
+    // partials as the tensor itself holds
+    const int cl_max = 64;
     int cl = 1;
-    while (cl * 2 <= q && cl * 2 <= 256) cl *= 2;
+    while (cl * 2 <= q && cl * 2 <= cl_max) cl *= 2;
     if (cl > q) cl = q;
     g.cl = cl;
     g.pl = 256 / cl;
@@ -111,7 +115,8 @@ static ColGeom col_geom(long long M, int C)
     long long want = 1024 / g.cgroups;                // target ~1024 blocks in total (4 per CU)
     if (want < 1) want = 1;
     long long rpb = cdiv64(M, want);
-    const long long min_rows = (long long)g.pl * 4;   // at least 4 rows per thread (small layers: spread wide)
+    long long min_rows = (long long)g.pl * 4;         // at least 4 rows per thread (small layers: spread wide)
+    if (min_rows < 32) min_rows = 32;
     if (rpb < min_rows) rpb = min_rows;
     g.rows_per_block = rpb;
     g.rblocks = (int)cdiv64(M, rpb);
