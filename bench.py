@@ -501,6 +501,7 @@ def bench_infer(args):
         net.predict(x)
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
     roi_ms, _ = net.kernel_ms("roialign_fwd")
+    dec_ms, _ = net.kernel_ms("mask_deconv_fwd")
     R = cfg.TRAIN_ROIS_PER_IMAGE
     M = bsz * R * 14 * 14
     flop = 2.0 * M * 9 * 256 * 256
@@ -510,13 +511,18 @@ def bench_infer(args):
            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "Rice 416x416 inference forward, batch %d, N_BOX=5 (R=845 boxes/img, all through the mask head as the "
-                                  "reference graph does, model.py:926-931), fp32 trunk + bf16 ROIAlign / 3x3 convs / deconv with fp32 accumulation; the timed forwards are replays of one captured hipGraph "
+                                  "reference graph does, model.py:926-931), fp32 trunk (frozen BatchNorm + ReLU6 folded into the depthwise / pointwise conv epilogues) + bf16 ROIAlign / 3x3 convs / deconv with fp32 accumulation; the timed forwards are replays of one captured hipGraph "
                                   "(cfg.INFERENCE_HIP_GRAPH, as detect() runs them), kernel timings from a separate eager pass" % bsz,
                       "global_batch": bsz, "parallelism": "dp1"},
-           "roofline": {"kernel": "gemm_bf16_256<CONV3> (mask-head 3x3 conv, bf16 operands, fp32 accumulate, M=%d K=2304 N=256)" % M,
+           "roofline": {"kernel": "conv3_bf16_256 (mask-head 3x3 conv as an implicit GEMM with the activation block resident in LDS across the nine taps, "
+                                  "bf16 operands, fp32 accumulate, M=%d K=2304 N=256)" % M,
                         "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
                         "traffic": None, "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * M * 256 * 2 + 9 * 256 * 256 * 2,
                         "launches_timed": conv_n, "avg_launch_ms": conv_ms,
+                        "deconv_mask": {"kernel": "gemm_bf16_256<PLAIN, DECONV_MASK> + deconv_mask_finish (2x2/s2 transposed conv + ReLU + 1x1 mask conv + sigmoid, "
+                                                  "the 28x28x256 tensor never written)", "bound": "mfma", "avg_ms": dec_ms,
+                                        "algorithmic_flop": 2.0 * M * 256 * 4 * 256,
+                                        "achieved": 2.0 * M * 256 * 4 * 256 / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else 0.0, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s"},
                         "roialign": {"kernel": "crop_fwd_bf16_kernel", "bound": "hbm", "avg_ms": roi_ms,
                                      "algorithmic_bytes": M * 256 * 2.0 + bsz * 52 * 52 * 256 * 4.0,
                                      "achieved": (M * 256 * 2.0 + bsz * 52 * 52 * 256 * 4.0) / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,

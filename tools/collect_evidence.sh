@@ -21,9 +21,20 @@ cp gpurun_out/prof_${TAG}x6/${TAG}x6_bench_kernel_stats.csv gpurun_out/prof_${TA
   for k in wino_fwd wino63_fwd wino_bwd_data deconv_mask_fwd; do
     KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --iters 10 2>&1 | grep -vE "amdgpu.ids|^$" | tail -1
   done
+  echo "--- bf16 inference kernels (default; bf16_no_c3=1 = the nine-fetch implicit GEMM; bf16_no256=1 = the 128^2 kernels; bf16_loopn=1)"
+  python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no_c3=1 python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
+  python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_loopn=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
+  echo "--- tools/overlap_mm_boundary.py"
+  python tools/overlap_mm_boundary.py 2>&1 | tail -1
   echo "--- tools/pw_layers.py"
   python tools/pw_layers.py 2>&1 | grep -E "total"
 } > $OUT/${TAG}_kbench.txt
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/ovl tools/mfma_valu_overlap.hip 2>/dev/null && /tmp/ovl > $OUT/${TAG}_mfma_valu_overlap.txt 2>&1
 head -c 400 $OUT/${TAG}_bench.json; echo; head -c 300 $OUT/${TAG}_bench_bf16x6.json; echo; head -c 300 $OUT/${TAG}_bench_rice416_bf16.json; echo
-cat $OUT/${TAG}_timeline.txt | grep -E "wall" ; cat $OUT/${TAG}x6_timeline.txt | grep -E "wall"
+bash tools/profile_infer.sh $TAG > $OUT/infer_top.txt 2>&1
+cp gpurun_out/prof_infer_$TAG/${TAG}_infer_kernel_stats.csv $OUT/
+cat $OUT/${TAG}_timeline.txt | grep -E "wall" ; cat $OUT/${TAG}x6_timeline.txt | grep -E "wall"; head -8 $OUT/infer_top.txt
