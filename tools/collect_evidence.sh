@@ -1,8 +1,8 @@
 #!/bin/bash
-# Everything profiles/<tag>_* is made of, in one gpurun call:   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r2f'
+# Everything profiles/<tag>_* is made of, in one gpurun call:   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r2g'
 #   bench lines (default config with variants + CPU baseline; FP32_MATMUL=bf16x6; rice416-bf16), rocprofv3 kernel stats / by-grid /
 #   step timeline for both matmul modes, the per-kernel micro-benchmarks, the MFMA/VALU overlap microbenchmark.
-TAG=${1:-r2f}
+TAG=${1:-r2g}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT

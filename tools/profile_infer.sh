@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 kernel statistics of the inference bench line (bench.py --config rice416-bf16).   gpurun -- 'bash tools/profile_infer.sh r2f'
+# rocprofv3 kernel statistics of the inference bench line (bench.py --config rice416-bf16).   gpurun -- 'bash tools/profile_infer.sh r2g'
 #   -> gpurun_out/prof_infer_<tag>/<tag>_infer_kernel_stats.csv and a top-kernel table on stdout
-TAG=${1:-r2f}
+TAG=${1:-r2g}
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_infer_$TAG
