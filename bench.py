@@ -405,6 +405,8 @@ def bench_train(args, rank, world, local):
         vbytes = float(400 * args.batch * R if t63 else ptiles) * 256 * 4          # the timed boundary launches are all on the conv2-4 tiling
         roofline["hbm_stages"] = ([hbm_obj("wino_in_kernel (input transform: activation -> V)", float(M) * 256 * 4 + vbytes, win_ms)] if win_n else []) + [
             hbm_obj("%s (layer boundary M_i -> V_{i+1} through LDS)" % ("wino63_boundary_kernel<FROM_M, TO_V>" if t63 else "wino_out_in_kernel"), 2 * vbytes, woi_ms)]
+    wtxt = ("mixed F(6,3)/F(4,3) tiling of the 14x14 maps, 400 point-tiles per ROI; F(4,3)/F(2,3) elsewhere" if net.wino_tiles == "f63"
+            else "mixed F(4,3)/F(2,3) tiling, 484 point-tiles per 14x14 ROI")
     res = {
         "metric": "images/sec fwd+bwd, %dx%d Shapes batch %d, at %d MI355X" % (args.size, args.size, args.batch, world),
         "value": args.batch * world * args.steps / elapsed,
@@ -419,8 +421,8 @@ def bench_train(args, rank, world, local):
                                "gradients are structural zeros (dense-backward time in variants.dense_mask_backward); " % (
                                    args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R,
                                    "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS) + "3x3 convs: " +
-                               {"auto": "fp32 Winograd F(4x4,3x3) for launches >= 16384 pixels, direct implicit GEMM below",
-                                "winograd": "fp32 Winograd F(4x4,3x3)", "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO] +
+                               {"auto": "fp32 Winograd for launches >= 16384 pixels (%s), direct implicit GEMM below" % wtxt,
+                                "winograd": "fp32 Winograd (%s)" % wtxt, "direct": "direct implicit GEMM"}[cfg.CONV3X3_ALGO] +
                                "; Winograd multiply products: " + ("native fp32 MFMA" if net.fp32_matmul == "native" else
                                "FP32_MATMUL='bf16x6' (each fp32 product = six exact bf16 piece products, fp32 accumulation)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
