@@ -508,6 +508,14 @@ def bench_infer(args):
     M = bsz * R * 14 * 14
     flop = 2.0 * M * 9 * 256 * 256
     ach = flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    traffic, traffic_src = None, None
+    try:        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE at M = 921984), scaled to this launch's rows
+        pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_bf16.json")))["conv3x3_bf16_fwd_default"]
+        traffic = pm["hbm_traffic_bytes_corrected"] * M / 921984.0
+        traffic_src = ("profiles/r2_pmc_bf16.json (separate rocprofv3 --pmc passes on tools/kbench.py conv3x3_bf16_fwd, M = 921984: FETCH_SIZE x2 + "
+                       "WRITE_SIZE), scaled by M; not re-measured in this run")
+    except Exception:
+        pass
     res = {"metric": "images/sec inference, Rice 416x416, 5 anchors, 28x28 mask head, bf16 mask head, 1 MI355X",
            "value": bsz * args.steps / el, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": max(2, args.warmup),
            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -519,7 +527,7 @@ def bench_infer(args):
            "roofline": {"kernel": "conv3_bf16_256 (mask-head 3x3 conv as an implicit GEMM with the activation block resident in LDS across the nine taps, "
                                   "bf16 operands, fp32 accumulate, M=%d K=2304 N=256)" % M,
                         "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
-                        "traffic": None, "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * M * 256 * 2 + 9 * 256 * 256 * 2,
+                        "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * M * 256 * 2 + 9 * 256 * 256 * 2,
                         "launches_timed": conv_n, "avg_launch_ms": conv_ms,
                         "deconv_mask": {"kernel": "gemm_bf16_256<PLAIN, DECONV_MASK> + deconv_mask_finish (2x2/s2 transposed conv + ReLU + 1x1 mask conv + sigmoid, "
                                                   "the 28x28x256 tensor never written)", "bound": "mfma", "avg_ms": dec_ms,

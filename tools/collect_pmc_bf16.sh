@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes on the two bf16 inference kernels at the config-2/3 mask-head shape (tools/kbench.py conv3x3_bf16_fwd, deconv_mask_bf16_fwd):
-# SQ counters in their own runs (with --kernel-trace only), effective clock from GRBM_GUI_ACTIVE.   gpurun -- 'bash tools/collect_pmc_bf16.sh r2'
+# SQ counters and FETCH_SIZE / WRITE_SIZE, each set in its own run (with --kernel-trace only), effective clock from GRBM_GUI_ACTIVE.   gpurun -- 'bash tools/collect_pmc_bf16.sh r2'
 #   -> gpurun_out/pmc_bf16_<tag>/<tag>_pmc_bf16.json
 TAG=${1:-r2}
 cd /tmp && export TMPDIR=/tmp
@@ -15,6 +15,8 @@ for k in conv3x3_bf16_fwd deconv_mask_bf16_fwd; do
     d=$OUT/${k}_${opt:-default}
     rocprofv3 --pmc $SQ1 --kernel-trace --output-format csv -d ${d}_1 -o p -- env KBENCH_OPTIONS=$opt python tools/kbench.py $k --iters 3 > /dev/null 2>&1
     rocprofv3 --pmc $SQ2 --kernel-trace --output-format csv -d ${d}_2 -o p -- env KBENCH_OPTIONS=$opt python tools/kbench.py $k --iters 3 > /dev/null 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d ${d}_3 -o p -- env KBENCH_OPTIONS=$opt python tools/kbench.py $k --iters 3 > /dev/null 2>&1
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d ${d}_4 -o p -- env KBENCH_OPTIONS=$opt python tools/kbench.py $k --iters 3 > /dev/null 2>&1
   done
 done
 python - "$OUT" "$TAG" <<'PY'
@@ -25,7 +27,7 @@ res = {"note": "per launch; SQ_* counters summed over the chip, SQ_WAVE_CYCLES-c
 for d in sorted(glob.glob(out + "/*_1")):
     key = os.path.basename(d)[:-2]
     ent = {}
-    for part in ("_1", "_2"):
+    for part in ("_1", "_2", "_3", "_4"):
         dd = d[:-2] + part
         try:
             rows = [r for r in csv.DictReader(open(dd + "/p_counter_collection.csv")) if "bf16_256" in r["Kernel_Name"]]
@@ -45,8 +47,11 @@ for d in sorted(glob.glob(out + "/*_1")):
         ent["mfma_pipe_busy"] = ent["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
         ent["waves_parked_frac"] = ent["SQ_WAIT_ANY"] / ent["SQ_WAVE_CYCLES"]
         ent["waves_issue_stalled_frac"] = ent["SQ_WAIT_INST_ANY"] / ent["SQ_WAVE_CYCLES"]
+    if "FETCH_SIZE" in ent and "WRITE_SIZE" in ent:
+        # KB -> bytes; gfx950 counts 128-byte read requests at 64 B (calibrated in tools/collect_pmc.sh against a kernel of known size)
+        ent["hbm_traffic_bytes_corrected"] = 1024.0 * (2 * ent["FETCH_SIZE"] + ent["WRITE_SIZE"])
     res[key] = ent
 json.dump(res, open("%s/%s_pmc_bf16.json" % (out, tag), "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
 PY
-rm -rf $OUT/*_1 $OUT/*_2
+rm -rf $OUT/*_1 $OUT/*_2 $OUT/*_3 $OUT/*_4
