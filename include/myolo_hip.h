@@ -352,6 +352,17 @@ size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout);
 int myolo_wino63_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
                                    const float* shift, const float* ka, const float* kb, int act, float* dw, int N, int Cin, int Cout,
                                    void* ws, size_t ws_bytes, void* stream);
+/* conv1's backward with ONE pass over y_pre: the lazily formed gradient of the conv's output is transformed both ways in one kernel --
+ * V (operand of the data gradient) and Q (operand of the weight gradient), myolo_wino63_plane_elems(N, C) floats each -- and the two
+ * gradients are finished by the calls below (on different streams if the caller likes: they share nothing but read-only inputs).
+ * Same results as myolo_wino63_bwd_data_lazybn + myolo_wino63_bwd_weight_lazybn, bit for bit. */
+int myolo_wino63_lazybn_transforms(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
+                                   const float* ka, const float* kb, int act, float* V, float* Q, int N, int C, void* stream);
+size_t myolo_wino63_bwd_data_from_v_ws_bytes(int N, int Cin, int Cout);
+int myolo_wino63_bwd_data_from_v(const float* V, const float* w, float* dx, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+size_t myolo_wino63_bwd_weight_from_q_ws_bytes(int N, int Cin, int Cout);
+int myolo_wino63_bwd_weight_from_q(const float* v_saved, const float* Q, float* dw, int N, int Cin, int Cout, void* ws, size_t ws_bytes,
+                                   void* stream);
 /* the three conv operators as single calls, mirroring myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2 for the scratch size) */
 size_t myolo_conv3x3_wino63_ws_bytes(int N, int Cin, int Cout, int which);
 int myolo_conv3x3_wino63_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int N,

@@ -168,6 +168,7 @@ struct W63Args {
     int FH, FW;
     // FROM_M with BatchNorm statistics: per-image partial sums [NR][2*C] (sum | sum of squares) of the values written to y
     double* stats;
+    float* Qn;               // TO_VQ: the adjoint-output-transformed planes (TO_Q alone writes them to Vn)
 };
 
 __device__ __forceinline__ float w63_act(float v, int act)
@@ -248,7 +249,7 @@ __device__ __forceinline__ void w63_back_v(const W63Args& a, const W63Planes& pl
 
 // Q = A dY A^T of one tile (class CY x CX) from the LDS tile (holding dY) -> Q planes
 template <int CY, int CX>
-__device__ __forceinline__ void w63_back_q(const W63Args& a, const W63Planes& pl, const float* act_lds, int oy, int ox, int lane)
+__device__ __forceinline__ void w63_back_q(float* __restrict__ dst, const W63Planes& pl, const float* act_lds, int oy, int ox, int lane)
 {
     constexpr int MY = CY, MX = CX;
     float tmp[8][6];
@@ -270,7 +271,7 @@ __device__ __forceinline__ void w63_back_q(const W63Args& a, const W63Planes& pl
         w63_a<CX>(d, r);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (w63_used<CX>(j)) a.Vn[W63_ADDR(pl, i, j)] = r[j];
+            if (w63_used<CX>(j)) dst[W63_ADDR(pl, i, j)] = r[j];
     }
 }
 
@@ -294,7 +295,7 @@ __device__ __forceinline__ W63CropAxis w63_crop_axis(float b0, float b1, int siz
 }
 
 enum { W63_FROM_M = 0, W63_FROM_ACT = 1, W63_FROM_LAZY = 2, W63_FROM_CROP = 3 };
-enum { W63_TO_V = 0, W63_TO_NONE = 1, W63_TO_Q = 2 };
+enum { W63_TO_V = 0, W63_TO_NONE = 1, W63_TO_Q = 2, W63_TO_VQ = 3 };      // TO_VQ: both transforms of ONE tile fill (V -> a.Vn, Q -> a.Qn)
 
 template <int FRONT, int BACK>
 __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
@@ -399,11 +400,12 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
     }
     if (BACK == W63_TO_NONE) return;
     __syncthreads();
-    if (BACK == W63_TO_Q) {
+    if (BACK == W63_TO_Q || BACK == W63_TO_VQ) {
+        float* qd = BACK == W63_TO_Q ? a.Vn : a.Qn;
         const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;
-        if (ty == 0) { if (tx == 0) w63_back_q<6, 6>(a, pl, act_lds, oy, ox, lane); else w63_back_q<6, 4>(a, pl, act_lds, oy, ox, lane); }
-        else         { if (tx == 0) w63_back_q<4, 6>(a, pl, act_lds, oy, ox, lane); else w63_back_q<4, 4>(a, pl, act_lds, oy, ox, lane); }
-        return;
+        if (ty == 0) { if (tx == 0) w63_back_q<6, 6>(qd, pl, act_lds, oy, ox, lane); else w63_back_q<6, 4>(qd, pl, act_lds, oy, ox, lane); }
+        else         { if (tx == 0) w63_back_q<4, 6>(qd, pl, act_lds, oy, ox, lane); else w63_back_q<4, 4>(qd, pl, act_lds, oy, ox, lane); }
+        if (BACK == W63_TO_Q) return;
     }
     const int py0 = ty == 0 ? -1 : 1 + 4 * ty, px0 = tx == 0 ? -1 : 1 + 4 * tx;           // patch origin: -1, 5, 9
     if (ty == 0) { if (tx == 0) w63_back_v<6, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<6, 4>(a, pl, act_lds, py0, px0, lane); }
@@ -684,6 +686,67 @@ int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, co
     if (rc != MYOLO_OK) return rc;
     W63Args b{Mp, nullptr, dx, nullptr, nullptr, nullptr, nullptr, N, Cin, MYOLO_ACT_NONE};
     w63_launch<W63_FROM_M, W63_TO_NONE>(b, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* The two transforms of conv1's backward from ONE pass over y_pre: the lazily formed gradient of the conv's output (see
+ * myolo_wino63_bwd_data_lazybn) fills the 14x14 tile in LDS once, then goes out as V (input transform: operand of the data gradient) and
+ * as Q (adjoint output transform: operand of the weight gradient).  V, Q: myolo_wino63_plane_elems(N, C) floats each. */
+int myolo_wino63_lazybn_transforms(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
+                                   const float* ka, const float* kb, int act, float* V, float* Q, int N, int C, void* stream)
+{
+    MYOLO_REQUIRE(y_pre && inv && scale && shift && ka && kb && V && Q && N > 0 && (C % W63_CS) == 0, "wino63_lazybn_transforms: bad arguments");
+    W63Args a{y_pre, V, nullptr, nullptr, nullptr, scale, shift, N, C, act, dy_compact, inv, ka, kb};
+    a.Qn = Q;
+    w63_launch<W63_FROM_LAZY, W63_TO_VQ>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+size_t myolo_wino63_bwd_data_from_v_ws_bytes(int N, int Cin, int Cout)
+{
+    return align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)) + align256(myolo_wino63_plane_elems(N, Cin) * sizeof(float));
+}
+
+/* the rest of the data gradient: dx = output transform of (V x rotated, (ci,co)-exchanged filters); V from myolo_wino63_lazybn_transforms */
+int myolo_wino63_bwd_data_from_v(const float* V, const float* w, float* dx, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(V && w && dx && N > 0, "wino63_bwd_data_from_v: bad arguments");
+    MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cout, Cin), "wino63_bwd_data_from_v: unsupported channel counts (%d -> %d)", Cin, Cout);
+    MYOLO_NEED_WS(myolo_wino63_bwd_data_from_v_ws_bytes(N, Cin, Cout));
+    hipStream_t s = (hipStream_t)stream;
+    float* U = (float*)ws;
+    float* Mp = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
+    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, w63_layout(Cout, Cin), 1);
+    const int rc = myolo_wino63_multiply(V, U, Mp, N, Cout, Cin, stream);
+    if (rc != MYOLO_OK) return rc;
+    W63Args b{Mp, nullptr, dx, nullptr, nullptr, nullptr, nullptr, N, Cin, MYOLO_ACT_NONE};
+    w63_launch<W63_FROM_M, W63_TO_NONE>(b, s);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+size_t myolo_wino63_bwd_weight_from_q_ws_bytes(int N, int Cin, int Cout)
+{
+    long long rows[3];
+    w63_run_rows(N, rows);
+    const int nq[3] = {36, 24, 4};
+    size_t pb = 0;
+    for (int k = 0; k < 3; ++k) { const size_t b = myolo_gemm_tn_batched_ws_bytes(rows[k], Cin, Cout, nq[k]); if (b > pb) pb = b; }
+    return align256((size_t)64 * Cin * Cout * sizeof(float)) + align256(pb);
+}
+
+/* the rest of the weight gradient: dU[q] = V_saved[q]^T Q[q], dw = G8^T dU G8; Q from myolo_wino63_lazybn_transforms */
+int myolo_wino63_bwd_weight_from_q(const float* v_saved, const float* Q, float* dw, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(v_saved && Q && dw && N > 0 && (Cin % W63_CS) == 0 && (Cout % W63_CS) == 0, "wino63_bwd_weight_from_q: bad arguments");
+    MYOLO_NEED_WS(myolo_wino63_bwd_weight_from_q_ws_bytes(N, Cin, Cout));
+    float* dU = (float*)ws;
+    void* part = (char*)ws + align256((size_t)64 * Cin * Cout * sizeof(float));
+    const size_t part_bytes = ws_bytes - (size_t)((char*)part - (char*)ws);
+    const int rc = w63_tn_and_dw(v_saved, Q, dU, dw, N, Cin, Cout, part, part_bytes, (hipStream_t)stream);
+    if (rc != MYOLO_OK) return rc;
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

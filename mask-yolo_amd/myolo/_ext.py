@@ -67,6 +67,9 @@ SIGS = {
     "myolo_conv3x3_wino63_bwd_data": [P, P, P, I, I, I, P, Z, P],
     "myolo_conv3x3_wino63_bwd_weight": [P, P, P, P, I, I, I, P, Z, P],
     "myolo_wino63_bwd_data_lazybn": [P, P, P, P, P, P, P, I, P, P, I, I, I, P, Z, P],
+    "myolo_wino63_lazybn_transforms": [P, P, P, P, P, P, P, I, P, P, I, I, P],
+    "myolo_wino63_bwd_data_from_v": [P, P, P, I, I, I, P, Z, P],
+    "myolo_wino63_bwd_weight_from_q": [P, P, P, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_fused_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
@@ -138,6 +141,9 @@ def load():
     lib.myolo_conv3x3_wino63_ws_bytes.restype = Z
     lib.myolo_wino63_bwd_weight_ws_bytes.argtypes = [I, I, I]
     lib.myolo_wino63_bwd_weight_ws_bytes.restype = Z
+    for fn in (lib.myolo_wino63_bwd_data_from_v_ws_bytes, lib.myolo_wino63_bwd_weight_from_q_ws_bytes):
+        fn.argtypes = [I, I, I]
+        fn.restype = Z
     lib.myolo_wino63_output_transform_bn_ws_bytes.argtypes = [I, I]
     lib.myolo_wino63_output_transform_bn_ws_bytes.restype = Z
     lib.myolo_wino63_ok.argtypes = [I, I, I, I]
@@ -151,7 +157,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_conv3x3_wino_fused_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_conv3x3_wino_fused_ws_bytes",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -228,6 +234,14 @@ def wino63_ws_bytes(n, cin, cout, which):
 
 def wino63_bwd_weight_ws_bytes(n, cin, cout):
     return int(load().myolo_wino63_bwd_weight_ws_bytes(int(n), int(cin), int(cout)))
+
+
+def wino63_bwd_data_from_v_ws_bytes(n, cin, cout):
+    return int(load().myolo_wino63_bwd_data_from_v_ws_bytes(int(n), int(cin), int(cout)))
+
+
+def wino63_bwd_weight_from_q_ws_bytes(n, cin, cout):
+    return int(load().myolo_wino63_bwd_weight_from_q_ws_bytes(int(n), int(cin), int(cout)))
 
 
 def wino63_out_bn_ws_bytes(n, c):

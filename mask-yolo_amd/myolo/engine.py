@@ -170,6 +170,7 @@ class Net(object):
         self.fused_frozen_bn = True       # bn_act_fwd on moving statistics: one launch instead of coefficients + apply
         self.fold_frozen_bn = True        # train=False forwards: that BatchNorm + ReLU6 in the epilogue of the depthwise / pointwise conv
         self._fz_table = None
+        self.merge_conv1_bwd_transforms = True    # conv1's backward: the V and Q transforms of the lazily formed gradient from one pass over y_pre
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
         self.class_weights = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float32), device=self.dev)
         self.adam_t = 0
@@ -1070,15 +1071,27 @@ class Net(object):
             lazy = (X.ptr(c1), X.ptr(da), X.ptr(inv_d), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(kab[0]), X.ptr(kab[1]), act)
             self.g["myolo_mask_conv1/bias"].zero_()
             v63 = self.tape.pop("conv1_V_fmt", "f43") == "f63"      # the layout the forward left conv1's V planes in
+            d63 = self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, cin)
+            merged = v63 and d63 and self.merge_conv1_bwd_transforms
+            if merged:
+                # ONE pass over conv1's output forms the lazily built gradient tile and sends it out both ways: V (data gradient) and Q
+                # (weight gradient); the two gradients then finish on their own streams
+                pe = X.wino63_plane_elems(NR, MASK_FILTERS)
+                Vd, Qd = self._new(pe), self._new(pe)
+                X.call("myolo_wino63_lazybn_transforms", *lazy, X.ptr(Vd), X.ptr(Qd), NR, MASK_FILTERS, X.stream())
 
             def conv1_wgrad(wsp, wsz):
-                if v63:
+                if merged:
+                    X.call("myolo_wino63_bwd_weight_from_q", X.ptr(v1), X.ptr(Qd), X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, cin, MASK_FILTERS,
+                           wsp, wsz, X.stream())
+                elif v63:
                     X.call("myolo_wino63_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, cin, MASK_FILTERS,
                            wsp, wsz, X.stream())
                 else:
                     X.call("myolo_conv3x3_wino_bwd_weight_lazybn", X.ptr(v1), *lazy, X.ptr(self.g["myolo_mask_conv1/kernel"]), NR, ps, ps,
                            cin, MASK_FILTERS, wsp, wsz, X.stream())
-            wg_bytes = X.wino63_bwd_weight_ws_bytes(NR, cin, MASK_FILTERS) if v63 else X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2)
+            wg_bytes = (X.wino63_bwd_weight_from_q_ws_bytes(NR, cin, MASK_FILTERS) if merged else
+                        X.wino63_bwd_weight_ws_bytes(NR, cin, MASK_FILTERS) if v63 else X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2))
             if self.overlap_conv1_wgrad:
                 self._ws_wgrad.ensure(wg_bytes)
                 cur = torch.cuda.current_stream()
@@ -1087,14 +1100,18 @@ class Net(object):
                     conv1_wgrad(self._ws_wgrad.ptr, self._ws_wgrad.size)
                     if self.on_bucket_ready:          # every other gradient of the mask-head bucket was complete at the fork
                         self.on_bucket_ready(2)
-                for t in (v1, c1, da, inv_d, kab):
+                for t in (v1, c1, da, inv_d, kab) + ((Qd,) if merged else ()):
                     t.record_stream(self._wgrad_stream)
                 self._wgrad_pending = True
                 self.ws.ensure(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1))
             else:
                 self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), wg_bytes))
                 conv1_wgrad(*self._wsargs())
-            if self.wino_tiles == "f63" and X.wino63_ok(ps, ps, MASK_FILTERS, cin):
+            if merged:
+                self.ws.ensure(X.wino63_bwd_data_from_v_ws_bytes(NR, cin, MASK_FILTERS))
+                X.call("myolo_wino63_bwd_data_from_v", X.ptr(Vd), X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, cin, MASK_FILTERS,
+                       *self._wsargs(), X.stream())
+            elif d63:
                 self.ws.ensure(X.wino63_bwd_data_ws_bytes(NR, cin, MASK_FILTERS))
                 X.call("myolo_wino63_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, cin, MASK_FILTERS,
                        *self._wsargs(), X.stream())

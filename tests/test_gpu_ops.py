@@ -778,6 +778,16 @@ def test_winograd_f63_conv1_pieces():
     for got, want, what in ((dw63, dw43, "dw"), (dx63, dx43, "dx")):
         err = float((got - want).abs().max()) / float(want.abs().max())
         assert err < 1e-4, (what, err)
+    # (e) the merged form the engine uses: ONE kernel sends the lazily formed gradient out as V and as Q, the two gradients finish separately
+    pe = X.wino63_plane_elems(nb, Co)
+    Vd, Qd = new(pe), new(pe)
+    dwm, dxm = new(3, 3, C, Co), new(nb, 14, 14, C)
+    X.call("myolo_wino63_lazybn_transforms", *lazy, X.ptr(Vd), X.ptr(Qd), nb, Co, st)
+    X.call("myolo_wino63_bwd_weight_from_q", X.ptr(V2), X.ptr(Qd), X.ptr(dwm), nb, C, Co, *wsa, st)
+    X.call("myolo_wino63_bwd_data_from_v", X.ptr(Vd), X.ptr(w_t), X.ptr(dxm), nb, C, Co, *wsa, st)
+    torch.cuda.synchronize()
+    assert X.wino63_bwd_weight_from_q_ws_bytes(nb, C, Co) <= wsb.numel() and X.wino63_bwd_data_from_v_ws_bytes(nb, C, Co) <= wsb.numel()
+    assert torch.equal(dwm, dw63) and torch.equal(dxm, dx63)
 
 
 @pytest.mark.parametrize("N,Cin,Cout", [(11, 256, 256), (3, 64, 256)])
