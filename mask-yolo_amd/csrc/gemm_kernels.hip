@@ -1282,8 +1282,8 @@ __global__ __launch_bounds__(256) void pw_skinny_fwd_kernel(const float* __restr
     for (int r = 0; r < 4; ++r) xr[r] = x + (r0 + r < M ? r0 + r : M - 1) * (long long)K + k0;
     const float* wp = w + (long long)k0 * N + col;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 2
-    for (int k = 0; k < kq; k += 4) {
+#pragma unroll 8
+    for (int k = 0; k < kq; k += 4) {        // eight iterations' loads in flight: the loop is pure load latency
         const float w0 = wp[(long long)k * N], w1 = wp[(long long)(k + 1) * N], w2 = wp[(long long)(k + 2) * N], w3 = wp[(long long)(k + 3) * N];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
