@@ -682,10 +682,11 @@ struct OpConv1Dw {
     __device__ void operator()(long long r, int c, float4* acc) const
     {
         const int Ho = H / 2, Wo = W / 2;
-        const int ox = (int)(r % Wo);
-        long long t = r / Wo;
-        const int oy = (int)(t % Ho);
-        const int n = (int)(t / Ho);
+        const unsigned ru = (unsigned)r;                 // rows < 2^31 (checked by the launcher): 32-bit divisions
+        const unsigned t = ru / (unsigned)Wo;
+        const int ox = (int)(ru - t * (unsigned)Wo);
+        const int n = (int)(t / (unsigned)Ho);
+        const int oy = (int)(t - (unsigned)n * (unsigned)Ho);
         const float4 g = ld4g(dy + r * Co + c);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -1557,6 +1558,7 @@ int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, in
 {
     MYOLO_REQUIRE(x && dy && dw && N > 0 && (Cout & 3) == 0, "conv3x3s2_c3_bwd_weight: bad arguments");
     const long long M = (long long)N * (H / 2) * (W / 2);
+    MYOLO_REQUIRE(M < (1ll << 31), "conv3x3s2_c3_bwd_weight: more than 2^31 output pixels");
     const size_t pb = col_ws_bytes(M, Cout, 27);
     MYOLO_NEED_WS(align256(pb) + 27 * Cout * sizeof(double));
     double* part = (double*)ws;
