@@ -491,11 +491,11 @@ __device__ __forceinline__ void epi_plain_256(f32x16 (&acc)[4][2], const Bf16Arg
 #define T2M 256
 #define T2N 256
 
-// LOOPN (EP_DECONV_MASK, ablation switch bf16_loopn): one workgroup per 256 rows walks ALL column blocks (the four taps of the transposed
-// conv) in one software-pipelined loop, the previous tap's epilogue running while the next tap's tiles arrive.  Measured 0.89 ms against
-// 0.85 ms for a workgroup per (row tile, tap) at M = 921984: the fused op was slow (1.30 ms) because of its epilogue -- per-element class
-// tests and table loads that spilled -- not because of operand latency; with the epilogue specialised on the class count both forms run
-// at about the same speed and the simpler grid stays the default.
+// LOOPN (EP_DECONV_MASK): one workgroup per 256 rows walks ALL column blocks (the four taps of the transposed conv) in one software-
+// pipelined loop: K is only Cin = 256 deep, so a workgroup per (row tile, tap) spends as long waiting for its first operands and in its
+// epilogue as in its four k tiles; in the long loop the next tap's tiles arrive while the previous tap's epilogue runs, and three of the
+// four fetches of the activation tile come from L2.  In the inference step 0.62 against 0.67 ms (stand-alone at M = 921984: 0.85 against
+// 0.89 ms) once the epilogue stopped spilling (class-count specialisation, pixel indices formed once); bf16_no_loopn=1 is the ablation.
 template <int AMODE, int EPI, bool LOOPN = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
 {
@@ -615,6 +615,21 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
     // mask conv.  A lane owns one pixel per t and 32 of the wave's 64 channels, so the channel sum is almost entirely in registers; the
     // two halves meet with one shuffle.  The 64-column slabs are summed by the finish kernel.  Two pixels (t) at a time keep the
     // partial sums in 8 registers.
+    // EP_DECONV_MASK: output pixel (on the 2H x 2W grid, tap (0,0)) of this lane's four rows, formed once -- the epilogue runs per column
+    // block with every register taken, and the 64-bit divisions of the row -> (image, y, x) mapping used to spill there
+    long long pixb[4] = {-1, -1, -1, -1};
+    if constexpr (EPI == EP_DECONV_MASK) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long long row = m0 + wm * 128 + t * 32 + (lane & 31);
+            if (row < p.M) {
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                pixb[t] = n_img * 4 * hw + (long long)(2 * y) * 2 * p.W + 2 * x;
+            }
+        }
+    }
     auto mask_epilogue_nc = [&](auto ncc, int nb) {
         constexpr int NC = decltype(ncc)::value;                       // classes this instance accumulates (2 or 4); p.ncls <= NC
         const int tap2 = nb / p.Co;
@@ -655,12 +670,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
                 const int slab = c0w / 64;                                 // 64-column slabs: Co/64 of them per tap
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const long long row = m0 + wm * 128 + (2 * tp + t) * 32 + l31;
-                    if (row >= p.M) continue;
-                    const long long n_img = row / hw;
-                    const int rem = (int)(row - n_img * hw);
-                    const int y = rem / p.W, x = rem - y * p.W;
-                    const long long pix = n_img * 4 * hw + (long long)(2 * y + (tap2 >> 1)) * 2 * p.W + 2 * x + (tap2 & 1);
+                    if (pixb[2 * tp + t] < 0) continue;
+                    const long long pix = pixb[2 * tp + t] + (long long)(tap2 >> 1) * 2 * p.W + (tap2 & 1);
                     float* dst = p.part + ((long long)slab * 4 * p.M + pix) * p.ncls;
 #pragma unroll
                     for (int c = 0; c < NC; ++c) if (c < p.ncls) dst[c] = ps[t][c];
@@ -1128,9 +1139,9 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
     const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
     const long long tiles256 = cdiv64(M, T2M) * (a.N / T2N);
     const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
-    if (!no256 && (Cout % T2N) == 0 && Cout <= 512 && g_myolo_opt.bf16_loopn && (tiles256 >= 1536 || force256))
-        // ablation: one workgroup per 256 rows, all four taps in one pipelined loop (measured 0.89 ms against 0.85 ms for a workgroup per
-        // (row tile, tap); same Cout/64 column slabs in all three kernels)
+    if (!no256 && (Cout % T2N) == 0 && Cout <= 512 && !g_myolo_opt.bf16_no_loopn && (tiles256 >= 1536 || force256))
+        // one workgroup per 256 rows walks all four taps in one pipelined loop (bf16_no_loopn=1: a workgroup per (row tile, tap); same
+        // Cout/64 column slabs in all three kernels)
         hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, true>), dim3((unsigned)cdiv64(M, T2M)), dim3(512), 0, (hipStream_t)stream, a);
     else if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256))
         hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);

@@ -18,7 +18,7 @@ struct MyoloOptions {
     int wino_w256;        // winograd multiply: 128x256 block tiles
     int bf16_regstage;    // bf16 gemm: register-staged variant instead of LDS-DMA
     int bf16_no256;       // bf16 gemm: never the 256x256-tile kernel
-    int bf16_loopn;       // bf16 deconv+mask: one workgroup per row tile walks all four taps in one pipelined loop (ablation)
+    int bf16_no_loopn;    // bf16 deconv+mask: a workgroup per (row tile, tap) instead of one per row tile walking all four taps (ablation)
     int bf16_no_c3;       // bf16 3x3 conv: the nine-fetch implicit GEMM instead of the LDS-resident activation block (ablation)
     int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
     int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS

@@ -164,9 +164,9 @@ def test_deconv_mask_fused_bf16(N, H, W, Cin, Cout, C):
     d = O.relu(O.deconv2x2s2(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64)))
     ref = 1 / (1 + np.exp(-(d.reshape(-1, Cout) @ w2 + b2))).reshape(N, 2 * H, 2 * W, C)
     assert np.abs(p.cpu().numpy() - ref).max() < 1e-5
-    if Cout % 256 == 0:          # the 256x256-tile kernel forced onto this small shape: a workgroup per (row tile, tap), and the all-taps loop
+    if Cout % 256 == 0:          # the 256x256-tile kernel forced onto this small shape: a workgroup per (row tile, tap) and the (default) all-taps loop
         for loopn in (0, 1):
-            with X.option("bf16_force256", 1), X.option("bf16_loopn", loopn):
+            with X.option("bf16_force256", 1), X.option("bf16_no_loopn", 1 - loopn):
                 p2 = torch.full((N, 2 * H, 2 * W, C), float("nan"), device=DEV)
                 X.call("myolo_deconv2x2s2_mask_bf16_fwd", X.ptr(to_bf16_dev(x)), X.ptr(to_bf16_dev(w.reshape(4 * Cout, Cin))), X.ptr(dt(b)),
                        X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p2), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())

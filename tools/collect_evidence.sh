@@ -21,12 +21,12 @@ cp gpurun_out/prof_${TAG}x6/${TAG}x6_bench_kernel_stats.csv gpurun_out/prof_${TA
   for k in wino_fwd wino63_fwd wino_bwd_data deconv_mask_fwd; do
     KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --iters 10 2>&1 | grep -vE "amdgpu.ids|^$" | tail -1
   done
-  echo "--- bf16 inference kernels (default; bf16_no_c3=1 = the nine-fetch implicit GEMM; bf16_no256=1 = the 128^2 kernels; bf16_loopn=1)"
+  echo "--- bf16 inference kernels (default; bf16_no_c3=1 = the nine-fetch implicit GEMM; bf16_no256=1 = the 128^2 kernels; bf16_no_loopn=1)"
   python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
   KBENCH_OPTIONS=bf16_no_c3=1 python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
   KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
   python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_loopn=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no_loopn=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
   KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
   echo "--- tools/overlap_mm_boundary.py"
   python tools/overlap_mm_boundary.py 2>&1 | tail -1
