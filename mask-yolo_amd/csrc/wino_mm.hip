@@ -168,19 +168,21 @@ __global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
     const unsigned rowb = (unsigned)p.K * 4u;
     unsigned goff = ((unsigned)r4 * (unsigned)p.K + (unsigned)kq) * 4u;      // advanced by 64 bytes per chunk
     const int soff = r4 * MM_LD + kq;
-    float4 sa[2], sb[4];
-    auto gload = [&]() {
+    // two sets of staging registers: chunk c+3 is requested while chunk c is multiplied (a chunk is ~2 us of MFMA work; with one set
+    // -- two chunks ahead -- the loads of a tile whose operands come from HBM under the other workgroups' write traffic arrived late)
+    float4 sa[2][2], sb[2][4];
+    auto gload = [&](int set) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) sa[i] = mm_bufld4(ra, goff + (unsigned)(64 * i) * rowb);
+        for (int i = 0; i < 2; ++i) sa[set][i] = mm_bufld4(ra, goff + (unsigned)(64 * i) * rowb);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) sb[i] = mm_bufld4(rb, goff + (unsigned)(64 * i) * rowb);
+        for (int i = 0; i < 4; ++i) sb[set][i] = mm_bufld4(rb, goff + (unsigned)(64 * i) * rowb);
         goff += MM_BK * 4u;
     };
-    auto sstore = [&](int buf) {
+    auto sstore = [&](int buf, int set) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&As[buf][soff + 64 * i * MM_LD]) = sa[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(&As[buf][soff + 64 * i * MM_LD]) = sa[set][i];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[buf][soff + 64 * i * MM_LD]) = sb[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(&Bs[buf][soff + 64 * i * MM_LD]) = sb[set][i];
     };
     // MFMA role: lane (l31, half) holds k = 8*half + 4*q + s of rows / columns l31 (+32 t, +32 u)
     const int aoff = (wm * 64 + l31) * MM_LD + half * 8;
@@ -202,9 +204,10 @@ __global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     const int nk = p.K / MM_BK;
-    gload();
-    sstore(0);
-    if (nk > 1) gload();
+    gload(0);
+    sstore(0, 0);
+    if (nk > 1) gload(1);
+    if (nk > 2) gload(0);
     __syncthreads();
     fread(0, 0);
 
@@ -213,17 +216,24 @@ __global__ __launch_bounds__(256, 2) void wino_mm_kernel(MMArgs p)
         _Pragma("unroll") for (int u = 0; u < 4; ++u)                                                                  \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f4c(fa[q][t], s), f4c(fb[q][u], s), acc[t][u], 0, 0, 0);
 
-    for (int c = 0; c < nk; ++c) {
-        const int cur = c & 1;
-        fread(cur, 1);                       // second-half fragments, used 32 MFMAs from now
-        MM_STEP(0, 0) MM_STEP(0, 1) MM_STEP(0, 2) MM_STEP(0, 3)
-        if (c + 1 < nk) sstore(cur ^ 1);     // chunk c+1 (loaded one chunk ago) -> the buffer whose last reader was chunk c-1
-        if (c + 2 < nk) gload();             // chunk c+2 into the same staging registers
-        MM_STEP(1, 0)
-        __syncthreads();
-        if (c + 1 < nk) fread(cur ^ 1, 0);   // first-half fragments of chunk c+1 under the rest of this chunk
-        MM_STEP(1, 1) MM_STEP(1, 2) MM_STEP(1, 3)
+#define MM_CHUNK(c, cur)                                                                                               \
+    {                                                                                                                  \
+        fread(cur, 1);                       /* second-half fragments, used 32 MFMAs from now */                       \
+        MM_STEP(0, 0) MM_STEP(0, 1) MM_STEP(0, 2) MM_STEP(0, 3)                                                        \
+        if ((c) + 1 < nk) sstore(cur ^ 1, cur ^ 1);   /* chunk c+1 (requested two chunks ago) -> the buffer chunk c-1 used */ \
+        if ((c) + 3 < nk) gload(cur ^ 1);             /* chunk c+3 into the set just emptied */                          \
+        MM_STEP(1, 0)                                                                                                  \
+        __syncthreads();                                                                                               \
+        if ((c) + 1 < nk) fread(cur ^ 1, 0); /* first-half fragments of chunk c+1 under the rest of this chunk */      \
+        MM_STEP(1, 1) MM_STEP(1, 2) MM_STEP(1, 3)                                                                      \
     }
+    int c = 0;
+    for (; c + 1 < nk; c += 2) {             // two chunks per trip: the LDS buffer and the staging set of a chunk are its parity
+        MM_CHUNK(c, 0)
+        MM_CHUNK(c + 1, 1)
+    }
+    if (c < nk) MM_CHUNK(c, 0)
+#undef MM_CHUNK
 #undef MM_STEP
 
     if constexpr (EPI == MM_EP_DECONV_MASK) {
