@@ -17,7 +17,7 @@ new = '''## 5. Results (round 2, measured on 1× MI355X by `bench.py`; evidence 
 
 | Config | img/s | step ms | dominant kernel (`roofline`) | whole 3×3 conv op | other `roofline` objects | CPU restatement |
 |---|---|---|---|---|---|---|
-| Shapes 224², B=32, fp32, N_BOX=3 (R=147), all-ROI forward (**headline**; `profiles/r2g_bench.json`) | **%.1f** (round 1: 857–865) | **%.2f** | `wino_mm_kernel`: ONE launch of the 64 per-point GEMMs of the Winograd multiply on the F(6,3)/F(4,3) tiling (14 = 6+4+4: 400 point-tiles per ROI, 0.247 TFLOP): **%.2f ms = %.0f TFLOP/s = %.1f %%** of the 157.3 TFLOP/s fp32 MFMA peak; HBM traffic 3.96 GB vs 3.87 GB algorithmic (`r2_pmc_wino63_multiply.json`); `SQ_VALU_MFMA_BUSY_CYCLES` = the minimum for that work; MFMA pipe busy 79.8 %% at an effective 2.0 GHz. (Same kernel on the F(4,3)/F(2,3) tiling, 484 point-tiles: 2.51 ms = 119 TFLOP/s = 75.7 %%; rocBLAS `bmm` on those shapes: 112–114 TFLOP/s) | %.2f ms (round 1: 4.33) = %.0f direct-equivalent TFLOP/s | depthwise (14 layers, in-step events) %.2f ms; stand-alone 0.148 ms = 4.5 TB/s = 57 %% of 8 TB/s (round 1: 43 %%); ROIAlign fwd fused into conv1's input transform %.2f ms (= %.0f %% of 8 TB/s on SURVEY §8(d) bytes; the kernel writes the 2.0× larger Winograd image at 4.2 TB/s), stand-alone 0.17–0.21 ms = 57–70 %%; ROIAlign bwd 0.41 ms = 2.4 TB/s (round 1: 0.73 ms); pointwise (14 layers) %.2f ms = %.0f TFLOP/s = %.0f %% of the fp32 MFMA peak; Winograd layer boundary %.2f ms = %.2f TB/s (a plain device copy: 4.9 TB/s) | **%.2f img/s**: 32-image training step of the torch-CPU fp32 restatement, 16 threads (all usable cores of an EPYC 9575F), median of 2 after 1 warm-up |
+| Shapes 224², B=32, fp32, N_BOX=3 (R=147), all-ROI forward (**headline**; `profiles/r2g_bench.json`) | **%.1f** (round 1: 857–865) | **%.2f** | `wino_mm_kernel`: ONE launch of the 64 per-point GEMMs of the Winograd multiply on the F(6,3)/F(4,3) tiling (14 = 6+4+4: 400 point-tiles per ROI, 0.247 TFLOP): **%.2f ms = %.0f TFLOP/s = %.1f %%** of the 157.3 TFLOP/s fp32 MFMA peak; HBM traffic 3.90 GB vs 3.87 GB algorithmic (`r2_pmc_wino63_multiply.json`); `SQ_VALU_MFMA_BUSY_CYCLES` = the minimum for that work; MFMA pipe busy 82 %% at an effective 2.02 GHz. (Same kernel on the F(4,3)/F(2,3) tiling, 484 point-tiles: 2.51 ms = 119 TFLOP/s = 75.7 %%; rocBLAS `bmm` on those shapes: 112–114 TFLOP/s) | %.2f ms (round 1: 4.33) = %.0f direct-equivalent TFLOP/s | depthwise (14 layers, in-step events) %.2f ms; stand-alone 0.148 ms = 4.5 TB/s = 57 %% of 8 TB/s (round 1: 43 %%); ROIAlign fwd fused into conv1's input transform %.2f ms (= %.0f %% of 8 TB/s on SURVEY §8(d) bytes; the kernel writes the 2.0× larger Winograd image at 4.2 TB/s), stand-alone 0.17–0.21 ms = 57–70 %%; ROIAlign bwd 0.41 ms = 2.4 TB/s (round 1: 0.73 ms); pointwise (14 layers) %.2f ms = %.0f TFLOP/s = %.0f %% of the fp32 MFMA peak; Winograd layer boundary %.2f ms = %.2f TB/s (a plain device copy: 4.9 TB/s) | **%.2f img/s**: 32-image training step of the torch-CPU fp32 restatement, 16 threads (all usable cores of an EPYC 9575F), median of 2 after 1 warm-up |
 | same, `FP32_MATMUL="bf16x6"` (opt-in, DESIGN §3 / §8: six exact bf16 piece products per fp32 product; `profiles/r2g_bench_bf16x6.json`, also `variants.winograd_multiply_bf16x6` of the headline run: %.1f ms) | **%.1f** | **%.2f** | `wino_mm_x6_kernel`: %.2f ms = %.0f TFLOP/s of bf16 piece products = %.0f %% of 2.5 PFLOP/s (%.0f fp32-equivalent TFLOP/s); bf16 pipe busy 65 %% at an effective 1.67 GHz (PMC on the 484-point-tile launch) | %.2f ms; fused deconv+mask GEMM 2.43 ms (native 3.99) | | |
 | headline config, dense mask-head backward (`variants.dense_mask_backward`) | %.1f | %.1f | | | | |
 | headline config, positives-only forward (`variants.mask_head_forward_on_positives_only`, opt-in, DESIGN §4b) | %.1f | %.1f (bf16x6: %.1f) | | | | |
