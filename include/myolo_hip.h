@@ -7,6 +7,11 @@
  * cited next to it (paths relative to the reference root); INTEGRATION.md shows the ctypes
  * binding a maintainer would add.
  *
+ * This header is the OPERATOR API: one entry point per reference op (forward / data gradient / weight gradient), housekeeping
+ * and the RCCL wrappers -- what a maintainer replacing a Keras layer binds.  The stage-level entry points the engine
+ * (myolo/engine.py) composes its fused pipelines from (Winograd transform / multiply stages, lazy-BatchNorm gradients, row-sparse
+ * helpers, producer-fused BatchNorm statistics) live in myolo_hip_internal.h; their buffers have library-owned layouts.
+ *
  * Conventions
  *   - every tensor is NHWC, contiguous, float32 unless stated; 2-D views are [rows, channels];
  *   - the CALLER owns every buffer (kernels never allocate); `ws` is caller-provided scratch of
@@ -138,10 +143,6 @@ int myolo_bn_stats(const float* x, const float* gamma, const float* beta,
                    int64_t M, int C, void* ws, size_t ws_bytes, void* stream);
 int myolo_bn_frozen_coeffs(const float* gamma, const float* beta, const float* moving_mean,
                            const float* moving_var, float* scale, float* shift, int C, void* stream);
-/* the same coefficients for many layers in one launch: table [nlayers][6] int64 (device) = element offsets of gamma, beta into params,
- * of the moving mean, moving variance into stats, of the layer's output into coeffs (scale[C] then shift[C]), and C */
-int myolo_bn_frozen_coeffs_batched(const float* params, const float* stats, const int64_t* table, int nlayers, float* coeffs,
-                                   void* stream);
 int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, float* y,
                        int64_t M, int C, int act, void* stream);
 /* frozen BatchNorm + activation in one launch: myolo_bn_frozen_coeffs followed by myolo_bn_apply_act (same results; scale / shift are
@@ -153,25 +154,7 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma,
                      float* dx, float* dgamma, float* dbeta,
                      int64_t M, int C, int act, int batch_stats, void* ws, size_t ws_bytes, void* stream);
 
-/* frozen BatchNormalization (training=False, model.py:696,702,708) + ReLU/ReLU6 backward from the POST-activation tensor
- * a = act(gamma*xhat + beta): where the activation passes gradient xhat = (a - beta)/gamma, so the pre-BN tensor is not needed.
- * dx = scale * dy * [act passes], dgamma = sum dz*xhat, dbeta = sum dz.  ws as bn_act_bwd. */
-int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const float* gamma, const float* beta, const float* scale,
-                                 float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act,
-                                 void* ws, size_t ws_bytes, void* stream);
 
-/* Exact-sparsity helpers for the mask head backward (build_mask_graph model.py:690-708: bn1 is the only
- * batch-statistics layer, so behind it only ROIs with a positive target carry non-zero gradient):
- * gather_groups: dst[i] = src[idx[i]] for groups of group_elems floats (one ROI's rows);
- * bn_act_bwd_rowsparse: training-mode BN+activation backward where the upstream gradient is given only
- *   for the n_groups row groups idx[] (compact dy [n_groups*group_rows, C]; inv[group] = slot or -1);
- *   results are identical to bn_act_bwd on the zero-padded dense gradient. */
-int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n, int64_t group_elems, void* stream);
-int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const int32_t* idx, const int32_t* inv,
-                               const float* mean, const float* var, const float* scale, const float* shift,
-                               float* dx, float* dgamma, float* dbeta,
-                               int64_t M, int C, int n_groups, int group_rows, int act,
-                               void* ws, size_t ws_bytes, void* stream);
 
 /* ---- tf.image.crop_and_resize, bilinear, extrapolation 0 (PyramidROIAlign model.py:385-387) ----
  * boxes [nb,4] = (y1,x1,y2,x2) normalised as crop_and_resize reads them; box_ind [nb] int32. */
@@ -266,55 +249,8 @@ int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias
  * fwd: optional scale/shift = folded frozen BatchNorm applied after the bias (as conv3x3_affine_act_fwd); v_keep
  * (nullable) receives the transformed input [36][N*ceil(H/4)*ceil(W/4)][Cin] so bwd_weight can reuse it (v_saved). ---- */
 size_t myolo_conv3x3_wino_ws_bytes(int N, int H, int W, int Cin, int Cout, int which);
-/* elements of the 36 transformed planes V (or M) of an [N,H,W,C] tensor (<= 36*N*ceil(H/4)*ceil(W/4)*C: with mixed tiling --
- * F(2,3) on a last tile row / column that holds <= 2 outputs, e.g. 14 = 4+4+4+2 -- reduced tiles have no row in the planes of
- * the points they do not use; at 14x14 that is 484 instead of 576 point-tiles per image) */
-size_t myolo_wino_plane_elems(int N, int H, int W, int C);
-/* floats to allocate for U of myolo_wino_weight_transform (1.5 x 36*Cin*Cout: room for the split-bf16 layout of option "wino_x6") */
-size_t myolo_wino_u_elems(int Cin, int Cout);
 int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
                            int N, int H, int W, int Cin, int Cout, int act, float* v_keep, void* ws, size_t ws_bytes, void* stream);
-/* the forward's four stages, callable on their own: U = 36 planes of Cin*Cout transformed filter taps (flip=1: of the rotated
- * filter with the channel roles exchanged, for the data gradient: call the multiply with (Cout, Cin) then).  U is OPAQUE between
- * myolo_wino_weight_transform and myolo_wino_multiply: the element order inside a plane is the one the multiply kernel chosen
- * for (Cin, Cout) wants ([K][N], or [N][K] for csrc/wino_mm.hip when K % 16 == 0 and N % 256 == 0).  V and M = 36 planes of myolo_wino_plane_elems(N,H,W,C) elements in total (a buffer of 36*T*C floats,
- * T = N*ceil(H/4)*ceil(W/4), always suffices); planes are ordered by point group, see csrc/wino_kernels.hip */
-int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream);
-int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
-int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
-int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
-                                int N, int H, int W, int C, int act, void* stream);
-/* ROIAlign (myolo_crop_and_resize_fwd: same boxes / box_ind / sampling) fused into the input transform of the conv that
- * consumes the crops: V [36][nb*ceil(crop_h/4)*ceil(crop_w/4)][C] directly from the feature map [B,FH,FW,C] */
-int myolo_wino_input_transform_roialign(const float* feature, const float* boxes, const int32_t* box_ind, float* V, int B, int FH, int FW,
-                                        int C, int nb, int crop_h, int crop_w, void* stream);
-/* input transform with the producing layer's BatchNorm apply + activation folded into the load (scale/shift per channel) */
-int myolo_wino_input_transform_affine(const float* x, const float* scale, const float* shift, int act, float* V, int N, int H, int W,
-                                      int C, void* stream);
-/* output transform (+bias) that also produces the training-mode BatchNorm statistics of what it writes: same outputs as
- * myolo_bn_stats (mean, var, folded scale/shift, moving averages; model.py:690).  C/4 must divide 256. */
-size_t myolo_wino_output_transform_bn_ws_bytes(int C);
-int myolo_wino_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int H, int W, int C, const float* gamma,
-                                         const float* beta, float* mean, float* var, float* scale, float* shift, float* moving_mean,
-                                         float* moving_var, void* ws, size_t ws_bytes, void* stream);
-/* conv gradients whose incoming gradient sits behind a training-mode BatchNorm + activation with a row-sparse upstream
- * gradient (bn1 of the mask head, model.py:690 -- only the positive ROIs carry gradient, myolo_mask_loss_graph
- * model.py:739-746): bn_bwd_rowsparse_coeffs reduces dgamma / dbeta and leaves the per-channel terms ka, kb of
- * dx = scale*dz + ka + kb*x; the *_lazybn gradients form dx while loading the pre-BN tensor, so it is never written. */
-int myolo_bn_bwd_rowsparse_coeffs(const float* dy_compact, const float* x, const int32_t* idx, const float* mean, const float* var,
-                                  const float* scale, const float* shift, float* dgamma, float* dbeta, float* ka, float* kb, int64_t M,
-                                  int C, int n_groups, int group_rows, int act, void* ws, size_t ws_bytes, void* stream);
-int myolo_conv3x3_wino_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
-                                       const float* shift, const float* ka, const float* kb, int act, const float* w, float* dx, int N,
-                                       int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-int myolo_conv3x3_wino_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv,
-                                         const float* scale, const float* shift, const float* ka, const float* kb, int act, float* dw,
-                                         int N, int H, int W, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-/* layer boundary between two Winograd convs in one pass per image: M of conv_i -> (+bias, affine, act) -> V of conv_{i+1}
- * through LDS; the activation itself goes to y only for images with flags[img] != 0 (flags NULL: all; y NULL: none).
- * Needs C % 32 == 0 and ceil(H/4)*ceil(W/4) <= 32 (14x14: 16 tiles). */
-int myolo_wino_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
-                                      const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream);
 int myolo_conv3x3_wino_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int Cin, int Cout,
                                 void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int H, int W,
@@ -326,43 +262,6 @@ int myolo_conv3x3_wino_bwd_weight(const float* x, const float* v_saved, const fl
  * H = W = 14, channels multiples of 64, Cin % 16 == 0, Cout % 256 == 0.  The reference op: the conv2-4 / bn / ReLU stages of
  * build_mask_graph (model.py:693-709). ---- */
 int    myolo_wino63_ok(int H, int W, int Cin, int Cout);
-size_t myolo_wino63_plane_elems(int N, int C);
-size_t myolo_wino63_u_elems(int Cin, int Cout);
-int myolo_wino63_weight_transform(const float* w, float* U, int Cin, int Cout, void* stream);
-int myolo_wino63_multiply(const float* V, const float* U, float* M, int N, int Cin, int Cout, void* stream);
-/* x [N,14,14,C] -> act(x*scale + shift) (scale NULL: identity) -> V; the activation also goes to y (NULL: nowhere) where flags[img] != 0
- * (flags NULL: everywhere) */
-int myolo_wino63_input_transform(const float* x, const float* scale, const float* shift, int act, float* y, const int32_t* flags, float* V,
-                                 int N, int C, void* stream);
-/* layer boundary in one kernel: M_i -> act((A^T m A + bias)*scale + shift) -> V_{i+1}; y / flags as above */
-int myolo_wino63_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
-                                        const int32_t* flags, float* Vn, int N, int C, int act, void* stream);
-int myolo_wino63_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y, int N, int C, int act,
-                                  void* stream);
-/* conv1 of the mask head on this tiling: ROIAlign fused into the input transform (myolo_wino_input_transform_roialign), the output
- * transform that also yields the training-mode BatchNorm statistics (myolo_wino_output_transform_bn_stats), and the weight gradient
- * from the kept V planes and the lazily formed output gradient (myolo_conv3x3_wino_bwd_weight_lazybn) */
-int myolo_wino63_input_transform_roialign(const float* feature, const float* boxes, const int32_t* box_ind, float* V, int B, int FH, int FW,
-                                          int C, int nb, void* stream);
-size_t myolo_wino63_output_transform_bn_ws_bytes(int N, int C);
-int myolo_wino63_output_transform_bn_stats(const float* M, const float* bias, float* y, int N, int C, const float* gamma, const float* beta,
-                                           float* mean, float* var, float* scale, float* shift, float* moving_mean, float* moving_var,
-                                           void* ws, size_t ws_bytes, void* stream);
-size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout);
-int myolo_wino63_bwd_weight_lazybn(const float* v_saved, const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale,
-                                   const float* shift, const float* ka, const float* kb, int act, float* dw, int N, int Cin, int Cout,
-                                   void* ws, size_t ws_bytes, void* stream);
-/* conv1's backward with ONE pass over y_pre: the lazily formed gradient of the conv's output is transformed both ways in one kernel --
- * V (operand of the data gradient) and Q (operand of the weight gradient), myolo_wino63_plane_elems(N, C) floats each -- and the two
- * gradients are finished by the calls below (on different streams if the caller likes: they share nothing but read-only inputs).
- * Same results as myolo_wino63_bwd_data_lazybn + myolo_wino63_bwd_weight_lazybn, bit for bit. */
-int myolo_wino63_lazybn_transforms(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
-                                   const float* ka, const float* kb, int act, float* V, float* Q, int N, int C, void* stream);
-size_t myolo_wino63_bwd_data_from_v_ws_bytes(int N, int Cin, int Cout);
-int myolo_wino63_bwd_data_from_v(const float* V, const float* w, float* dx, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
-size_t myolo_wino63_bwd_weight_from_q_ws_bytes(int N, int Cin, int Cout);
-int myolo_wino63_bwd_weight_from_q(const float* v_saved, const float* Q, float* dw, int N, int Cin, int Cout, void* ws, size_t ws_bytes,
-                                   void* stream);
 /* the three conv operators as single calls, mirroring myolo_conv3x3_wino_{fwd,bwd_data,bwd_weight} (which = 0, 1, 2 for the scratch size) */
 size_t myolo_conv3x3_wino63_ws_bytes(int N, int Cin, int Cout, int which);
 int myolo_conv3x3_wino63_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y, int N,
@@ -370,18 +269,6 @@ int myolo_conv3x3_wino63_fwd(const float* x, const float* w, const float* bias, 
 int myolo_conv3x3_wino63_bwd_data(const float* dy, const float* w, float* dx, int N, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 int myolo_conv3x3_wino63_bwd_weight(const float* x, const float* v_saved, const float* dy, float* dw, int N, int Cin, int Cout, void* ws,
                                     size_t ws_bytes, void* stream);
-/* myolo_conv3x3_wino_bwd_data_lazybn on this tiling (same operands; needs myolo_wino63_ok(14, 14, Cout, Cin)) */
-size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout);
-int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
-                                 const float* ka, const float* kb, int act, const float* w, float* dx, int N, int Cin, int Cout, void* ws,
-                                 size_t ws_bytes, void* stream);
-
-/* The same convolution for 14x14 maps as ONE kernel (csrc/wino_fused.hip): input transform into LDS, the 36 products on MFMA,
- * output transform from the accumulators -- neither V nor M reaches HBM.  Uniform F(4,3) tiling (576 point-tiles per image).
- * Needs H = W = 14, Cin % 8 == 0, Cout % 64 == 0, act NONE | RELU; ws holds the re-arranged transformed filters. */
-size_t myolo_conv3x3_wino_fused_ws_bytes(int Cin, int Cout);
-int myolo_conv3x3_wino_fused_fwd(const float* x, const float* w, const float* bias, const float* scale, const float* shift, float* y,
-                                 int N, int H, int W, int Cin, int Cout, int act, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- bf16 inference path of the mask head (BASELINE.json configs[3]: Rice 416x416, bf16, inference-only) ----
  * Activations are bf16 (uint16_t bit patterns, NHWC), accumulation fp32 on v_mfma_f32_32x32x16_bf16.  All four
@@ -406,6 +293,17 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
 /* myolo_mask 1x1 + sigmoid (model.py:713-714) from bf16 activations; fp32 weights and probabilities */
 int myolo_mask_head_out_bf16_fwd(const uint16_t* x, const float* w, const float* bias, float* p,
                                  int64_t M, int Cin, int C, void* stream);
+
+/* ---- plain fp32 matrix product with the way its products are formed chosen per call (csrc/wino_mm.hip) ----
+ * C [M][N] = A [M][K] * B, B given as [N][K] (b_is_nk = 1) or [K][N] (b_is_nk = 0); K % 16 == 0, N % 256 == 0, 16-byte aligned.
+ * MYOLO_PRODUCTS_NATIVE: v_mfma_f32_32x32x2_f32.  MYOLO_PRODUCTS_BF16X6: every fp32 operand split EXACTLY into three bf16
+ * pieces, each fp32 product accumulated in fp32 from its six piece products >= 2^-24 relative (cfg.FP32_MATMUL, DESIGN.md
+ * section 8): fp32-level error; an Inf operand gives NaN (Inf - Inf in the split) where the native product gives +-Inf. */
+#define MYOLO_PRODUCTS_NATIVE 0
+#define MYOLO_PRODUCTS_BF16X6 1
+size_t myolo_matmul_f32_ws_bytes(int K, int N, int b_is_nk, int products);
+int myolo_matmul_f32(const float* A, const float* B, float* C, int64_t M, int K, int N, int b_is_nk, int products,
+                     void* ws, size_t ws_bytes, void* stream);
 
 /* ---- small elementwise helpers ---- */
 int myolo_add_inplace(float* a, const float* b, int64_t n, void* stream);      /* a += b */

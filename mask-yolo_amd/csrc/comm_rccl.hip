@@ -23,6 +23,7 @@ struct Rccl {
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     bool ok = false;
+    char why[192] = "no dlopen attempted";      // dlerror() text captured once, at load time (a later dlerror() may return NULL)
 };
 Rccl g_rccl;
 std::once_flag g_once;
@@ -33,8 +34,11 @@ void load_rccl()
     for (const char* n : names) {
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.h) break;
+        const char* e = dlerror();
+        snprintf(g_rccl.why, sizeof(g_rccl.why), "%s", e ? e : "dlopen failed");
     }
     if (!g_rccl.h) return;
+    snprintf(g_rccl.why, sizeof(g_rccl.why), "symbols missing");
     g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(g_rccl.h, "ncclGetUniqueId");
     g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(g_rccl.h, "ncclCommInitRank");
     g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(g_rccl.h, "ncclAllReduce");
@@ -48,7 +52,7 @@ int need_rccl(const char* who)
 {
     std::call_once(g_once, load_rccl);
     if (!g_rccl.ok) {
-        myolo_set_error("%s: librccl.so could not be loaded (%s)", who, g_rccl.h ? "symbols missing" : dlerror());
+        myolo_set_error("%s: librccl.so could not be loaded (%s)", who, g_rccl.why);
         return MYOLO_ECOMM;
     }
     return MYOLO_OK;

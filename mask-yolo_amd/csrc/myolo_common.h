@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include "../../include/myolo_hip.h"
+#include "../../include/myolo_hip_internal.h"
 
 extern "C" void myolo_set_error(const char* fmt, ...);
 

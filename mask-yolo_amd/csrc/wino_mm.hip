@@ -486,11 +486,14 @@ int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nr
 
 // ---- split filters for a plain [K][N]-shaped operand (not a Winograd plane sequence) ----
 // out: the operand order of wino_mm_x6_kernel, [k / 16][n / 32][piece][(k / 8) % 2][n % 32][k % 8] bf16, of B[k][n] = src[n * K + k]
-__global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restrict__ src, __bf16* __restrict__ out, int K, int N)
+// (src_kn = 1: B[k][n] = src[k * N + n], the natural [K][N] layout of a Keras 1x1 kernel)
+__global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restrict__ src, __bf16* __restrict__ out, int K, int N, int src_kn = 0)
 {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)K * N) return;
-    const int n = (int)(idx / K), k = (int)(idx - (long long)n * K);
+    int n, k;
+    if (src_kn) { k = (int)(idx / N); n = (int)(idx - (long long)k * N); }
+    else { n = (int)(idx / K); k = (int)(idx - (long long)n * K); }
     const float v = src[idx];
     const __bf16 p1 = (__bf16)v;
     const float r1 = v - (float)p1;
@@ -520,12 +523,65 @@ int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, cons
     const long long tiles = (long long)R.mtiles * (N / MM_BN);
     if (g_myolo_opt.wino_x6) {
         const long long total = (long long)K * N;
-        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N);
+        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 0);
         a.Bt = (const float*)split;
         hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
     } else {
         a.Bt = w;
         hipLaunchKernelGGL(wino_mm_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
     }
+    return MYOLO_OK;
+}
+
+// =====================================================================================================================
+// Plain fp32 matrix product through the kernels above, the way its products are formed chosen PER CALL (no process switch):
+//     C [M][N] = A [M][K] * B,   B given as [N][K] (b_is_nk = 1: the transposed operand both kernels want) or [K][N] (b_is_nk = 0).
+// products = MYOLO_PRODUCTS_NATIVE: v_mfma_f32_32x32x2_f32;  MYOLO_PRODUCTS_BF16X6: six exact bf16 piece products per fp32 product.
+// Used by the 1x1 convolutions with K, N multiples of (16, 256) and by tests/test_gpu_ops.py::test_bf16x6_* (special values, K = 2304).
+__global__ __launch_bounds__(256) void mm_transpose_kn_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, int N)
+{
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (k0 + j < K && n0 + tx < N) t[j][tx] = src[(long long)(k0 + j) * N + n0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (n0 + j < N && k0 + tx < K) dst[(long long)(n0 + j) * K + k0 + tx] = t[tx][j];
+}
+
+extern "C" size_t myolo_matmul_f32_ws_bytes(int K, int N, int b_is_nk, int products)
+{
+    if (products == MYOLO_PRODUCTS_BF16X6) return align256((size_t)K * N * 6);
+    return b_is_nk ? 0 : align256((size_t)K * N * 4);
+}
+
+extern "C" int myolo_matmul_f32(const float* A, const float* B, float* C, int64_t M, int K, int N, int b_is_nk, int products,
+                                void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(A && B && C && M > 0 && K >= MM_BK && (K % MM_BK) == 0 && N >= MM_BN && (N % MM_BN) == 0,
+                  "matmul_f32: needs M > 0, K %% %d == 0, N %% %d == 0", MM_BK, MM_BN);
+    MYOLO_REQUIRE(products == MYOLO_PRODUCTS_NATIVE || products == MYOLO_PRODUCTS_BF16X6, "matmul_f32: products must be MYOLO_PRODUCTS_NATIVE or MYOLO_PRODUCTS_BF16X6");
+    MYOLO_REQUIRE((((uintptr_t)A | (uintptr_t)B | (uintptr_t)C) & 15) == 0, "matmul_f32: operands must be 16-byte aligned");
+    MYOLO_NEED_WS(myolo_matmul_f32_ws_bytes(K, N, b_is_nk, products));
+    hipStream_t s = (hipStream_t)stream;
+    MMArgs a{};
+    a.A = A; a.C = C; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
+    MMRun& R = a.run[0];
+    R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
+    R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
+    const long long tiles = (long long)R.mtiles * (N / MM_BN);
+    if (products == MYOLO_PRODUCTS_BF16X6) {
+        const long long total = (long long)K * N;
+        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, B, (__bf16*)ws, K, N, b_is_nk ? 0 : 1);
+        a.Bt = (const float*)ws;
+        hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    } else {
+        if (!b_is_nk) {
+            hipLaunchKernelGGL(mm_transpose_kn_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, B, (float*)ws, K, N);
+            a.Bt = (const float*)ws;
+        } else a.Bt = B;
+        hipLaunchKernelGGL(wino_mm_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    }
+    MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

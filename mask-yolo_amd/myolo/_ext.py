@@ -1,4 +1,4 @@
-"""ctypes binding of libmyolo_hip.so (the C-ABI declared in include/myolo_hip.h).
+"""ctypes binding of libmyolo_hip.so (the C-ABI declared in include/myolo_hip.h and include/myolo_hip_internal.h).
 
 PyTorch is used only as the owner of device memory and streams: every function here takes
 torch tensors, checks dtype/contiguity/device, and passes raw device pointers plus the current
@@ -70,7 +70,6 @@ SIGS = {
     "myolo_wino63_lazybn_transforms": [P, P, P, P, P, P, P, I, P, P, I, I, P],
     "myolo_wino63_bwd_data_from_v": [P, P, P, I, I, I, P, Z, P],
     "myolo_wino63_bwd_weight_from_q": [P, P, P, I, I, I, P, Z, P],
-    "myolo_conv3x3_wino_fused_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_deconv2x2s2_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
@@ -94,6 +93,7 @@ SIGS = {
     "myolo_mask_head_out_bwd": [P, P, P, P, P, P, L, I, I, P, Z, P],
     "myolo_mask_bce": [P, P, P, F, P, P, I, I, I, I, P, Z, P],
     "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
+    "myolo_matmul_f32": [P, P, P, L, I, I, I, I, P, Z, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],
     "myolo_set_option": [ctypes.c_char_p, I],
@@ -125,8 +125,8 @@ def load():
     lib.myolo_workspace_bytes.restype = Z
     lib.myolo_conv3x3_wino_ws_bytes.argtypes = [I, I, I, I, I, I]
     lib.myolo_conv3x3_wino_ws_bytes.restype = Z
-    lib.myolo_conv3x3_wino_fused_ws_bytes.argtypes = [I, I]
-    lib.myolo_conv3x3_wino_fused_ws_bytes.restype = Z
+    lib.myolo_matmul_f32_ws_bytes.argtypes = [I, I, I, I]
+    lib.myolo_matmul_f32_ws_bytes.restype = Z
     lib.myolo_wino_plane_elems.argtypes = [I, I, I, I]
     lib.myolo_wino_plane_elems.restype = Z
     lib.myolo_wino_u_elems.argtypes = [I, I]
@@ -157,7 +157,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_conv3x3_wino_fused_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -214,8 +214,11 @@ def wino_ws_bytes(n, h, w, cin, cout, which):
     return int(load().myolo_conv3x3_wino_ws_bytes(int(n), int(h), int(w), int(cin), int(cout), int(which)))
 
 
-def wino_fused_ws_bytes(cin, cout):
-    return int(load().myolo_conv3x3_wino_fused_ws_bytes(int(cin), int(cout)))
+PRODUCTS_NATIVE, PRODUCTS_BF16X6 = 0, 1
+
+
+def matmul_ws_bytes(k, n, b_is_nk, products):
+    return int(load().myolo_matmul_f32_ws_bytes(int(k), int(n), int(b_is_nk), int(products)))
 
 
 def wino_u_elems(cin, cout):

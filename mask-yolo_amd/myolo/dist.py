@@ -101,7 +101,9 @@ class GradReducer(object):
             X.call("myolo_comm_unique_id", ctypes.addressof(ident))
         if dist.is_initialized() and self.world > 1:
             box = [bytes(ident.raw)]
-            dist.broadcast_object_list(box, src=0, group=self.group)
+            # `rank` is the GROUP rank; broadcast takes a GLOBAL rank: the group's first member holds the id
+            src = dist.get_global_rank(self.group, 0) if self.group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=self.group)
             ident = (ctypes.c_char * 128).from_buffer_copy(box[0])
         comm = ctypes.c_void_p()
         with torch.cuda.device(self.flat.device):
@@ -135,11 +137,18 @@ class GradReducer(object):
                 self._issued[i] = False
 
     def close(self):
-        if self.comm is not None:
+        """destroy the C-ABI RCCL communicator (idempotent; also run from __del__ so a dropped reducer does not leak it)."""
+        comm, self.comm = getattr(self, "comm", None), None
+        if comm is not None:
             from . import _ext as X
             torch.cuda.synchronize(self.flat.device)
-            X.call("myolo_comm_destroy", self.comm)
-            self.comm = None
+            X.call("myolo_comm_destroy", comm)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:          # interpreter teardown: the library or torch may already be gone
+            pass
 
     @property
     def grad_scale(self):

@@ -190,7 +190,7 @@ class Net(object):
         self.fp32_matmul = getattr(cfg, "FP32_MATMUL", "native")
         if self.fp32_matmul not in ("native", "bf16x6"):
             raise ValueError("FP32_MATMUL must be 'native' or 'bf16x6' (got %r)" % (self.fp32_matmul,))
-        X.set_option("wino_x6", 1 if self.fp32_matmul == "bf16x6" else 0)
+        self._activate()
         self.sparse_mask_bwd = True
         # exact-sparsity FORWARD of the mask head (see mask_head_fwd_positives): conv2-4 / deconv / myolo_mask only on
         # the positive ROIs.  Same loss, gradients and BN state; the training graph's unused myolo_mask rows of the
@@ -203,6 +203,12 @@ class Net(object):
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
         self.timings = {}                 # tag -> [(start_event, end_event), ...]
         self.load_state_dict(init_state_dict(cfg, seed))
+
+    def _activate(self):
+        """The library's kernel-choice switches are process-wide (myolo_set_option); this Net's choices are (re)applied at the start
+        of every step / forward, so several Nets with different cfg.FP32_MATMUL can live in one process (an inference MaskYOLO
+        beside a trainer).  Captured hipGraphs are keyed by the mode they were captured under (predict_graphed)."""
+        X.set_option("wino_x6", 1 if self.fp32_matmul == "bf16x6" else 0)
 
     # ------------------------------------------------------------------ state
     def trainable_names(self):
@@ -228,6 +234,7 @@ class Net(object):
                 raise KeyError("missing tensors: %s" % missing[:5])
 
     def grads_dict(self):
+        self.join_conv1_wgrad()           # conv1's weight gradient may still be running on its side stream
         return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items()}
 
     # ------------------------------------------------------------------ helpers
@@ -1160,6 +1167,7 @@ class Net(object):
 
     def forward_backward(self, db):
         """One training forward + backward on a device batch.  Gradients land in self.flat_g."""
+        self._activate()
         cfg = self.cfg
         self.tape = {}
         images = db["images"]
@@ -1241,6 +1249,7 @@ class Net(object):
         -- decode, mask targets, ROIAlign, mask head, both losses (model.py:872-904) -- in Keras' test phase, i.e. every
         BatchNormalization on its moving statistics, no gradient, no state change.  Returns the loss terms as device
         tensors (yolo_terms[8], mask_terms[2]); 'yolo' mode batches (three arrays) give the YOLO loss only."""
+        self._activate()
         cfg = self.cfg
         self.tape = {}
         images = db["images"]
@@ -1280,6 +1289,7 @@ class Net(object):
     def forward_backward_yolo(self, db):
         """'yolo' mode training step (model.py:906-920: outputs [yolo_output, yolo_sum_loss]): backbone + YOLO head
         + yolo_custom_loss, no feature_map / ROIAlign / mask head.  db needs images, true_boxes, y_true."""
+        self._activate()
         cfg = self.cfg
         self.tape = {}
         images = db["images"]
@@ -1301,6 +1311,7 @@ class Net(object):
 
     def adam_step(self, lr, b1=0.9, b2=0.999, eps=1e-8):
         """Keras Adam (model.py:1071-1075) over the whole flat buffer."""
+        self.join_conv1_wgrad()
         if self.before_optimizer:
             self.before_optimizer()
         self.adam_t += 1
@@ -1316,6 +1327,7 @@ class Net(object):
 
     def predict(self, images):
         """inference graph (model.py:922-936): -> yolo_output, detections [B,R,6], myolo_mask."""
+        self._activate()
         cfg = self.cfg
         self.tape = {}
         B = images.shape[0]
@@ -1337,6 +1349,7 @@ class Net(object):
 
     def predict_detections(self, images):
         """first half of the inference graph: -> yolo_output, detections [B,R,6], and the feature map the mask head reads."""
+        self._activate()
         cfg = self.cfg
         self.tape = {}
         B = images.shape[0]
@@ -1349,6 +1362,7 @@ class Net(object):
 
     def predict_masks(self, feature, rois):
         """second half for a chosen subset of boxes: rois [B, n, 4] (the first four detection columns) -> [B, n, mh, mw, C]."""
+        self._activate()
         cfg = self.cfg
         Fm, fshape = feature
         self.tape = {}
@@ -1363,7 +1377,7 @@ class Net(object):
         """predict() replayed from a captured hipGraph (one per input shape): the ~150 launches of an inference forward cost
         one graph launch on the host.  Same kernels, same buffers for the weights (updates are seen), static input / output
         buffers: the returned tensors are overwritten by the next call with the same shape."""
-        key = (tuple(images.shape), self.cfg.INFERENCE_DTYPE, self.conv3x3_algo)
+        key = (tuple(images.shape), self.cfg.INFERENCE_DTYPE, self.conv3x3_algo, self.fp32_matmul, self.wino_tiles)
         ent = self._graphs.get(key)
         if ent is None:
             static_in = images.clone()
@@ -1395,6 +1409,7 @@ class Net(object):
 
     def predict_yolo(self, images):
         """'yolo' mode forward (model.py:906-920)."""
+        self._activate()
         self.tape = {}
         cfg = self.cfg
         _, _, yo = self.trunk_fwd(images, False)

@@ -71,10 +71,11 @@ def read_keras_h5(path, opener=None):
         root = f["model_weights"] if "model_weights" in f else f
         layers = _names(root.attrs.get("layer_names"))
         # large name lists are split into layer_names0, layer_names1, ... (saving.py save_attributes_to_hdf5_group)
-        k = 0
-        while not layers and ("layer_names%d" % k) in root.attrs:
-            layers += _names(root.attrs["layer_names%d" % k])
-            k += 1
+        if not layers:
+            k = 0
+            while ("layer_names%d" % k) in root.attrs:
+                layers += _names(root.attrs["layer_names%d" % k])
+                k += 1
         for lname in layers:
             g = root[lname]
             wnames = _names(g.attrs.get("weight_names"))

@@ -130,26 +130,35 @@ def mask_bce_t(tmask, tcls, pred):
 
 
 class TorchRef(object):
-    def __init__(self, P_np, cfg, dtype=torch.float64):
+    def __init__(self, P_np, cfg, dtype=torch.float64, capture=False):
+        """capture=True: keep every BatchNorm's input (NHWC numpy, keyed by the BN layer name) and the deconv output ("deconv/out")
+        of the last forward in self.cap -- the tensors every ReLU / ReLU6 decision of the backward is read from
+        (tests: test_gradients_with_oracle_activation_masks_hold_maxnorm at config 2)."""
         self.cfg, self.dtype = cfg, dtype
+        self.capture, self.cap = capture, {}
         self.P = {k: _t(v, dtype) for k, v in P_np.items()}
         self.train_names = trainable_names(P_np)
         for k in self.train_names:
             self.P[k].requires_grad_(True)
 
+    def _keep(self, name, x):
+        if self.capture:
+            self.cap[name] = x.detach().permute(0, 2, 3, 1).contiguous().numpy()
+        return x
+
     def _block(self, x, bid, stride, train):
         P = self.P
         n = "conv_dw_%d" % bid
-        x = _dw(x, P[n + "/depthwise_kernel"], stride)
+        x = self._keep(n + "_bn", _dw(x, P[n + "/depthwise_kernel"], stride))
         x = _relu6(_bn(x, P[n + "_bn/gamma"], P[n + "_bn/beta"], P[n + "_bn/moving_mean"], P[n + "_bn/moving_variance"], train))
         n = "conv_pw_%d" % bid
-        x = _conv(x, P[n + "/kernel"])
+        x = self._keep(n + "_bn", _conv(x, P[n + "/kernel"]))
         return _relu6(_bn(x, P[n + "_bn/gamma"], P[n + "_bn/beta"], P[n + "_bn/moving_mean"], P[n + "_bn/moving_variance"], train))
 
     def trunk(self, images, train):
         P, cfg = self.P, self.cfg
         x = _t(images, self.dtype).permute(0, 3, 1, 2)
-        x = _conv(x, P["conv1/kernel"], stride=2, pad=(1, 1, 1, 1))
+        x = self._keep("conv1_bn", _conv(x, P["conv1/kernel"], stride=2, pad=(1, 1, 1, 1)))
         x = _relu6(_bn(x, P["conv1_bn/gamma"], P["conv1_bn/beta"], P["conv1_bn/moving_mean"], P["conv1_bn/moving_variance"], train))
         bid = 1
         for f, s in BACKBONE_BLOCKS:
@@ -174,12 +183,12 @@ class TorchRef(object):
         x = crop_and_resize_t(Fm, boxes, bidx, ps, ps)
         for i in range(1, 5):
             n = "myolo_mask_conv%d" % i
-            x = _conv(x, P[n + "/kernel"], pad=(1, 1, 1, 1), bias=P[n + "/bias"])
             b = "myolo_mask_bn%d" % i
+            x = self._keep(b, _conv(x, P[n + "/kernel"], pad=(1, 1, 1, 1), bias=P[n + "/bias"]))
             x = torch.relu(_bn(x, P[b + "/gamma"], P[b + "/beta"], P[b + "/moving_mean"], P[b + "/moving_variance"],
                                train and i == 1))
         w = P["myolo_mask_deconv/kernel"].permute(3, 2, 0, 1)      # [Cin,Cout,kh,kw]
-        x = torch.relu(Fn.conv_transpose2d(x, w, bias=P["myolo_mask_deconv/bias"], stride=2))
+        x = torch.relu(self._keep("deconv/out", Fn.conv_transpose2d(x, w, bias=P["myolo_mask_deconv/bias"], stride=2)))
         z = _conv(x, P["myolo_mask/kernel"], bias=P["myolo_mask/bias"])
         return torch.sigmoid(z)                                    # [N,C,h,w]
 

@@ -222,81 +222,124 @@ def test_full_size_step_sparse_equals_dense_and_is_reproducible():
     assert float(d) < 1e-4, float(d)                                               # sparse == dense gradients
 
 
-def test_train_step_config2_matches_torch_ref():
+SAFE_BATCH_START = 1224      # tools/find_safe_config2_batch.py: every proposal's best IoU is >= 4.9e-3 away from the 0.5 threshold
+_CFG2 = {}
+
+
+def _config2_case():
+    """configs[1] case shared by the tests below: the pinned batch (SAFE_BATCH_START), the weights, and ONE step of the fp32
+    torch-CPU restatement with every BatchNorm input and the deconv output captured."""
+    if not _CFG2:
+        from myolo.config import make_config, ShapesConfig
+        from myolo.shapes import make_shapes_samples
+        from myolo.myolo_utils import BatchGenerator
+        from oracle import np_model
+        from oracle.torch_ref import TorchRef
+        torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+        cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], ALPHA=1.0, BATCH_SIZE=32)
+        P = np_model.init_params(cfg, seed=0, bias_scale=0.05)
+        ref = TorchRef(P, cfg, torch.float32, capture=True)
+        H, W = cfg.IMAGE_SHAPE[:2]
+        samples = make_shapes_samples(32, cfg, start_index=SAFE_BATCH_START)
+        batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
+        r = ref.train_step(batch)
+        prop = O.yolo_decode(r["yolo_output"], cfg.ANCHORS, cfg.GRID_W)
+        gtn = O.norm_boxes(batch[4], H, W)
+        margin = np.stack([np.abs(O.overlaps(prop[b], gtn[b]).max(1) - 0.5) for b in range(32)])
+        # the pinned batch must BE safe (a change of the generator or the initialiser would move it): fail, do not fall back
+        assert float(margin.min()) > 1e-3, "SAFE_BATCH_START no longer names a batch clear of the IoU threshold: rerun tools/find_safe_config2_batch.py"
+        _CFG2.update(cfg=cfg, P=P, batch=batch, r=r, cap=ref.cap)
+    return _CFG2
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
+
+
+@pytest.mark.parametrize("fp32_matmul", ["bf16x6", "native"])
+def test_train_step_config2_matches_torch_ref(fp32_matmul):
     """BASELINE.json configs[1] end to end: Shapes 224x224, batch 32, MobileNet alpha 1.0, N_BOX=3 (R=147) -- one whole
     training step of the HIP path against the fp32 torch-CPU restatement (oracle/torch_ref.py; model.py:86-242, 668-754,
-    787-941) on the same seeded batch and weights.
+    787-941) on the same seeded batch and weights, under both ways of forming the fp32 products (cfg.FP32_MATMUL).
+    The batch is pinned by index: all 4704 proposals sit >= 4.9e-3 from the IoU 0.5 threshold under the oracle's trunk, so
+    NOTHING here is conditional:
+      * the positive/negative partition and the class id of every ROI bit-exact;
       * losses within 1e-4, yolo_output / feature_map / ROIs within 1e-3 (max-norm, relative);
-      * the positive/negative partition and class ids of every ROI bit-exact wherever the oracle's IoU sits further from
-        the 0.5 threshold than fp32 noise (1e-4) -- with 4704 ROIs per batch a few can sit on the threshold, and the batch
-        with the fewest such ROIs out of a handful of seeded candidates is used; on ROIs that agree, the mask
-        probabilities hold 1e-3 where the ROIAlign sample grid is clear of the image border;
-      * gradients within the relative-L2 bound of the small-size test (ReLU branch flips, see
-        test_gradients_with_oracle_activation_masks_hold_maxnorm)."""
-    from myolo.config import make_config, ShapesConfig
+      * mask probabilities within 1e-3 on every ROI whose ROIAlign sample grid is clear of the image border (an
+        extrapolation test that flips on ~1e-3 px noise zeroes a whole sample row);
+      * gradients within the relative-L2 bound of the small-size test (ReLU branch flips; the max-norm bound with the branches
+        forced is the next test)."""
+    from myolo.config import make_config
     from myolo.model import MaskYOLO
-    from myolo.shapes import make_shapes_samples
-    from myolo.myolo_utils import BatchGenerator
-    from oracle import np_model
-    from oracle.torch_ref import TorchRef
-    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
-    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], ALPHA=1.0, BATCH_SIZE=32)
-    P = np_model.init_params(cfg, seed=0, bias_scale=0.05)
-    ref = TorchRef(P, cfg, torch.float32)
-    H, W = cfg.IMAGE_SHAPE[:2]
-    best = None
-    for cand in range(4):
-        samples = make_shapes_samples(32, cfg, start_index=1000 + 32 * cand)
-        batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
-        with torch.no_grad():
-            _, _, yo = ref.trunk(batch[0], True)
-        prop = O.yolo_decode(yo.numpy(), cfg.ANCHORS, cfg.GRID_W)
-        gtn = O.norm_boxes(batch[4], H, W)
-        margin = np.stack([np.abs(O.overlaps(prop[b], gtn[b]).max(1) - 0.5) for b in range(32)])     # [32, R]
-        unsafe = int((margin < 1e-4).sum())
-        if best is None or unsafe < best[0]:
-            best = (unsafe, batch, margin)
-        if unsafe == 0:
-            break
-    unsafe, batch, margin = best
-    r = ref.train_step(batch)
+    c = _config2_case()
+    cfg, P, batch, r = make_config(type(c["cfg"]), FP32_MATMUL=fp32_matmul), c["P"], c["batch"], c["r"]
     model = MaskYOLO(mode="training", config=cfg)
+    assert model.net.fp32_matmul == fp32_matmul
     model.load_state_dict(P)
     out = model.train_on_batch(batch, learning_rate=0.0)
     grads = model.net.grads_dict()
+    assert _rel(out["yolo_output"], r["yolo_output"]) < 1e-3
+    assert _rel(out["feature_map"], r["feature_map"]) < 1e-3
+    assert np.array_equal(out["target_class_ids"], r["target_class_ids"]), "partition / class ids differ on a batch clear of the IoU threshold"
+    assert (out["target_class_ids"] > 0).sum() >= 10
+    assert _rel(out["output_rois"], r["output_rois"]) < 1e-3
+    for k in ("yolo_sum_loss", "mask_loss", "loss"):
+        assert abs(out[k] - r[k]) <= 1e-4 * max(1.0, abs(r[k])), (k, out[k], r[k])
+    rb = O.roi_boxes_to_crop_order(r["output_rois"].reshape(-1, 4), cfg.ROI_BOX_ORDER)
+    fh = r["feature_map"].shape[1]
+    ok = np.ones(rb.shape[0], bool)
+    for lo, hi in ((rb[:, 0], rb[:, 2]), (rb[:, 1], rb[:, 3])):
+        cc = O._crop_coords(lo, hi, fh, cfg.MASK_POOL_SIZE)
+        ok &= np.minimum(np.abs(cc), np.abs(cc - (fh - 1))).min(1) > 2e-2
+    got = out["myolo_mask"].reshape((-1,) + out["myolo_mask"].shape[2:])
+    assert ok.sum() > 1000 and _rel(got[ok], r["myolo_mask"][ok]) < 1e-3
+    worst, wk = 0.0, None
+    for k, g in r["grads"].items():
+        if k == "myolo_mask_conv1/bias":
+            continue
+        e = float(np.linalg.norm(grads[k].astype(np.float64) - g) / max(1e-30, np.linalg.norm(g)))
+        if e > worst:
+            worst, wk = e, k
+    assert worst < 2e-2, (wk, worst)
 
-    def rel(a, b):
-        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-        return float(np.abs(a - b).max() / max(1e-30, np.abs(b).max()))
-    assert rel(out["yolo_output"], r["yolo_output"]) < 1e-3
-    assert rel(out["feature_map"], r["feature_map"]) < 1e-3
-    safe = margin >= 1e-4                                               # per proposal, in proposal order
-    # rois are positives-first per image (model.py:593): compare the SETS through the class ids of the safe proposals
-    same_part = np.array_equal(out["target_class_ids"], r["target_class_ids"])
-    if unsafe == 0:
-        assert same_part, "partition / class ids differ although every IoU is clear of the 0.5 threshold"
-    assert (out["target_class_ids"] > 0).sum() >= 1
-    n_diff = int((out["target_class_ids"] != r["target_class_ids"]).sum())
-    assert n_diff <= 2 * unsafe, (n_diff, unsafe)
-    if same_part:
-        assert rel(out["output_rois"], r["output_rois"]) < 1e-3
-        for k in ("yolo_sum_loss", "mask_loss", "loss"):
-            assert abs(out[k] - r[k]) <= 1e-4 * max(1.0, abs(r[k])), (k, out[k], r[k])
-        rb = O.roi_boxes_to_crop_order(r["output_rois"].reshape(-1, 4), cfg.ROI_BOX_ORDER)
-        fh = r["feature_map"].shape[1]
-        ok = np.ones(rb.shape[0], bool)
-        for lo, hi in ((rb[:, 0], rb[:, 2]), (rb[:, 1], rb[:, 3])):
-            c = O._crop_coords(lo, hi, fh, cfg.MASK_POOL_SIZE)
-            ok &= np.minimum(np.abs(c), np.abs(c - (fh - 1))).min(1) > 2e-2
-        got = out["myolo_mask"].reshape((-1,) + out["myolo_mask"].shape[2:])
-        assert ok.sum() > 1000 and rel(got[ok], r["myolo_mask"][ok]) < 1e-3
-        worst, wk = 0.0, None
-        for k, g in r["grads"].items():
-            if k == "myolo_mask_conv1/bias":
-                continue
-            e = float(np.linalg.norm(grads[k].astype(np.float64) - g) / max(1e-30, np.linalg.norm(g)))
-            if e > worst:
-                worst, wk = e, k
-        assert worst < 2e-2, (wk, worst)
-    else:
-        assert abs(out["yolo_sum_loss"] - r["yolo_sum_loss"]) <= 1e-4 * max(1.0, abs(r["yolo_sum_loss"]))
+
+def test_config2_gradients_with_oracle_activation_masks_hold_maxnorm():
+    """tests/test_gpu_step.py::test_gradients_with_oracle_activation_masks_hold_maxnorm at the FULL configs[1] size (VERDICT r2
+    item 4b): the GPU backward reads the oracle's BatchNorm inputs and deconv output (Net.tape_hook overwrites the saved tensors
+    between forward and backward), so both sides take the same ReLU / ReLU6 branches -- then EVERY gradient of the 224x224 / batch 32
+    step holds north_star's max-norm 1e-3 bound.  Dense mask-head backward (the path that keeps every pre-BN tensor)."""
+    from myolo.model import MaskYOLO
+    c = _config2_case()
+    cfg, P, batch, r, cap = c["cfg"], c["P"], c["batch"], c["r"], c["cap"]
+    model = MaskYOLO(mode="training", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+    net.sparse_mask_bwd = False
+    forced = []
+
+    def hook(n):
+        for name in list(n.tape):
+            if name in cap and isinstance(n.tape[name], tuple) and torch.is_tensor(n.tape[name][0]):
+                y = n.tape[name][0]
+                y.copy_(torch.from_numpy(cap[name].reshape(y.shape)))
+                forced.append(name)
+        d = n.tape["mask"][2]
+        d.copy_(torch.from_numpy(cap["deconv/out"].reshape(d.shape)))
+    net.tape_hook = hook
+    # ... and the same ROIs: the oracle's decoded proposals replace the GPU's (they agree to ~1e-6, but an ROIAlign sample row within
+    # that distance of the map's border is zeroed on one side only -- crop_and_resize's extrapolation test is one more hard branch)
+    prop = torch.from_numpy(O.yolo_decode(r["yolo_output"], cfg.ANCHORS, cfg.GRID_W))
+    net.proposals_hook = lambda proposals, db: proposals.copy_(prop.to(proposals.device).reshape(proposals.shape))
+    out = model.train_on_batch(batch, learning_rate=0.0)
+    grads = net.grads_dict()
+    assert len(forced) == 29 + 4, sorted(forced)
+    assert np.array_equal(out["target_class_ids"], r["target_class_ids"])
+    worst, wk = 0.0, None
+    for k, g in r["grads"].items():
+        if k == "myolo_mask_conv1/bias":
+            continue
+        e = _rel(grads[k], g)
+        if e > worst:
+            worst, wk = e, k
+    assert worst < 1e-3, (wk, worst)

@@ -79,8 +79,11 @@ def _make_case(base, size, alpha, B, seed=0, need_pos=2, min_margin=1e-3, min_ro
     raise RuntimeError("no batch with positive ROIs and safe decision margins found")
 
 
-def compare_step(cfg, P, batch, ref, verbose=False):
+def compare_step(cfg, P, batch, ref, verbose=False, fp32_matmul=None):
+    if fp32_matmul is not None:                  # the same case under the other way of forming the fp32 products (cfg.FP32_MATMUL)
+        cfg = make_config(type(cfg), FP32_MATMUL=fp32_matmul)
     model = MaskYOLO(mode="training", config=cfg)
+    assert fp32_matmul is None or model.net.fp32_matmul == fp32_matmul
     model.load_state_dict(P)
     out = model.train_on_batch(batch, learning_rate=0.0)
     grads = model.net.grads_dict()
@@ -117,19 +120,24 @@ def compare_step(cfg, P, batch, ref, verbose=False):
     return rows
 
 
-def test_train_step_config1_matches_oracle():
+FP32_MATMUL_MODES = ["bf16x6", "native"]         # both ways of forming the fp32 products run in every driver pass
+
+
+@pytest.mark.parametrize("fp32_matmul", FP32_MATMUL_MODES)
+def test_train_step_config1_matches_oracle(fp32_matmul):
     """BASELINE.json configs[0]: Shapes 128x128, 3 classes, batch 4, MobileNet alpha 0.5."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
-    rows = compare_step(cfg, P, batch, ref)
+    rows = compare_step(cfg, P, batch, ref, fp32_matmul=fp32_matmul)
     bad = [r for r in rows if r[1] > TOL]
     assert not bad, bad
 
 
-def test_train_step_head_config_nbox5():
+@pytest.mark.parametrize("fp32_matmul", FP32_MATMUL_MODES)
+def test_train_step_head_config_nbox5(fp32_matmul):
     """repository-HEAD head (N_BOX=5, config.py:28 anchors).  (128x128, batch 4: smaller cases leave
     <30 samples per channel in the deepest BatchNorms and fp32-vs-fp32 noise alone exceeds 1e-2.)"""
     cfg, P, batch, ref = make_case(ShapesHeadConfig, 128, 0.5, 4, seed=1, need_pos=1)
-    rows = compare_step(cfg, P, batch, ref)
+    rows = compare_step(cfg, P, batch, ref, fp32_matmul=fp32_matmul)
     bad = [r for r in rows if r[1] > TOL]
     assert not bad, bad
 

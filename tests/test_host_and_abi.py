@@ -115,10 +115,13 @@ def test_decode_one_yolo_output_and_unmold_mask():
 
 
 # ---------------------------------------------------------------- C-ABI boundary
-def _header_functions():
-    txt = open(os.path.join(ROOT, "include", "myolo_hip.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return re.findall(r"\b(?:int|size_t|const char\*)\s+(myolo_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S)
+def _header_functions(which=("myolo_hip.h", "myolo_hip_internal.h")):
+    out = []
+    for h in which:
+        txt = open(os.path.join(ROOT, "include", h)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out += re.findall(r"\b(?:int|size_t|const char\*)\s+(myolo_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S)
+    return out
 
 
 def test_library_exports_every_declared_symbol():
@@ -129,10 +132,14 @@ def test_library_exports_every_declared_symbol():
     names = [n for n, _ in decl]
     assert len(names) >= 35 and len(set(names)) == len(names)
     for n in names:
-        assert hasattr(lib, n), "symbol %s declared in include/myolo_hip.h is not exported" % n
+        assert hasattr(lib, n), "symbol %s declared in include/myolo_hip*.h is not exported" % n
     assert set(_ext.exported_symbols()) == set(names), set(_ext.exported_symbols()) ^ set(names)
     assert lib.myolo_version() >= 100
     assert isinstance(lib.myolo_last_error_string(), bytes)
+    # the operator API (what INTEGRATION.md documents) stays small and free of stage-level names
+    ops = [n for n, _ in _header_functions(("myolo_hip.h",))]
+    assert len(ops) <= 70, len(ops)
+    assert not [n for n in ops if "lazybn" in n or "_transform" in n or "rowsparse" in n or "_from_" in n], ops
 
 
 def test_ctypes_signatures_match_header_arity():

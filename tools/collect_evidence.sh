@@ -14,7 +14,7 @@ cp gpurun_out/prof_$TAG/${TAG}_bench_kernel_stats.csv gpurun_out/prof_$TAG/${TAG
 bash tools/profile_step.sh ${TAG}x6 --fp32-matmul bf16x6 > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}x6/${TAG}x6_bench_kernel_stats.csv gpurun_out/prof_${TAG}x6/${TAG}x6_bench_kernel_by_grid.csv gpurun_out/prof_${TAG}x6/${TAG}x6_timeline.txt $OUT/
 {
-  for k in wino_fwd wino63_fwd wino_bwd_data wino_bwd_weight conv3x3_fwd deconv_mask_fwd roialign_fwd roialign_bwd dw wino_fused_fwd; do
+  for k in wino_fwd wino63_fwd wino_bwd_data wino_bwd_weight conv3x3_fwd deconv_mask_fwd roialign_fwd roialign_bwd dw; do
     python tools/kbench.py $k --iters 10 2>&1 | grep -vE "amdgpu.ids|^$" | tail -16
   done
   echo "--- KBENCH_OPTIONS=wino_x6=1"

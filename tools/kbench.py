@@ -68,14 +68,6 @@ def main():
         ms = timeit(fn, a.iters)
         flop = 2.0 * M * C * 4 * C
         print("deconv_mask_bf16_fwd (ncls=%d) M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500 bf16 dense)" % (ncls, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0))
-    elif a.which == "wino_fused_fwd":
-        x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
-        wsw = torch.empty(X.wino_fused_ws_bytes(C, C), dtype=torch.uint8, device=dev)
-        fn = lambda: X.call("myolo_conv3x3_wino_fused_fwd", X.ptr(x), X.ptr(w), X.ptr(b), None, None, X.ptr(y), NR, ps, ps, C, C, 1, wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
-        ms = timeit(fn, a.iters)
-        flop = 2.0 * M * 9 * C * C
-        wfl = 2.0 * 576 * NR * C * C
-        print("wino_fused_fwd NR=%d: %.3f ms  %.1f direct-equivalent TFLOP/s; Winograd FLOPs (576 point-tiles/ROI) %.1f TFLOP/s = %.1f%% of 157.3" % (NR, ms, flop / ms / 1e9, wfl / ms / 1e9, wfl / ms / 1e9 / 1.573))
     elif a.which == "wino63_fwd":
         # the F(6,3)/F(4,3) tiling (csrc/wino63_kernels.hip): input transform -> one-launch multiply -> output transform
         x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
