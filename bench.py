@@ -183,14 +183,30 @@ class KernelTimer(object):
         return tot / max(1, steps), n // max(1, steps)
 
 
-def timed_steps(net, dbs, steps, lr, barrier):
+def timed_steps(net, dbs, steps, lr, barrier, per_step=None):
+    """K steps between two barriers (host wall clock = the reported time).  per_step (a list): filled with the K step durations in ms
+    from HIP events recorded on the compute stream at the step boundaries (no synchronisation inside the region)."""
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
     barrier()
     t0 = time.perf_counter()
     out = None
     for i in range(steps):
+        if evs:
+            evs[i].record()
         out = net.train_step(dbs[i % len(dbs)], lr)
+    if evs:
+        evs[steps].record()
     barrier()
-    return time.perf_counter() - t0, out
+    el = time.perf_counter() - t0
+    if evs:
+        per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
+    return el, out
+
+
+def percentiles(ms):
+    a = np.sort(np.asarray(ms, np.float64))
+    return {"p10": float(np.percentile(a, 10)), "p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)),
+            "min": float(a[0]), "max": float(a[-1]), "n": int(a.size), "source": "HIP events on the compute stream at the step boundaries, inside the timed region"}
 
 
 def bench_train(args, rank, world, local):
@@ -238,7 +254,10 @@ def bench_train(args, rank, world, local):
     dom_tags = {"mask_conv3x3_fwd", "wino_multiply"}
     net.timed_tags = set(dom_tags)
     net.timings = {}
-    elapsed, out = timed_steps(net, dbs, args.steps, args.lr, barrier)
+    step_ms = []
+    net.host_wait_s = 0.0
+    elapsed, out = timed_steps(net, dbs, args.steps, args.lr, barrier, per_step=step_ms)
+    npos_wait_ms = 1e3 * net.host_wait_s / max(1, args.steps)
     elapsed = maxr(elapsed)
     loss = float(out["yolo_terms"][0]) + float(out["mask_terms"][0])
     assert np.isfinite(loss), "non-finite loss in the timed region"
@@ -257,6 +276,7 @@ def bench_train(args, rank, world, local):
     kt = KernelTimer(net)
     dw_ms, _ = kt.total_ms_per_step("dw", ksteps)
     pw_ms, _ = kt.total_ms_per_step("pw", ksteps)
+    layer_ms = {tag: net.kernel_ms(tag)[0] for tag in list(net.timings) if tag[:2] in ("dw", "pw")}
     roi_ms, _ = net.kernel_ms("roialign_fwd")
     win_ms, win_n = net.kernel_ms("wino_in")
     woi_ms, woi_n = net.kernel_ms("wino_out_in")
@@ -279,10 +299,10 @@ def bench_train(args, rank, world, local):
             lambda: setattr(net, "sparse_mask_bwd", False), lambda: setattr(net, "sparse_mask_bwd", True),
             "mask-head backward on ALL ROIs (conv2-4 / deconv / myolo_mask dense): the structural zeros behind bn1 are not "
             "exploited; same gradients (tests/test_gpu_step.py::test_sparse_mask_backward_equals_dense)")
-        from myolo import _ext as Xo
-        other = "native" if net.fp32_matmul == "bf16x6" else "bf16x6"
-        variants["winograd_multiply_%s" % other] = run_variant(
-            lambda: Xo.set_option("wino_x6", 1 if other == "bf16x6" else 0), lambda: Xo.set_option("wino_x6", 0 if other == "bf16x6" else 1),
+        mine = net.fp32_matmul
+        other = "native" if mine == "bf16x6" else "bf16x6"
+        variants["fp32_products_%s" % other] = run_variant(
+            lambda: setattr(net, "fp32_matmul", other), lambda: setattr(net, "fp32_matmul", mine),
             "cfg.FP32_MATMUL='%s' instead of '%s': the Winograd multiply's fp32 products formed %s; identical fp32 inputs, outputs and "
             "accumulation, error against fp64 not larger than the native path's (tests/test_gpu_ops.py::test_wino_multiply_bf16x6_accuracy)"
             % (other, net.fp32_matmul, "from six exact bf16 piece products on the bf16 matrix pipe (csrc/wino_mm.hip)" if other == "bf16x6"
@@ -309,6 +329,35 @@ def bench_train(args, rank, world, local):
                 sweep["n_pos_%d" % k] = {"images_per_sec": v["value"], "ms_per_step": v["ms_per_step"]}
             variants["n_pos_sweep"] = sweep
 
+    extras = {}
+    if world == 1 and not args.no_extras:
+        from myolo import _ext as Xe
+        # (a) measured HBM copy bandwidth of a hand-written float4 kernel, beside the nominal peak
+        try:
+            extras["hbm_copy_measured_gbs"] = Xe.measure_hbm_copy_gbs(device=dev)
+        except Exception as e:
+            extras["hbm_copy_measured_gbs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # (b) what the three real gradient buckets cost as RCCL collectives on the comm stream while backward runs: a 1-rank
+        #     communicator through the C-ABI (launch + stream + kernel cost of the exchange, not the wire), and the step with it
+        try:
+            probe = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], always=True, backend="capi", timing=True)
+            probe.attach(net)
+            for i in range(2):
+                net.train_step(dbs[i % nb], args.lr)
+            probe.bucket_ms()                                    # drop the warm-up pairs
+            probe._ms = [[] for _ in probe._ms]
+            el, _ = timed_steps(net, dbs, args.steps, args.lr, barrier)
+            extras["comm_overlap_probe_ms"] = {
+                "bucket_allreduce_ms": probe.bucket_ms(), "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
+                "ms_per_step_with_probe": 1e3 * el / args.steps,
+                "note": "1-rank RCCL communicator (myolo_comm_* through the C-ABI): the three real buckets all-reduced on the comm stream "
+                        "as backward completes them [backbone, yolo head + feature_map, mask head]; cost of issuing the exchange, not of the wire"}
+            probe.close()
+        except Exception as e:
+            extras["comm_overlap_probe_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        finally:
+            net.on_bucket_ready, net.before_optimizer, net.grad_scale = reducer.bucket_ready, reducer.wait, reducer.grad_scale
+        extras["host_wait_on_n_pos_ms_per_step"] = npos_wait_ms
     if rank != 0:
         return None
     R = cfg.TRAIN_ROIS_PER_IMAGE
@@ -393,14 +442,23 @@ def bench_train(args, rank, world, local):
                 "depthwise": hbm_obj("dw_fwd_kernel, the 14 depthwise 3x3 layers of backbone + YOLO head (sum over the layers, one step)",
                                      dwb, dw_ms, note="SURVEY 8(d): activation in + out once, 20.97 MB/img at 224^2 alpha 1"),
                 "roialign": hbm_obj("ROIAlign forward (fused into conv1's Winograd input transform when CONV3X3_ALGO != direct)", roi_bytes, roi_ms,
-                                    note="SURVEY 8(d) bytes: the [B*R,14,14,256] crops + one read of the feature map; the fused kernel "
-                                         "writes the 36-plane Winograd image instead (2.9x those bytes), or nothing at all in the fused conv"),
+                                    note="SURVEY 8(d) bytes: the [B*R,14,14,256] crops + one read of the feature map; the fused kernel of the default "
+                                         "path writes conv1's Winograd image instead: %s" % (
+                                             "64 planes / 400 point-tiles per ROI = 2.04x those bytes" if c1_63 else "36 planes / 484 point-tiles per ROI = 2.47x those bytes"),
+                                    written_bytes=float(ptiles if not t63 else 400 * args.batch * R) * 256 * 4 if mul_n else roi_bytes,
+                                    achieved_on_written_bytes=(float(ptiles if not t63 else 400 * args.batch * R) * 256 * 4 / (roi_ms * 1e-3) / 1e9) if (mul_n and roi_ms > 0) else None),
                 "pointwise": {"kernel": "gemm_nn<PLAIN> 1x1 convs, the 14 pointwise layers (sum over the layers, one step)", "bound": "mfma+hbm",
                               "algorithmic_flop": pwf, "algorithmic_bytes": pwb, "avg_ms": pw_ms,
                               "achieved_tflops": pwf / (pw_ms * 1e-3) / 1e12 if pw_ms > 0 else 0.0,
                               "frac_of_fp32_mfma_peak": pwf / (pw_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if pw_ms > 0 else 0.0,
                               "achieved_gbs": pwb / (pw_ms * 1e-3) / 1e9 if pw_ms > 0 else 0.0,
                               "frac_of_hbm_peak": pwb / (pw_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pw_ms > 0 else 0.0}}
+    roofline["trunk_layers"] = trunk_layer_table(args.size, args.alpha, args.batch, layer_ms)
+    mf = [l for l in roofline["trunk_layers"] if l["layer"].startswith("pw") and l["roof"] == "mfma" and l["ms"] > 0]
+    if mf:
+        fl, ms_ = sum(l["flop"] for l in mf), sum(l["ms"] for l in mf)
+        roofline["pointwise"]["mfma_bound_layers"] = {"layers": [l["layer"] for l in mf], "flop": fl, "ms": ms_, "achieved_tflops": fl / (ms_ * 1e-3) / 1e12,
+                                                      "frac_of_fp32_mfma_peak": fl / (ms_ * 1e-3) / 1e12 / FP32_MFMA_PEAK}
     if mul_n and woi_n:
         vbytes = float(400 * args.batch * R if t63 else ptiles) * 256 * 4          # the timed boundary launches are all on the conv2-4 tiling
         roofline["hbm_stages"] = ([hbm_obj("wino_in_kernel (input transform: activation -> V)", float(M) * 256 * 4 + vbytes, win_ms)] if win_n else []) + [
@@ -415,7 +473,8 @@ def bench_train(args, rank, world, local):
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"winograd_tiles": net.wino_tiles, "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
+        "step_ms": percentiles(step_ms),
+        "config": {"winograd_tiles": net.wino_tiles, "fp32_products": net.fp32_matmul, "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
                                "(fwd+bwd+Adam%s); mask head FORWARD on %s ROIs; mask-head BACKWARD behind bn1 (conv2-4, deconv, myolo_mask) on "
                                "the positive ROIs only -- exact: bn2-4 are frozen and the loss reads positives only, so the other ROIs' "
                                "gradients are structural zeros (dense-backward time in variants.dense_mask_backward); " % (
@@ -436,6 +495,7 @@ def bench_train(args, rank, world, local):
                        "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
                        "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
                                "on the comm stream as soon as backward completes it"}
+    res.update(extras)
     if variants:
         res["variants"] = variants
     if args.cpu_images > 0 and world == 1:
@@ -463,6 +523,33 @@ def dw_layers(size, alpha):
 
 def dw_bytes(size, alpha, batch):
     return float(sum(batch * (h * h + (h // s) * (h // s)) * c * 4 for h, c, s in dw_layers(size, alpha)))
+
+
+def trunk_layer_table(size, alpha, batch, layer_ms):
+    """one row per depthwise / pointwise layer: SURVEY 8(d) bytes (in + out once, + weights) and flops, the HIP-event time of its
+    forward launch in the step (second pass), and the roof that bounds it: arithmetic intensity against the machine balance
+    157.3 TFLOP/s / 8 TB/s = 19.7 flop/B."""
+    outs = [int(f * alpha) for f in (64, 64, 128, 256, 256, 512, 512, 512, 512, 512, 512, 512, 1024, 1024)]
+    rows = []
+    for i, ((h, c, s), co) in enumerate(zip(dw_layers(size, alpha), outs), 1):
+        ho = h // s
+        for kind in ("dw", "pw"):
+            if kind == "dw":
+                by = batch * (h * h + ho * ho) * c * 4.0 + 9 * c * 4.0
+                fl = 2.0 * 9 * batch * ho * ho * c
+                shape = "%dx%dx%d s%d" % (h, h, c, s)
+            else:
+                m = batch * ho * ho
+                by = 4.0 * (m * c + m * co + c * co)
+                fl = 2.0 * m * c * co
+                shape = "M=%d %d->%d" % (m, c, co)
+            ms = float(layer_ms.get("%s%d_fwd" % (kind, i), 0.0))
+            roof = "mfma" if fl / by > FP32_MFMA_PEAK * 1e12 / (HBM_PEAK_GBS * 1e9) else "hbm"
+            gbs = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            tf = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            rows.append({"layer": "%s%d" % (kind, i), "shape": shape, "bytes": by, "flop": fl, "ms": ms, "gbs": gbs, "tflops": tf, "roof": roof,
+                         "frac": (tf / FP32_MFMA_PEAK) if roof == "mfma" else (gbs / HBM_PEAK_GBS)})
+    return rows
 
 
 def pw_flops_bytes(size, alpha, batch):
@@ -561,11 +648,12 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--mask-head-rois", choices=["all", "positives"], default="all",
                     help="cfg.TRAIN_MASK_HEAD_ROIS of the run that produces `value` (default: all ROIs, as the reference graph)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra objects of the default line (HBM copy bandwidth, comm probe, N_BOX=5 and Rice-416 bf16 runs)")
     ap.add_argument("--no-variant", action="store_true", help="skip the extra timed runs (dense backward, positives-only forward, n_pos sweep)")
     ap.add_argument("--conv3x3", choices=["auto", "direct", "winograd"], default="auto", help="cfg.CONV3X3_ALGO")
     ap.add_argument("--comm", choices=["torch", "capi"], default="torch",
                     help="N>1: gradient all-reduce through torch.distributed (nccl = RCCL) or through the library's own myolo_comm_* entry points")
-    ap.add_argument("--fp32-matmul", choices=["native", "bf16x6"], default="native", help="cfg.FP32_MATMUL (how the Winograd multiply forms its fp32 products)")
+    ap.add_argument("--fp32-matmul", choices=["native", "bf16x6"], default="bf16x6", help="cfg.FP32_MATMUL (how the Winograd multiply forms its fp32 products)")
     ap.add_argument("--wino-tiles", choices=["f43", "f63"], default=None, help="cfg.WINOGRAD_TILES (default: the config's)")
     ap.add_argument("--force-pos", type=int, default=0, metavar="K",
                     help="replace the first K proposals of every image by a ground-truth box for the WHOLE run (the n_pos sweep's hook): the step "
@@ -596,6 +684,30 @@ def main():
         res = bench_infer(args) if rank == 0 else None
     else:
         res = bench_train(args, rank, world, local)
+        if world == 1 and not args.no_extras and args.nbox == 3 and args.size == 224:
+            # ONE driver command, all single-GPU configurations: after the timed region of the headline,
+            # SURVEY 8(d)'s secondary head (N_BOX=5, R=245) and BASELINE configs[3] (Rice 416 bf16 inference), each its own object
+            import copy
+            torch.cuda.empty_cache()
+            try:
+                a5 = copy.copy(args)
+                a5.nbox, a5.no_variant, a5.no_extras, a5.cpu_images, a5.warmup = 5, True, True, 0, 3
+                r5 = bench_train(a5, rank, world, local)
+                res["secondary_nbox5"] = {k: r5[k] for k in ("metric", "value", "unit", "ms_per_step", "step_ms")}
+                res["secondary_nbox5"].update(workload="the same step with the repository-HEAD head: N_BOX=5, config.py:28 anchors, R=245 ROIs/img (SURVEY 8(d) 'report both')",
+                                              n_pos_mean=r5["config"]["n_pos_mean"], dominant_kernel_frac=r5["roofline"]["frac"],
+                                              dominant_kernel_ms=r5["roofline"]["avg_launch_ms"])
+            except Exception as e:
+                res["secondary_nbox5"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+            try:
+                ai = copy.copy(args)
+                ai.batch, ai.batch_given, ai.cpu_images, ai.steps, ai.warmup = 4, True, 0, max(20, args.steps), 3
+                ri = bench_infer(ai)
+                res["inference_rice416_bf16"] = {k: ri[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline")}
+                res["inference_rice416_bf16"]["workload"] = ri["config"]["workload"]
+            except Exception as e:
+                res["inference_rice416_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -136,6 +136,11 @@ size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout);
 int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
                                  const float* ka, const float* kb, int act, const float* w, float* dx, int N, int Cin, int Cout, void* ws,
                                  size_t ws_bytes, void* stream);
+/* ---- HBM stream-copy microbenchmark (the measured copy bandwidth printed beside the nominal 8 TB/s): dst = src over
+ * nbytes (multiple of 16), hand-written float4 kernel, 4 loads in flight per thread.  variant 0 default cache policy, 1 non-temporal
+ * stores, 2 non-temporal loads + stores, 3 read only, 4 write only; blocks <= 0: 8 workgroups per CU. ---- */
+int myolo_stream_copy(const void* src, void* dst, size_t nbytes, int variant, int blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1322,6 +1322,41 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
         p[i] = p[i] - lr_t * mi / (sqrtf(vi) + eps);
     }
 }
+// ---------------------------------------------------------------------------------------
+// HBM stream-copy microbenchmark ("verify on the box with a stream-copy microbench and report the measured copy
+// bandwidth alongside the nominal peak").  dst[i] = src[i] over float4 elements; each thread keeps UNR independent 16-byte loads in
+// flight; variant 0: default cache policy, 1: non-temporal stores, 2: non-temporal loads and stores, 3: read only (sum into one
+// store per thread: the read-side ceiling), 4: write only.
+// ---------------------------------------------------------------------------------------
+template <int VARIANT>
+__global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4n* __restrict__ src, f32x4n* __restrict__ dst, long long n4)
+{
+    constexpr int UNR = 4;
+    const long long stride = (long long)gridDim.x * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    f32x4n acc = {0.f, 0.f, 0.f, 0.f};
+    for (; i + (UNR - 1) * stride < n4; i += UNR * stride) {
+        f32x4n v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (VARIANT == 4) v[u] = acc;
+            else if (VARIANT == 2) v[u] = __builtin_nontemporal_load(src + i + u * stride);
+            else v[u] = src[i + u * stride];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (VARIANT == 3) acc += v[u];
+            else if (VARIANT == 1 || VARIANT == 2) __builtin_nontemporal_store(v[u], dst + i + u * stride);
+            else dst[i + u * stride] = v[u];
+        }
+    }
+    for (; i < n4; i += stride) {
+        if (VARIANT == 3) acc += src[i];
+        else dst[i] = (VARIANT == 4) ? acc : src[i];
+    }
+    if (VARIANT == 3 && acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[0] = acc;      // keeps the loads alive; practically never taken
+}
+
 __global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, long long n)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1740,6 +1775,27 @@ int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n, flo
     MYOLO_REQUIRE(p && g && m && v && n > 0, "adam_step: bad arguments");
     hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long long)n, lr_t, beta1,
                        beta2, eps, grad_scale);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_stream_copy(const void* src, void* dst, size_t nbytes, int variant, int blocks, void* stream)
+{
+    MYOLO_REQUIRE(src && dst && nbytes >= 16 && (nbytes & 15) == 0 && (((uintptr_t)src | (uintptr_t)dst) & 15) == 0 && variant >= 0 && variant <= 4,
+                  "stream_copy: needs 16-byte aligned buffers, a multiple of 16 bytes and variant 0..4");
+    const long long n4 = (long long)(nbytes / 16);
+    if (blocks <= 0) blocks = 256 * 8;           // 8 workgroups of 256 threads per CU
+    const dim3 g((unsigned)blocks), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    const f32x4n* sp = (const f32x4n*)src;
+    f32x4n* dp = (f32x4n*)dst;
+    switch (variant) {
+    case 0: hipLaunchKernelGGL(stream_copy_kernel<0>, g, b, 0, s, sp, dp, n4); break;
+    case 1: hipLaunchKernelGGL(stream_copy_kernel<1>, g, b, 0, s, sp, dp, n4); break;
+    case 2: hipLaunchKernelGGL(stream_copy_kernel<2>, g, b, 0, s, sp, dp, n4); break;
+    case 3: hipLaunchKernelGGL(stream_copy_kernel<3>, g, b, 0, s, sp, dp, n4); break;
+    default: hipLaunchKernelGGL(stream_copy_kernel<4>, g, b, 0, s, sp, dp, n4); break;
+    }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

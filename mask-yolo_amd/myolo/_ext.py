@@ -94,6 +94,7 @@ SIGS = {
     "myolo_mask_bce": [P, P, P, F, P, P, I, I, I, I, P, Z, P],
     "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
     "myolo_matmul_f32": [P, P, P, L, I, I, I, I, P, Z, P],
+    "myolo_stream_copy": [P, P, Z, I, I, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],
     "myolo_set_option": [ctypes.c_char_p, I],
@@ -203,6 +204,26 @@ class option(object):
     def __exit__(self, *exc):
         set_option(self.name, self.old)
         return False
+
+
+def measure_hbm_copy_gbs(nbytes=2 << 30, iters=5, device="cuda:0"):
+    """{variant name: read+write GB/s} of the hand-written float4 stream-copy kernel (myolo_stream_copy) on buffers far larger than
+    the 256 MiB Infinity Cache, timed with HIP events on the current stream.  'read_only' / 'write_only' count one direction."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    src.zero_()
+    dst.zero_()
+    out = {}
+    for name, variant, factor in (("float4", 0, 2.0), ("float4_nt_store", 1, 2.0), ("float4_nt_load_store", 2, 2.0), ("read_only", 3, 1.0), ("write_only", 4, 1.0)):
+        call("myolo_stream_copy", src.data_ptr(), dst.data_ptr(), nbytes, variant, 0, stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            call("myolo_stream_copy", src.data_ptr(), dst.data_ptr(), nbytes, variant, 0, stream())
+        e1.record()
+        torch.cuda.synchronize()
+        out[name] = factor * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    return out
 
 
 def workspace_bytes(rows, cin, cout):

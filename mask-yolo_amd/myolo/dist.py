@@ -83,10 +83,10 @@ class GradReducer(object):
         self.active = self.world > 1 or (always and (dist.is_initialized() or backend == "capi"))
         if self.cuda and self.active:
             self.comm_stream = torch.cuda.Stream(device=flat_grad.device)
-            self.done = [torch.cuda.Event(enable_timing=self.timing) for _ in self.ranges]
-            self.started = [torch.cuda.Event(enable_timing=True) for _ in self.ranges] if self.timing else None
+            self.done = [torch.cuda.Event() for _ in self.ranges]
+            # timing: one (start, end) event pair per collective, kept until bucket_ms() reads them -- nothing synchronises inside a step
+            self._pairs = [[] for _ in self.ranges]
             self._ms = [[] for _ in self.ranges]
-            self._issued = [False] * len(self.ranges)
         if backend == "capi" and self.active:
             if not self.cuda:
                 raise ValueError("backend 'capi' (RCCL through the C-ABI) needs device tensors")
@@ -131,10 +131,9 @@ class GradReducer(object):
 
     def _collect(self):
         torch.cuda.synchronize(self.flat.device)
-        for i, was in enumerate(self._issued):
-            if was:
-                self._ms[i].append(self.started[i].elapsed_time(self.done[i]))
-                self._issued[i] = False
+        for i, pairs in enumerate(self._pairs):
+            self._ms[i] += [a.elapsed_time(b) for a, b in pairs]
+            del pairs[:]
 
     def close(self):
         """destroy the C-ABI RCCL communicator (idempotent; also run from __del__ so a dropped reducer does not leak it)."""
@@ -162,20 +161,22 @@ class GradReducer(object):
         if self.cuda:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream())
-            if self.timing and self._issued[i]:
-                self._collect()                      # the previous step's pair of this bucket, before its events are reused
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
                 if self.timing:
-                    self.started[i].record(self.comm_stream)
+                    if len(self._pairs[i]) >= 512:           # nobody is reading: keep the most recent ones
+                        del self._pairs[i][:256]
+                    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    t0.record(self.comm_stream)
                 if self.backend == "capi":
                     from . import _ext as X
                     X.call("myolo_allreduce_sum_f32", view.data_ptr(), hi - lo, self.comm, self.comm_stream.cuda_stream)
                 else:
                     dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                self.done[i].record(self.comm_stream)
                 if self.timing:
-                    self._issued[i] = True
+                    t1.record(self.comm_stream)
+                    self._pairs[i].append((t0, t1))
+                self.done[i].record(self.comm_stream)
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -12,6 +12,8 @@ yolo_branch_graph :249-278; feature_map :848; DecodeYOLOLayer :1442-1473; Detect
 :605-661; build_mask_graph :668-715; yolo_custom_loss :86-242; myolo_mask_loss_graph :718-754;
 compile :1062-1094 (loss sum + Adam).
 """
+import time
+
 import numpy as np
 import torch
 
@@ -202,6 +204,7 @@ class Net(object):
         self._bind_cache = {}
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
         self.timings = {}                 # tag -> [(start_event, end_event), ...]
+        self.host_wait_s = 0.0            # wall time the host spent blocked on the n_pos copy (bench.py reports it per step)
         self.load_state_dict(init_state_dict(cfg, seed))
 
     def _activate(self):
@@ -883,7 +886,9 @@ class Net(object):
     def _positive_index(self, B, R):
         """(NP, idx_d, inv_d): flat ROI indices of the positives (the first n_pos rows of each image,
         model.py:593) and the inverse map, from the async copy started by _start_npos_copy."""
-        self._npos_ready.synchronize()
+        t0 = time.perf_counter()
+        self._npos_ready.synchronize()          # the step's one host wait: the per-image positive counts (32 ints) from mid-forward
+        self.host_wait_s += time.perf_counter() - t0
         npos_h = self._npos_pinned.numpy()
         pos = np.concatenate([np.arange(b * R, b * R + int(npos_h[b]), dtype=np.int32) for b in range(B)]) if B else np.zeros(0, np.int32)
         NP = int(pos.shape[0])

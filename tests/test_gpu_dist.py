@@ -1,11 +1,13 @@
-"""Data-parallel step on real kernels: two processes share cuda:0, rendezvous over gloo (it accepts
+"""Data-parallel step on real kernels: 2 / 4 / 8 processes share cuda:0, rendezvous over gloo (it accepts
 device tensors), each runs the REAL engine (myolo.engine.Net) on its own shard with the bucketed, overlapped GradReducer.
-  * the all-reduced, 1/world-scaled gradient equals the mean of the two single-rank gradients (<= 1e-5 relative);
+  * the all-reduced, 1/world-scaled gradient equals the mean of the `world` single-rank gradients (<= 1e-5 relative) -- SURVEY
+    8(e)'s "8-rank averaged gradient == mean of 8 single-GPU gradients on the same shards";
   * after Adam every rank holds bit-identical weights;
   * with frozen layers (set_trainable / the yolo_trainable=False recipe) the frozen weights stay bit-identical -- the
     reducer is joined before the freeze mask is applied (round-1 advisor finding).
-RCCL itself needs one GPU per rank; on this 1-GPU box it is exercised as a 1-rank communicator through the C-ABI
-(myolo_comm_*), which checks the dlopen'ed librccl, the stream plumbing and the timing instrumentation."""
+RCCL itself needs one GPU per rank; on a 1-GPU box it is exercised as a 1-rank communicator through the C-ABI
+(myolo_comm_*), which checks the dlopen'ed librccl, the stream plumbing and the timing instrumentation; on a box with >= 2 GPUs
+test_two_rank_step_over_rccl runs the same parity check over real RCCL, through torch.distributed (nccl) and through the C-ABI."""
 import os
 import socket
 
@@ -24,7 +26,7 @@ def _free_port():
     return p
 
 
-def _case():
+def _case(world=2):
     from myolo.config import make_config, ShapesConfig
     from myolo.shapes import make_shapes_samples
     from myolo.myolo_utils import BatchGenerator
@@ -32,32 +34,41 @@ def _case():
     cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4)
     P = init_state_dict(cfg, seed=5)
     batches = []
-    for r in range(2):
+    for r in range(world):
         samples = make_shapes_samples(4, cfg, start_index=40 + 4 * r)
         batches.append(BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0][0])
     return cfg, P, batches
 
 
-def _worker(rank, world, port, q, freeze):
+def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch"):
     import torch.distributed as dist
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    dev = "cuda:%d" % rank if backend == "nccl" else "cuda:0"       # RCCL: one GPU per rank; gloo: every rank on cuda:0
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(dev))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from myolo.model import MaskYOLO
         from myolo.dist import GradReducer
-        cfg, P, batches = _case()
-        # ---- single-rank gradients of BOTH shards (no communication) -> their mean is the expected exchanged gradient
-        solo = MaskYOLO(mode="training", config=cfg, device="cuda:0")
-        local = []
+        cfg, P, batches = _case(world)
+        # ---- single-rank gradients of EVERY shard (no communication) -> their mean is the expected exchanged gradient
+        solo = MaskYOLO(mode="training", config=cfg, device=dev)
+        expect = None
         for b in batches:
             solo.load_state_dict(P)
             solo.net.forward_backward(solo.net.to_device_batch(b))
-            local.append(solo.net.flat_g.clone())
-        expect = (local[0] + local[1]) * 0.5
+            solo.net.join_conv1_wgrad()
+            torch.cuda.synchronize()
+            expect = solo.net.flat_g.double() if expect is None else expect + solo.net.flat_g.double()
+        expect = (expect / world).float()
+        del solo
         # ---- the data-parallel step: own shard, bucketed overlapped all-reduce, 1/world inside Adam
-        model = MaskYOLO(mode="training", config=cfg, device="cuda:0")
+        model = MaskYOLO(mode="training", config=cfg, device=dev)
         model.load_state_dict(P)
-        model._reducer = GradReducer(model.net.flat_g, model.net.bucket_ranges, timing=True).attach(model.net)
+        model._reducer = GradReducer(model.net.flat_g, model.net.bucket_ranges, timing=True, backend=reducer).attach(model.net)
         assert model._reducer.world == world and model._reducer.ranks_seen() == world
         if freeze:
             model.set_trainable(r"(myolo_mask.*)|(feature_map)|(conv_23)|(conv_.w_1[0-4].*)")   # the mask side has no gradient when a random-init batch has no positive ROI
@@ -74,8 +85,13 @@ def _worker(rank, world, port, q, freeze):
         else:
             err = float(((got - expect).abs().max() / expect.abs().max()).item())
         after = model.net.flat_p.clone()
-        gathered = [torch.zeros(after.numel()) for _ in range(world)]
-        dist.all_gather(gathered, after.cpu())
+        if backend == "nccl":
+            gathered = [torch.zeros_like(after) for _ in range(world)]
+            dist.all_gather(gathered, after)
+            gathered = [t.cpu() for t in gathered]
+        else:
+            gathered = [torch.zeros(after.numel()) for _ in range(world)]
+            dist.all_gather(gathered, after.cpu())
         same = all(torch.equal(gathered[0], t) for t in gathered)
         frozen_ok = "ok"
         if freeze:
@@ -86,29 +102,45 @@ def _worker(rank, world, port, q, freeze):
                 frozen_ok = "trainable weights did not move"
         ms = model._reducer.bucket_ms()
         q.put((rank, err, same, frozen_ok, str(ms) if not (ms is not None and len(ms) == 3 and all(v >= 0 for v in ms)) else "ok"))
+        if model._reducer.backend == "capi":
+            model._reducer.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("freeze", [False, True])
-def test_two_rank_step_real_engine_gloo_on_one_gpu(freeze):
+def _run_ranks(world, freeze, backend="gloo", reducer="torch"):
     import torch.multiprocessing as mp
-    world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, freeze)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, freeze, backend, reducer)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in range(world))
+    res = sorted(q.get(timeout=900) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
+    assert [r[0] for r in res] == list(range(world))
     for rank, err, same, frozen_ok, timed in res:
         assert err < 1e-5, (rank, err)                # averaged gradient == mean of the single-rank gradients
         assert same, "ranks hold different weights after Adam"
         assert frozen_ok == "ok", frozen_ok
         assert timed == "ok", timed
+
+
+@pytest.mark.parametrize("world,freeze", [(2, False), (2, True), (4, False), (8, False)])
+def test_n_rank_step_real_engine_gloo_on_one_gpu(world, freeze):
+    """SURVEY 8(e)'s parity test as worded, for 2 / 4 / 8 ranks (the ranks share the one GPU of the box; the transport is gloo)."""
+    _run_ranks(world, freeze)
+
+
+@pytest.mark.parametrize("reducer", ["torch", "capi"])
+def test_two_rank_step_over_rccl(reducer):
+    """The same check over real RCCL, one GPU per rank: through torch.distributed's nccl backend and through the library's own
+    myolo_comm_* entry points.  Needs >= 2 visible GPUs (the driver's 1-GPU test box skips it; an 8-GPU node runs it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL has one device per rank)")
+    _run_ranks(2, False, backend="nccl", reducer=reducer)
 
 
 def test_rccl_through_the_c_abi_one_rank():
