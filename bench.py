@@ -357,7 +357,10 @@ def bench_train(args, rank, world, local):
             extras["comm_overlap_probe_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             net.on_bucket_ready, net.before_optimizer, net.grad_scale = reducer.bucket_ready, reducer.wait, reducer.grad_scale
-        extras["host_wait_on_n_pos_ms_per_step"] = npos_wait_ms
+        extras["host_wait_on_n_pos_ms_per_step"] = {
+            "value": npos_wait_ms, "note": "wall time the HOST thread is blocked on the per-image positive counts (the step's one device-to-host "
+            "read, issued mid-forward on a copy stream): the host runs a whole step ahead of the GPU, so this is host idle time while the GPU "
+            "drains its queue -- the GPU itself never waits for it (kernel time == wall time, profiles/r3_timeline.txt)"}
     if rank != 0:
         return None
     R = cfg.TRAIN_ROIS_PER_IMAGE
@@ -668,6 +671,12 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         relaunch_under_torchrun(args.gpus)
 
+    # stdout carries exactly ONE line (the JSON): everything else any library prints to file descriptor 1 (RCCL's version banner at
+    # communicator creation, for one) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     from myolo import dist as mdist
     rank, world, local = mdist.init_from_env()
     if world != args.gpus:
@@ -709,7 +718,8 @@ def main():
             except Exception as e:
                 res["inference_rice416_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -136,6 +136,31 @@ size_t myolo_wino63_bwd_data_ws_bytes(int N, int Cin, int Cout);
 int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, const int32_t* inv, const float* scale, const float* shift,
                                  const float* ka, const float* kb, int act, const float* w, float* dx, int N, int Cin, int Cout, void* ws,
                                  size_t ws_bytes, void* stream);
+/* ---- training-mode BatchNorm fusion of the trunk (model.py:42-79, 249-278 with every BatchNormalization on batch statistics):
+ * "*_bnstats_fwd" = the conv AND the batch statistics of its output (mean, biased variance, folded scale / shift, Keras moving averages:
+ * exactly what myolo_bn_stats produces) -- the statistics are reduced from partial sums the conv kernel leaves in its epilogue, so the
+ * output is not re-read; "in_scale / in_shift / in_act" = the PRODUCING layer's BatchNorm apply + activation, performed on the load of
+ * its pre-BN output, so the normalised activation is never written (NULL: the input is used as it is).  The "*_bwd_weight_affine_in"
+ * gradients re-normalise the same pre-BN tensor on load.  Results equal the unfused sequences up to fp32 summation order. ---- */
+size_t myolo_conv3x3s2_c3_bnstats_ws_bytes(int N, int H, int W, int Cout);
+int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, const float* gamma, const float* beta, float* mean, float* var,
+                                   float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout,
+                                   void* ws, size_t ws_bytes, void* stream);
+size_t myolo_dwconv3x3_bnstats_ws_bytes(int N, int H, int W, int C, int stride);
+int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
+                                const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
+                                float* moving_mean, float* moving_var, int N, int H, int W, int C, int stride,
+                                void* ws, size_t ws_bytes, void* stream);
+int myolo_dwconv3x3_bwd_weight_affine_in(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
+                                         int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
+int    myolo_pwconv1x1_bnstats_ok(int Cin, int Cout);
+size_t myolo_pwconv1x1_bnstats_ws_bytes(int64_t M, int Cin, int Cout);
+int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
+                                const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
+                                float* moving_mean, float* moving_var, int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+int myolo_pwconv1x1_bwd_weight_affine_in(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
+                                         int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- HBM stream-copy microbenchmark (the measured copy bandwidth printed beside the nominal 8 TB/s): dst = src over
  * nbytes (multiple of 16), hand-written float4 kernel, 4 loads in flight per thread.  variant 0 default cache policy, 1 non-temporal
  * stores, 2 non-temporal loads + stores, 3 read only, 4 write only; blocks <= 0: 8 workgroups per CU. ---- */

@@ -50,6 +50,11 @@ struct GemmArgs {
     int batch;               // TN split partial layout [split][batch][K*N]
     const float* w2;         // EP_DECONV_MASK: the 1x1 mask conv's kernel [Co][ncls]
     int ncls;                // EP_DECONV_MASK: classes (<= 4); partial logits go to `part` [slab][4*M][ncls]
+    // training-mode BatchNorm fusion of the pointwise convs (AM_PLAIN; model.py:68-77 / 256-268 on batch statistics):
+    const float* a_scale;    // NN: A := act(A * a_scale[k] + a_shift[k]) on load (the producing layer's BatchNorm + activation, never written);
+    const float* a_shift;    // TN: the same per column ka of A (the weight gradient's x operand)
+    int a_act;
+    double* stat;            // NN, EP_PLAIN, ksplits == 1: per row-tile partial sums of the OUTPUT columns, [M tiles][2][N] doubles (sum, sum of squares)
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -528,11 +533,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         else { const int per_tap = p.Cc / BK; tap = kt_begin / per_tap; c0 = (kt_begin - tap * per_tap) * BK; }
     }
     float4 ra[2], rb[NB];
+    float4 rsc = make_float4(1.f, 1.f, 1.f, 1.f), rsh = make_float4(0.f, 0.f, 0.f, 0.f);     // AM_PLAIN prologue: this k tile's per-k affine
 
     auto gload = [&]() {
         if (AMODE == AM_PLAIN) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) ra[i] = bufld4(ra_desc, avalid[i] ? arow[i] + (unsigned)c0 * 4u : OOB_OFF);
+            if (p.a_scale) { rsc = ld4(p.a_scale + c0 + akq); rsh = ld4(p.a_shift + c0 + akq); }
         } else if (AMODE == AM_CONV3) {
             const int ty = (tap * 11) >> 5, tx = tap - ty * 3;          // tap/3 for tap < 9
             const int shift = ((ty - 1) * p.W + (tx - 1)) * p.Cc + c0;   // elements
@@ -567,6 +574,13 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         }
     };
     auto sstore = [&](int buf) {
+        if (AMODE == AM_PLAIN && p.a_scale) {          // (rows beyond M become act(shift): they are neither stored nor counted)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ra[i].x = gemm_act(fmaf(ra[i].x, rsc.x, rsh.x), p.a_act); ra[i].y = gemm_act(fmaf(ra[i].y, rsc.y, rsh.y), p.a_act);
+                ra[i].z = gemm_act(fmaf(ra[i].z, rsc.z, rsh.z), p.a_act); ra[i].w = gemm_act(fmaf(ra[i].w, rsc.w, rsh.w), p.a_act);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             As[buf][akq + 0][ar + 64 * i] = ra[i].x;
@@ -706,6 +720,41 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_fast(GemmArgs p)
         col_affine(p, colc, cs[u], ct[u]);
     }
     const int act = p.act;
+    if constexpr (AMODE == AM_PLAIN && EPI == EP_PLAIN) {
+        if (p.stat) {
+            // column sums of what this tile writes (bias included, before any epilogue affine): lane -> its 32 row slots, then the
+            // other half-wave (same columns, other rows), then the two waves that share the columns through LDS (free after the k
+            // loop); one row of partials per row tile, summed later in a fixed order by colreduce_finish: bit-reproducible
+            float s1[WNT], s2[WNT];
+#pragma unroll
+            for (int u = 0; u < WNT; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= p.M) continue;
+#pragma unroll
+                    for (int u = 0; u < WNT; ++u) { const float v = acc[t][u][r] + cb[u]; s1[u] += v; s2[u] = fmaf(v, v, s2[u]); }
+                }
+            float* sred = &Bs[0][0][0];               // [2 (wm)][2 (sum, sumsq)][BN_]
+#pragma unroll
+            for (int u = 0; u < WNT; ++u) {
+                s1[u] += __shfl_xor(s1[u], 32, 64);
+                s2[u] += __shfl_xor(s2[u], 32, 64);
+                if (half == 0) {
+                    sred[(wm * 2 + 0) * BN_ + wn * 32 * WNT + u * 32 + l31] = s1[u];
+                    sred[(wm * 2 + 1) * BN_ + wn * 32 * WNT + u * 32 + l31] = s2[u];
+                }
+            }
+            __syncthreads();
+            if (tid < 2 * BN_) {
+                const int v = tid / BN_, cc = tid - v * BN_;
+                if (n0 + cc < p.N)
+                    p.stat[((m0 / BM) * 2 + v) * p.N + n0 + cc] = (double)sred[(0 * 2 + v) * BN_ + cc] + (double)sred[(1 * 2 + v) * BN_ + cc];
+            }
+        }
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -815,10 +864,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     float4 ra[2], rb[2];
+    bool rav[2] = {false, false};
+    float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AMODE == AM_PLAIN && p.a_scale && ka_ok) { tsc = ld4(p.a_scale + ka); tsh = ld4(p.a_shift + ka); }
     auto gload = [&]() {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const bool mv = mrow[i] < me;
+            rav[i] = mv && ka_ok;
             unsigned aoff = OOB_OFF;
             if (AMODE == AM_PLAIN) {
                 if (mv && ka_ok) aoff = alin[i];
@@ -844,6 +897,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
         }
     };
     auto sstore = [&](int buf) {
+        if (AMODE == AM_PLAIN && p.a_scale) {          // x := act(x * scale + shift) for the rows that exist (padding rows stay 0)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                if (rav[i]) {
+                    ra[i].x = gemm_act(fmaf(ra[i].x, tsc.x, tsh.x), p.a_act); ra[i].y = gemm_act(fmaf(ra[i].y, tsc.y, tsh.y), p.a_act);
+                    ra[i].z = gemm_act(fmaf(ra[i].z, tsc.z, tsh.z), p.a_act); ra[i].w = gemm_act(fmaf(ra[i].w, tsc.w, tsh.w), p.a_act);
+                }
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<float4*>(&As[buf][lr + 8 * i][c4]) = ra[i];
@@ -907,7 +968,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_fast(GemmArgs p)
 // ------------------------------------------------------------------------------------------
 template <int KT, int NT>
 __global__ __launch_bounds__(256) void pw_wgrad_thin(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part,
-                                                     long long M, int Cin, int Cout)
+                                                     long long M, int Cin, int Cout, const float* __restrict__ a_scale,
+                                                     const float* __restrict__ a_shift, int a_act)
 {
     __shared__ float red[4][32 * 32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -919,6 +981,9 @@ __global__ __launch_bounds__(256) void pw_wgrad_thin(const float* __restrict__ x
         for (int b = 0; b < NT; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    float xs[KT], xt[KT];                       // x := act(x * scale + shift) on load (the producing BatchNorm, see GemmArgs::a_scale)
+#pragma unroll
+    for (int a = 0; a < KT; ++a) { xs[a] = a_scale ? a_scale[32 * a + l31] : 1.f; xt[a] = a_scale ? a_shift[32 * a + l31] : 0.f; }
     const long long nwaves = (long long)gridDim.x * 4;
     const long long w0 = (long long)blockIdx.x * 4 + wave;
     // rows in chunks of 2*RS per wave-iteration (RS MFMA steps of 2 rows): RS independent loads per operand tile in flight
@@ -930,7 +995,11 @@ __global__ __launch_bounds__(256) void pw_wgrad_thin(const float* __restrict__ x
             const long long m = m0 + 2 * st + half;
             const bool ok = m < M;
 #pragma unroll
-            for (int a = 0; a < KT; ++a) xa[st][a] = ok ? x[m * Cin + 32 * a + l31] : 0.f;
+            for (int a = 0; a < KT; ++a) {
+                float v = ok ? x[m * Cin + 32 * a + l31] : 0.f;
+                if (a_scale && ok) v = gemm_act(fmaf(v, xs[a], xt[a]), a_act);
+                xa[st][a] = v;
+            }
 #pragma unroll
             for (int b = 0; b < NT; ++b) yb[st][b] = ok ? dy[m * Cout + 32 * b + l31] : 0.f;
         }
@@ -1094,8 +1163,10 @@ static int launch_transpose(const float* in, float* out, int R, int C, int nz, i
 }
 
 template <int AMODE, int EPI>
-static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, size_t sk_ws_bytes = 0, long long sk_max_tiles = 512)
+static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, size_t sk_ws_bytes = 0, long long sk_max_tiles = 512,
+                     int* path = nullptr)      // *path: 0 generic kernel, 1 fast kernel, >= 2 fast kernel with that many K splits
 {
+    if (path) *path = 0;
     const long long tiles = cdiv64(a.M, BM) * ((a.N + BN - 1) / BN);
     if (tiles <= 0) return MYOLO_OK;
     const bool aligned = (a.N & 3) == 0 && (a.ldb & 3) == 0 && ((uintptr_t)a.A & 15) == 0 && ((uintptr_t)a.B & 15) == 0;
@@ -1115,7 +1186,8 @@ static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, si
             if ((size_t)splits * per > sk_ws_bytes) splits = (int)(sk_ws_bytes / per);
             if (splits < 2) splits = 1;
         }
-        if (g_myolo_opt.gemm_w256 && (a.N % 256) == 0 && tiles >= 1024) {
+        if (path) *path = splits > 1 ? splits : 1;
+        if (g_myolo_opt.gemm_w256 && (a.N % 256) == 0 && tiles >= 1024 && !a.stat) {
             const long long tiles256 = cdiv64(a.M, BM) * (a.N / 256);
             hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI, 4>), dim3((unsigned)tiles256), dim3(256), 0, s, a);
             return MYOLO_OK;
@@ -1123,6 +1195,7 @@ static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, si
         if (splits > 1) {
             am.ksplits = splits;
             am.part = (float*)sk_ws;
+            am.stat = nullptr;                 // (column statistics come out of the one-pass epilogue only; the caller runs a statistics pass)
             hipLaunchKernelGGL((gemm_nn_fast<AMODE, EPI>), dim3((unsigned)tiles, splits), dim3(256), 0, s, a);
             const long long total = a.M * (long long)(a.N / 4);
             int blocks = (int)((total + 255) / 256);
@@ -1360,8 +1433,29 @@ int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
     return MYOLO_OK;
 }
 
+static int pw_bwd_weight_impl(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
+                              int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+
 int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
                                int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    return pw_bwd_weight_impl(x, nullptr, nullptr, MYOLO_ACT_NONE, dy, dw, M, Cin, Cout, ws, ws_bytes, stream);
+}
+
+/* the same gradient when the conv's input was act_in(x * in_scale + in_shift) formed on load (myolo_pwconv1x1_bnstats_fwd): x is the
+ * producing layer's pre-BN output, normalised again on load here.  Needs Cin % 4 == 0, Cout % 4 == 0 (the fast kernels). */
+int myolo_pwconv1x1_bwd_weight_affine_in(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
+                                         int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(in_scale && in_shift && (Cin & 3) == 0 && (Cout & 3) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
+                  !g_myolo_opt.gemm_generic, "pwconv1x1_bwd_weight_affine_in: needs in_scale / in_shift, Cin %% 4 == 0, Cout %% 4 == 0, 16-byte aligned operands");
+    return pw_bwd_weight_impl(x, in_scale, in_shift, in_act, dy, dw, M, Cin, Cout, ws, ws_bytes, stream);
+}
+
+}  // extern "C"
+
+static int pw_bwd_weight_impl(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
+                              int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && dy && dw && M > 0, "pwconv1x1_bwd_weight: bad arguments");
     if ((Cin == 32 || Cin == 64) && (Cout == 64 || Cout == 128) && M >= 16384 && !g_myolo_opt.gemm_generic) {
@@ -1371,7 +1465,7 @@ int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
         if (ws && need <= ws_bytes) {
             hipStream_t s = (hipStream_t)stream;
             float* part = (float*)ws;
-#define THIN(KT_, NT_) hipLaunchKernelGGL((pw_wgrad_thin<KT_, NT_>), dim3(nblk), dim3(256), 0, s, x, dy, part, (long long)M, Cin, Cout)
+#define THIN(KT_, NT_) hipLaunchKernelGGL((pw_wgrad_thin<KT_, NT_>), dim3(nblk), dim3(256), 0, s, x, dy, part, (long long)M, Cin, Cout, in_scale, in_shift, in_act)
             if (Cin == 32 && Cout == 64) THIN(1, 2);
             else if (Cin == 32 && Cout == 128) THIN(1, 4);
             else if (Cin == 64 && Cout == 64) THIN(2, 2);
@@ -1385,10 +1479,76 @@ int myolo_pwconv1x1_bwd_weight(const float* x, const float* dy, float* dw,
     }
     GemmArgs a = {};
     a.A = x; a.B = dy; a.M = M; a.N = Cout; a.K = Cin; a.lda = Cin; a.ldb = Cout;
+    a.a_scale = in_scale; a.a_shift = in_shift; a.a_act = in_act;
     int rc = launch_tn<AM_PLAIN>(a, dw, ws, ws_bytes, (hipStream_t)stream, "pwconv1x1_bwd_weight");
     if (rc) return rc;
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
+}
+
+extern "C" {
+
+/* Training-mode depthwise block, second half (keras_applications _depthwise_conv_block, model.py:68-77 / 256-268, BatchNormalization on
+ * batch statistics): y = act_in(x * in_scale + in_shift) @ w and the BatchNorm statistics of y (what myolo_bn_stats gives: mean, var,
+ * folded scale / shift, moving averages) -- the producing layer's BatchNorm + ReLU6 applied while the GEMM loads its A operand, the
+ * column sums of the output taken in the GEMM's epilogue; two launches (GEMM, finish).  in_scale == NULL: x as it is.
+ * Needs Cin % 16 == 0, Cout % 4 == 0, 16-byte aligned operands (myolo_pwconv1x1_bnstats_ok). */
+int myolo_pwconv1x1_bnstats_ok(int Cin, int Cout) { return (Cin % BK) == 0 && (Cout & 3) == 0 && !g_myolo_opt.gemm_generic ? 1 : 0; }
+
+// scratch of the split-K form the launcher may pick for the small deep layers (fewer than 128 output tiles): 8 partial outputs
+static size_t pw_split_bytes(int64_t M, int Cout)
+{
+    const long long tiles = cdiv64(M, BM) * ((Cout + BN - 1) / BN);
+    return tiles < 128 ? align256((size_t)8 * M * Cout * sizeof(float)) : 0;
+}
+
+size_t myolo_pwconv1x1_bnstats_ws_bytes(int64_t M, int Cin, int Cout)
+{
+    const size_t tiles = (size_t)cdiv64(M, BM);
+    const size_t fused = align256(tiles * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double));
+    // split-K path / ablation: the partial outputs, then a statistics pass over y (<= 1024 slabs of 2*Cout doubles)
+    const size_t split = pw_split_bytes(M, Cout) + align256((size_t)1024 * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double));
+    return fused > split ? fused : split;
+}
+
+}  // extern "C"
+
+// statistics pass over a [M][C] tensor + finish (csrc/mem_kernels.hip)
+int myolo_bn_stats_launch(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
+                          float* moving_mean, float* moving_var, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s);
+
+extern "C" {
+
+int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
+                                const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
+                                float* moving_mean, float* moving_var, int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && gamma && beta && mean && var && scale && shift && M > 0 && !in_scale == !in_shift, "pwconv1x1_bnstats_fwd: bad arguments");
+    MYOLO_REQUIRE(myolo_pwconv1x1_bnstats_ok(Cin, Cout) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0,
+                  "pwconv1x1_bnstats_fwd: needs Cin %% 16 == 0, Cout %% 4 == 0 and 16-byte aligned operands");
+    MYOLO_NEED_WS(myolo_pwconv1x1_bnstats_ws_bytes(M, Cin, Cout));
+    hipStream_t s = (hipStream_t)stream;
+    GemmArgs a = {};
+    a.A = x; a.B = w; a.C = y; a.M = M; a.N = Cout; a.K = Cin;
+    a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = MYOLO_ACT_NONE;
+    a.a_scale = in_scale; a.a_shift = in_shift; a.a_act = in_act;
+    const int tiles = (int)cdiv64(M, BM);
+    const size_t pbytes = align256((size_t)tiles * 2 * Cout * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + pbytes);
+    a.stat = g_myolo_opt.no_trunk_fusion ? nullptr : part;
+    int path = 0;
+    // the split-K scratch shares ws with the partials: when the launcher picks split-K it drops a.stat (nothing is written there)
+    const size_t skb = pw_split_bytes(M, Cout);
+    launch_nn<AM_PLAIN, EP_PLAIN>(a, s, skb ? ws : nullptr, skb, 128, &path);
+    MYOLO_CHECK_LAUNCH();
+    if (path == 1 && !g_myolo_opt.no_trunk_fusion) {
+        myolo_bn_stats_from_partials(part, tot, tiles, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
+    // split-K (the 7x7 layers: a few MB) or the ablation switch: a statistics pass over y
+    return myolo_bn_stats_launch(y, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, M, Cout, (char*)ws + skb, ws_bytes - skb, s);
 }
 
 int myolo_conv3x3_fwd(const float* x, const float* w, const float* bias, float* y,

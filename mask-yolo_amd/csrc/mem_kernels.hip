@@ -39,7 +39,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_sparse_kernel(const float* __re
 // conv1: pad(1,1) + 3x3 stride 2, Cin = 3
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ y, int N, int H, int W, int Co)
+                                                        float* __restrict__ y, int N, int H, int W, int Co, double* __restrict__ stat)
 {
     extern __shared__ __attribute__((aligned(16))) float ws[];     // [27][Co]
     for (int i = threadIdx.x; i < 27 * Co; i += blockDim.x) ws[i] = w[i];
@@ -643,6 +643,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     const long long total = (long long)N * Ho * Wo * cq;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
+    float4 s1 = f4zero(), s2 = f4zero();         // stat: this thread's channel quad is the same in every iteration (256 % cq == 0)
     for (; i < total; i += stride) {
         const int c = (int)(i % cq) * 4;
         long long pix = i / cq;
@@ -670,6 +671,27 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
             }
         }
         st4g(y + i * 4, acc);
+        s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+        s2 = f4fma(acc, acc, s2);
+    }
+    if (stat) {          // per-workgroup partial sums of the output (BatchNorm statistics, finished by colreduce_finish<FinBnStats>)
+        __shared__ float4 red[256];
+        const int tid = threadIdx.x, cl = cq, pl = 256 / cl, cl_i = tid % cl;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            __syncthreads();
+            red[tid] = v == 0 ? s1 : s2;
+            __syncthreads();
+            if (tid < cl) {
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                for (int j = 0; j < pl; ++j) {
+                    const float4 t = red[j * cl + cl_i];
+                    a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
+                }
+                double* o = stat + ((long long)blockIdx.x * 2 + v) * Co + cl_i * 4;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+            }
+        }
     }
 }
 
@@ -713,10 +735,15 @@ struct OpConv1Dw {
 // loaded once per thread instead of up to 9 times).
 // ---------------------------------------------------------------------------------------
 struct DwAffine { const float* scale; const float* shift; int act; };   // scale == nullptr: none
+// training-mode fusion (model.py:57-66 with BatchNormalization on batch statistics): `in` = the PRODUCING layer's BatchNorm apply +
+// activation, done on the load of its pre-BN output (zero padding stays zero) -- the normalised tensor is never written;
+// `stat` != nullptr: per-workgroup partial sums (sum, sum of squares) of THIS conv's output per channel, [workgroup][2][C] doubles,
+// finished by colreduce_finish<FinBnStats> -- the statistics pass over the output disappears.  Needs 256 % (C/4) == 0.
+struct DwFuse { DwAffine in; double* stat; };
 
 template <int S, int TW, int TH>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                     float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, DwAffine af)
+                                                     float* __restrict__ y, int N, int H, int W, int C, int Ho, int Wo, DwAffine af, DwFuse fu)
 {
     // grid: x = (w-tile, channel quad) pairs, y = group of TH output rows, z = image: no 64-bit div/mod per thread.
     // The thread walks down the (TH-1)*S+3 input rows of its strip once (sliding window: every input row is loaded once per
@@ -727,14 +754,17 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     const int cq = C / 4;
     const int wtiles = (Wo + TW - 1) / TW;
     const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (unsigned)(wtiles * cq)) return;
-    const int wt = e / (unsigned)cq;
-    const int c = (e - wt * cq) * 4;
+    const bool live = e < (unsigned)(wtiles * cq);
+    if (!live && !fu.stat) return;                       // (with statistics every thread reaches the workgroup reduction)
+    const int wt = live ? e / (unsigned)cq : 0;
+    const int c = live ? (e - wt * cq) * 4 : 0;
     const int oy0 = blockIdx.y * TH, n = blockIdx.z;
     const int ox0 = wt * TW;
     float4 wv[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) wv[k] = ld4g(w + k * C + c);
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = f4zero();
+    if (fu.in.scale) { isc = ld4g(fu.in.scale + c); ish = ld4g(fu.in.shift + c); }
     float4 acc[TH][TW];
 #pragma unroll
     for (int r = 0; r < TH; ++r)
@@ -749,7 +779,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
             const int ix = ox0 * S + k - plft;
-            col[k] = (rowin && ix >= 0 && ix < W) ? ld4g(rowp + (long long)ix * C) : f4zero();
+            const bool in = rowin && ix >= 0 && ix < W;
+            col[k] = in ? ld4g(rowp + (long long)ix * C) : f4zero();
+            if (fu.in.scale && in) {
+                col[k].x = actf(fmaf(col[k].x, isc.x, ish.x), fu.in.act); col[k].y = actf(fmaf(col[k].y, isc.y, ish.y), fu.in.act);
+                col[k].z = actf(fmaf(col[k].z, isc.z, ish.z), fu.in.act); col[k].w = actf(fmaf(col[k].w, isc.w, ish.w), fu.in.act);
+            }
         }
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
@@ -767,21 +802,47 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
     // inference: the folded frozen BatchNorm + activation on the way out (same fma as bn_apply_kernel: bit-identical to the two-launch form)
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = f4zero();
     if (af.scale) { sc = ld4g(af.scale + c); sh = ld4g(af.shift + c); }
+    float4 s1 = f4zero(), s2 = f4zero();
 #pragma unroll
     for (int r = 0; r < TH; ++r) {
         const int oy = oy0 + r;
-        if (oy >= Ho) continue;
+        if (oy >= Ho || !live) continue;
         float* yrow = y + (((long long)n * Ho + oy) * Wo) * C + c;
 #pragma unroll
         for (int j = 0; j < TW; ++j)
             if (ox0 + j < Wo) {
                 float4 o = acc[r][j];
+                s1.x += o.x; s1.y += o.y; s1.z += o.z; s1.w += o.w;
+                s2 = f4fma(o, o, s2);
                 if (af.scale) {
                     o.x = actf(fmaf(o.x, sc.x, sh.x), af.act); o.y = actf(fmaf(o.y, sc.y, sh.y), af.act);
                     o.z = actf(fmaf(o.z, sc.z, sh.z), af.act); o.w = actf(fmaf(o.w, sc.w, sh.w), af.act);
                 }
                 st4g(yrow + (long long)(ox0 + j) * C, o);
             }
+    }
+    if (fu.stat) {
+        // workgroup reduction over the threads that share a channel quad (tid % cq; 256 % cq == 0 -- checked by the launcher), in
+        // double from here on; one row of partials per workgroup
+        __shared__ float4 red[256];
+        const int tid = threadIdx.x, cl = cq < 256 ? cq : 256, pl = 256 / cl, cl_i = tid % cl;
+        const long long blk = blockIdx.x + (long long)gridDim.x * (blockIdx.y + (long long)gridDim.y * blockIdx.z);
+        const int cq0 = (int)((blockIdx.x * 256u) % (unsigned)cq);           // first channel quad of this workgroup (cq > 256: a slice)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            __syncthreads();
+            red[tid] = v == 0 ? s1 : s2;
+            __syncthreads();
+            if (tid < cl) {
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                for (int j = 0; j < pl; ++j) {
+                    const float4 t = red[j * cl + cl_i];
+                    a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
+                }
+                double* o = fu.stat + (blk * 2 + v) * C + (cq0 + cl_i) * 4;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+            }
+        }
     }
 }
 
@@ -822,8 +883,11 @@ struct OpDwDw {
     const float* x;
     const float* dy;
     int H, W, C, Ho, Wo, S;
+    DwAffine in;         // scale != nullptr: x is the producing layer's pre-BN output, normalised + activated on load (see DwFuse)
     __device__ void operator()(long long r, int c, float4* acc) const
     {
+        float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = f4zero();
+        if (in.scale) { isc = ld4g(in.scale + c); ish = ld4g(in.shift + c); }
         const int pt = (S == 1) ? 1 : 0;
         const unsigned ru = (unsigned)r;                 // rows < 2^31 (checked by the launcher)
         const unsigned t = ru / (unsigned)Wo;
@@ -837,8 +901,14 @@ struct OpDwDw {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * S + kx - pt;
-                if (iy >= 0 && iy < H && ix >= 0 && ix < W)
-                    acc[ky * 3 + kx] = f4fma(ld4g(x + (((long long)n * H + iy) * W + ix) * C + c), g, acc[ky * 3 + kx]);
+                if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                    float4 v = ld4g(x + (((long long)n * H + iy) * W + ix) * C + c);
+                    if (in.scale) {
+                        v.x = actf(fmaf(v.x, isc.x, ish.x), in.act); v.y = actf(fmaf(v.y, isc.y, ish.y), in.act);
+                        v.z = actf(fmaf(v.z, isc.z, ish.z), in.act); v.w = actf(fmaf(v.w, isc.w, ish.w), in.act);
+                    }
+                    acc[ky * 3 + kx] = f4fma(v, g, acc[ky * 3 + kx]);
+                }
             }
         }
     }
@@ -1401,6 +1471,20 @@ void myolo_bn_stats_from_partials(const double* part, double* tot, int nblk, int
                        FinBnStats{gamma, beta, mean, var, scale, shift, mmean, mvar, M, g_myolo_opt.bn_fused_tf_variance});
 }
 
+// statistics pass over x [M][C] + finish, for other translation units (gemm_kernels.hip: the split-K pointwise layers)
+int myolo_bn_stats_launch(const float* x, const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
+                          float* moving_mean, float* moving_var, long long M, int C, void* ws, size_t ws_bytes, hipStream_t s)
+{
+    const size_t pb = col_ws_bytes(M, C, 2);
+    MYOLO_NEED_WS(align256(pb) + 2 * C * sizeof(double));
+    double* part = (double*)ws;
+    double* tot = (double*)((char*)ws + align256(pb));
+    OpStats op{x, C};
+    run_colreduce(op, M, C, part, tot, s, FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance});
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
 // =======================================================================================
 extern "C" {
 
@@ -1583,9 +1667,47 @@ int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y, int N, int 
     MYOLO_REQUIRE(x && w && y && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0, "conv3x3s2_c3_fwd: bad arguments");
     const long long total = (long long)N * (H / 2) * (W / 2) * (Cout / 4);
     hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), (hipStream_t)stream,
-                       x, w, y, N, H, W, Cout);
+                       x, w, y, N, H, W, Cout, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
+}
+
+/* conv_block of the backbone in training mode (model.py:42-52): the conv and the batch statistics of its output (what myolo_bn_stats
+ * gives) in two launches -- the conv leaves per-workgroup partial sums, the finish turns them into mean / var / scale / shift / moving
+ * averages.  ws: myolo_conv3x3s2_c3_bnstats_ws_bytes. */
+size_t myolo_conv3x3s2_c3_bnstats_ws_bytes(int N, int H, int W, int Cout)
+{
+    const long long M = (long long)N * (H / 2) * (W / 2);
+    const size_t fused = align256((size_t)1024 * 2 * Cout * sizeof(double)) + 2 * Cout * sizeof(double);
+    const size_t plain = align256(col_ws_bytes(M, Cout, 2)) + 2 * Cout * sizeof(double);
+    return fused > plain ? fused : plain;
+}
+
+int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, const float* gamma, const float* beta, float* mean, float* var,
+                                   float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout,
+                                   void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && gamma && beta && mean && var && scale && shift && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0,
+                  "conv3x3s2_c3_bnstats_fwd: bad arguments");
+    MYOLO_NEED_WS(myolo_conv3x3s2_c3_bnstats_ws_bytes(N, H, W, Cout));
+    hipStream_t s = (hipStream_t)stream;
+    const long long M = (long long)N * (H / 2) * (W / 2);
+    const long long total = M * (Cout / 4);
+    const int cq = Cout / 4;
+    if (cq <= 256 && (256 % cq) == 0 && !g_myolo_opt.no_trunk_fusion) {
+        int blocks = ew_blocks(total);
+        if (blocks > 1024) blocks = 1024;
+        double* part = (double*)ws;
+        double* tot = (double*)((char*)ws + align256((size_t)1024 * 2 * Cout * sizeof(double)));
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, part);
+        hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((Cout + 3) / 4), dim3(256), 0, s, part, tot, blocks, 2 * Cout, Cout,
+                           FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance});
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
+    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, (double*)nullptr);
+    MYOLO_CHECK_LAUNCH();
+    return myolo_bn_stats_launch(y, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, M, Cout, ws, ws_bytes, s);
 }
 
 int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* ws,
@@ -1605,29 +1727,41 @@ int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, in
     return MYOLO_OK;
 }
 
-static int dw_fwd_launch(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, DwAffine af, void* stream)
+// workgroups of the depthwise forward launch for this shape (= rows of statistics partials of the fused form)
+static void dw_fwd_grid(int N, int H, int W, int C, int stride, int& which, dim3& grid)
 {
-    MYOLO_REQUIRE(x && w && y && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3[_affine_act]_fwd: bad arguments");
-    MYOLO_REQUIRE(stride == 1 || ((H & 1) == 0 && (W & 1) == 0), "dwconv3x3[_affine_act]_fwd: stride 2 needs even H, W");
-    hipStream_t s = (hipStream_t)stream;
     const int Ho = H / stride, Wo = W / stride;
     if (stride == 1) {
         const int per_row = ((Wo + 3) / 4) * (C / 4);
         // strips of 4 output rows where that still leaves >= ~1000 workgroups; the small late layers keep more, shorter strips
         const long long wg4 = (long long)((per_row + 255) / 256) * ((Ho + 3) / 4) * N;
-        if (Ho >= 4 && wg4 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1)
-            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 4>), dim3((per_row + 255) / 256, (Ho + 3) / 4, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
-        else if (Ho >= 2 && !g_myolo_opt.dw_rows1)
-            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
-        else
-            hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
+        if (Ho >= 4 && wg4 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1) { which = 0; grid = dim3((per_row + 255) / 256, (Ho + 3) / 4, N); }
+        else if (Ho >= 2 && !g_myolo_opt.dw_rows1) { which = 1; grid = dim3((per_row + 255) / 256, (Ho + 1) / 2, N); }
+        else { which = 2; grid = dim3((per_row + 255) / 256, Ho, N); }
     } else {
         const int per_row = ((Wo + 1) / 2) * (C / 4);
         const long long wg2 = (long long)((per_row + 255) / 256) * ((Ho + 1) / 2) * N;
-        if (Ho >= 2 && wg2 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1)
-            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 2>), dim3((per_row + 255) / 256, (Ho + 1) / 2, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
-        else
-            hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 1>), dim3((per_row + 255) / 256, Ho, N), dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af);
+        if (Ho >= 2 && wg2 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1) { which = 3; grid = dim3((per_row + 255) / 256, (Ho + 1) / 2, N); }
+        else { which = 4; grid = dim3((per_row + 255) / 256, Ho, N); }
+    }
+}
+
+static int dw_fwd_launch(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, DwAffine af, void* stream,
+                         DwFuse fu = DwFuse{{nullptr, nullptr, MYOLO_ACT_NONE}, nullptr})
+{
+    MYOLO_REQUIRE(x && w && y && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3[_affine_act]_fwd: bad arguments");
+    MYOLO_REQUIRE(stride == 1 || ((H & 1) == 0 && (W & 1) == 0), "dwconv3x3[_affine_act]_fwd: stride 2 needs even H, W");
+    hipStream_t s = (hipStream_t)stream;
+    const int Ho = H / stride, Wo = W / stride;
+    int which;
+    dim3 grid;
+    dw_fwd_grid(N, H, W, C, stride, which, grid);
+    switch (which) {
+    case 0: hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 4>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
+    case 1: hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 2>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
+    case 2: hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 1>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
+    case 3: hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 2>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
+    default: hipLaunchKernelGGL((dw_fwd_kernel<2, 2, 1>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
     }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
@@ -1647,6 +1781,56 @@ int myolo_dwconv3x3_affine_act_fwd(const float* x, const float* w, const float* 
     return dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{scale, shift, act}, stream);
 }
 
+/* Training-mode depthwise block, first half (keras_applications _depthwise_conv_block, model.py:68-77 / 256-268, with BatchNormalization
+ * on batch statistics): y = dwconv3x3(act_in(x * in_scale + in_shift)) and the BatchNorm statistics of y (what myolo_bn_stats gives) in
+ * TWO launches -- the conv, which leaves per-workgroup partial sums of its own output, and the finish.  in_scale == NULL: x is used as
+ * it is.  The normalised input is never written and y is not re-read for its statistics. */
+size_t myolo_dwconv3x3_bnstats_ws_bytes(int N, int H, int W, int C, int stride)
+{
+    int which;
+    dim3 grid;
+    dw_fwd_grid(N, H, W, C, stride, which, grid);
+    const size_t fused = align256((size_t)grid.x * grid.y * grid.z * 2 * C * sizeof(double)) + 2 * C * sizeof(double);
+    const long long M = (long long)N * (H / stride) * (W / stride);
+    const size_t plain = align256(col_ws_bytes(M, C, 2)) + 2 * C * sizeof(double);
+    return fused > plain ? fused : plain;
+}
+
+int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
+                                const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
+                                float* moving_mean, float* moving_var, int N, int H, int W, int C, int stride,
+                                void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(gamma && beta && mean && var && scale && shift && !in_scale == !in_shift, "dwconv3x3_bnstats_fwd: bad arguments");
+    MYOLO_REQUIRE(N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bnstats_fwd: bad arguments");
+    MYOLO_NEED_WS(myolo_dwconv3x3_bnstats_ws_bytes(N, H, W, C, stride));
+    hipStream_t s = (hipStream_t)stream;
+    const long long M = (long long)N * (H / stride) * (W / stride);
+    const int cq = C / 4;
+    const DwAffine in{in_scale, in_shift, in_act};
+    const FinBnStats fin{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance};
+    if (cq <= 256 && (256 % cq) == 0 && !g_myolo_opt.no_trunk_fusion) {
+        int which;
+        dim3 grid;
+        dw_fwd_grid(N, H, W, C, stride, which, grid);
+        const int nblk = (int)(grid.x * grid.y * grid.z);
+        double* part = (double*)ws;
+        double* tot = (double*)((char*)ws + align256((size_t)nblk * 2 * C * sizeof(double)));
+        const int rc = dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream, DwFuse{in, part});
+        if (rc != MYOLO_OK) return rc;
+        hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C, fin);
+    } else {           // channel counts the in-kernel reduction does not take: the conv (input still normalised on load), then the statistics pass
+        const int rc = dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream, DwFuse{in, nullptr});
+        if (rc != MYOLO_OK) return rc;
+        double* part = (double*)ws;
+        double* tot = (double*)((char*)ws + align256(col_ws_bytes(M, C, 2)));
+        OpStats op{y, C};
+        run_colreduce(op, M, C, part, tot, s, fin);
+    }
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
 int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, void* stream)
 {
     MYOLO_REQUIRE(dy && w && dx && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_data: bad arguments");
@@ -1661,8 +1845,28 @@ int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, 
     return MYOLO_OK;
 }
 
+static int dw_bwd_weight_impl(const float* x, DwAffine in, const float* dy, float* dw, int N, int H, int W, int C, int stride, void* ws,
+                              size_t ws_bytes, void* stream);
+
 int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int stride, void* ws,
                                size_t ws_bytes, void* stream)
+{
+    return dw_bwd_weight_impl(x, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, dy, dw, N, H, W, C, stride, ws, ws_bytes, stream);
+}
+
+/* the same gradient when the conv's input was act_in(x * in_scale + in_shift) formed on load (myolo_dwconv3x3_bnstats_fwd): x is the
+ * producing layer's pre-BN output, normalised again on load here */
+int myolo_dwconv3x3_bwd_weight_affine_in(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
+                                         int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(in_scale && in_shift, "dwconv3x3_bwd_weight_affine_in: bad arguments");
+    return dw_bwd_weight_impl(x, DwAffine{in_scale, in_shift, in_act}, dy, dw, N, H, W, C, stride, ws, ws_bytes, stream);
+}
+
+}  // extern "C"
+
+static int dw_bwd_weight_impl(const float* x, DwAffine in, const float* dy, float* dw, int N, int H, int W, int C, int stride, void* ws,
+                              size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && dy && dw && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_weight: bad arguments");
     const int Ho = H / stride, Wo = W / stride;
@@ -1672,11 +1876,13 @@ int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int N
     double* part = (double*)ws;
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
-    OpDwDw op{x, dy, H, W, C, Ho, Wo, stride};
+    OpDwDw op{x, dy, H, W, C, Ho, Wo, stride, in};
     run_colreduce(op, M, C, part, tot, s, FinD2F{dw});
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
+
+extern "C" {
 
 int myolo_crop_and_resize_fwd(const float* image, const float* boxes, const int32_t* box_ind, float* out, int B, int H, int W,
                               int C, int nb, int crop_h, int crop_w, void* stream)

@@ -28,6 +28,7 @@ struct MyoloOptions {
     int wino_x6;          // winograd multiply on the bf16 matrix pipe: 6 piece products per fp32 product, fp32 accumulation (csrc/wino_mm.hip)
     int wino_no_bt;       // winograd multiply: gemm_nn_fast on [K][N] filters instead of wino_mm_kernel on transposed ones
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)
+    int no_trunk_fusion;  // *_bnstats_fwd: the conv, then a separate statistics pass (ablation of the producer-fused BatchNorm statistics)
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
     // 1 = Keras 2.2.x on TF-1.x through tf.nn.fused_batch_norm (Bessel-corrected batch variance, then Keras' n/(n-(1+eps)));
     // 0 = Keras' factor on the biased variance (non-fused backend path).

@@ -95,6 +95,11 @@ SIGS = {
     "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
     "myolo_matmul_f32": [P, P, P, L, I, I, I, I, P, Z, P],
     "myolo_stream_copy": [P, P, Z, I, I, P],
+    "myolo_conv3x3s2_c3_bnstats_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, Z, P],
+    "myolo_dwconv3x3_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_dwconv3x3_bwd_weight_affine_in": [P, P, P, I, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_pwconv1x1_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, Z, P],
+    "myolo_pwconv1x1_bwd_weight_affine_in": [P, P, P, I, P, P, L, I, I, P, Z, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],
     "myolo_set_option": [ctypes.c_char_p, I],
@@ -128,6 +133,14 @@ def load():
     lib.myolo_conv3x3_wino_ws_bytes.restype = Z
     lib.myolo_matmul_f32_ws_bytes.argtypes = [I, I, I, I]
     lib.myolo_matmul_f32_ws_bytes.restype = Z
+    lib.myolo_conv3x3s2_c3_bnstats_ws_bytes.argtypes = [I, I, I, I]
+    lib.myolo_conv3x3s2_c3_bnstats_ws_bytes.restype = Z
+    lib.myolo_dwconv3x3_bnstats_ws_bytes.argtypes = [I, I, I, I, I]
+    lib.myolo_dwconv3x3_bnstats_ws_bytes.restype = Z
+    lib.myolo_pwconv1x1_bnstats_ws_bytes.argtypes = [L, I, I]
+    lib.myolo_pwconv1x1_bnstats_ws_bytes.restype = Z
+    lib.myolo_pwconv1x1_bnstats_ok.argtypes = [I, I]
+    lib.myolo_pwconv1x1_bnstats_ok.restype = I
     lib.myolo_wino_plane_elems.argtypes = [I, I, I, I]
     lib.myolo_wino_plane_elems.restype = Z
     lib.myolo_wino_u_elems.argtypes = [I, I]
@@ -158,7 +171,8 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes", "myolo_conv3x3s2_c3_bnstats_ws_bytes", "myolo_dwconv3x3_bnstats_ws_bytes",
+                              "myolo_pwconv1x1_bnstats_ws_bytes", "myolo_pwconv1x1_bnstats_ok",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
 
@@ -236,6 +250,22 @@ def wino_ws_bytes(n, h, w, cin, cout, which):
 
 
 PRODUCTS_NATIVE, PRODUCTS_BF16X6 = 0, 1
+
+
+def conv1_bnstats_ws_bytes(n, h, w, cout):
+    return int(load().myolo_conv3x3s2_c3_bnstats_ws_bytes(int(n), int(h), int(w), int(cout)))
+
+
+def dw_bnstats_ws_bytes(n, h, w, c, stride):
+    return int(load().myolo_dwconv3x3_bnstats_ws_bytes(int(n), int(h), int(w), int(c), int(stride)))
+
+
+def pw_bnstats_ws_bytes(m, cin, cout):
+    return int(load().myolo_pwconv1x1_bnstats_ws_bytes(int(m), int(cin), int(cout)))
+
+
+def pw_bnstats_ok(cin, cout):
+    return bool(load().myolo_pwconv1x1_bnstats_ok(int(cin), int(cout)))
 
 
 def matmul_ws_bytes(k, n, b_is_nk, products):

@@ -106,6 +106,11 @@ class Config(object):
     # (14 = 4+4+4+2: 484 point-tiles per ROI); "f63" = conv2-4 with one F(6,3) and two F(4,3) tiles per direction (14 = 6+4+4: 400
     # point-tiles, 17 % fewer multiplications and plane bytes; fp32 error 1.2-1.5x the f43 tiling's, csrc/wino63_kernels.hip).
     WINOGRAD_TILES = "f63"
+    # Training forwards of the trunk (backbone + YOLO head): True = every BatchNorm's batch statistics are reduced from partial sums the
+    # producing conv leaves in its epilogue, and its apply + ReLU6 happen while the consuming conv loads its input -- four launches per
+    # depthwise-separable block instead of eight, the normalised activations never written; the backward re-normalises the saved pre-BN
+    # tensors on load.  False = conv, statistics pass, apply pass as separate launches (same results up to fp32 summation order).
+    FUSE_TRUNK_BN = True
     # detect(): replay the inference forward from a captured hipGraph (one capture per input shape) instead of ~150 launches
     INFERENCE_HIP_GRAPH = True
     # detect() keeps at most 10 boxes (model.py:1290-1304).  True: ROIAlign + mask head run on those survivors only instead

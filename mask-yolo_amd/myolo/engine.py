@@ -171,6 +171,9 @@ class Net(object):
         self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
         self.fused_frozen_bn = True       # bn_act_fwd on moving statistics: one launch instead of coefficients + apply
         self.fold_frozen_bn = True        # train=False forwards: that BatchNorm + ReLU6 in the epilogue of the depthwise / pointwise conv
+        # training forwards of the trunk: every BatchNorm's batch statistics come out of the producing conv's epilogue and its apply +
+        # ReLU6 happen on the consumer's load -- the normalised activations are never written (dw_block_fwd / dw_block_bwd)
+        self.fuse_trunk_bn = bool(getattr(cfg, "FUSE_TRUNK_BN", True))
         self._fz_table = None
         self.merge_conv1_bwd_transforms = True    # conv1's backward: the V and Q transforms of the lazily formed gradient from one pass over y_pre
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float32), device=self.dev)
@@ -426,8 +429,41 @@ class Net(object):
         base = self._fz_coeffs.data_ptr()
         return base + 4 * off, base + 4 * (off + C)
 
+    # A "lazy" activation: ("lazy", y_pre, bn_layer) = act(BN(y_pre)) of a training-mode BatchNorm whose scale / shift sit in
+    # self.bnbuf[bn_layer][2:4]; consumers normalise y_pre while loading it.  _in_args gives the four C-ABI arguments (x, in_scale,
+    # in_shift, in_act) for either a plain tensor or such a reference.
+    @staticmethod
+    def _is_lazy(a):
+        return isinstance(a, tuple) and a[0] == "lazy"
+
+    def _in_args(self, a):
+        if self._is_lazy(a):
+            _, y, bn = a
+            buf = self.bnbuf[bn]
+            return X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU6
+        return X.ptr(a), None, None, ACT_NONE
+
+    def _materialize(self, a):
+        """the activation of a lazy reference as a tensor (one bn_apply launch); a plain tensor is returned as it is"""
+        if not self._is_lazy(a):
+            return a
+        _, y, bn = a
+        buf = self.bnbuf[bn]
+        out = self._new(*y.shape)
+        X.call("myolo_bn_apply_act", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(out), y.shape[0], y.shape[1], ACT_RELU6, X.stream())
+        return out
+
+    def _bn_args(self, name):
+        buf = self.bnbuf[name]
+        return (X.ptr(self.p[name + "/gamma"]), X.ptr(self.p[name + "/beta"]), X.ptr(buf[0]), X.ptr(buf[1]), X.ptr(buf[2]), X.ptr(buf[3]),
+                X.ptr(self.s[name + "/moving_mean"]), X.ptr(self.s[name + "/moving_variance"]))
+
+    def _block_fusable(self, C, Co):
+        return self.fuse_trunk_bn and C % 4 == 0 and X.pw_bnstats_ok(C, Co)
+
     def dw_block_fwd(self, bid, a, shape, stride, train):
-        """a [N*H*W, C] activation, shape=(N,H,W,C).  Returns (activation, new shape)."""
+        """a [N*H*W, C] activation (or a lazy reference to one, training only), shape=(N,H,W,C).  Returns (activation, new shape);
+        in fused training mode the returned activation is a lazy reference."""
         N, H, W, C = shape
         Ho, Wo = H // stride, W // stride
         dwn, pwn = "conv_dw_%d" % bid, "conv_pw_%d" % bid
@@ -444,13 +480,31 @@ class Net(object):
             self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_affine_act_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), sc, sh,
                              ACT_RELU6, X.ptr(ap), N * Ho * Wo, C, Co, *self._wsargs(), X.stream())
             return ap, (N, Ho, Wo, Co)
-        y = self._new(N * Ho * Wo, C)
+        Co = self.p[pwn + "/kernel"].shape[3]
+        M = N * Ho * Wo
+        if train and self._block_fusable(C, Co):
+            # training-mode fusion (model.py:57-66 on batch statistics): four launches per block -- depthwise conv (input normalised on
+            # load, output statistics in its epilogue), finish, pointwise GEMM (A operand normalised on load, column statistics in its
+            # epilogue), finish.  Neither normalised tensor is written; the backward re-normalises the pre-BN tensors on load.
+            y = self._new(M, C)
+            self.ws.ensure(max(X.dw_bnstats_ws_bytes(N, H, W, C, stride), X.pw_bnstats_ws_bytes(M, C, Co)))
+            self._call_timed("dw%d_fwd" % bid, "myolo_dwconv3x3_bnstats_fwd", *self._in_args(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(y),
+                             *self._bn_args(dwn + "_bn"), N, H, W, C, stride, *self._wsargs(), X.stream())
+            self.tape[dwn + "_bn"] = (y, ACT_RELU6, True)
+            ad = ("lazy", y, dwn + "_bn")
+            y2 = self._new(M, Co)
+            self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_bnstats_fwd", *self._in_args(ad), X.ptr(self.p[pwn + "/kernel"]), X.ptr(y2),
+                             *self._bn_args(pwn + "_bn"), M, C, Co, *self._wsargs(), X.stream())
+            self.tape[pwn + "_bn"] = (y2, ACT_RELU6, True)
+            self.tape["blk%d" % bid] = (a, shape, stride, ad)
+            return ("lazy", y2, pwn + "_bn"), (N, Ho, Wo, Co)
+        a = self._materialize(a)
+        y = self._new(M, C)
         self._call_timed("dw%d_fwd" % bid, "myolo_dwconv3x3_fwd", X.ptr(a), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(y),
                          N, H, W, C, stride, X.stream())
         ad = self.bn_act_fwd(dwn + "_bn", y, ACT_RELU6, train)
-        Co = self.p[pwn + "/kernel"].shape[3]
-        y2 = self._new(N * Ho * Wo, Co)
-        self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), None, X.ptr(y2), N * Ho * Wo, C, Co,
+        y2 = self._new(M, Co)
+        self._call_timed("pw%d_fwd" % bid, "myolo_pwconv1x1_fwd", X.ptr(ad), X.ptr(self.p[pwn + "/kernel"]), None, X.ptr(y2), M, C, Co,
                          *self._wsargs(), X.stream())
         ap = self.bn_act_fwd(pwn + "_bn", y2, ACT_RELU6, train)
         self.tape["blk%d" % bid] = (a, shape, stride, ad)
@@ -464,12 +518,20 @@ class Net(object):
         Co = self.p[pwn + "/kernel"].shape[3]
         M = N * Ho * Wo
         dy2 = self.bn_act_bwd(pwn + "_bn", da)
-        X.call("myolo_pwconv1x1_bwd_weight", X.ptr(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co, *self._wsargs(), X.stream())
+        if self._is_lazy(ad):       # the forward normalised the depthwise output on load: so does the weight gradient
+            X.call("myolo_pwconv1x1_bwd_weight_affine_in", *self._in_args(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co,
+                   *self._wsargs(), X.stream())
+        else:
+            X.call("myolo_pwconv1x1_bwd_weight", X.ptr(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co, *self._wsargs(), X.stream())
         dad = self._new(M, C)
         X.call("myolo_pwconv1x1_bwd_data", X.ptr(dy2), X.ptr(self.p[pwn + "/kernel"]), X.ptr(dad), M, C, Co, *self._wsargs(), X.stream())
         dy = self.bn_act_bwd(dwn + "_bn", dad)
-        X.call("myolo_dwconv3x3_bwd_weight", X.ptr(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride,
-               *self._wsargs(), X.stream())
+        if self._is_lazy(a):
+            X.call("myolo_dwconv3x3_bwd_weight_affine_in", *self._in_args(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride,
+                   *self._wsargs(), X.stream())
+        else:
+            X.call("myolo_dwconv3x3_bwd_weight", X.ptr(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride,
+                   *self._wsargs(), X.stream())
         dx = self._new(N * H * W, C)
         X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(dx), N, H, W, C, stride, X.stream())
         return dx
@@ -482,14 +544,24 @@ class Net(object):
         if not train and self.fold_frozen_bn:
             self._frozen_affine_all()
         y = self._new(N * (H // 2) * (W // 2), C0)
-        X.call("myolo_conv3x3s2_c3_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), X.ptr(y), N, H, W, C0, X.stream())
-        a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)
+        if train and self.fuse_trunk_bn and C0 % 4 == 0:
+            # conv_block (model.py:42-52): the conv leaves the partial sums of its BatchNorm statistics; the apply + ReLU6 go into the first
+            # depthwise conv's load
+            self.ws.ensure(X.conv1_bnstats_ws_bytes(N, H, W, C0))
+            X.call("myolo_conv3x3s2_c3_bnstats_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), X.ptr(y), *self._bn_args("conv1_bn"),
+                   N, H, W, C0, *self._wsargs(), X.stream())
+            self.tape["conv1_bn"] = (y, ACT_RELU6, True)
+            a = ("lazy", y, "conv1_bn")
+        else:
+            X.call("myolo_conv3x3s2_c3_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), X.ptr(y), N, H, W, C0, X.stream())
+            a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)
         shape = (N, H // 2, W // 2, C0)
         self.tape["images"] = images
         bid = 1
         for f, s in BACKBONE_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
+        a = self._materialize(a)          # C4 feeds feature_map's 3x3 conv and the YOLO head: written once (28x28x512)
         C4, c4shape = a, shape
         n, h, w, c = c4shape
         Cf = cfg.TOP_FEATURE_MAP_DEPTH
@@ -498,6 +570,7 @@ class Net(object):
         for f, s in YOLO_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
+        a = self._materialize(a)          # input of conv_23 and of its weight gradient (7x7x1024)
         n2, h2, w2, c2 = shape
         D = cfg.N_BOX * (5 + cfg.NUM_CLASSES)
         yo = self._new(n2 * h2 * w2, D)

@@ -188,7 +188,7 @@ class TorchRef(object):
             x = torch.relu(_bn(x, P[b + "/gamma"], P[b + "/beta"], P[b + "/moving_mean"], P[b + "/moving_variance"],
                                train and i == 1))
         w = P["myolo_mask_deconv/kernel"].permute(3, 2, 0, 1)      # [Cin,Cout,kh,kw]
-        x = torch.relu(self._keep("deconv/out", Fn.conv_transpose2d(x, w, bias=P["myolo_mask_deconv/bias"], stride=2)))
+        x = self._keep("deconv/out", torch.relu(Fn.conv_transpose2d(x, w, bias=P["myolo_mask_deconv/bias"], stride=2)))      # post-ReLU, as the engine tapes it
         z = _conv(x, P["myolo_mask/kernel"], bias=P["myolo_mask/bias"])
         return torch.sigmoid(z)                                    # [N,C,h,w]
 

@@ -982,3 +982,106 @@ def test_dwconv3x3_affine_act_fwd_equals_conv_then_frozen_bn(N, H, W, C, stride)
     torch.cuda.synchronize()
     assert torch.equal(y1, y2)
 
+
+
+# ----------------------------------------------------------------------------------------
+# training-mode BatchNorm fusion of the trunk (include/myolo_hip_internal.h "*_bnstats_fwd", "*_bwd_weight_affine_in"):
+# model.py:42-79, 249-278 with BatchNormalization on batch statistics, against the oracle's conv -> bn_train -> relu6 chain
+# ----------------------------------------------------------------------------------------
+def _check_bn_outputs(y_ref2d, g, b, mm, mv, mean, var, scale, shift, tmm, tmv):
+    """mean / var / folded scale, shift / Keras moving averages of a fused kernel against oracle.bn_train on the reference output"""
+    M = y_ref2d.shape[0]
+    _, cache = O.bn_train(y_ref2d, g, b)
+    check(mean, cache[2], 1e-5, "fused bn mean")
+    check(var, cache[3], 1e-4, "fused bn var")
+    sc_ref = g / np.sqrt(cache[3] + 1e-3)
+    check(scale, sc_ref, 1e-4, "fused bn scale")
+    check(shift, b - cache[2] * sc_ref, 1e-4, "fused bn shift")
+    rmm, rmv = O.bn_moving_update(mm, mv, cache[2], cache[3], M)
+    check(tmm, rmm, 1e-5, "fused moving mean")
+    check(tmv, rmv, 1e-5, "fused moving var")
+
+
+@pytest.mark.parametrize("nofuse", [0, 1])
+@pytest.mark.parametrize("N,H,W,C,stride,lazy", [(2, 16, 16, 32, 1, True), (2, 16, 16, 32, 2, True), (3, 14, 14, 512, 1, True), (3, 14, 14, 512, 2, False),
+                                                 (2, 8, 8, 1024, 1, True), (1, 14, 10, 64, 2, True), (2, 12, 12, 16, 1, True), (2, 6, 6, 24, 1, True),
+                                                 (32, 28, 28, 256, 1, True)])
+def test_dwconv3x3_bnstats_fwd_and_affine_in_weight_gradient(N, H, W, C, stride, lazy, nofuse):
+    """depthwise conv whose input is relu6(x * in_scale + in_shift) formed on load, with the batch statistics of its output from the
+    conv's own epilogue; and its weight gradient re-normalising x on load.  (C = 24: a channel count the in-kernel reduction does
+    not take -- the entry point falls back to a statistics pass.)"""
+    rng = np.random.default_rng(21)
+    x, w = rnd(rng, N, H, W, C, scale=2.0), rnd(rng, 3, 3, C)
+    isc, ish = (1 + rnd(rng, C, scale=0.3)), rnd(rng, C, scale=0.5) + 1.0
+    g, b = 1 + rnd(rng, C, scale=0.2), rnd(rng, C, scale=0.3)
+    mm, mv = rnd(rng, C, scale=0.1), 1 + np.abs(rnd(rng, C, scale=0.1))
+    a_in = O.relu6(x * isc + ish) if lazy else x
+    ref = O.dwconv3x3(a_in, w, stride)
+    Ho, Wo = ref.shape[1], ref.shape[2]
+    y = new(N, Ho, Wo, C)
+    mean, var, scale, shift = new(C), new(C), new(C), new(C)
+    tmm, tmv = dt(mm), dt(mv)
+    wsb = torch.empty(X.dw_bnstats_ws_bytes(N, H, W, C, stride), dtype=torch.uint8, device=DEV)
+    with X.option("no_trunk_fusion", nofuse):
+        X.call("myolo_dwconv3x3_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(isc)) if lazy else None, X.ptr(dt(ish)) if lazy else None, 2, X.ptr(dt(w)), X.ptr(y),
+               X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv),
+               N, H, W, C, stride, wsb.data_ptr(), wsb.numel(), X.stream())
+    check(y, ref, what="fused dw fwd")
+    _check_bn_outputs(ref.reshape(-1, C), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)
+    if lazy:
+        dy = rnd(rng, N, Ho, Wo, C)
+        _, rdw = O.dwconv3x3_bwd(a_in, w, dy, stride)
+        dw = new(3, 3, C)
+        X.call("myolo_dwconv3x3_bwd_weight_affine_in", X.ptr(dt(x)), X.ptr(dt(isc)), X.ptr(dt(ish)), 2, X.ptr(dt(dy)), X.ptr(dw), N, H, W, C, stride,
+               *ws(), X.stream())
+        check(dw, rdw, what="dw dw with the input normalised on load")
+
+
+@pytest.mark.parametrize("nofuse", [0, 1])
+@pytest.mark.parametrize("M,Cin,Cout,lazy", [(300, 32, 64, True), (4096, 64, 128, True), (25088, 64, 64, True), (6272, 512, 512, True), (1568, 512, 1024, True),
+                                             (1568, 1024, 1024, False), (130, 16, 16, True), (20003, 32, 64, True), (257, 256, 512, True), (100352, 64, 128, True)])
+def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy, nofuse):
+    """pointwise conv whose A operand is relu6(x * in_scale + in_shift) formed on load, with the batch statistics of its output from
+    the GEMM epilogue (one pass) or, for the split-K shapes (M = 1568), from a statistics pass; and its weight gradient
+    re-normalising x on load (thin-layer kernel, 128x128-tile kernel)."""
+    rng = np.random.default_rng(22)
+    x, w = rnd(rng, M, Cin, scale=2.0), rnd(rng, Cin, Cout, scale=0.1)
+    isc, ish = (1 + rnd(rng, Cin, scale=0.3)), rnd(rng, Cin, scale=0.5) + 1.0
+    g, b = 1 + rnd(rng, Cout, scale=0.2), rnd(rng, Cout, scale=0.3)
+    mm, mv = rnd(rng, Cout, scale=0.1), 1 + np.abs(rnd(rng, Cout, scale=0.1))
+    a_in = (O.relu6(x * isc + ish) if lazy else x).astype(np.float64)
+    ref = a_in @ w
+    y = new(M, Cout)
+    mean, var, scale, shift = new(Cout), new(Cout), new(Cout), new(Cout)
+    tmm, tmv = dt(mm), dt(mv)
+    wsb = torch.empty(X.pw_bnstats_ws_bytes(M, Cin, Cout), dtype=torch.uint8, device=DEV)
+    with X.option("no_trunk_fusion", nofuse):
+        X.call("myolo_pwconv1x1_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(isc)) if lazy else None, X.ptr(dt(ish)) if lazy else None, 2, X.ptr(dt(w)), X.ptr(y),
+               X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv),
+               M, Cin, Cout, wsb.data_ptr(), wsb.numel(), X.stream())
+    check(y, ref, what="fused pw fwd")
+    _check_bn_outputs(ref.astype(np.float32), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)
+    if lazy:
+        dy = rnd(rng, M, Cout)
+        dw = new(Cin, Cout)
+        X.call("myolo_pwconv1x1_bwd_weight_affine_in", X.ptr(dt(x)), X.ptr(dt(isc)), X.ptr(dt(ish)), 2, X.ptr(dt(dy)), X.ptr(dw), M, Cin, Cout, *ws(), X.stream())
+        check(dw, a_in.T @ dy, what="pw dw with the input normalised on load")
+
+
+@pytest.mark.parametrize("nofuse", [0, 1])
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (8, 64, 64, 32)])
+def test_conv1_bnstats_fwd(N, H, W, Co, nofuse):
+    rng = np.random.default_rng(23)
+    x, w = rng.random((N, H, W, 3), dtype=np.float32), rnd(rng, 3, 3, 3, Co, scale=0.3)
+    g, b = 1 + rnd(rng, Co, scale=0.2), rnd(rng, Co, scale=0.3)
+    mm, mv = rnd(rng, Co, scale=0.1), 1 + np.abs(rnd(rng, Co, scale=0.1))
+    ref = O.conv2d(x, w, stride=2, pads=(1, 1, 1, 1), acc=np.float64)
+    y = new(N, H // 2, W // 2, Co)
+    mean, var, scale, shift = new(Co), new(Co), new(Co), new(Co)
+    tmm, tmv = dt(mm), dt(mv)
+    wsb = torch.empty(X.conv1_bnstats_ws_bytes(N, H, W, Co), dtype=torch.uint8, device=DEV)
+    with X.option("no_trunk_fusion", nofuse):
+        X.call("myolo_conv3x3s2_c3_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(y), X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var),
+               X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv), N, H, W, Co, wsb.data_ptr(), wsb.numel(), X.stream())
+    check(y, ref, what="fused conv1 fwd")
+    _check_bn_outputs(ref.reshape(-1, Co).astype(np.float32), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)

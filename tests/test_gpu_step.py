@@ -334,6 +334,38 @@ def test_fp32_matmul_bf16x6_step_matches_native():
     X.set_option("wino_x6", 0)
 
 
+def test_fused_trunk_batchnorm_step_equals_unfused():
+    """cfg.FUSE_TRUNK_BN (default on): the trunk's BatchNorm statistics from the producing conv's epilogue and its apply + ReLU6 on the
+    consumer's load (forward), the weight gradients re-normalising the pre-BN tensors on load (backward) -- against the unfused
+    launch sequence on the same batch and weights: same arithmetic up to fp32 summation order, so activations and losses agree to 1e-5,
+    the integer outputs exactly, and every gradient to 1e-3 relative L2 (a ReLU6 decision that sits on ~1e-6 noise can flip)."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    outs, grads, states, launches = [], [], [], []
+    for fuse in (True, False):
+        c = make_config(type(cfg), FUSE_TRUNK_BN=fuse)
+        model = MaskYOLO(mode="training", config=c)
+        model.load_state_dict(P)
+        assert model.net.fuse_trunk_bn == fuse
+        outs.append(model.train_on_batch(batch, learning_rate=1e-3))
+        grads.append(model.net.grads_dict())
+        states.append(model.net.state_dict())
+        launches.append(sum(1 for k in model.net.tape if k.startswith("blk")))
+    o1, o0 = outs
+    assert np.array_equal(o1["target_class_ids"], o0["target_class_ids"]) and np.array_equal(o1["n_pos"], o0["n_pos"])
+    for k in ("yolo_output", "feature_map", "myolo_mask"):
+        assert rel(o1[k], o0[k]) < 1e-5, (k, rel(o1[k], o0[k]))
+    for k in ("yolo_sum_loss", "mask_loss", "loss"):
+        assert abs(o1[k] - o0[k]) <= 1e-5 * max(1.0, abs(o0[k])), (k, o1[k], o0[k])
+    for k in grads[0]:
+        if k == "myolo_mask_conv1/bias":
+            continue
+        e = float(np.linalg.norm(grads[0][k].astype(np.float64) - grads[1][k]) / max(1e-30, np.linalg.norm(grads[1][k])))
+        assert e < 1e-3, (k, e)
+    for k in states[0]:          # weights after one Adam step; BatchNorm moving statistics
+        if "moving_" in k:
+            assert np.abs(states[0][k] - states[1][k]).max() <= 1e-5 * max(1.0, np.abs(states[1][k]).max()), k
+
+
 def test_positives_only_forward_without_positives():
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     b2 = [a.copy() for a in batch]
