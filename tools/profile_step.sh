@@ -66,6 +66,23 @@ if len(starts) >= 3:
         for k, (t, n) in sorted(acc.items(), key=lambda kv: -kv[1][0])[:12]:
             print("      %-66s %3d x  %8.1f us" % (k, n, t / 1e3))
 PY
+python - "$OUT/bench/bench_kernel_trace.csv" > "$OUT/${TAG}_step_sequence.txt" <<'PY'
+# every kernel of the last complete step in start order: offset from the step's start, duration, gap to the end of the previous
+# kernel on the timeline (negative = overlapped with it: another stream), stream / queue id, grid, name
+import csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("conv1_fwd_kernel")]
+if len(starts) >= 3:
+    a, b = starts[-2], starts[-1]
+    t0 = int(rows[a]["Start_Timestamp"])
+    prev_end = t0
+    print("%10s %9s %8s %6s %-18s %s" % ("start_us", "dur_us", "gap_us", "queue", "grid", "kernel"))
+    for r in rows[a:b]:
+        s0, e0 = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        grid = "x".join(r[k] for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
+        print("%10.1f %9.1f %8.1f %6s %-18s %s" % ((s0 - t0) / 1e3, (e0 - s0) / 1e3, (s0 - prev_end) / 1e3, r.get("Queue_Id", "?"), grid, r["Kernel_Name"].split("(")[0][:90]))
+        prev_end = max(prev_end, e0)
+PY
 cat "$OUT/${TAG}_timeline.txt"
 rm -rf $OUT/bench
 tail -2 $OUT/bench_under_rocprof.log | cut -c1-300
