@@ -28,6 +28,7 @@ struct MyoloOptions {
     int wino_x6;          // winograd multiply on the bf16 matrix pipe: 6 piece products per fp32 product, fp32 accumulation (csrc/wino_mm.hip)
     int wino_no_bt;       // winograd multiply: gemm_nn_fast on [K][N] filters instead of wino_mm_kernel on transposed ones
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)
+    int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)
     int no_trunk_fusion;  // *_bnstats_fwd: the conv, then a separate statistics pass (ablation of the producer-fused BatchNorm statistics)
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
     // 1 = Keras 2.2.x on TF-1.x through tf.nn.fused_batch_norm (Bessel-corrected batch variance, then Keras' n/(n-(1+eps)));
@@ -79,6 +80,11 @@ int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, cons
                          long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s);
 int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nruns, const long long* rows, const long long* a_off,
                                const long long* b_off, const long long* c_off, const int* nq, int K, int N, hipStream_t s);
+// csrc/wino_mm.hip: C[z] = A[z]^T B[z] with six exact bf16 piece products per fp32 product (the Winograd weight gradient under "wino_x6")
+bool myolo_gemm_tn_x6_ok(int Ka, int N);
+size_t myolo_gemm_tn_x6_ws_bytes(int nruns, const long long* rows, const int* nq, int Ka, int N);
+int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, const long long* rows, const long long* a_off, const long long* b_off,
+                          const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s);
 size_t myolo_gemm_tn_batched_ws_bytes(long long M, int Ka, int N, int batch);
 int myolo_gemm_tn_batched(const float* A, const float* B, float* C, long long M, int Ka, int N, int batch, void* ws, size_t ws_bytes,
                           hipStream_t s);

@@ -614,6 +614,13 @@ static int w63_tn_and_dw(const float* V, const float* Q, float* dU, float* dw, i
     const int nq[3] = {36, 24, 4};
     const long long prow[3] = {0, 36 * rows[0], 36 * rows[0] + 24 * rows[1]};
     const long long pq[3] = {0, 36, 60};
+    if (myolo_gemm_tn_x6_ok(Cin, Cout)) {          // FP32_MATMUL = "bf16x6": all 64 planes in one launch of wino_tn_x6_kernel (csrc/wino_mm.hip)
+        const long long ao[3] = {prow[0] * Cin, prow[1] * Cin, prow[2] * Cin}, bo[3] = {prow[0] * Cout, prow[1] * Cout, prow[2] * Cout};
+        const int rc = myolo_gemm_tn_x6_runs(V, Q, dU, 3, rows, ao, bo, nq, Cin, Cout, part, part_bytes, s);
+        if (rc != MYOLO_OK) return rc;
+        hipLaunchKernelGGL(wino63_dw_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, dU, dw, Cin, Cout);
+        return MYOLO_OK;
+    }
     for (int k = 0; k < 3; ++k) {
         const int rc = myolo_gemm_tn_batched(V + prow[k] * Cin, Q + prow[k] * Cout, dU + pq[k] * (long long)Cin * Cout, rows[k], Cin, Cout, nq[k],
                                              part, part_bytes, s);
@@ -632,6 +639,7 @@ size_t myolo_wino63_bwd_weight_ws_bytes(int N, int Cin, int Cout)
     const int nq[3] = {36, 24, 4};
     size_t pb = 0;
     for (int k = 0; k < 3; ++k) { const size_t b = myolo_gemm_tn_batched_ws_bytes(rows[k], Cin, Cout, nq[k]); if (b > pb) pb = b; }
+    if (Cin % 256 == 0 && Cout % 256 == 0) { const size_t b = myolo_gemm_tn_x6_ws_bytes(3, rows, nq, Cin, Cout); if (b > pb) pb = b; }
     return align256((size_t)64 * Cin * Cout * sizeof(float)) + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)) + align256(pb);
 }
 
@@ -734,6 +742,7 @@ size_t myolo_wino63_bwd_weight_from_q_ws_bytes(int N, int Cin, int Cout)
     const int nq[3] = {36, 24, 4};
     size_t pb = 0;
     for (int k = 0; k < 3; ++k) { const size_t b = myolo_gemm_tn_batched_ws_bytes(rows[k], Cin, Cout, nq[k]); if (b > pb) pb = b; }
+    if (Cin % 256 == 0 && Cout % 256 == 0) { const size_t b = myolo_gemm_tn_x6_ws_bytes(3, rows, nq, Cin, Cout); if (b > pb) pb = b; }
     return align256((size_t)64 * Cin * Cout * sizeof(float)) + align256(pb);
 }
 

@@ -585,3 +585,259 @@ extern "C" int myolo_matmul_f32(const float* A, const float* B, float* C, int64_
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
+
+// =====================================================================================================================
+// Weight-gradient product of the Winograd conv on the bf16 matrix pipe at fp32 accuracy ("bf16x6", see wino_mm_x6_kernel):
+//     C[z] (Ka x N) = A[z]^T (Ka x M) * B[z] (M x N),   A [M][Ka], B [M][N] dense row-major (the V and Q planes of conv1's backward,
+//     model.py:687-690: dU[q] = V[q]^T Q[q]), M = rows of the plane = the reduction index.
+// Both operands have the reduction index as their SLOW axis, the MFMA wants 8 consecutive k per lane: a loader thread owns one column
+// of one operand and fetches its 16 rows of the chunk with 16 dword loads (every wave-level load is a contiguous 256-byte row segment),
+// splits them EXACTLY into three bf16 pieces (truncation: and / sub / perm) and writes them k-contiguous into the LDS row record of
+// its column -- the transposition happens in the register -> LDS step, no strided access anywhere.  256 x 256 tile per workgroup (each
+// plane element is read from HBM once: the kernel is bound by its 3.9 GB of operand traffic, not by the matrix pipe), 8 waves of
+// 128 x 64 (4 x 2 MFMA tiles x 6 piece products), M split over workgroups, fp32 partial tiles summed in a fixed order by
+// tn_x6_reduce_kernel (bit-reproducible).  One barrier per 16-deep chunk; chunk c+1 is split into the other LDS buffer behind the MFMAs
+// of chunk c, chunk c+2 is in flight from HBM meanwhile.
+#define TN_T 256               // tile edge (rows of C and columns of C per workgroup)
+struct TNRun {
+    long long rows;            // M of every plane of the run
+    long long a_off, b_off;    // element offsets of the run's first plane in A / B (planes rows*Ka, rows*N apart)
+    long long rows_per_split;  // multiple of 16
+    long long unit0;           // first (plane, split) unit of the run
+    int plane0;                // index of the run's first plane in C
+    int nq;                    // planes in the run
+    int splits;
+};
+struct TNArgs {
+    const float* A;
+    const float* B;
+    float* part;               // [(plane, split) unit][Ka][N] fp32 partial products
+    float* C;                  // [planes][Ka][N]
+    int Ka, N;
+    int nruns;
+    int tiles_k, tiles_n;      // Ka / 256, N / 256
+    TNRun run[4];
+};
+
+__global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char Ls[2][2][TN_T * X6_REC];      // [buffer][A | B][column record]: 112 KB
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3, half = lane >> 5, l31 = lane & 31;
+    // unit = ((plane, split) pair, tile): tiles of one pair are consecutive workgroups
+    const int ntile = p.tiles_k * p.tiles_n;
+    const long long pair = blockIdx.x / ntile;
+    const int tile = (int)(blockIdx.x - pair * ntile);
+    const int kat = tile / p.tiles_n, nt = tile - kat * p.tiles_n;
+    int ri = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < p.nruns && pair >= p.run[k].unit0) ri = k;
+    const TNRun& R = p.run[ri];
+    const long long local = pair - R.unit0;
+    const int z = (int)(local / R.splits), sp = (int)(local - (long long)z * R.splits);
+    const long long r0 = (long long)sp * R.rows_per_split;
+    long long r1 = r0 + R.rows_per_split;
+    if (r1 > R.rows) r1 = R.rows;
+    const long long nrows = r1 > r0 ? r1 - r0 : 0;
+    const int nk = (int)((nrows + MM_BK - 1) / MM_BK);
+
+    // loader role: thread = (operand tid >> 8, column tid & 255); 16 rows of the chunk
+    const int op = tid >> 8, col = tid & 255;
+    const int ld = op ? p.N : p.Ka;
+    const float* base = op ? p.B + R.b_off + ((long long)z * R.rows + r0) * p.N + nt * TN_T
+                           : p.A + R.a_off + ((long long)z * R.rows + r0) * p.Ka + kat * TN_T;
+    const __amdgpu_buffer_rsrc_t rs = mm_rsrc(base, (nrows * ld - (op ? nt : kat) * TN_T) * 4);      // rows beyond the split read 0
+    const unsigned voff = (unsigned)col * 4u;
+    const unsigned rowb = (unsigned)ld * 4u;
+    unsigned soff = 0;                                   // byte offset of the chunk's first row (advances by 16 rows)
+    float st[16];
+    auto gload = [&]() {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) st[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)(soff + (unsigned)k * rowb), 0));
+        soff += 16u * rowb;
+    };
+    unsigned char* const wbase = &Ls[0][op][col * X6_REC];
+    auto split_store = [&](int buf, int h) {             // rows 8h .. 8h+7 of the staged chunk -> the three pieces of k half h
+        u32x4 p1, p2, p3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float a0 = st[8 * h + 2 * e], a1 = st[8 * h + 2 * e + 1];
+            const float b0 = x6_rest(a0), b1 = x6_rest(a1);
+            p1[e] = x6_top(a0, a1);
+            p2[e] = x6_top(b0, b1);
+            p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
+        }
+        unsigned char* w = wbase + buf * (2 * TN_T * X6_REC) + h * 16;
+        *reinterpret_cast<u32x4*>(w) = p1;
+        *reinterpret_cast<u32x4*>(w + 32) = p2;
+        *reinterpret_cast<u32x4*>(w + 64) = p3;
+    };
+    // MFMA role: A-operand rows = C rows (columns of A): wm*128 + t*32 + l31; B-operand = C columns: wn*64 + u*32 + l31
+    const int afr = (wm * 128 + l31) * X6_REC + half * 16;           // + t * 32 * X6_REC, + piece * 32
+    const int bfr = (wn * 64 + l31) * X6_REC + half * 16;            // + u * 32 * X6_REC
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    if (nk > 0) {
+        gload();
+        split_store(0, 0);
+        split_store(0, 1);
+        if (nk > 1) gload();
+    }
+    __syncthreads();
+    for (int c = 0; c < nk; ++c) {
+        const int cur = c & 1;
+        const bool more = c + 1 < nk;
+        const unsigned char* la = &Ls[cur][0][0];
+        const unsigned char* lb = &Ls[cur][1][0];
+        bf16x8 fb[2][3], fa[3], fn[3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) fb[u][pc] = *reinterpret_cast<const bf16x8*>(lb + bfr + u * 32 * X6_REC + pc * 32);
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc) fa[pc] = *reinterpret_cast<const bf16x8*>(la + afr + pc * 32);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < 3) {
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) fn[pc] = *reinterpret_cast<const bf16x8*>(la + afr + (t + 1) * 32 * X6_REC + pc * 32);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {             // smallest terms first
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[u][2], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[2], fb[u][0], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[u][1], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[u][1], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1], fb[u][0], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[u][0], acc[t][u], 0, 0, 0);
+            }
+            // chunk c+1 (in the staging registers since the previous chunk) goes into the other buffer in two slices behind the MFMAs
+            // of row tiles 0 and 1 (that buffer's last readers passed the previous barrier); chunk c+2 is requested behind row tile 2
+            if (t == 0 && more) split_store(cur ^ 1, 0);
+            if (t == 1 && more) split_store(cur ^ 1, 1);
+            if (t == 2 && c + 2 < nk) gload();
+            if (t < 3) { fa[0] = fn[0]; fa[1] = fn[1]; fa[2] = fn[2]; }
+        }
+        __syncthreads();
+    }
+    // ---- partial tile -> part[pair][kat*256 + row][nt*256 + col]: 128-byte row segments per 32 lanes
+    float* Pp = p.part + pair * (long long)p.Ka * p.N + ((long long)kat * TN_T + wm * 128) * p.N + nt * TN_T + wn * 64 + l31;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) Pp[(long long)row * p.N + u * 32] = acc[t][u][r];
+        }
+}
+
+// C[plane] = sum over the plane's splits of part[(plane, split)], fixed order; grid (element quads / 256, planes)
+__global__ __launch_bounds__(256) void tn_x6_reduce_kernel(TNArgs p)
+{
+    const int plane = blockIdx.y;
+    int ri = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+        if (k < p.nruns && plane >= p.run[k].plane0) ri = k;
+    const TNRun& R = p.run[ri];
+    const long long n4 = (long long)p.Ka * p.N / 4;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4* src = reinterpret_cast<const float4*>(p.part) + (R.unit0 + (long long)(plane - R.plane0) * R.splits) * n4 + i;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 4 <= R.splits; k += 4) {
+        const float4 a = src[(long long)k * n4], b = src[(long long)(k + 1) * n4], c = src[(long long)(k + 2) * n4], d = src[(long long)(k + 3) * n4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+        s.x += b.x; s.y += b.y; s.z += b.z; s.w += b.w;
+        s.x += c.x; s.y += c.y; s.z += c.z; s.w += c.w;
+        s.x += d.x; s.y += d.y; s.z += d.z; s.w += d.w;
+    }
+    for (; k < R.splits; ++k) {
+        const float4 a = src[(long long)k * n4];
+        s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+    }
+    reinterpret_cast<float4*>(p.C)[(long long)plane * n4 + i] = s;
+}
+
+/* whether dU[q] = V[q]^T Q[q] of a (Cin, Cout) layer runs on wino_tn_x6_kernel (option "wino_x6") */
+bool myolo_gemm_tn_x6_ok(int Ka, int N) { return g_myolo_opt.wino_x6 && !g_myolo_opt.tn_no_x6 && Ka >= TN_T && (Ka % TN_T) == 0 && N >= TN_T && (N % TN_T) == 0; }
+
+// split plan shared by the size query and the launcher: ~3 equal-work units per CU
+static long long tn_x6_plan(int nruns, const long long* rows, const int* nq, int Ka, int N, TNArgs* a)
+{
+    const int ntile = (Ka / TN_T) * (N / TN_T);
+    long long total_rows = 0;
+    for (int r = 0; r < nruns; ++r) total_rows += rows[r] * nq[r];
+    const long long target_units = 3 * 256;
+    long long rps = ((total_rows * ntile + target_units - 1) / target_units + MM_BK - 1) / MM_BK * MM_BK;
+    if (rps < 8 * MM_BK) rps = 8 * MM_BK;
+    long long pairs = 0;
+    for (int iter = 0; iter < 64; ++iter) {
+        pairs = 0;
+        for (int r = 0; r < nruns; ++r) pairs += (long long)nq[r] * ((rows[r] + rps - 1) / rps);
+        if (pairs * ntile <= target_units || rps >= total_rows) break;
+        rps += MM_BK;
+    }
+    if (a) {
+        long long unit = 0;
+        int plane = 0;
+        a->nruns = 0;
+        for (int r = 0; r < nruns; ++r) {
+            if (rows[r] <= 0 || nq[r] <= 0) continue;
+            TNRun& R = a->run[a->nruns++];
+            R.rows = rows[r]; R.nq = nq[r]; R.plane0 = plane; R.unit0 = unit;
+            R.splits = (int)((rows[r] + rps - 1) / rps);
+            R.rows_per_split = ((rows[r] + R.splits - 1) / R.splits + MM_BK - 1) / MM_BK * MM_BK;       // equal slices of the plane
+            unit += (long long)R.nq * R.splits;
+            plane += nq[r];
+        }
+    }
+    return pairs;
+}
+
+size_t myolo_gemm_tn_x6_ws_bytes(int nruns, const long long* rows, const int* nq, int Ka, int N)
+{
+    return align256((size_t)tn_x6_plan(nruns, rows, nq, Ka, N, nullptr) * Ka * N * sizeof(float));
+}
+
+/* For every run r and plane z < nq[r]:  C[plane0_r + z] (Ka x N) = A_r[z]^T B_r[z], A_r = A + a_off[r] (planes rows[r]*Ka apart),
+ * B_r = B + b_off[r] (rows[r]*N apart); C planes are Ka*N apart in run order.  part: myolo_gemm_tn_x6_ws_bytes.  Two launches. */
+int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, const long long* rows, const long long* a_off, const long long* b_off,
+                          const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s)
+{
+    if (nruns < 0 || nruns > 4 || Ka < TN_T || (Ka % TN_T) || N < TN_T || (N % TN_T) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) {
+        myolo_set_error("gemm_tn_x6_runs: needs Ka %% %d == 0, N %% %d == 0, <= 4 runs, 16-byte aligned operands", TN_T, TN_T);
+        return MYOLO_EINVAL;
+    }
+    TNArgs a{};
+    a.A = A; a.B = B; a.C = C; a.part = (float*)part; a.Ka = Ka; a.N = N; a.tiles_k = Ka / TN_T; a.tiles_n = N / TN_T;
+    const long long pairs = tn_x6_plan(nruns, rows, nq, Ka, N, &a);
+    if ((size_t)pairs * Ka * N * sizeof(float) > part_bytes || !part) {
+        myolo_set_error("gemm_tn_x6_runs: workspace too small (%zu needed, %zu given)", (size_t)pairs * Ka * N * sizeof(float), part_bytes);
+        return MYOLO_EWORKSPACE;
+    }
+    int k = 0, planes = 0;
+    for (int r = 0; r < nruns; ++r) {
+        if (rows[r] <= 0 || nq[r] <= 0) continue;
+        if ((a_off[r] | b_off[r]) & 3) { myolo_set_error("gemm_tn_x6_runs: run offsets must be multiples of 4 elements"); return MYOLO_EINVAL; }
+        a.run[k].a_off = a_off[r]; a.run[k].b_off = b_off[r];
+        planes += nq[r];
+        ++k;
+    }
+    if (pairs <= 0) return MYOLO_OK;
+    hipLaunchKernelGGL(wino_tn_x6_kernel, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
+    const long long n4 = (long long)Ka * N / 4;
+    hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), planes), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}

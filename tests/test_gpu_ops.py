@@ -885,10 +885,15 @@ def test_winograd_f63_conv1_pieces():
     assert torch.equal(dwm, dw63) and torch.equal(dxm, dx63)
 
 
-@pytest.mark.parametrize("N,Cin,Cout", [(11, 256, 256), (3, 64, 256)])
-def test_winograd_f63_conv_operators(N, Cin, Cout):
+@pytest.mark.parametrize("x6", [0, 1])
+@pytest.mark.parametrize("N,Cin,Cout", [(11, 256, 256), (3, 64, 256), (40, 256, 256), (5, 256, 512)])
+def test_winograd_f63_conv_operators(N, Cin, Cout, x6, request):
     """myolo_conv3x3_wino63_{fwd,bwd_data,bwd_weight}: the three operators as single calls on the F(6,3)/F(4,3) tiling, against the
-    float64 oracle at the suite's 1e-3 bound (the compacted mask-head backward at realistic positive counts runs through them)."""
+    float64 oracle at the suite's 1e-3 bound (the compacted mask-head backward at realistic positive counts runs through them).
+    x6 = 1: six exact bf16 piece products per fp32 product -- the multiply (wino_mm_x6_kernel) and, for channel counts that are
+    multiples of 256, the weight gradient's dU = V^T Q (wino_tn_x6_kernel, one launch over the 64 planes + a fixed-order reduce)."""
+    old = X.set_option("wino_x6", x6)
+    request.addfinalizer(lambda: X.set_option("wino_x6", old))
     rng = np.random.default_rng(21)
     H = W = 14
     x, w, b, dy = rnd(rng, N, H, W, Cin), rnd(rng, 3, 3, Cin, Cout, scale=0.05), rnd(rng, Cout), rnd(rng, N, H, W, Cout)
@@ -906,6 +911,14 @@ def test_winograd_f63_conv_operators(N, Cin, Cout):
     check(dw, rdw, what="wino63 dw (saved V)")
     X.call("myolo_conv3x3_wino63_bwd_weight", X.ptr(x_t), None, X.ptr(dy_t), X.ptr(dw2), N, Cin, Cout, *wsa, st)
     check(dw2, rdw, what="wino63 dw (from x)")
+    if x6:          # the split-product weight gradient against the fp32-MFMA one on the same operands: fp32-level agreement, and reproducible
+        dw3, dw4 = new(3, 3, Cin, Cout), new(3, 3, Cin, Cout)
+        with X.option("tn_no_x6", 1):
+            X.call("myolo_conv3x3_wino63_bwd_weight", None, X.ptr(vk), X.ptr(dy_t), X.ptr(dw3), N, Cin, Cout, *wsa, st)
+        X.call("myolo_conv3x3_wino63_bwd_weight", None, X.ptr(vk), X.ptr(dy_t), X.ptr(dw4), N, Cin, Cout, *wsa, st)
+        torch.cuda.synchronize()
+        assert float((dw - dw3).abs().max()) <= 2e-5 * float(dw3.abs().max())
+        assert torch.equal(dw, dw4)
     if X.wino63_ok(14, 14, Cout, Cin):
         dx = new(N, H, W, Cin)
         X.call("myolo_conv3x3_wino63_bwd_data", X.ptr(dy_t), X.ptr(w_t), X.ptr(dx), N, Cin, Cout, *wsa, st)

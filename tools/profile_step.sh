@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --steps 5 --warmup 2 --cpu-images 0 --no-variant "$@" > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -o bench -- python bench.py --steps 5 --warmup 2 --cpu-images 0 --no-variant --no-extras "$@" > $OUT/bench_under_rocprof.log 2>&1
 cp $OUT/bench/bench_kernel_stats.csv $OUT/${TAG}_bench_kernel_stats.csv
 python - "$OUT/bench/bench_kernel_trace.csv" "$OUT/${TAG}_bench_kernel_by_grid.csv" <<'PY'
 import csv, collections, sys
