@@ -220,6 +220,10 @@ def bench_train(args, rank, world, local):
                       **({"WINOGRAD_TILES": args.wino_tiles} if args.wino_tiles else {}))
     model = MaskYOLO(mode="training", config=cfg, device=dev, seed=0)      # same seed -> same weights on every rank
     net = model.net
+    for kv in args.net_attr:
+        name, _, val = kv.partition("=")
+        assert hasattr(net, name), "unknown engine attribute %s" % name
+        setattr(net, name, type(getattr(net, name))(int(val)))
     reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1)
     reducer.attach(net)
     ranks_seen = reducer.ranks_seen() if world > 1 else 1
@@ -488,7 +492,7 @@ def bench_train(args, rank, world, local):
                                "; Winograd multiply products: " + ("native fp32 MFMA" if net.fp32_matmul == "native" else
                                "FP32_MATMUL='bf16x6' (each fp32 product = six exact bf16 piece products, fp32 accumulation)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "forced_positives": args.force_pos,
+                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "net_attrs": list(args.net_attr), "forced_positives": args.force_pos,
                    "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
         "roofline": roofline,
     }
@@ -661,6 +665,8 @@ def main():
     ap.add_argument("--force-pos", type=int, default=0, metavar="K",
                     help="replace the first K proposals of every image by a ground-truth box for the WHOLE run (the n_pos sweep's hook): the step "
                          "at the positive counts a trained net produces; recorded in config.forced_positives")
+    ap.add_argument("--net-attr", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine (myolo.engine.Net) scheduling switches for this run, e.g. overlap_conv1_wgrad=0; recorded in config.net_attrs")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="myolo_set_option switches for this run (kernel A/B comparisons, e.g. wino_x6=1); recorded in config.lib_options")
     args = ap.parse_args()

@@ -169,6 +169,7 @@ struct W63Args {
     // FROM_M with BatchNorm statistics: per-image partial sums [NR][2*C] (sum | sum of squares) of the values written to y
     double* stats;
     float* Qn;               // TO_VQ: the adjoint-output-transformed planes (TO_Q alone writes them to Vn)
+    int order;               // workgroup order, see the kernel (set by w63_launch from option "w63_order")
 };
 
 __device__ __forceinline__ float w63_act(float v, int act)
@@ -301,9 +302,14 @@ template <int FRONT, int BACK>
 __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float act_lds[];         // [14][14][64]
-    const long long img = blockIdx.x;
+    // workgroup -> (image, 64-channel slice).  a.order = 1: the slices of one image are consecutive workgroups, so the workgroups in
+    // flight together touch whole [C]-wide rows of the planes (1 KB at C = 256) instead of a quarter of each row four times over
+    const int ns = a.C / W63_CS;
+    const long long unit = blockIdx.x;
+    const long long img = a.order ? unit / ns : unit % a.NR;
+    const int slice = (int)(a.order ? unit - img * ns : unit / a.NR);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.y * W63_CS + lane;
+    const int c = slice * W63_CS + lane;
     const int ty = wave / 3, tx = wave - ty * 3;
     const W63Planes pl = w63_planes(a.NR, img, ty, tx, a.C, c);
     const bool wr = a.y && (!a.flags || a.flags[img] != 0);
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
         const float* bxp = a.boxes + img * 4;
         const float by1 = bxp[0], bx1 = bxp[1], by2 = bxp[2], bx2 = bxp[3];
         const int cq = (lane & 15) * 4;
-        const float* fb = a.src + (long long)a.bind[img] * a.FH * a.FW * a.C + blockIdx.y * W63_CS + cq;
+        const float* fb = a.src + (long long)a.bind[img] * a.FH * a.FW * a.C + slice * W63_CS + cq;
         constexpr int NP = 3;                                                          // pixels (x 4 corners) in flight per lane
         constexpr int STEP = 4 * W63_TILES;                                            // pixels per pass of the workgroup
         for (int p0 = wave * 4 + (lane >> 4); p0 < W63_HW * W63_HW; p0 += NP * STEP) {
@@ -494,7 +500,9 @@ static int w63_launch(const W63Args& a, hipStream_t s)
         (void)hipFuncSetAttribute((const void*)wino63_boundary_kernel<FRONT, BACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
-    hipLaunchKernelGGL((wino63_boundary_kernel<FRONT, BACK>), dim3((unsigned)a.NR, a.C / W63_CS), dim3(W63_TILES * 64), lds, s, a);
+    W63Args b = a;
+    b.order = g_myolo_opt.w63_order ? 0 : 1;
+    hipLaunchKernelGGL((wino63_boundary_kernel<FRONT, BACK>), dim3((unsigned)(a.NR * (a.C / W63_CS))), dim3(W63_TILES * 64), lds, s, b);
     return MYOLO_OK;
 }
 

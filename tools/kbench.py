@@ -68,6 +68,50 @@ def main():
         ms = timeit(fn, a.iters)
         flop = 2.0 * M * C * 4 * C
         print("deconv_mask_bf16_fwd (ncls=%d) M=%d: %.3f ms  %.1f TFLOP/s (%.1f%% of 2500 bf16 dense)" % (ncls, M, ms, flop / ms / 1e9, flop / ms / 1e9 / 25.0))
+    elif a.which == "wino63_wgrad":
+        # conv1's weight-gradient product dU = V^T Q over the 64 planes + the dU -> dw transform (myolo_wino63_bwd_weight_from_q)
+        pe = X.wino63_plane_elems(NR, C)
+        V, Q, dw = rn(pe), rn(pe), torch.empty(3, 3, C, C, device=dev)
+        wsw = torch.empty(X.wino63_bwd_weight_from_q_ws_bytes(NR, C, C), dtype=torch.uint8, device=dev)
+        fn = lambda: X.call("myolo_wino63_bwd_weight_from_q", X.ptr(V), X.ptr(Q), X.ptr(dw), NR, C, C, wsw.data_ptr(), wsw.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        flop = 2.0 * 400 * NR * C * C
+        print("wino63_wgrad NR=%d: %.3f ms  %.1f fp32-equivalent TFLOP/s; operand bytes %.2f GB -> %.0f GB/s" % (NR, ms, flop / ms / 1e9, 2 * pe * 4 / 1e9, 2 * pe * 4 / ms / 1e6))
+    elif a.which == "wino63_boundary":
+        # the layer boundary M_i -> (output transform, bias, affine, ReLU) -> LDS -> input transform -> V_{i+1}: reads and writes one plane set each
+        pe = X.wino63_plane_elems(NR, C)
+        Mp, Vn, b, sc, sh = rn(pe), torch.empty(pe, device=dev), rn(C), rn(C), rn(C)
+        fn = lambda: X.call("myolo_wino63_output_input_transform", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), None, None, X.ptr(Vn), NR, C, 1, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("wino63_boundary<M,V> NR=%d: %.3f ms  %.0f GB/s (%.2f GB read + written)" % (NR, ms, 2 * pe * 4 / ms / 1e6, 2 * pe * 4 / 1e9))
+        y = torch.empty(M, C, device=dev)
+        fn = lambda: X.call("myolo_wino63_output_transform", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(y), NR, C, 1, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("wino63_boundary<M,none> NR=%d: %.3f ms  %.0f GB/s" % (NR, ms, (pe + M * C) * 4 / ms / 1e6))
+        fn = lambda: X.call("myolo_wino63_input_transform", X.ptr(y), X.ptr(sc), X.ptr(sh), 1, None, None, X.ptr(Vn), NR, C, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("wino63_boundary<act,V> NR=%d: %.3f ms  %.0f GB/s" % (NR, ms, (pe + M * C) * 4 / ms / 1e6))
+    elif a.which == "wino63_mm":
+        pe = X.wino63_plane_elems(NR, C)
+        V, Mp, w = rn(pe), torch.empty(pe, device=dev), rn(3, 3, C, C) * 0.02
+        U = torch.empty(X.wino63_u_elems(C, C), device=dev)
+        X.call("myolo_wino63_weight_transform", X.ptr(w), X.ptr(U), C, C, st)
+        fn = lambda: X.call("myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(Mp), NR, C, C, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        flop = 2.0 * 400 * NR * C * C
+        print("wino63_mm NR=%d: %.3f ms  %.1f fp32-equivalent TFLOP/s" % (NR, ms, flop / ms / 1e9))
+    elif a.which == "copy":
+        # HBM stream copy: the hand-written float4 kernel (myolo_stream_copy) over grid sizes, beside torch's copy_
+        nbytes = 2 << 30
+        src, dst = torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        src.zero_(); dst.zero_()
+        for variant, name, factor in ((0, "float4", 2), (1, "nt store", 2), (2, "nt load+store", 2), (3, "read only", 1), (4, "write only", 1)):
+            for blocks in (256, 512, 1024, 2048, 4096, 8192, 16384):
+                fn = lambda: X.call("myolo_stream_copy", src.data_ptr(), dst.data_ptr(), nbytes, variant, blocks, st)   # noqa: E731
+                ms = timeit(fn, a.iters)
+                print("copy %-14s blocks %5d: %.3f ms  %.0f GB/s" % (name, blocks, ms, factor * nbytes / ms / 1e6))
+        ms = timeit(lambda: dst.copy_(src), a.iters)
+        print("torch copy_: %.3f ms  %.0f GB/s" % (ms, 2 * nbytes / ms / 1e6))
     elif a.which == "wino63_fwd":
         # the F(6,3)/F(4,3) tiling (csrc/wino63_kernels.hip): input transform -> one-launch multiply -> output transform
         x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
