@@ -1162,6 +1162,10 @@ static int launch_transpose(const float* in, float* out, int R, int C, int nz, i
     return 0;
 }
 
+// pointwise layers on the bf16x6 kernels (128 x 256 / 256 x 256 tiles) only from this many rows up: the 7x7 layers (1568 rows) have too
+// few tiles for them and keep the split-K fp32 kernels (measured: 52 -> 72 us and 75 -> 123 us the other way round)
+static inline long long pw_x6_min_rows() { return g_myolo_opt.pw_x6_min_rows > 0 ? g_myolo_opt.pw_x6_min_rows : 4096; }
+
 template <int AMODE, int EPI>
 static int launch_nn(const GemmArgs& a, hipStream_t s, void* sk_ws = nullptr, size_t sk_ws_bytes = 0, long long sk_max_tiles = 512,
                      int* path = nullptr)      // *path: 0 generic kernel, 1 fast kernel, >= 2 fast kernel with that many K splits
@@ -1423,6 +1427,12 @@ int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
     MYOLO_REQUIRE(dy && w && dx && M > 0, "pwconv1x1_bwd_data: bad arguments");
     MYOLO_NEED_WS((size_t)Cin * Cout * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
+    if (g_myolo_opt.wino_x6 && !g_myolo_opt.pw_no_x6 && (Cin % 256) == 0 && (Cout % 16) == 0 && M >= pw_x6_min_rows() &&
+        ws_bytes >= myolo_matmul_f32_ws_bytes(Cout, Cin, 1, MYOLO_PRODUCTS_BF16X6) && (((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0) {
+        // FP32_MATMUL = "bf16x6": dx [M][Cin] = dy [M][Cout] * w^T, and w [Cin][Cout] IS the transposed operand [N][K] the NT kernel wants:
+        // no transpose launch, six exact bf16 piece products per fp32 product on the bf16 matrix pipe (csrc/wino_mm.hip)
+        return myolo_matmul_f32(dy, w, dx, M, Cout, Cin, 1, MYOLO_PRODUCTS_BF16X6, ws, ws_bytes, stream);
+    }
     launch_transpose(w, (float*)ws, Cin, Cout, 1, 0, s);        // ws = w^T [Cout][Cin]
     GemmArgs a = {};
     a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = M; a.N = Cin; a.K = Cout;
@@ -1477,6 +1487,17 @@ static int pw_bwd_weight_impl(const float* x, const float* in_scale, const float
             return MYOLO_OK;
         }
     }
+    if (g_myolo_opt.wino_x6 && !g_myolo_opt.pw_no_x6 && myolo_gemm_tn_x6_ok(Cin, Cout) && M >= pw_x6_min_rows() && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) == 0) {
+        // FP32_MATMUL = "bf16x6": dw [Cin][Cout] = x^T dy on wino_tn_x6_kernel (256 x 256 tiles, M split over workgroups, fixed-order reduce)
+        const long long rows[1] = {M}, off[1] = {0};
+        const int nq[1] = {1};
+        if (myolo_gemm_tn_x6_ws_bytes(1, rows, nq, Cin, Cout) <= ws_bytes && ws) {
+            const int rc = myolo_gemm_tn_x6_runs(x, dy, dw, 1, rows, off, off, nq, Cin, Cout, ws, ws_bytes, (hipStream_t)stream, in_scale, in_shift, in_act);
+            if (rc) return rc;
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+    }
     GemmArgs a = {};
     a.A = x; a.B = dy; a.M = M; a.N = Cout; a.K = Cin; a.lda = Cin; a.ldb = Cout;
     a.a_scale = in_scale; a.a_shift = in_shift; a.a_act = in_act;
@@ -1505,7 +1526,8 @@ static size_t pw_split_bytes(int64_t M, int Cout)
 size_t myolo_pwconv1x1_bnstats_ws_bytes(int64_t M, int Cin, int Cout)
 {
     const size_t tiles = (size_t)cdiv64(M, BM);
-    const size_t fused = align256(tiles * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double));
+    const size_t fused = align256(tiles * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double)) +
+                         ((Cin >= 256 && (Cout % 256) == 0) ? myolo_pw_x6_split_bytes(Cin, Cout) : 0);
     // split-K path / ablation: the partial outputs, then a statistics pass over y (<= 1024 slabs of 2*Cout doubles)
     const size_t split = pw_split_bytes(M, Cout) + align256((size_t)1024 * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double));
     return fused > split ? fused : split;
@@ -1536,6 +1558,16 @@ int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const flo
     const size_t pbytes = align256((size_t)tiles * 2 * Cout * sizeof(double));
     double* part = (double*)ws;
     double* tot = (double*)((char*)ws + pbytes);
+    if (myolo_pw_x6_ok(Cin, Cout) && M >= pw_x6_min_rows() && !g_myolo_opt.no_trunk_fusion) {
+        // FP32_MATMUL = "bf16x6": the layers with >= 256 input and a multiple of 256 output channels on the bf16 matrix pipe (six exact piece
+        // products per fp32 product, csrc/wino_mm.hip), same on-load BatchNorm and epilogue column sums; three launches (split, GEMM, finish)
+        void* split = (char*)ws + pbytes + align256(2 * Cout * sizeof(double));
+        myolo_pw_x6_fwd(x, in_scale, in_shift, in_act, w, y, part, M, Cin, Cout, split, s);
+        MYOLO_CHECK_LAUNCH();
+        myolo_bn_stats_from_partials(part, tot, tiles, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     a.stat = g_myolo_opt.no_trunk_fusion ? nullptr : part;
     int path = 0;
     // the split-K scratch shares ws with the partials: when the launcher picks split-K it drops a.stat (nothing is written there)

@@ -28,7 +28,10 @@ struct MyoloOptions {
     int wino_x6;          // winograd multiply on the bf16 matrix pipe: 6 piece products per fp32 product, fp32 accumulation (csrc/wino_mm.hip)
     int wino_no_bt;       // winograd multiply: gemm_nn_fast on [K][N] filters instead of wino_mm_kernel on transposed ones
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)
+    int w63_persist;      // wino63 boundary kernels: > 0 = that many workgroups per CU walk the (image, slice) units in a loop
     int w63_order;        // wino63 boundary kernels: 1 = the previous workgroup order (all images of channel slice 0, then slice 1, ...)
+    int pw_x6_min_rows;   // pointwise convs: fewest rows for the bf16x6 kernels (0 = default 4096)
+    int pw_no_x6;         // pointwise convs with >= 256 channels: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)
     int no_trunk_fusion;  // *_bnstats_fwd: the conv, then a separate statistics pass (ablation of the producer-fused BatchNorm statistics)
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
@@ -85,7 +88,13 @@ int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nr
 bool myolo_gemm_tn_x6_ok(int Ka, int N);
 size_t myolo_gemm_tn_x6_ws_bytes(int nruns, const long long* rows, const int* nq, int Ka, int N);
 int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, const long long* rows, const long long* a_off, const long long* b_off,
-                          const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s);
+                          const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s,
+                          const float* a_scale = nullptr, const float* a_shift = nullptr, int a_act = 0);
+// pointwise convs with >= 256 channels under "wino_x6" (csrc/wino_mm.hip)
+bool myolo_pw_x6_ok(int K, int N);
+size_t myolo_pw_x6_split_bytes(int K, int N);
+int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y, double* stat,
+                    long long M, int K, int N, void* split, hipStream_t s);
 size_t myolo_gemm_tn_batched_ws_bytes(long long M, int Ka, int N, int batch);
 int myolo_gemm_tn_batched(const float* A, const float* B, float* C, long long M, int Ka, int N, int batch, void* ws, size_t ws_bytes,
                           hipStream_t s);

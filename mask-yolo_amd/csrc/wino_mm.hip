@@ -49,6 +49,12 @@ struct MMArgs {
     const float* w2;       // [Co][ncls]: the 1x1 mask conv
     float* part;           // [Co/128 slabs][4*M pixels][ncls] partial logits
     int H, W, Co, ncls;
+    // PW (pointwise conv of the trunk in training mode, see gemm_kernels.hip myolo_pwconv1x1_bnstats_fwd): A := act(A * a_scale[k] + a_shift[k])
+    // on load; stat: per row-tile partial sums of the output columns [M tiles][2][N] doubles
+    const float* a_scale;
+    const float* a_shift;
+    int a_act;
+    double* stat;
     MMRun run[4];
 };
 
@@ -283,7 +289,14 @@ __device__ __forceinline__ bf16x8 x6_ldb(__amdgpu_buffer_rsrc_t r, unsigned voff
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int EPI>
+__device__ __forceinline__ float mm_act(float v, int act)
+{
+    if (act == MYOLO_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == MYOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+template <int EPI, bool PW = false>
 __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][MM_BM * X6_REC];
@@ -323,12 +336,28 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     unsigned aoffg = ((unsigned)arow * (unsigned)p.K + (unsigned)ah * 8u) * 4u;            // + 64 bytes per chunk
     const int asto = arow * X6_REC + ah * 16;                                              // + piece * 32
     float4 sa[2];
+    float4 psc[2], psh[2];                     // PW: this chunk's per-k affine (k = kch + ah*8 .. +7)
+    int kch = ah * 8;
     auto gload = [&]() {
         sa[0] = mm_bufld4(ra, aoffg);
         sa[1] = mm_bufld4(ra, aoffg + 16u);
         aoffg += MM_BK * 4u;
+        if (PW && p.a_scale) {
+            psc[0] = *reinterpret_cast<const float4*>(p.a_scale + kch); psc[1] = *reinterpret_cast<const float4*>(p.a_scale + kch + 4);
+            psh[0] = *reinterpret_cast<const float4*>(p.a_shift + kch); psh[1] = *reinterpret_cast<const float4*>(p.a_shift + kch + 4);
+            kch += MM_BK;
+        }
+    };
+    auto affine = [&]() {                      // the producing layer's BatchNorm + activation on the staged chunk (rows beyond M are never stored / counted)
+        if (PW && p.a_scale) {
+            sa[0].x = mm_act(fmaf(sa[0].x, psc[0].x, psh[0].x), p.a_act); sa[0].y = mm_act(fmaf(sa[0].y, psc[0].y, psh[0].y), p.a_act);
+            sa[0].z = mm_act(fmaf(sa[0].z, psc[0].z, psh[0].z), p.a_act); sa[0].w = mm_act(fmaf(sa[0].w, psc[0].w, psh[0].w), p.a_act);
+            sa[1].x = mm_act(fmaf(sa[1].x, psc[1].x, psh[1].x), p.a_act); sa[1].y = mm_act(fmaf(sa[1].y, psc[1].y, psh[1].y), p.a_act);
+            sa[1].z = mm_act(fmaf(sa[1].z, psc[1].z, psh[1].z), p.a_act); sa[1].w = mm_act(fmaf(sa[1].w, psc[1].w, psh[1].w), p.a_act);
+        }
     };
     auto sstore = [&](int buf) {
+        affine();
         const float x[8] = {sa[0].x, sa[0].y, sa[0].z, sa[0].w, sa[1].x, sa[1].y, sa[1].z, sa[1].w};
         float r1[8], r2[8];
 #pragma unroll
@@ -384,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         const bool more = c + 1 < nk;
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) fa[1][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + 32 * X6_REC + pc * 32);
+        affine();                                                       // (PW) chunk c+1's BatchNorm + activation, with the coefficients its gload fetched
         const float x[8] = {sa[0].x, sa[0].y, sa[0].z, sa[0].w, sa[1].x, sa[1].y, sa[1].z, sa[1].w};
         u32x4 p1, p2, p3;
         if (c + 2 < nk) gload();                                        // chunk c+2 (x[] holds copies of chunk c+1)
@@ -435,6 +465,40 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     if constexpr (EPI == MM_EP_DECONV_MASK) {
         mm_deconv_mask_epilogue(p, acc, m0, M, n0, wm, wn, half, l31);
         return;
+    }
+    if constexpr (PW) {
+        if (p.stat) {
+            // column sums of the tile (BatchNorm statistics of the conv's output): lane -> its 32 row slots, the other half-wave, the two
+            // waves sharing the columns through LDS (free after the loop); one row of partials per row tile: fixed-order finish
+            float s1[4], s2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row >= M) continue;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const float v = acc[t][u][r]; s1[u] += v; s2[u] = fmaf(v, v, s2[u]); }
+                }
+            __syncthreads();                                     // (every wave is past its last fragment read)
+            float* sred = reinterpret_cast<float*>(&As[0][0]);   // [2 (wm)][2 (sum, sumsq)][256]
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                s1[u] += __shfl_xor(s1[u], 32, 64);
+                s2[u] += __shfl_xor(s2[u], 32, 64);
+                if (half == 0) {
+                    sred[(wm * 2 + 0) * MM_BN + wn * 128 + u * 32 + l31] = s1[u];
+                    sred[(wm * 2 + 1) * MM_BN + wn * 128 + u * 32 + l31] = s2[u];
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < 2 * MM_BN; e += 256) {
+                const int v = e / MM_BN, cc = e - v * MM_BN;
+                p.stat[((m0 / MM_BM) * 2 + v) * p.N + n0 + cc] = (double)sred[(0 * 2 + v) * MM_BN + cc] + (double)sred[(1 * 2 + v) * MM_BN + cc];
+            }
+        }
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -609,6 +673,9 @@ struct TNRun {
     int splits;
 };
 struct TNArgs {
+    const float* a_scale;      // A := act(A * a_scale[col] + a_shift[col]) on load (rows that exist), NULL: none
+    const float* a_shift;
+    int a_act;
     const float* A;
     const float* B;
     float* part;               // [(plane, split) unit][Ka][N] fp32 partial products
@@ -659,8 +726,18 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
         soff += 16u * rowb;
     };
     unsigned char* const wbase = &Ls[0][op][col * X6_REC];
+    // the A operand may be a pre-BN tensor whose BatchNorm + activation is applied on load (pointwise weight gradient): this thread's
+    // column has one scale / shift; padding rows (beyond the split) must stay 0
+    const bool pro = p.a_scale != nullptr && op == 0;
+    const float csc = pro ? p.a_scale[kat * TN_T + col] : 1.f, csh = pro ? p.a_shift[kat * TN_T + col] : 0.f;
+    long long rows_staged = 0;                           // first row (within the split) of the chunk in the staging registers
     auto split_store = [&](int buf, int h) {             // rows 8h .. 8h+7 of the staged chunk -> the three pieces of k half h
         u32x4 p1, p2, p3;
+        if (pro) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (rows_staged + 8 * h + j < nrows) st[8 * h + j] = mm_act(fmaf(st[8 * h + j], csc, csh), p.a_act);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a0 = st[8 * h + 2 * e], a1 = st[8 * h + 2 * e + 1];
@@ -696,6 +773,7 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
     for (int c = 0; c < nk; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < nk;
+        rows_staged = (long long)(c + 1) * MM_BK;         // the staging registers hold chunk c+1 until it is split below
         const unsigned char* la = &Ls[cur][0][0];
         const unsigned char* lb = &Ls[cur][1][0];
         bf16x8 fb[2][3], fa[3], fn[3];
@@ -814,7 +892,8 @@ size_t myolo_gemm_tn_x6_ws_bytes(int nruns, const long long* rows, const int* nq
 /* For every run r and plane z < nq[r]:  C[plane0_r + z] (Ka x N) = A_r[z]^T B_r[z], A_r = A + a_off[r] (planes rows[r]*Ka apart),
  * B_r = B + b_off[r] (rows[r]*N apart); C planes are Ka*N apart in run order.  part: myolo_gemm_tn_x6_ws_bytes.  Two launches. */
 int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, const long long* rows, const long long* a_off, const long long* b_off,
-                          const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s)
+                          const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s,
+                          const float* a_scale, const float* a_shift, int a_act)
 {
     if (nruns < 0 || nruns > 4 || Ka < TN_T || (Ka % TN_T) || N < TN_T || (N % TN_T) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) {
         myolo_set_error("gemm_tn_x6_runs: needs Ka %% %d == 0, N %% %d == 0, <= 4 runs, 16-byte aligned operands", TN_T, TN_T);
@@ -822,6 +901,7 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
     }
     TNArgs a{};
     a.A = A; a.B = B; a.C = C; a.part = (float*)part; a.Ka = Ka; a.N = N; a.tiles_k = Ka / TN_T; a.tiles_n = N / TN_T;
+    a.a_scale = a_scale; a.a_shift = a_shift; a.a_act = a_act;
     const long long pairs = tn_x6_plan(nruns, rows, nq, Ka, N, &a);
     if ((size_t)pairs * Ka * N * sizeof(float) > part_bytes || !part) {
         myolo_set_error("gemm_tn_x6_runs: workspace too small (%zu needed, %zu given)", (size_t)pairs * Ka * N * sizeof(float), part_bytes);
@@ -839,5 +919,28 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
     hipLaunchKernelGGL(wino_tn_x6_kernel, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
     const long long n4 = (long long)Ka * N / 4;
     hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), planes), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}
+
+
+/* pointwise conv of the trunk on the bf16 matrix pipe with six exact piece products (FP32_MATMUL = "bf16x6", layers with Cout % 256 == 0):
+ * y [M][N] = act_in(x * in_scale + in_shift) [M][K] * w [K][N], optional per-row-tile partial sums of y's columns (stat).
+ * ws: the split filters (K*N*6 bytes).  Two launches (split, GEMM). */
+bool myolo_pw_x6_ok(int K, int N) { return g_myolo_opt.wino_x6 && !g_myolo_opt.pw_no_x6 && K >= 256 && (K % MM_BK) == 0 && (N % MM_BN) == 0; }
+size_t myolo_pw_x6_split_bytes(int K, int N) { return align256((size_t)K * N * 6); }
+int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y, double* stat,
+                    long long M, int K, int N, void* split, hipStream_t s)
+{
+    MMArgs a{};
+    a.A = x; a.C = y; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
+    a.a_scale = in_scale; a.a_shift = in_shift; a.a_act = in_act; a.stat = stat;
+    MMRun& R = a.run[0];
+    R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
+    R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
+    const long long tiles = (long long)R.mtiles * (N / MM_BN);
+    const long long total = (long long)K * N;
+    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 1);
+    a.Bt = (const float*)split;
+    hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
 }

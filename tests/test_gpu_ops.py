@@ -84,6 +84,30 @@ def test_pwconv1x1(M, Cin, Cout, bias):
     check(dw, x.astype(np.float64).T @ dy, what="pw dw")
 
 
+@pytest.mark.parametrize("M,Cin,Cout", [(6272, 512, 512), (25088, 256, 512), (1568, 1024, 1024), (1300, 512, 256), (2049, 256, 256), (1100, 256, 1024)])
+def test_pwconv1x1_gradients_bf16x6(M, Cin, Cout, request):
+    """FP32_MATMUL = "bf16x6" (library switch wino_x6): the data and weight gradients of the pointwise layers with multiples of 256
+    channels run on wino_mm_x6_kernel (NT: w itself is the transposed operand) / wino_tn_x6_kernel -- against float64 at the suite's
+    bound, and against the fp32-MFMA kernels on the same operands at fp32 level."""
+    old = X.set_option("wino_x6", 1)
+    request.addfinalizer(lambda: X.set_option("wino_x6", old))
+    rng = np.random.default_rng(41)
+    x, w, dy = rnd(rng, M, Cin), rnd(rng, Cin, Cout, scale=0.1), rnd(rng, M, Cout)
+    xt, wt, dyt = dt(x), dt(w), dt(dy)
+    res = {}
+    for no in (0, 1):
+        with X.option("pw_no_x6", no):
+            dx, dw = new(M, Cin), new(Cin, Cout)
+            X.call("myolo_pwconv1x1_bwd_data", X.ptr(dyt), X.ptr(wt), X.ptr(dx), M, Cin, Cout, *ws(), X.stream())
+            X.call("myolo_pwconv1x1_bwd_weight", X.ptr(xt), X.ptr(dyt), X.ptr(dw), M, Cin, Cout, *ws(), X.stream())
+            torch.cuda.synchronize()
+            res[no] = (dx, dw)
+    check(res[0][0], dy.astype(np.float64) @ w.T, what="pw dx (bf16x6)")
+    check(res[0][1], x.astype(np.float64).T @ dy, what="pw dw (bf16x6)")
+    for a, b in zip(res[0], res[1]):
+        assert float((a - b).abs().max()) <= 3e-5 * float(b.abs().max())
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 32, 64), (2, 7, 9, 16, 48), (1, 28, 28, 128, 256), (5, 14, 14, 256, 256)])
 def test_conv3x3(N, H, W, Cin, Cout):
     rng = np.random.default_rng(2)
@@ -1050,13 +1074,18 @@ def test_dwconv3x3_bnstats_fwd_and_affine_in_weight_gradient(N, H, W, C, stride,
         check(dw, rdw, what="dw dw with the input normalised on load")
 
 
+@pytest.mark.parametrize("x6", [0, 1])
 @pytest.mark.parametrize("nofuse", [0, 1])
 @pytest.mark.parametrize("M,Cin,Cout,lazy", [(300, 32, 64, True), (4096, 64, 128, True), (25088, 64, 64, True), (6272, 512, 512, True), (1568, 512, 1024, True),
-                                             (1568, 1024, 1024, False), (130, 16, 16, True), (20003, 32, 64, True), (257, 256, 512, True), (100352, 64, 128, True)])
-def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy, nofuse):
+                                             (1568, 1024, 1024, False), (130, 16, 16, True), (20003, 32, 64, True), (257, 256, 512, True), (100352, 64, 128, True),
+                                             (25088, 256, 256, True), (3000, 256, 512, False)])
+def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy, nofuse, x6, request):
     """pointwise conv whose A operand is relu6(x * in_scale + in_shift) formed on load, with the batch statistics of its output from
     the GEMM epilogue (one pass) or, for the split-K shapes (M = 1568), from a statistics pass; and its weight gradient
-    re-normalising x on load (thin-layer kernel, 128x128-tile kernel)."""
+    re-normalising x on load (thin-layer kernel, 128x128-tile kernel).  x6 = 1 (FP32_MATMUL = "bf16x6"): the layers with >= 256 input and
+    a multiple of 256 output channels run on wino_mm_x6_kernel<PLAIN, PW> / wino_tn_x6_kernel with the same prologue and epilogue."""
+    old = X.set_option("wino_x6", x6)
+    request.addfinalizer(lambda: X.set_option("wino_x6", old))
     rng = np.random.default_rng(22)
     x, w = rnd(rng, M, Cin, scale=2.0), rnd(rng, Cin, Cout, scale=0.1)
     isc, ish = (1 + rnd(rng, Cin, scale=0.3)), rnd(rng, Cin, scale=0.5) + 1.0

@@ -49,10 +49,12 @@ for target, kname, key, alg_bytes, alg_flop in (
     try:
         v, ns, n = per_launch("%s_sq" % target, kname)
         e["sq"] = v; e["sq_avg_ns_per_launch"] = ns
-        if v.get("SQ_BUSY_CU_CYCLES"):
-            e["mfma_busy_frac_of_cu_busy"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / v["SQ_BUSY_CU_CYCLES"]
         if v.get("GRBM_GUI_ACTIVE") and ns:
-            e["effective_clock_ghz"] = v["GRBM_GUI_ACTIVE"] / ns
+            cyc = v["GRBM_GUI_ACTIVE"] / 8                      # the counter sums the 8 XCDs
+            e["effective_clock_ghz"] = cyc / ns
+            e["mfma_pipe_busy"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024 / cyc      # 256 CUs x 4 SIMDs
+            if alg_flop:          # six 32x32x16 bf16 MFMAs (32768 flop, 32 cycles each) per 16-deep fp32 block of 32x32
+                e["mfma_busy_cycles_minimum"] = 6 * alg_flop / 32768 * 32
     except Exception as ex:
         e["sq_error"] = str(ex)
     res[key] = e
