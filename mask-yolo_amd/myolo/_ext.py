@@ -11,7 +11,8 @@ import torch
 
 _LIB = None
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libmyolo_hip.so")
+# MYOLO_LIB: an alternative build of the same C-ABI (the sanitizer build of __graft_entry__.build_sanitized(), used by the host-side tests)
+LIB_PATH = os.environ.get("MYOLO_LIB") or os.path.join(_HERE, "_lib", "libmyolo_hip.so")
 
 P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_size_t
 
