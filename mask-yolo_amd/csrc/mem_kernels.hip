@@ -39,7 +39,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"w63_persist", &MyoloOptions::w63_persist}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"w63_persist", &MyoloOptions::w63_persist}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -913,6 +913,95 @@ struct OpDwDw {
         }
     }
 };
+
+
+// Depthwise weight gradient with the forward kernel's access pattern: a thread owns a TH x TW block of OUTPUT pixels of one channel
+// quad, keeps their dy in registers and walks down the (TH-1)*S+3 input rows of the block once (each x element is loaded once per
+// block instead of once per tap, as the generic OpDwDw column reduction does): acc[ky][kx] += x[r*S+ky][j*S+kx] * dy[r][j].
+// The 9 partial sums of a workgroup's threads that share a channel quad are combined through LDS (double from there on) into one row
+// of partials per workgroup, finished by colreduce_finish<FinD2F> in a fixed order.  `in` != none: x is the producing layer's pre-BN
+// output, normalised + activated on load (zero padding stays zero).  Needs 256 % (C/4) == 0.
+template <int S, int TW, int TH>
+__global__ __launch_bounds__(256, 2) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
+                                                       int N, int H, int W, int C, int Ho, int Wo, DwAffine in, int zb)
+{
+    constexpr int NC = (TW - 1) * S + 3;
+    constexpr int NR = (TH - 1) * S + 3;
+    const int pt = (S == 1) ? 1 : 0, plft = (S == 1) ? 1 : 0;
+    const int cq = C / 4;
+    const int wtiles = (Wo + TW - 1) / TW;
+    const unsigned e = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = e < (unsigned)(wtiles * cq);
+    const int wt = live ? e / (unsigned)cq : 0;
+    const int c = live ? (e - wt * cq) * 4 : 0;
+    const int ox0 = wt * TW;
+    float4 isc = make_float4(1.f, 1.f, 1.f, 1.f), ish = f4zero();
+    if (in.scale) { isc = ld4g(in.scale + c); ish = ld4g(in.shift + c); }
+    float4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f4zero();
+    // a workgroup walks (image, row group) units with stride gridDim.y (zb = number of units): the workgroup-level reduction of the 9 sums
+    // and its row of partials (9 C doubles) are paid once per workgroup, not once per 8 output pixels
+    const int rgroups = (Ho + TH - 1) / TH;
+#pragma unroll 1
+    for (int u = blockIdx.y; u < zb; u += gridDim.y) {
+    const int n = u / rgroups;
+    const int oy0 = (u - n * rgroups) * TH;
+    float4 g[TH][TW];
+#pragma unroll
+    for (int r = 0; r < TH; ++r)
+#pragma unroll
+        for (int j = 0; j < TW; ++j) {
+            const bool ok = live && oy0 + r < Ho && ox0 + j < Wo;
+            g[r][j] = ok ? ld4g(dy + ((((long long)n * Ho + oy0 + r) * Wo) + ox0 + j) * C + c) : f4zero();
+        }
+#pragma unroll
+    for (int ri = 0; ri < NR; ++ri) {
+        const int iy = oy0 * S + ri - pt;
+        const bool rowin = live && iy >= 0 && iy < H;
+        const float* rowp = x + (((long long)n * H + (rowin ? iy : 0)) * W) * C + c;
+        float4 col[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int ix = ox0 * S + k - plft;
+            const bool inb = rowin && ix >= 0 && ix < W;
+            col[k] = inb ? ld4g(rowp + (long long)ix * C) : f4zero();
+            if (in.scale && inb) {
+                col[k].x = actf(fmaf(col[k].x, isc.x, ish.x), in.act); col[k].y = actf(fmaf(col[k].y, isc.y, ish.y), in.act);
+                col[k].z = actf(fmaf(col[k].z, isc.z, ish.z), in.act); col[k].w = actf(fmaf(col[k].w, isc.w, ish.w), in.act);
+            }
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if ((ri - ky) >= 0 && ((ri - ky) % S) == 0 && (ri - ky) / S < TH) {
+                const int r = (ri - ky) / S;
+#pragma unroll
+                for (int j = 0; j < TW; ++j)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = f4fma(col[j * S + kx], g[r][j], acc[ky * 3 + kx]);
+            }
+        }
+    }
+    }
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, cl = cq < 256 ? cq : 256, pl = 256 / cl, cl_i = tid % cl;
+    const long long blk = blockIdx.x + (long long)gridDim.x * blockIdx.y;
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        __syncthreads();
+        red[tid] = acc[v];
+        __syncthreads();
+        if (tid < cl) {
+            double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+            for (int j = 0; j < pl; ++j) {
+                const float4 t = red[j * cl + cl_i];
+                a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
+            }
+            double* o = part + (blk * 9 + v) * C + cl_i * 4;
+            o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+        }
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // crop_and_resize (ROIAlign).  One channel-quad lane per output element quad; the 64 lanes of a
@@ -1871,11 +1960,37 @@ static int dw_bwd_weight_impl(const float* x, DwAffine in, const float* dy, floa
     MYOLO_REQUIRE(x && dy && dw && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_weight: bad arguments");
     const int Ho = H / stride, Wo = W / stride;
     const long long M = (long long)N * Ho * Wo;
+    hipStream_t s = (hipStream_t)stream;
+    const int cq = C / 4;
+    if (cq <= 256 && (256 % cq) == 0 && !g_myolo_opt.dw_wgrad_generic) {
+        // tiled kernel: 2 rows x 4 columns (stride 1) / 2 x 2 (stride 2) of output pixels per thread
+        const int TW = stride == 1 ? 4 : 2, TH = 2;
+        const int wt = (Wo + TW - 1) / TW, per_row = wt * cq;
+        // ~768 workgroups in all (three per CU), each walking its share of the (image, row group) units
+        const int gx = (per_row + 255) / 256;
+        const int units = ((Ho + TH - 1) / TH) * N;
+        int gy = 768 / gx;
+        if (gy < 1) gy = 1;
+        if (gy > units) gy = units;
+        const int zb = units;
+        const dim3 grid(gx, gy, 1);
+        const long long nblk = (long long)grid.x * grid.y;
+        const size_t pb2 = align256((size_t)nblk * 9 * C * sizeof(double));
+        if (pb2 + 9 * C * sizeof(double) <= ws_bytes && ws && nblk <= (1 << 20)) {
+            double* part2 = (double*)ws;
+            double* tot2 = (double*)((char*)ws + pb2);
+            if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<1, 4, 2>), grid, dim3(256), 0, s, x, dy, part2, N, H, W, C, Ho, Wo, in, zb);
+            else hipLaunchKernelGGL((dw_wgrad_kernel<2, 2, 2>), grid, dim3(256), 0, s, x, dy, part2, N, H, W, C, Ho, Wo, in, zb);
+            const int nvc = 9 * C;
+            hipLaunchKernelGGL((colreduce_finish<FinD2F>), dim3((nvc + 7) / 8), dim3(256), 0, s, part2, tot2, (int)nblk, nvc, C, FinD2F{dw});
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+    }
     const size_t pb = col_ws_bytes(M, C, 9);
     MYOLO_NEED_WS(align256(pb) + 9 * C * sizeof(double));
     double* part = (double*)ws;
     double* tot = (double*)((char*)ws + align256(pb));
-    hipStream_t s = (hipStream_t)stream;
     OpDwDw op{x, dy, H, W, C, Ho, Wo, stride, in};
     run_colreduce(op, M, C, part, tot, s, FinD2F{dw});
     MYOLO_CHECK_LAUNCH();

@@ -31,6 +31,7 @@ struct MyoloOptions {
     int w63_persist;      // wino63 boundary kernels: > 0 = that many workgroups per CU walk the (image, slice) units in a loop
     int w63_order;        // wino63 boundary kernels: 1 = the previous workgroup order (all images of channel slice 0, then slice 1, ...)
     int pw_x6_min_rows;   // pointwise convs: fewest rows for the bf16x6 kernels (0 = default 4096)
+    int dw_wgrad_generic; // depthwise weight gradient: the generic 9-accumulator column reduction instead of the tiled kernel (ablation)
     int pw_no_x6;         // pointwise convs with >= 256 channels: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)
     int no_trunk_fusion;  // *_bnstats_fwd: the conv, then a separate statistics pass (ablation of the producer-fused BatchNorm statistics)
