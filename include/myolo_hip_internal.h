@@ -140,16 +140,17 @@ int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, co
  * "*_bnstats_fwd" = the conv AND the batch statistics of its output (mean, biased variance, folded scale / shift, Keras moving averages:
  * exactly what myolo_bn_stats produces) -- the statistics are reduced from partial sums the conv kernel leaves in its epilogue, so the
  * output is not re-read; "in_scale / in_shift / in_act" = the PRODUCING layer's BatchNorm apply + activation, performed on the load of
- * its pre-BN output, so the normalised activation is never written (NULL: the input is used as it is).  The "*_bwd_weight_affine_in"
+ * its pre-BN output, so the normalised activation is never written (NULL: the input is used as it is).  "phases": 3 = both launches
+ * (the conv, then the statistics finish); 1 / 2 = only the first / second, for callers that bracket the conv kernel with events.  The "*_bwd_weight_affine_in"
  * gradients re-normalise the same pre-BN tensor on load.  Results equal the unfused sequences up to fp32 summation order. ---- */
 size_t myolo_conv3x3s2_c3_bnstats_ws_bytes(int N, int H, int W, int Cout);
 int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, const float* gamma, const float* beta, float* mean, float* var,
-                                   float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout,
+                                   float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout, int phases,
                                    void* ws, size_t ws_bytes, void* stream);
 size_t myolo_dwconv3x3_bnstats_ws_bytes(int N, int H, int W, int C, int stride);
 int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
                                 const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
-                                float* moving_mean, float* moving_var, int N, int H, int W, int C, int stride,
+                                float* moving_mean, float* moving_var, int N, int H, int W, int C, int stride, int phases,
                                 void* ws, size_t ws_bytes, void* stream);
 int myolo_dwconv3x3_bwd_weight_affine_in(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
                                          int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
@@ -157,7 +158,7 @@ int    myolo_pwconv1x1_bnstats_ok(int Cin, int Cout);
 size_t myolo_pwconv1x1_bnstats_ws_bytes(int64_t M, int Cin, int Cout);
 int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
                                 const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
-                                float* moving_mean, float* moving_var, int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
+                                float* moving_mean, float* moving_var, int64_t M, int Cin, int Cout, int phases, void* ws, size_t ws_bytes, void* stream);
 int myolo_pwconv1x1_bwd_weight_affine_in(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* dy, float* dw,
                                          int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream);
 

@@ -1543,9 +1543,9 @@ extern "C" {
 
 int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
                                 const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
-                                float* moving_mean, float* moving_var, int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
+                                float* moving_mean, float* moving_var, int64_t M, int Cin, int Cout, int phases, void* ws, size_t ws_bytes, void* stream)
 {
-    MYOLO_REQUIRE(x && w && y && gamma && beta && mean && var && scale && shift && M > 0 && !in_scale == !in_shift, "pwconv1x1_bnstats_fwd: bad arguments");
+    MYOLO_REQUIRE(x && w && y && gamma && beta && mean && var && scale && shift && M > 0 && !in_scale == !in_shift && (phases & 3) != 0, "pwconv1x1_bnstats_fwd: bad arguments");
     MYOLO_REQUIRE(myolo_pwconv1x1_bnstats_ok(Cin, Cout) && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)y & 15) == 0,
                   "pwconv1x1_bnstats_fwd: needs Cin %% 16 == 0, Cout %% 4 == 0 and 16-byte aligned operands");
     MYOLO_NEED_WS(myolo_pwconv1x1_bnstats_ws_bytes(M, Cin, Cout));
@@ -1562,19 +1562,27 @@ int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const flo
         // FP32_MATMUL = "bf16x6": the layers with >= 256 input and a multiple of 256 output channels on the bf16 matrix pipe (six exact piece
         // products per fp32 product, csrc/wino_mm.hip), same on-load BatchNorm and epilogue column sums; three launches (split, GEMM, finish)
         void* split = (char*)ws + pbytes + align256(2 * Cout * sizeof(double));
-        myolo_pw_x6_fwd(x, in_scale, in_shift, in_act, w, y, part, M, Cin, Cout, split, s);
+        if (phases & 1) myolo_pw_x6_fwd(x, in_scale, in_shift, in_act, w, y, part, M, Cin, Cout, split, s);
         MYOLO_CHECK_LAUNCH();
-        myolo_bn_stats_from_partials(part, tot, tiles, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
+        if (phases & 2) myolo_bn_stats_from_partials(part, tot, tiles, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
     a.stat = g_myolo_opt.no_trunk_fusion ? nullptr : part;
-    int path = 0;
     // the split-K scratch shares ws with the partials: when the launcher picks split-K it drops a.stat (nothing is written there)
     const size_t skb = pw_split_bytes(M, Cout);
-    launch_nn<AM_PLAIN, EP_PLAIN>(a, s, skb ? ws : nullptr, skb, 128, &path);
-    MYOLO_CHECK_LAUNCH();
-    if (path == 1 && !g_myolo_opt.no_trunk_fusion) {
+    // the launcher's own rule (launch_nn): split-K only for < 128 output tiles, K >= 256, and at least two splits of >= 8 k tiles
+    const long long otiles = cdiv64(M, BM) * ((Cout + BN - 1) / BN);
+    const int nkt = Cin / BK;
+    const bool one_pass = !(skb != 0 && !g_myolo_opt.no_splitk && nkt >= 16 && otiles < 128 && (1024 / otiles >= 2) && nkt / 8 >= 2);
+    if (phases & 1) {
+        int path = 0;
+        launch_nn<AM_PLAIN, EP_PLAIN>(a, s, skb ? ws : nullptr, skb, 128, &path);
+        MYOLO_CHECK_LAUNCH();
+        if ((path == 1) != one_pass && path != 0) { myolo_set_error("pwconv1x1_bnstats_fwd: launcher path %d disagrees with the planned one", path); return MYOLO_EINVAL; }
+    }
+    if (!(phases & 2)) return MYOLO_OK;
+    if (one_pass && !g_myolo_opt.no_trunk_fusion) {
         myolo_bn_stats_from_partials(part, tot, tiles, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;

@@ -1773,10 +1773,10 @@ size_t myolo_conv3x3s2_c3_bnstats_ws_bytes(int N, int H, int W, int Cout)
 }
 
 int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, const float* gamma, const float* beta, float* mean, float* var,
-                                   float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout,
+                                   float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout, int phases,
                                    void* ws, size_t ws_bytes, void* stream)
 {
-    MYOLO_REQUIRE(x && w && y && gamma && beta && mean && var && scale && shift && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0,
+    MYOLO_REQUIRE(x && w && y && gamma && beta && mean && var && scale && shift && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0 && (phases & 3) != 0,
                   "conv3x3s2_c3_bnstats_fwd: bad arguments");
     MYOLO_NEED_WS(myolo_conv3x3s2_c3_bnstats_ws_bytes(N, H, W, Cout));
     hipStream_t s = (hipStream_t)stream;
@@ -1788,14 +1788,16 @@ int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, con
         if (blocks > 1024) blocks = 1024;
         double* part = (double*)ws;
         double* tot = (double*)((char*)ws + align256((size_t)1024 * 2 * Cout * sizeof(double)));
-        hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, part);
-        hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((Cout + 3) / 4), dim3(256), 0, s, part, tot, blocks, 2 * Cout, Cout,
-                           FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance});
+        if (phases & 1) hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, part);
+        if (phases & 2)
+            hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((Cout + 3) / 4), dim3(256), 0, s, part, tot, blocks, 2 * Cout, Cout,
+                               FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance});
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, (double*)nullptr);
+    if (phases & 1) hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
+    if (!(phases & 2)) return MYOLO_OK;
     return myolo_bn_stats_launch(y, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, M, Cout, ws, ws_bytes, s);
 }
 
@@ -1887,10 +1889,10 @@ size_t myolo_dwconv3x3_bnstats_ws_bytes(int N, int H, int W, int C, int stride)
 
 int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y,
                                 const float* gamma, const float* beta, float* mean, float* var, float* scale, float* shift,
-                                float* moving_mean, float* moving_var, int N, int H, int W, int C, int stride,
+                                float* moving_mean, float* moving_var, int N, int H, int W, int C, int stride, int phases,
                                 void* ws, size_t ws_bytes, void* stream)
 {
-    MYOLO_REQUIRE(gamma && beta && mean && var && scale && shift && !in_scale == !in_shift, "dwconv3x3_bnstats_fwd: bad arguments");
+    MYOLO_REQUIRE(gamma && beta && mean && var && scale && shift && !in_scale == !in_shift && (phases & 3) != 0, "dwconv3x3_bnstats_fwd: bad arguments");
     MYOLO_REQUIRE(N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bnstats_fwd: bad arguments");
     MYOLO_NEED_WS(myolo_dwconv3x3_bnstats_ws_bytes(N, H, W, C, stride));
     hipStream_t s = (hipStream_t)stream;
@@ -1905,16 +1907,22 @@ int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const flo
         const int nblk = (int)(grid.x * grid.y * grid.z);
         double* part = (double*)ws;
         double* tot = (double*)((char*)ws + align256((size_t)nblk * 2 * C * sizeof(double)));
-        const int rc = dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream, DwFuse{in, part});
-        if (rc != MYOLO_OK) return rc;
-        hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C, fin);
+        if (phases & 1) {
+            const int rc = dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream, DwFuse{in, part});
+            if (rc != MYOLO_OK) return rc;
+        }
+        if (phases & 2) hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C, fin);
     } else {           // channel counts the in-kernel reduction does not take: the conv (input still normalised on load), then the statistics pass
-        const int rc = dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream, DwFuse{in, nullptr});
-        if (rc != MYOLO_OK) return rc;
-        double* part = (double*)ws;
-        double* tot = (double*)((char*)ws + align256(col_ws_bytes(M, C, 2)));
-        OpStats op{y, C};
-        run_colreduce(op, M, C, part, tot, s, fin);
+        if (phases & 1) {
+            const int rc = dw_fwd_launch(x, w, y, N, H, W, C, stride, DwAffine{nullptr, nullptr, MYOLO_ACT_NONE}, stream, DwFuse{in, nullptr});
+            if (rc != MYOLO_OK) return rc;
+        }
+        if (phases & 2) {
+            double* part = (double*)ws;
+            double* tot = (double*)((char*)ws + align256(col_ws_bytes(M, C, 2)));
+            OpStats op{y, C};
+            run_colreduce(op, M, C, part, tot, s, fin);
+        }
     }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

@@ -96,10 +96,10 @@ SIGS = {
     "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
     "myolo_matmul_f32": [P, P, P, L, I, I, I, I, P, Z, P],
     "myolo_stream_copy": [P, P, Z, I, I, P],
-    "myolo_conv3x3s2_c3_bnstats_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, P, Z, P],
-    "myolo_dwconv3x3_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_conv3x3s2_c3_bnstats_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_dwconv3x3_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_dwconv3x3_bwd_weight_affine_in": [P, P, P, I, P, P, I, I, I, I, I, P, Z, P],
-    "myolo_pwconv1x1_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, P, Z, P],
+    "myolo_pwconv1x1_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, Z, P],
     "myolo_pwconv1x1_bwd_weight_affine_in": [P, P, P, I, P, P, L, I, I, P, Z, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],

@@ -1062,7 +1062,7 @@ def test_dwconv3x3_bnstats_fwd_and_affine_in_weight_gradient(N, H, W, C, stride,
     with X.option("no_trunk_fusion", nofuse):
         X.call("myolo_dwconv3x3_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(isc)) if lazy else None, X.ptr(dt(ish)) if lazy else None, 2, X.ptr(dt(w)), X.ptr(y),
                X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv),
-               N, H, W, C, stride, wsb.data_ptr(), wsb.numel(), X.stream())
+               N, H, W, C, stride, 3, wsb.data_ptr(), wsb.numel(), X.stream())
     check(y, ref, what="fused dw fwd")
     _check_bn_outputs(ref.reshape(-1, C), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)
     if lazy:
@@ -1100,7 +1100,7 @@ def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy,
     with X.option("no_trunk_fusion", nofuse):
         X.call("myolo_pwconv1x1_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(isc)) if lazy else None, X.ptr(dt(ish)) if lazy else None, 2, X.ptr(dt(w)), X.ptr(y),
                X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv),
-               M, Cin, Cout, wsb.data_ptr(), wsb.numel(), X.stream())
+               M, Cin, Cout, 3, wsb.data_ptr(), wsb.numel(), X.stream())
     check(y, ref, what="fused pw fwd")
     _check_bn_outputs(ref.astype(np.float32), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)
     if lazy:
@@ -1124,6 +1124,6 @@ def test_conv1_bnstats_fwd(N, H, W, Co, nofuse):
     wsb = torch.empty(X.conv1_bnstats_ws_bytes(N, H, W, Co), dtype=torch.uint8, device=DEV)
     with X.option("no_trunk_fusion", nofuse):
         X.call("myolo_conv3x3s2_c3_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(y), X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var),
-               X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv), N, H, W, Co, wsb.data_ptr(), wsb.numel(), X.stream())
+               X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv), N, H, W, Co, 3, wsb.data_ptr(), wsb.numel(), X.stream())
     check(y, ref, what="fused conv1 fwd")
     _check_bn_outputs(ref.reshape(-1, Co).astype(np.float32), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)
