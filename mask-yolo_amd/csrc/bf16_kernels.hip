@@ -25,6 +25,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 template <int V> struct IntC { static constexpr int value = V; };
 enum { AM_PLAIN = 0, AM_CONV3 = 1 };
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 enum { EP_PLAIN = 0, EP_DECONV = 1, EP_DECONV_MASK = 2 };
 
 struct Bf16Args {
@@ -630,6 +631,25 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
             }
         }
     }
+    // EP_DECONV_MASK: the accumulators of a column block START at the deconv bias of their channel (the table is in LDS by now), so the
+    // epilogue is max(acc, 0) and the class FMAs -- one VALU instruction less per accumulator element
+    auto acc_start = [&](int nb) {
+        if constexpr (EPI == EP_DECONV_MASK) {
+            const int tap2 = nb / p.Co;
+            const int tb = LOOPN ? nb - tap2 * p.Co + wn * 64 : wn * 64;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = etab[tb + u * 32 + 8 * g + 4 * half + e].x;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc[t][u][4 * g + e] = b;
+                    }
+        }
+    };
+    acc_start(n0);
     auto mask_epilogue_nc = [&](auto ncc, int nb) {
         constexpr int NC = decltype(ncc)::value;                       // classes this instance accumulates (2 or 4); p.ncls <= NC
         const int tap2 = nb / p.Co;
@@ -655,9 +675,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
                         if constexpr (NC > 3) w3 = etab3[cl];
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            const float v = fmaxf(acc[2 * tp + t][u][4 * g + e] + bw.x, 0.f);
-                            ps[t][0] = fmaf(v, bw.y, ps[t][0]);
-                            ps[t][1] = fmaf(v, bw.z, ps[t][1]);
+                            const float v = fmaxf(acc[2 * tp + t][u][4 * g + e], 0.f);       // (the bias is in the accumulator since acc_start)
+                            // the first two classes as ONE packed fp32 FMA (v_pk_fma_f32)
+                            f32x2 pp = {ps[t][0], ps[t][1]};
+                            const f32x2 ww = {bw.y, bw.z}, vv = {v, v};
+                            pp = __builtin_elementwise_fma(vv, ww, pp);
+                            ps[t][0] = pp.x; ps[t][1] = pp.y;
                             if constexpr (NC > 2) ps[t][2] = fmaf(v, bw.w, ps[t][2]);
                             if constexpr (NC > 3) ps[t][3] = fmaf(v, w3, ps[t][3]);
                         }
@@ -743,12 +766,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
             const int kk = kt + 1;
             if (kk % nk == 0) {                       // a column block is complete: its epilogue, then the accumulators start over
                 mask_epilogue((kk / nk - 1) * T2N);
+                if constexpr (EPI == EP_DECONV_MASK) acc_start((kk / nk) * T2N < p.N ? (kk / nk) * T2N : 0);
+                else {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int u = 0; u < 2; ++u)
+                        for (int u = 0; u < 2; ++u)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+                            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+                }
             }
         }
     }

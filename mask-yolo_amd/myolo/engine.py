@@ -26,7 +26,7 @@ YOLO_BLOCKS = [(512, 2), (512, 1), (512, 1), (512, 1), (512, 1), (512, 1), (1024
 MASK_FILTERS = 256                                                                                 # model.py:688-711
 
 
-WINO_MIN_ROWS = 16384      # CONV3X3_ALGO='auto': output pixels from which the Winograd form of a 3x3 conv is used
+WINO_MIN_ROWS = 8192       # CONV3X3_ALGO='auto': output pixels from which the Winograd form of a 3x3 conv is used (Rice 416 at batch 4: feature_map has 10816)
 
 
 def layer_table(cfg):
