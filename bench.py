@@ -497,12 +497,13 @@ def bench_train(args, rank, world, local):
                                "; Winograd multiply products: " + ("native fp32 MFMA" if net.fp32_matmul == "native" else
                                "FP32_MATMUL='bf16x6' (each fp32 product = six exact bf16 piece products, fp32 accumulation)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "net_attrs": list(args.net_attr), "forced_positives": args.force_pos,
+                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "net_attrs": list(args.net_attr), "share_gpu": bool(args.share_gpu), "forced_positives": args.force_pos,
                    "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
         "roofline": roofline,
     }
     if world > 1:
-        res["comm"] = {"backend": "RCCL via %s" % ("the C-ABI (myolo_comm_*)" if args.comm == "capi" else "torch.distributed (nccl)"),
+        res["comm"] = {"backend": ("gloo (--share-gpu test mode: all ranks on one GPU)" if args.share_gpu else
+                                   "RCCL via %s" % ("the C-ABI (myolo_comm_*)" if args.comm == "capi" else "torch.distributed (nccl)")),
                        "rccl_ranks_seen": ranks_seen, "bucket_allreduce_ms": bucket_ms,
                        "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
                        "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
@@ -670,6 +671,9 @@ def main():
     ap.add_argument("--force-pos", type=int, default=0, metavar="K",
                     help="replace the first K proposals of every image by a ground-truth box for the WHOLE run (the n_pos sweep's hook): the step "
                          "at the positive counts a trained net produces; recorded in config.forced_positives")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST ONLY: every rank uses cuda:0 and the ranks rendezvous over gloo (RCCL needs one GPU per rank) -- exercises the whole "
+                         "N > 1 code path of this script on a one-GPU box; recorded in config.share_gpu, never a throughput claim")
     ap.add_argument("--net-attr", action="append", default=[], metavar="NAME=VALUE",
                     help="engine (myolo.engine.Net) scheduling switches for this run, e.g. overlap_conv1_wgrad=0; recorded in config.net_attrs")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
@@ -689,7 +693,9 @@ def main():
     os.dup2(2, 1)
 
     from myolo import dist as mdist
-    rank, world, local = mdist.init_from_env()
+    rank, world, local = mdist.init_from_env("gloo" if args.share_gpu else None)
+    if args.share_gpu:
+        local = 0
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torchrun --nproc-per-node %d, or plain `python bench.py --gpus %d`)"
                          % (args.gpus, world, args.gpus, args.gpus))

@@ -183,3 +183,28 @@ def test_engine_step_with_capi_reducer_is_bit_identical_to_no_reducer():
         if red:
             red.close()
     assert torch.equal(outs[0], outs[1])
+
+
+def test_bench_multi_rank_path_on_one_gpu(tmp_path):
+    """`python bench.py --gpus 2` end to end on this one-GPU box: the script re-launches itself under torch.distributed.run, two ranks
+    build the engine, exchange gradients every step (gloo instead of RCCL: --share-gpu puts both ranks on cuda:0), take the MAX over
+    ranks of the timed region, and rank 0 prints ONE JSON line on stdout with n_gpus = 2, the comm object (two ranks seen, three
+    bucket timings) and weak-scaling semantics (global batch = 2 x per-GPU batch).  What the driver's 8-GPU command runs, minus the wire."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "3", "--warmup", "1", "--batch", "4",
+                        "--size", "128", "--alpha", "0.5", "--cpu-images", "0"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                                   # stdout carries exactly the JSON line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["config"]["share_gpu"] is True
+    assert d["comm"]["rccl_ranks_seen"] == 2 and len(d["comm"]["bucket_allreduce_ms"]) == 3 and all(v > 0 for v in d["comm"]["bucket_allreduce_ms"])
+    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert "variants" in d and "dense_mask_backward" in d["variants"]            # the variants ran in lockstep on both ranks
