@@ -1658,6 +1658,12 @@ int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, flo
     MYOLO_REQUIRE(Cin > 0 && Cout > 0, "deconv2x2s2_fwd: bad channels");
     MYOLO_NEED_WS((size_t)4 * Cin * Cout * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
+    if (myolo_deconv_x6_ok(Cin, Cout, 0) && (long long)N * H * W >= 4096 && ws_bytes >= (size_t)4 * Cin * Cout * 6 &&
+        (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0) {
+        myolo_deconv_x6_fwd(x, w, bias, y, (long long)N * H * W, H, W, Cin, Cout, act, ws, s);      // FP32_MATMUL = "bf16x6" (csrc/wino_mm.hip)
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     launch_transpose(w, (float*)ws, 4 * Cout, Cin, 1, 0, s);     // ws[ci][(ky,kx,co)]
     GemmArgs a = {};
     a.A = x; a.B = (const float*)ws; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
@@ -1721,6 +1727,12 @@ int myolo_deconv2x2s2_bwd_data(const float* dy, const float* w, float* dx,
 {
     MYOLO_REQUIRE(dy && w && dx && N > 0, "deconv2x2s2_bwd_data: bad arguments");
     MYOLO_REQUIRE(Cout % BK == 0, "deconv2x2s2_bwd_data: Cout must be a multiple of %d", BK);
+    if (myolo_deconv_x6_ok(Cin, Cout, 1) && (long long)N * H * W >= 4096 && ws && ws_bytes >= (size_t)4 * Cin * Cout * 6 &&
+        (((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0) {
+        myolo_deconv_x6_bwd_data(dy, w, dx, (long long)N * H * W, H, W, Cin, Cout, ws, (hipStream_t)stream);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     GemmArgs a = {};
     a.A = dy; a.B = w; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 4 * Cout;
     a.ldb = Cin; a.ldc = Cin; a.H = H; a.W = W; a.Cc = Cout;
@@ -1734,6 +1746,14 @@ int myolo_deconv2x2s2_bwd_weight(const float* x, const float* dy, float* dw,
 {
     MYOLO_REQUIRE(x && dy && dw && N > 0, "deconv2x2s2_bwd_weight: bad arguments");
     MYOLO_REQUIRE((Cout & 3) == 0, "deconv2x2s2_bwd_weight: Cout must be a multiple of 4");
+    if (g_myolo_opt.wino_x6 && !g_myolo_opt.deconv_no_x6 && (Cin % 256) == 0 && (Cout % 64) == 0 && ((4 * Cout) % 256) == 0 && (long long)N * H * W >= 4096 && ws &&
+        myolo_deconv_x6_bwd_weight_ws_bytes((long long)N * H * W, Cin, Cout) <= ws_bytes && (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dw) & 15) == 0) {
+        // FP32_MATMUL = "bf16x6": wino_tn_x6_kernel with the four taps of dy gathered into the A operand (csrc/wino_mm.hip)
+        const int rc = myolo_deconv_x6_bwd_weight(x, dy, dw, (long long)N * H * W, H, W, Cin, Cout, ws, ws_bytes, (hipStream_t)stream);
+        if (rc) return rc;
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     GemmArgs a = {};
     a.A = dy; a.B = x; a.M = (long long)N * H * W; a.N = Cin; a.K = 4 * Cout; a.ldb = Cin;
     a.H = H; a.W = W; a.Cc = Cout;

@@ -31,6 +31,7 @@ struct MyoloOptions {
     int w63_persist;      // wino63 boundary kernels: > 0 = that many workgroups per CU walk the (image, slice) units in a loop
     int w63_order;        // wino63 boundary kernels: 1 = the previous workgroup order (all images of channel slice 0, then slice 1, ...)
     int pw_x6_min_rows;   // pointwise convs: fewest rows for the bf16x6 kernels (0 = default 4096)
+    int deconv_no_x6;     // deconv forward / data gradient: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int dw_wgrad_generic; // depthwise weight gradient: the generic 9-accumulator column reduction instead of the tiled kernel (ablation)
     int pw_no_x6;         // pointwise convs with >= 256 channels: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)
@@ -91,6 +92,14 @@ size_t myolo_gemm_tn_x6_ws_bytes(int nruns, const long long* rows, const int* nq
 int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, const long long* rows, const long long* a_off, const long long* b_off,
                           const int* nq, int Ka, int N, void* part, size_t part_bytes, hipStream_t s,
                           const float* a_scale = nullptr, const float* a_shift = nullptr, int a_act = 0);
+// Conv2DTranspose 2x2/s2 forward (which = 0) / data gradient (which = 1) under "wino_x6" (csrc/wino_mm.hip)
+bool myolo_deconv_x6_ok(int Cin, int Co, int which);
+int myolo_deconv_x6_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int H, int W, int Cin, int Co, int act,
+                        void* split, hipStream_t s);
+int myolo_deconv_x6_bwd_data(const float* dy, const float* w, float* dx, long long M, int H, int W, int Cin, int Co, void* split, hipStream_t s);
+size_t myolo_deconv_x6_bwd_weight_ws_bytes(long long M, int Cin, int Co);
+int myolo_deconv_x6_bwd_weight(const float* x, const float* dy, float* dw, long long M, int H, int W, int Cin, int Co, void* part, size_t part_bytes,
+                               hipStream_t s);
 // pointwise convs with >= 256 channels under "wino_x6" (csrc/wino_mm.hip)
 bool myolo_pw_x6_ok(int K, int N);
 size_t myolo_pw_x6_split_bytes(int K, int N);

@@ -71,7 +71,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mm_rsrc(const float* base, lon
 }
 __device__ __forceinline__ float f4c(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
-enum { MM_EP_PLAIN = 0, MM_EP_DECONV_MASK = 1 };
+enum { MM_EP_PLAIN = 0, MM_EP_DECONV_MASK = 1, MM_EP_DECONV = 2 };     // DECONV: 2x2 / s2 transposed-conv scatter of a (tap, co) column tile + bias + activation
+enum { MM_A_PLAIN = 0, MM_A_DECONV = 1 };                               // DECONV: A row m = the four taps of output pixel block m gathered from [N,2H,2W,Cc] (K = 4 Cc)
 
 // Epilogue of the fused deconv + ReLU + 1x1 mask conv (model.py:711-714; csrc/gemm_kernels.hip EP_DECONV_MASK for 4 column tiles per
 // wave), shared by the fp32 and the bf16x6 kernel: both hold the 128 x 256 tile as 4 waves x (2 x 4) 32x32 accumulator tiles.
@@ -296,7 +297,7 @@ __device__ __forceinline__ float mm_act(float v, int act)
     return v;
 }
 
-template <int EPI, bool PW = false>
+template <int EPI, bool PW = false, int AG = MM_A_PLAIN>
 __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char As[2][MM_BM * X6_REC];
@@ -328,20 +329,44 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     const unsigned char* Bp = reinterpret_cast<const unsigned char*>(p.Bt) + (R.b_off + (long long)z * p.K * p.N) * 6;
     float* Cp = p.C + R.c_off + (long long)z * M * p.N;
     const long long mend = (m0 + MM_BM < M) ? m0 + MM_BM : M;
-    const __amdgpu_buffer_rsrc_t ra = mm_rsrc(Ap + m0 * p.K, (mend - m0) * p.K * 4);      // rows beyond M read 0
-    const __amdgpu_buffer_rsrc_t rb = mm_rsrc(reinterpret_cast<const float*>(Bp), (long long)p.K * p.N * 6);
-
     // A loader: thread = (row tid>>1, k half tid&1): 8 consecutive floats
     const int arow = tid >> 1, ah = tid & 1;
-    unsigned aoffg = ((unsigned)arow * (unsigned)p.K + (unsigned)ah * 8u) * 4u;            // + 64 bytes per chunk
+    __amdgpu_buffer_rsrc_t ra;
+    unsigned aoffg;                                                                        // + 64 bytes per chunk
+    unsigned ag_base = 0;                                                                  // AG: this row's tap-(0,0) pixel, bytes
+    if constexpr (AG == MM_A_DECONV) {
+        // A row m, column k = tap*Cc + c = dy[pixel(m, tap)][c], pixel(m, tap) = 4m - 2x + ky*2W + kx on the [N,2H,2W] grid (Cc = p.Co)
+        long long base_px = 4 * m0 - 2 * p.W; if (base_px < 0) base_px = 0;
+        long long end_px = 4 * (m0 + MM_BM) + 2 * p.W + 2; if (end_px > 4 * M) end_px = 4 * M;
+        ra = mm_rsrc(Ap + base_px * p.Co, (end_px - base_px) * p.Co * 4);
+        const long long mm = m0 + arow;
+        if (mm < M) {
+            const long long hw = (long long)p.H * p.W;
+            const int rem = (int)(mm - (mm / hw) * hw);
+            const int x = rem - (rem / p.W) * p.W;
+            ag_base = (unsigned)((4 * mm - 2 * x - base_px) * p.Co + ah * 8) * 4u;
+        } else ag_base = MM_OOB;
+        aoffg = ag_base;
+    } else {
+        ra = mm_rsrc(Ap + m0 * p.K, (mend - m0) * p.K * 4);                                // rows beyond M read 0
+        aoffg = ((unsigned)arow * (unsigned)p.K + (unsigned)ah * 8u) * 4u;
+    }
+    const __amdgpu_buffer_rsrc_t rb = mm_rsrc(reinterpret_cast<const float*>(Bp), (long long)p.K * p.N * 6);
+    int ag_k = 0;                                                                          // AG: first k of the next chunk to load
     const int asto = arow * X6_REC + ah * 16;                                              // + piece * 32
     float4 sa[2];
     float4 psc[2], psh[2];                     // PW: this chunk's per-k affine (k = kch + ah*8 .. +7)
     int kch = ah * 8;
     auto gload = [&]() {
+        if constexpr (AG == MM_A_DECONV) {
+            const int tap = ag_k / p.Co, c0 = ag_k - tap * p.Co;
+            const unsigned sh = (unsigned)(((tap >> 1) * 2 * p.W + (tap & 1)) * p.Co + c0) * 4u;
+            aoffg = ag_base == MM_OOB ? MM_OOB : ag_base + sh;
+            ag_k += MM_BK;
+        }
         sa[0] = mm_bufld4(ra, aoffg);
-        sa[1] = mm_bufld4(ra, aoffg + 16u);
-        aoffg += MM_BK * 4u;
+        sa[1] = mm_bufld4(ra, aoffg == MM_OOB ? MM_OOB : aoffg + 16u);
+        if constexpr (AG == MM_A_PLAIN) aoffg += MM_BK * 4u;
         if (PW && p.a_scale) {
             psc[0] = *reinterpret_cast<const float4*>(p.a_scale + kch); psc[1] = *reinterpret_cast<const float4*>(p.a_scale + kch + 4);
             psh[0] = *reinterpret_cast<const float4*>(p.a_shift + kch); psh[1] = *reinterpret_cast<const float4*>(p.a_shift + kch + 4);
@@ -499,6 +524,30 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
                 p.stat[((m0 / MM_BM) * 2 + v) * p.N + n0 + cc] = (double)sred[(0 * 2 + v) * MM_BN + cc] + (double)sred[(1 * 2 + v) * MM_BN + cc];
             }
         }
+    }
+    if constexpr (EPI == MM_EP_DECONV) {
+        // Conv2DTranspose 2x2 / s2 (model.py:711-712): this tile's 256 columns are 256 channels of ONE tap (Co % 256 == 0); row m of the
+        // GEMM = input pixel (n, y, x) -> output pixel (n, 2y + ky, 2x + kx); + bias, activation
+        const int tap = n0 / p.Co;
+        const int cb = n0 - tap * p.Co + wn * 128 + l31;
+        float bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = p.bias ? p.bias[cb + 32 * u] : 0.f;
+        const long long hw = (long long)p.H * p.W;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row >= M) continue;
+                const long long n_img = row / hw;
+                const int rem = (int)(row - n_img * hw);
+                const int y = rem / p.W, x = rem - y * p.W;
+                float* dst = p.C + (n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1)) * p.Co + cb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) dst[32 * u] = mm_act(acc[t][u][r] + bv[u], p.a_act);
+            }
+        return;
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -676,6 +725,7 @@ struct TNArgs {
     const float* a_scale;      // A := act(A * a_scale[col] + a_shift[col]) on load (rows that exist), NULL: none
     const float* a_shift;
     int a_act;
+    int gH, gW, gCo;           // AG (deconv weight gradient): A row m, column (tap, co) = dy[pixel(m, tap)][co] on the [N,2H,2W,Co] grid; Ka = 4 Co
     const float* A;
     const float* B;
     float* part;               // [(plane, split) unit][Ka][N] fp32 partial products
@@ -686,6 +736,7 @@ struct TNArgs {
     TNRun run[4];
 };
 
+template <bool AG = false>
 __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char Ls[2][2][TN_T * X6_REC];      // [buffer][A | B][column record]: 112 KB
@@ -715,12 +766,38 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
     const int ld = op ? p.N : p.Ka;
     const float* base = op ? p.B + R.b_off + ((long long)z * R.rows + r0) * p.N + nt * TN_T
                            : p.A + R.a_off + ((long long)z * R.rows + r0) * p.Ka + kat * TN_T;
-    const __amdgpu_buffer_rsrc_t rs = mm_rsrc(base, (nrows * ld - (op ? nt : kat) * TN_T) * 4);      // rows beyond the split read 0
-    const unsigned voff = (unsigned)col * 4u;
+    __amdgpu_buffer_rsrc_t rs = mm_rsrc(base, (nrows * ld - (op ? nt : kat) * TN_T) * 4);      // rows beyond the split read 0
+    unsigned voff = (unsigned)col * 4u;
     const unsigned rowb = (unsigned)ld * 4u;
     unsigned soff = 0;                                   // byte offset of the chunk's first row (advances by 16 rows)
+    // AG: the A operand is gathered -- row m, column (tap, co) = dy[pixel(m, tap)][co], pixel(m, tap) = 4m - 2(m mod W) + ky*2W + kx
+    long long g_m = r0, g_base_px = 0;                   // first row of the next chunk; first pixel the descriptor covers
+    int g_x = 0;                                         // g_m mod W
+    if constexpr (AG) {
+        if (op == 0) {
+            g_base_px = 4 * r0 - 2 * p.gW; if (g_base_px < 0) g_base_px = 0;
+            long long end_px = 4 * r1 + 2 * p.gW + 2; if (end_px > 4 * R.rows) end_px = 4 * R.rows;
+            rs = mm_rsrc(p.A + g_base_px * p.gCo, (end_px - g_base_px) * p.gCo * 4);
+            const int ka = kat * TN_T + col, tap = ka / p.gCo, co = ka - tap * p.gCo;
+            voff = (unsigned)(((tap >> 1) * 2 * p.gW + (tap & 1)) * p.gCo + co) * 4u;
+            g_x = (int)(r0 % p.gW);
+        }
+    }
     float st[16];
     auto gload = [&]() {
+        if (AG && op == 0) {
+            int xk = g_x;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const long long m = g_m + k;
+                const unsigned so = m < r1 ? (unsigned)((4 * m - 2 * xk - g_base_px) * p.gCo) * 4u : MM_OOB;
+                st[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(so == MM_OOB ? MM_OOB : voff + so), 0, 0));
+                if (++xk == p.gW) xk = 0;
+            }
+            g_m += 16;
+            g_x = xk;
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < 16; ++k) st[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)(soff + (unsigned)k * rowb), 0));
         soff += 16u * rowb;
@@ -916,7 +993,7 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
         ++k;
     }
     if (pairs <= 0) return MYOLO_OK;
-    hipLaunchKernelGGL(wino_tn_x6_kernel, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
+    hipLaunchKernelGGL(wino_tn_x6_kernel<false>, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
     const long long n4 = (long long)Ka * N / 4;
     hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), planes), dim3(256), 0, s, a);
     return MYOLO_OK;
@@ -942,5 +1019,73 @@ int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift
     hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 1);
     a.Bt = (const float*)split;
     hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}
+
+
+/* myolo_mask_deconv (Conv2DTranspose 2x2 / s2, model.py:711-712) forward and data gradient with six exact bf16 piece products per fp32
+ * product (FP32_MATMUL = "bf16x6"): the compacted mask-head backward rebuilds the deconv output of the positive ROIs and back-propagates
+ * through it with these.  fwd: y [N,2H,2W,Co] = act(deconv(x [M][Cin], w [2,2,Co,Cin]) + bias); bwd_data: dx [M][Cin] from dy [N,2H,2W,Co].
+ * split = scratch of 4*Cin*Co*6 bytes.  Need Cin % 16 == 0 and Co % 256 == 0 (fwd), Co % 16 == 0 and Cin % 256 == 0 (bwd_data). */
+bool myolo_deconv_x6_ok(int Cin, int Co, int which)
+{
+    if (!g_myolo_opt.wino_x6 || g_myolo_opt.deconv_no_x6) return false;
+    return which == 0 ? ((Cin % MM_BK) == 0 && Cin >= MM_BK && (Co % MM_BN) == 0) : ((Co % MM_BK) == 0 && (Cin % MM_BN) == 0);
+}
+int myolo_deconv_x6_fwd(const float* x, const float* w, const float* bias, float* y, long long M, int H, int W, int Cin, int Co, int act,
+                        void* split, hipStream_t s)
+{
+    const int K = Cin, N = 4 * Co;
+    MMArgs a{};
+    a.A = x; a.C = y; a.K = K; a.N = N; a.nruns = 1; a.bias = bias; a.H = H; a.W = W; a.Co = Co; a.a_act = act;
+    MMRun& R = a.run[0];
+    R.rows = M; R.nq = 1; R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
+    const long long total = (long long)K * N;
+    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 0);     // w = [N][K]
+    a.Bt = (const float*)split;
+    hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_DECONV, false, MM_A_PLAIN>), dim3((unsigned)((long long)R.mtiles * (N / MM_BN))), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}
+int myolo_deconv_x6_bwd_data(const float* dy, const float* w, float* dx, long long M, int H, int W, int Cin, int Co, void* split, hipStream_t s)
+{
+    const int K = 4 * Co, N = Cin;
+    MMArgs a{};
+    a.A = dy; a.C = dx; a.K = K; a.N = N; a.nruns = 1; a.H = H; a.W = W; a.Co = Co;
+    MMRun& R = a.run[0];
+    R.rows = M; R.nq = 1; R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
+    const long long total = (long long)K * N;
+    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 1);     // w = [K = (tap, co)][N = ci]
+    a.Bt = (const float*)split;
+    hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, false, MM_A_DECONV>), dim3((unsigned)((long long)R.mtiles * (N / MM_BN))), dim3(256), 0, s, a);
+    return MYOLO_OK;
+}
+
+
+/* weight gradient of the same transposed conv: dw [2,2,Co,Cin] = sum_m dy[pixel(m, tap)][co] * x[m][ci] on wino_tn_x6_kernel with the A operand
+ * gathered (Ka = 4 Co, N = Cin; both multiples of 256; W >= 1).  part: myolo_deconv_x6_bwd_weight_ws_bytes. */
+size_t myolo_deconv_x6_bwd_weight_ws_bytes(long long M, int Cin, int Co)
+{
+    const long long rows[1] = {M};
+    const int nq[1] = {1};
+    return myolo_gemm_tn_x6_ws_bytes(1, rows, nq, 4 * Co, Cin);
+}
+int myolo_deconv_x6_bwd_weight(const float* x, const float* dy, float* dw, long long M, int H, int W, int Cin, int Co, void* part, size_t part_bytes,
+                               hipStream_t s)
+{
+    const int Ka = 4 * Co, N = Cin;
+    TNArgs a{};
+    a.A = dy; a.B = x; a.C = dw; a.part = (float*)part; a.Ka = Ka; a.N = N; a.tiles_k = Ka / TN_T; a.tiles_n = N / TN_T;
+    a.gH = H; a.gW = W; a.gCo = Co;
+    const long long rows[1] = {M};
+    const int nq[1] = {1};
+    const long long pairs = tn_x6_plan(1, rows, nq, Ka, N, &a);
+    if ((size_t)pairs * Ka * N * sizeof(float) > part_bytes || !part) {
+        myolo_set_error("deconv_x6_bwd_weight: workspace too small (%zu needed, %zu given)", (size_t)pairs * Ka * N * sizeof(float), part_bytes);
+        return MYOLO_EWORKSPACE;
+    }
+    a.run[0].a_off = 0; a.run[0].b_off = 0;
+    hipLaunchKernelGGL(wino_tn_x6_kernel<true>, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
+    const long long n4 = (long long)Ka * N / 4;
+    hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, a);
     return MYOLO_OK;
 }

@@ -272,8 +272,13 @@ def test_winograd_error_is_at_fp32_level():
     assert ed < 5e-6 and ew < 5e-5, (ed, ew)
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 256, 256), (2, 5, 7, 32, 64)])
-def test_deconv2x2s2(N, H, W, Cin, Cout):
+@pytest.mark.parametrize("x6", [0, 1])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 14, 14, 256, 256), (2, 5, 7, 32, 64), (23, 14, 14, 256, 256), (25, 14, 13, 64, 256), (21, 14, 14, 512, 256)])
+def test_deconv2x2s2(N, H, W, Cin, Cout, x6, request):
+    """x6 = 1 (FP32_MATMUL = "bf16x6"): from 4096 input pixels up the forward (scatter epilogue) and the data gradient (the four taps
+    gathered into the A operand) run on wino_mm_x6_kernel -- the compacted mask-head backward at realistic positive counts."""
+    old = X.set_option("wino_x6", x6)
+    request.addfinalizer(lambda: X.set_option("wino_x6", old))
     rng = np.random.default_rng(3)
     x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 2, 2, Cout, Cin, scale=0.05), rnd(rng, Cout)
     dy = rnd(rng, N, 2 * H, 2 * W, Cout)
