@@ -162,11 +162,18 @@ class Net(object):
         self._ws_active = self._ws_main
         self._yolo_stream = torch.cuda.Stream(device=self.dev)
         self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
+        self.yolo_bwd_early = 0           # 1 = launched right behind the YOLO loss (under the mask head's FORWARD) instead of at the start of its backward
         # conv1's weight gradient (MFMA-bound, 2.7 ms, nothing downstream but the optimiser) on a third stream with its own
         # scratch, underneath conv1's data gradient -> ROIAlign backward -> backbone backward (launch- / HBM-bound small kernels)
         self._wgrad_stream = torch.cuda.Stream(device=self.dev)
         self._ws_wgrad = Workspace(self.dev)
         self.overlap_conv1_wgrad = True
+        # the trunk's weight-gradient kernels (no consumer but the optimiser) on their own stream and scratch, beside the
+        # BatchNorm-backward -> data-gradient chain that is the critical path of the trunk backward
+        self._twg_stream = torch.cuda.Stream(device=self.dev)
+        self._ws_twg = Workspace(self.dev)
+        self.overlap_trunk_wgrad = True
+        self._twg_pending = False
         # ... and started only when conv1's data gradient (the other matrix-pipe-bound kernel of that window) has been issued: two MFMA-bound
         # kernels sharing the chip each run at half speed, an MFMA-bound one beside the small HBM- / latency-bound kernels of the trunk
         # backward costs neither much (0 = start it together with the data gradient, as in round 2)
@@ -245,6 +252,7 @@ class Net(object):
 
     def grads_dict(self):
         self.join_conv1_wgrad()           # conv1's weight gradient may still be running on its side stream
+        self.join_trunk_wgrad()
         return {k: v.detach().cpu().numpy().copy() for k, v in self.g.items()}
 
     # ------------------------------------------------------------------ helpers
@@ -522,6 +530,28 @@ class Net(object):
         self.tape["blk%d" % bid] = (a, shape, stride, ad)
         return ap, (N, Ho, Wo, Co)
 
+    def _on_wgrad_stream(self, fn, tensors):
+        """run fn(ws_ptr, ws_size) -- a weight-gradient launch sequence whose inputs are complete on the current stream -- on the trunk's
+        weight-gradient stream (own scratch); `tensors` are kept from the allocator until that stream is done with them"""
+        if not self.overlap_trunk_wgrad:
+            return fn(*self._wsargs())
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._twg_stream.wait_event(ev)
+        with torch.cuda.stream(self._twg_stream):
+            fn(self._ws_twg.ptr, self._ws_twg.size)
+        for t in tensors:
+            if torch.is_tensor(t):
+                t.record_stream(self._twg_stream)
+        self._twg_pending = True
+
+    def join_trunk_wgrad(self):
+        """make the current stream wait for the trunk's weight-gradient stream"""
+        if self._twg_pending:
+            torch.cuda.current_stream().wait_stream(self._twg_stream)
+            self._twg_pending = False
+
     def dw_block_bwd(self, bid, da):
         a, shape, stride, ad = self.tape["blk%d" % bid]
         N, H, W, C = shape
@@ -530,20 +560,24 @@ class Net(object):
         Co = self.p[pwn + "/kernel"].shape[3]
         M = N * Ho * Wo
         dy2 = self.bn_act_bwd(pwn + "_bn", da)
-        if self._is_lazy(ad):       # the forward normalised the depthwise output on load: so does the weight gradient
-            X.call("myolo_pwconv1x1_bwd_weight_affine_in", *self._in_args(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co,
-                   *self._wsargs(), X.stream())
-        else:
-            X.call("myolo_pwconv1x1_bwd_weight", X.ptr(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co, *self._wsargs(), X.stream())
+        self._ws_twg.ensure(X.workspace_bytes(M, C, Co))
+
+        def pw_wgrad(wsp, wsz):
+            if self._is_lazy(ad):       # the forward normalised the depthwise output on load: so does the weight gradient
+                X.call("myolo_pwconv1x1_bwd_weight_affine_in", *self._in_args(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co, wsp, wsz, X.stream())
+            else:
+                X.call("myolo_pwconv1x1_bwd_weight", X.ptr(ad), X.ptr(dy2), X.ptr(self.g[pwn + "/kernel"]), M, C, Co, wsp, wsz, X.stream())
+        self._on_wgrad_stream(pw_wgrad, (dy2, ad))
         dad = self._new(M, C)
         X.call("myolo_pwconv1x1_bwd_data", X.ptr(dy2), X.ptr(self.p[pwn + "/kernel"]), X.ptr(dad), M, C, Co, *self._wsargs(), X.stream())
         dy = self.bn_act_bwd(dwn + "_bn", dad)
-        if self._is_lazy(a):
-            X.call("myolo_dwconv3x3_bwd_weight_affine_in", *self._in_args(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride,
-                   *self._wsargs(), X.stream())
-        else:
-            X.call("myolo_dwconv3x3_bwd_weight", X.ptr(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride,
-                   *self._wsargs(), X.stream())
+
+        def dw_wgrad(wsp, wsz):
+            if self._is_lazy(a):
+                X.call("myolo_dwconv3x3_bwd_weight_affine_in", *self._in_args(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride, wsp, wsz, X.stream())
+            else:
+                X.call("myolo_dwconv3x3_bwd_weight", X.ptr(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride, wsp, wsz, X.stream())
+        self._on_wgrad_stream(dw_wgrad, (dy, a))
         dx = self._new(N * H * W, C)
         X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(dx), N, H, W, C, stride, X.stream())
         return dx
@@ -643,13 +677,20 @@ class Net(object):
             dC4 = da
         else:
             Cf = dF.shape[1]
-            self.conv3x3_bwd_weight(C4, None, dF, "feature_map", n, h, w, c, Cf)
-            self.colsum(dF, self.g["feature_map/bias"])
+            def fm_wgrad(wsp, wsz):           # feature_map's weight and bias gradients: beside its data gradient and the backbone chain
+                prev, self._ws_active = self._ws_active, (self._ws_twg if self.overlap_trunk_wgrad else self._ws_active)
+                try:
+                    self.conv3x3_bwd_weight(C4, None, dF, "feature_map", n, h, w, c, Cf)
+                    self.colsum(dF, self.g["feature_map/bias"])
+                finally:
+                    self._ws_active = prev
+            self._on_wgrad_stream(fm_wgrad, (dF, C4))
             dC4 = self._new(n * h * w, c)
             self.conv3x3_bwd_data(dF, "feature_map", dC4, n, h, w, c, Cf)
             join()
             X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
         if self.on_bucket_ready:
+            self.join_trunk_wgrad()       # bucket 1 = YOLO head + feature_map: their weight gradients ran on the weight-gradient stream
             self.on_bucket_ready(1)
         da = dC4
         for _ in BACKBONE_BLOCKS:
@@ -660,6 +701,7 @@ class Net(object):
         N, H, W, _ = images.shape
         C0 = self.p["conv1/kernel"].shape[3]
         X.call("myolo_conv3x3s2_c3_bwd_weight", X.ptr(images), X.ptr(dy), X.ptr(self.g["conv1/kernel"]), N, H, W, C0, *self._wsargs(), X.stream())
+        self.join_trunk_wgrad()
         if self.on_bucket_ready:
             self.on_bucket_ready(0)
 
@@ -1305,6 +1347,8 @@ class Net(object):
                 self._ws_active = self._ws_main
         else:
             yolo_loss()
+        if self.overlap_yolo_bwd and self.yolo_bwd_early:
+            self.start_yolo_head_bwd(dyolo)
         if self.sparse_mask_fwd:
             if not self.sparse_mask_bwd:
                 raise RuntimeError("TRAIN_MASK_HEAD_ROIS='positives' needs the sparse backward (sparse_mask_bwd=True)")
@@ -1325,7 +1369,7 @@ class Net(object):
                    *self._wsargs(), X.stream())
         if self.tape_hook:
             self.tape_hook(self)
-        if self.overlap_yolo_bwd:
+        if self.overlap_yolo_bwd and not self.yolo_bwd_early:
             # under the compacted part of the mask head's backward (small launches on the positive ROIs), not under the big
             # forward GEMMs: two streams of small kernels fill the chip together, and the dense kernels keep it to themselves
             self.start_yolo_head_bwd(dyolo)
@@ -1408,6 +1452,7 @@ class Net(object):
     def adam_step(self, lr, b1=0.9, b2=0.999, eps=1e-8):
         """Keras Adam (model.py:1071-1075) over the whole flat buffer."""
         self.join_conv1_wgrad()
+        self.join_trunk_wgrad()
         if self.before_optimizer:
             self.before_optimizer()
         self.adam_t += 1
