@@ -341,6 +341,12 @@ def bench_train(args, rank, world, local):
             extras["hbm_copy_measured_gbs"] = Xe.measure_hbm_copy_gbs(device=dev)
         except Exception as e:
             extras["hbm_copy_measured_gbs"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # (a2) what the matrix pipes sustain with nothing else going on (register operands, no memory traffic), beside the nominal peaks:
+        #      the clock the power management grants under MFMA load is part of the roofline
+        try:
+            extras["mfma_measured_tflops"] = dict(Xe.measure_mfma_tflops(device=dev), nominal_bf16=BF16_MFMA_PEAK, nominal_f32=FP32_MFMA_PEAK)
+        except Exception as e:
+            extras["mfma_measured_tflops"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # (b) what the three real gradient buckets cost as RCCL collectives on the comm stream while backward runs: a 1-rank
         #     communicator through the C-ABI (launch + stream + kernel cost of the exchange, not the wire), and the step with it
         try:
@@ -595,7 +601,25 @@ def bench_infer(args):
     for _ in range(args.steps):
         run(x)
     torch.cuda.synchronize()
-    el = time.perf_counter() - t0
+    el1 = time.perf_counter() - t0
+    # throughput form (Net.predict_stream): `--in-flight` forwards at once, each on its own stream / hipGraph / scratch -- the launch-bound
+    # fp32 trunk of one batch runs underneath the matrix-pipe-bound mask head of the other.  Same kernels, bit-identical results
+    # (tests/test_gpu_step.py::test_predict_stream_matches_predict); every batch is a full forward of `--batch` images.
+    nfl = max(1, args.in_flight) if cfg.INFERENCE_HIP_GRAPH else 1
+    el = el1
+    if nfl > 1:
+        xs = [x] + [torch.rand(bsz, 416, 416, 3, device=dev) for _ in range(nfl - 1)]
+        def feed(n):
+            for i in range(n):
+                yield xs[i % nfl]
+        for _ in net.predict_stream(feed(max(2, args.warmup) * nfl), in_flight=nfl):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in net.predict_stream(feed(args.steps), in_flight=nfl):
+            pass
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
     # per-kernel timings (HIP events around eager launches) in a second pass, outside the timed region
     net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "mask_deconv_fwd"}
     net.timings = {}
@@ -620,10 +644,13 @@ def bench_infer(args):
            "value": bsz * args.steps / el, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": max(2, args.warmup),
            "ms_per_step": 1e3 * el / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16", "data": "synthetic",
+           "one_in_flight": {"value": bsz * args.steps / el1, "ms_per_step": 1e3 * el1 / args.steps,
+                             "note": "the same forwards strictly one after the other on one stream (Net.predict_graphed), as rounds 1-2 reported"},
            "config": {"workload": "Rice 416x416 inference forward, batch %d, N_BOX=5 (R=845 boxes/img, all through the mask head as the "
-                                  "reference graph does, model.py:926-931), fp32 trunk (frozen BatchNorm + ReLU6 folded into the depthwise / pointwise conv epilogues) + bf16 ROIAlign / 3x3 convs / deconv with fp32 accumulation; the timed forwards are replays of one captured hipGraph "
-                                  "(cfg.INFERENCE_HIP_GRAPH, as detect() runs them), kernel timings from a separate eager pass" % bsz,
-                      "global_batch": bsz, "parallelism": "dp1"},
+                                  "reference graph does, model.py:926-931), fp32 trunk (frozen BatchNorm + ReLU6 folded into the depthwise / pointwise conv epilogues) + bf16 ROIAlign / 3x3 convs / deconv with fp32 accumulation; the timed forwards are replays of captured hipGraphs "
+                                  "(cfg.INFERENCE_HIP_GRAPH, as detect() runs them), %d batch(es) in flight (Net.predict_stream: one stream, graph and scratch per lane; "
+                                  "ms_per_step = wall time / batches); kernel timings from a separate eager pass" % (bsz, nfl),
+                      "global_batch": bsz, "in_flight": nfl, "parallelism": "dp1"},
            "roofline": {"kernel": "conv3_bf16_256 (mask-head 3x3 conv as an implicit GEMM with the activation block resident in LDS across the nine taps, "
                                   "bf16 operands, fp32 accumulate, M=%d K=2304 N=256)" % M,
                         "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
@@ -655,6 +682,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--nbox", type=int, default=3, choices=[3, 5],
                     help="3 = self-consistent Shapes head (R=147, primary); 5 = repository-HEAD head (R=245)")
+    ap.add_argument("--in-flight", type=int, default=2, help="--config rice416-bf16: inference batches in flight (Net.predict_stream); 1 = strictly serial")
     ap.add_argument("--config", choices=["shapes224-train", "rice416-bf16"], default="shapes224-train",
                     help="shapes224-train = BASELINE configs[1] (the metric); rice416-bf16 = configs[3] inference throughput")
     ap.add_argument("--cpu-images", type=int, default=32, help="images in the CPU-baseline step (0 = skip; halved while host memory is short)")
@@ -730,7 +758,7 @@ def main():
                 ai = copy.copy(args)
                 ai.batch, ai.batch_given, ai.cpu_images, ai.steps, ai.warmup = 4, True, 0, max(20, args.steps), 3
                 ri = bench_infer(ai)
-                res["inference_rice416_bf16"] = {k: ri[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "roofline")}
+                res["inference_rice416_bf16"] = {k: ri[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "one_in_flight", "roofline")}
                 res["inference_rice416_bf16"]["workload"] = ri["config"]["workload"]
             except Exception as e:
                 res["inference_rice416_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -166,6 +166,10 @@ int myolo_pwconv1x1_bwd_weight_affine_in(const float* x, const float* in_scale, 
  * nbytes (multiple of 16), hand-written float4 kernel, 4 loads in flight per thread.  variant 0 default cache policy, 1 non-temporal
  * stores, 2 non-temporal loads + stores, 3 read only, 4 write only; blocks <= 0: 8 workgroups per CU. ---- */
 int myolo_stream_copy(const void* src, void* dst, size_t nbytes, int variant, int blocks, void* stream);
+/* Matrix-pipe ceiling probe: `blocks` workgroups of four waves (<= 0: 512 = two per CU), each wave `iters` rounds of eight independent
+ * accumulator blocks from register operands.  kind 0: v_mfma_f32_32x32x16_bf16 (32768 flop each), kind 1: v_mfma_f32_32x32x2_f32 (4096 flop each).
+ * flop per launch = blocks * 4 * iters * 8 * flop-per-instruction.  `out` (blocks * 256 floats) is practically never written. */
+int myolo_mfma_probe(int kind, int iters, int blocks, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1516,6 +1516,41 @@ __global__ __launch_bounds__(256) void stream_copy_kernel(const f32x4n* __restri
     if (VARIANT == 3 && acc.x + acc.y + acc.z + acc.w == 12345.678f) dst[0] = acc;      // keeps the loads alive; practically never taken
 }
 
+// ---------------------------------------------------------------------------------------
+// Matrix-pipe ceiling probe (the measured counterpart of the nominal MFMA peaks, as stream_copy_kernel is for HBM): every wave issues
+// `iters` rounds of eight INDEPENDENT accumulator blocks of one MFMA shape from constant register operands -- no memory traffic, no LDS,
+// no dependent-issue stalls -- so the rate it reaches is what the clock the power management grants under that load allows.
+//   kind 0: v_mfma_f32_32x32x16_bf16 (32768 flop per instruction)   kind 1: v_mfma_f32_32x32x2_f32 (4096 flop per instruction)
+// ---------------------------------------------------------------------------------------
+typedef __bf16 probe_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float probe_f32x16 __attribute__((ext_vector_type(16)));
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void mfma_probe_kernel(float* __restrict__ out, int iters, float seed)
+{
+    probe_f32x16 acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
+    const float av = seed + (float)(threadIdx.x & 7) * 0.125f, bv = seed * 0.5f + (float)(threadIdx.x & 3) * 0.25f;
+    probe_bf16x8 a8, b8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a8[e] = (__bf16)av; b8[e] = (__bf16)bv; }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (KIND == 0) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[b], 0, 0, 0);
+            else acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[b], 0, 0, 0);
+        }
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[b][r];
+    if (t == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = t;       // keeps the accumulators alive; practically never taken
+}
+
 __global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, long long n)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2125,6 +2160,17 @@ int myolo_stream_copy(const void* src, void* dst, size_t nbytes, int variant, in
     case 3: hipLaunchKernelGGL(stream_copy_kernel<3>, g, b, 0, s, sp, dp, n4); break;
     default: hipLaunchKernelGGL(stream_copy_kernel<4>, g, b, 0, s, sp, dp, n4); break;
     }
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+// flop of one launch = blocks * 4 waves * iters * 8 * (32768 | 4096); blocks <= 0: two workgroups per CU (two waves per SIMD)
+int myolo_mfma_probe(int kind, int iters, int blocks, float* out, void* stream)
+{
+    MYOLO_REQUIRE(out && iters > 0 && (kind == 0 || kind == 1), "mfma_probe: kind 0 (bf16 32x32x16) or 1 (f32 32x32x2), iters > 0, out = blocks*256 floats");
+    if (blocks <= 0) blocks = 512;
+    if (kind == 0) hipLaunchKernelGGL(mfma_probe_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.75f);
+    else hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.75f);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

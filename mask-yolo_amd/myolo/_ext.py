@@ -96,6 +96,7 @@ SIGS = {
     "myolo_adam_step": [P, P, P, P, L, F, F, F, F, F, P],
     "myolo_matmul_f32": [P, P, P, L, I, I, I, I, P, Z, P],
     "myolo_stream_copy": [P, P, Z, I, I, P],
+    "myolo_mfma_probe": [I, I, I, P, P],
     "myolo_conv3x3s2_c3_bnstats_fwd": [P, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_dwconv3x3_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_dwconv3x3_bwd_weight_affine_in": [P, P, P, I, P, P, I, I, I, I, I, P, Z, P],
@@ -243,6 +244,25 @@ def measure_hbm_copy_gbs(nbytes=2 << 30, iters=5, device="cuda:0"):
             torch.cuda.synchronize()
             out[name + suffix] = factor * nbytes * iters / (e0.elapsed_time(e1) * 1e-3) / 1e9
     return out
+
+
+def measure_mfma_tflops(iters=20000, reps=3, device="cuda:0"):
+    """{"bf16_32x32x16": TFLOP/s, "f32_32x32x2": TFLOP/s} the matrix pipes sustain with nothing else going on (myolo_mfma_probe: two
+    workgroups of four waves per CU, eight independent accumulator blocks per wave, register operands), timed with HIP events."""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    blocks = 2 * cus
+    out_buf = torch.zeros(blocks * 256, device=device)
+    res = {}
+    for name, kind, flop, it in (("bf16_32x32x16", 0, 32768.0, iters), ("f32_32x32x2", 1, 4096.0, iters // 2)):
+        call("myolo_mfma_probe", kind, 200, blocks, out_buf.data_ptr(), stream())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            call("myolo_mfma_probe", kind, it, blocks, out_buf.data_ptr(), stream())
+        e1.record()
+        torch.cuda.synchronize()
+        res[name] = blocks * 4.0 * it * 8 * flop * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    return res
 
 
 def workspace_bytes(rows, cin, cout):

@@ -155,7 +155,9 @@ class Net(object):
         for name, kind, shp, _ in self.table:
             if kind == "bn":
                 self.bnbuf[name] = torch.zeros(4, shp, **f32)        # mean, var, scale, shift
-        self._graphs = {}                 # predict_graphed: input shape -> (hipGraph, static input, static outputs)
+        self._graphs = {}                 # predict_graphed: (input shape, modes, lane) -> (hipGraph, static input, static outputs)
+        self._lanes = {}                  # predict_stream: lane -> its stream / scratch / coefficient buffers
+        self._cap_stream = None           # graph capture never happens with the default stream current (see _capture_predict)
         # a captured graph bakes in pointers to the scratch buffer: growing it (a bigger launch on the same Net) drops the graphs
         self._ws_main = Workspace(self.dev, on_realloc=self._graphs.clear)
         self._ws_side = Workspace(self.dev)    # scratch of the YOLO-head backward running on the side stream
@@ -1514,39 +1516,115 @@ class Net(object):
         self.tape = {}
         return pred.view(B, n, mh, mw, cfg.NUM_CLASSES)
 
-    def predict_graphed(self, images):
-        """predict() replayed from a captured hipGraph (one per input shape): the ~150 launches of an inference forward cost
-        one graph launch on the host.  Same kernels, same buffers for the weights (updates are seen), static input / output
-        buffers: the returned tensors are overwritten by the next call with the same shape."""
-        key = (tuple(images.shape), self.cfg.INFERENCE_DTYPE, self.conv3x3_algo, self.fp32_matmul, self.wino_tiles)
+    def _lane_state(self, lane):
+        """Everything a forward WRITES outside the allocator (scratch buffer, frozen-BatchNorm coefficient buffers), once per lane of
+        predict_stream, plus the lane's stream: two forwards in flight must not share them.  Lane 0 is the Net's own set."""
+        st = self._lanes.get(lane)
+        if st is None:
+            if self._fz_table is None:
+                self._frozen_affine_all()            # builds the (read-only) slot table every lane shares
+            st = {"stream": torch.cuda.Stream(device=self.dev)}
+            if lane > 0:
+                st["ws"] = Workspace(self.dev, on_realloc=self._graphs.clear)
+                st["bnbuf"] = {k: torch.zeros_like(v) for k, v in self.bnbuf.items()}
+                st["fz"] = torch.empty_like(self._fz_coeffs)
+            self._lanes[lane] = st
+        return st
+
+    def predict_graphed(self, images, lane=0):
+        """predict() replayed from a captured hipGraph (one per input shape and lane): the ~150 launches of an inference forward
+        cost one graph launch on the host.  Same kernels, same buffers for the weights (updates are seen), static input / output
+        buffers: the returned tensors are overwritten by the next call with the same shape on the same lane.  lane > 0: a second
+        (third ...) graph with its own scratch and static buffers, so that forwards of different lanes may run concurrently on
+        different streams (predict_stream)."""
+        key = (tuple(images.shape), self.cfg.INFERENCE_DTYPE, self.conv3x3_algo, self.fp32_matmul, self.wino_tiles, lane)
         ent = self._graphs.get(key)
-        if ent is None:
-            static_in = images.clone()
-            cur = torch.cuda.current_stream()
-            side = torch.cuda.Stream(device=self.dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):            # warm-up off the capture stream: workspace growth, caches, allocator pools
-                for _ in range(2):
-                    self.predict(static_in)
-            cur.wait_stream(side)
-            torch.cuda.synchronize()
+        if ent is None or ent[0] is None:
+            saved = None
+            if lane > 0:
+                st = self._lane_state(lane)
+                saved = (self._ws_main, self._ws_active, self.bnbuf, self._fz_coeffs)
+                self._ws_main = self._ws_active = st["ws"]
+                self.bnbuf, self._fz_coeffs = st["bnbuf"], st["fz"]
             try:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    outs = self.predict(static_in)
-                ent = (graph, static_in, outs)
-            except Exception as e:                   # capture is a launch mechanism, not a compute path: the same kernels run eagerly
-                import warnings
-                warnings.warn("hipGraph capture of the inference forward failed (%s: %s); launching eagerly" % (type(e).__name__, e))
-                torch.cuda.synchronize()
-                ent = (None, None, None)
-            self._graphs[key] = ent
-        if ent[0] is None:
-            return self.predict(images)
+                if ent is None:
+                    ent = self._capture_predict(images)
+                    self._graphs[key] = ent
+                if ent[0] is None:
+                    return self.predict(images)
+            finally:
+                if saved is not None:
+                    self._ws_main, self._ws_active, self.bnbuf, self._fz_coeffs = saved
         graph, static_in, outs = ent
         static_in.copy_(images)
         graph.replay()
         return outs
+
+    def _capture_predict(self, images):
+        cur = torch.cuda.current_stream()
+        if cur == torch.cuda.default_stream(self.dev):
+            # Measured (tools/experiments/README.md, "graph lanes"): a graph captured while the legacy default stream is current never
+            # overlaps with another stream's work when replayed, on whichever stream -- two lanes then run strictly one after the
+            # other.  Captured with a side stream current, the same graph overlaps (and may still be replayed on the default stream).
+            if self._cap_stream is None:
+                self._cap_stream = torch.cuda.Stream(device=self.dev)
+            self._cap_stream.wait_stream(cur)
+            with torch.cuda.stream(self._cap_stream):
+                ent = self._capture_predict(images)
+            cur.wait_stream(self._cap_stream)
+            return ent
+        static_in = images.clone()
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):            # warm-up off the capture stream: workspace growth, caches, allocator pools
+            for _ in range(2):
+                self.predict(static_in)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        try:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self.predict(static_in)
+            return (graph, static_in, outs)
+        except Exception as e:                   # capture is a launch mechanism, not a compute path: the same kernels run eagerly
+            import warnings
+            warnings.warn("hipGraph capture of the inference forward failed (%s: %s); launching eagerly" % (type(e).__name__, e))
+            torch.cuda.synchronize()
+            return (None, None, None)
+
+    def predict_stream(self, batches, in_flight=2):
+        """Throughput form of the inference forward: a generator over `batches` (an iterable of [B,H,W,3] device tensors of one shape)
+        that keeps `in_flight` forwards running at once -- lane i % in_flight, each lane its own stream, hipGraph, scratch and static
+        buffers -- and yields (yolo_output, detections, masks) per batch in submission order.  The trunk of one batch (small
+        launch-bound fp32 kernels) runs underneath the matrix-pipe-bound mask head of the other.  Same kernels and bit-identical
+        results as predict().  Submission runs two batches per lane ahead of the results handed out, so a lane never idles between
+        its batches (and the lanes drift out of phase instead of running trunk beside trunk); each result is copied out of its lane's
+        static buffers on the lane's stream, so it stays valid for as long as the caller keeps it."""
+        if in_flight < 1:
+            raise ValueError("in_flight must be >= 1")
+        cur = torch.cuda.current_stream()
+        pending = []
+
+        def hand_out():
+            ev, outs = pending.pop(0)
+            ev.synchronize()
+            for t in outs:
+                t.record_stream(cur)
+            return outs
+
+        for i, images in enumerate(batches):
+            if len(pending) == 2 * in_flight:
+                yield hand_out()
+            s = self._lane_state(i % in_flight)["stream"]
+            s.wait_stream(cur)
+            images.record_stream(s)
+            with torch.cuda.stream(s):
+                outs = tuple(t.clone() for t in self.predict_graphed(images, lane=i % in_flight))
+                ev = torch.cuda.Event()
+                ev.record(s)
+            pending.append((ev, outs))
+        while pending:
+            yield hand_out()
 
     def predict_yolo(self, images):
         """'yolo' mode forward (model.py:906-920)."""

@@ -554,6 +554,31 @@ def test_inference_hip_graph_replay_equals_eager_and_sees_weight_updates():
     assert len(net._graphs) == 1
 
 
+@pytest.mark.parametrize("in_flight", [1, 2, 3])
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_predict_stream_matches_predict(in_flight, dtype):
+    """Net.predict_stream: forwards of several batches in flight (one stream, hipGraph, scratch and coefficient buffers per lane) give,
+    batch by batch and in submission order, exactly what the eager forward gives; a weight update between two runs is seen by every lane."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=2, INFERENCE_DTYPE=dtype)
+    P = np_model.init_params(cfg, seed=3, bias_scale=0.05)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+    rng = np.random.default_rng(11)
+    xs = [torch.as_tensor(rng.random((2, 128, 128, 3), dtype=np.float32), device=net.dev) for _ in range(7)]
+    for rnd in range(2):
+        if rnd == 1:
+            net.flat_p.mul_(1.01)
+        want = [[t.clone() for t in net.predict(x)] for x in xs]
+        got = []
+        for outs in net.predict_stream(iter(xs), in_flight=in_flight):
+            got.append([t.clone() for t in outs])          # a lane's buffers are overwritten when the lane is reused
+        assert len(got) == len(xs)
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert all(torch.equal(a, b) for a, b in zip(g, w)), "batch %d of round %d differs (in_flight %d)" % (i, rnd, in_flight)
+    assert len(net._graphs) == in_flight
+
+
 def test_inference_folded_frozen_bn_equals_unfolded():
     """Net.fold_frozen_bn (BatchNorm on moving statistics + ReLU6 in the epilogue of the depthwise / pointwise conv in train=False
     forwards) changes the launch count, not one bit of the outputs."""

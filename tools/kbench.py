@@ -112,6 +112,15 @@ def main():
                 print("copy %-14s blocks %5d: %.3f ms  %.0f GB/s" % (name, blocks, ms, factor * nbytes / ms / 1e6))
         ms = timeit(lambda: dst.copy_(src), a.iters)
         print("torch copy_: %.3f ms  %.0f GB/s" % (ms, 2 * nbytes / ms / 1e6))
+    elif a.which == "mfma":
+        # matrix-pipe ceiling: myolo_mfma_probe (register operands, eight independent accumulator blocks per wave) over waves per SIMD
+        for kind, name, flop in ((0, "bf16 32x32x16", 32768.0), (1, "f32 32x32x2", 4096.0)):
+            for blocks in (256, 512, 1024):
+                it = 20000 if kind == 0 else 10000
+                out = torch.zeros(blocks * 256, device=dev)
+                fn = lambda: X.call("myolo_mfma_probe", kind, it, blocks, out.data_ptr(), st)   # noqa: E731
+                ms = timeit(fn, 3)
+                print("mfma %-14s blocks %5d: %.3f ms  %.1f TFLOP/s" % (name, blocks, ms, blocks * 4.0 * it * 8 * flop / ms / 1e9))
     elif a.which == "wino63_fwd":
         # the F(6,3)/F(4,3) tiling (csrc/wino63_kernels.hip): input transform -> one-launch multiply -> output transform
         x, w, b, y = rn(M, C), rn(3, 3, C, C) * 0.02, rn(C), torch.empty(M, C, device=dev)
