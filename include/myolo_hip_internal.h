@@ -167,7 +167,8 @@ int myolo_pwconv1x1_bwd_weight_affine_in(const float* x, const float* in_scale, 
  * stores, 2 non-temporal loads + stores, 3 read only, 4 write only; blocks <= 0: 8 workgroups per CU. ---- */
 int myolo_stream_copy(const void* src, void* dst, size_t nbytes, int variant, int blocks, void* stream);
 /* Matrix-pipe ceiling probe: `blocks` workgroups of four waves (<= 0: 512 = two per CU), each wave `iters` rounds of eight independent
- * accumulator blocks from register operands.  kind 0: v_mfma_f32_32x32x16_bf16 (32768 flop each), kind 1: v_mfma_f32_32x32x2_f32 (4096 flop each).
+ * accumulator blocks from register operands.  kind 0: v_mfma_f32_32x32x16_bf16 (32768 flop each), kind 1: v_mfma_f32_32x32x2_f32 (4096 flop each),
+ * kind 2 / 3: bf16 with the eight issues of a round on two alternating / one accumulator block (dependent-issue chains).
  * flop per launch = blocks * 4 * iters * 8 * flop-per-instruction.  `out` (blocks * 256 floats) is practically never written. */
 int myolo_mfma_probe(int kind, int iters, int blocks, float* out, void* stream);
 

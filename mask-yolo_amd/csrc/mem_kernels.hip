@@ -1537,6 +1537,15 @@ __global__ __launch_bounds__(256, 2) void mfma_probe_kernel(float* __restrict__ 
 #pragma unroll
     for (int e = 0; e < 8; ++e) { a8[e] = (__bf16)av; b8[e] = (__bf16)bv; }
     for (int it = 0; it < iters; ++it) {
+        if (KIND == 2 || KIND == 3) {        // bf16, dependent chains: KIND 2 = two accumulator blocks alternating (a dependent MFMA every second issue), 3 = one block
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const int k = KIND == 2 ? (b & 1) : 0;
+                acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[k], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            continue;
+        }
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             if (KIND == 0) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8, b8, acc[b], 0, 0, 0);
@@ -2167,9 +2176,11 @@ int myolo_stream_copy(const void* src, void* dst, size_t nbytes, int variant, in
 // flop of one launch = blocks * 4 waves * iters * 8 * (32768 | 4096); blocks <= 0: two workgroups per CU (two waves per SIMD)
 int myolo_mfma_probe(int kind, int iters, int blocks, float* out, void* stream)
 {
-    MYOLO_REQUIRE(out && iters > 0 && (kind == 0 || kind == 1), "mfma_probe: kind 0 (bf16 32x32x16) or 1 (f32 32x32x2), iters > 0, out = blocks*256 floats");
+    MYOLO_REQUIRE(out && iters > 0 && kind >= 0 && kind <= 3, "mfma_probe: kind 0 (bf16 32x32x16), 1 (f32 32x32x2), 2 / 3 (bf16, two / one dependent chains), iters > 0, out = blocks*256 floats");
     if (blocks <= 0) blocks = 512;
     if (kind == 0) hipLaunchKernelGGL(mfma_probe_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.75f);
+    else if (kind == 2) hipLaunchKernelGGL(mfma_probe_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.75f);
+    else if (kind == 3) hipLaunchKernelGGL(mfma_probe_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.75f);
     else hipLaunchKernelGGL(mfma_probe_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, out, iters, 0.75f);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

@@ -55,6 +55,7 @@ struct MMArgs {
     const float* a_shift;
     int a_act;
     double* stat;
+    int tune;              // MM_X6_TUNE builds only (tools/experiments/x6_tune.sh): timing-only ablations of wino_mm_x6_kernel, results are wrong
     MMRun run[4];
 };
 
@@ -366,7 +367,11 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         }
         sa[0] = mm_bufld4(ra, aoffg);
         sa[1] = mm_bufld4(ra, aoffg == MM_OOB ? MM_OOB : aoffg + 16u);
+#ifdef MM_X6_TUNE
+        if constexpr (AG == MM_A_PLAIN) { if (!(p.tune & 16)) aoffg += MM_BK * 4u; }
+#else
         if constexpr (AG == MM_A_PLAIN) aoffg += MM_BK * 4u;
+#endif
         if (PW && p.a_scale) {
             psc[0] = *reinterpret_cast<const float4*>(p.a_scale + kch); psc[1] = *reinterpret_cast<const float4*>(p.a_scale + kch + 4);
             psh[0] = *reinterpret_cast<const float4*>(p.a_shift + kch); psh[1] = *reinterpret_cast<const float4*>(p.a_shift + kch + 4);
@@ -436,13 +441,24 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     for (int c = 0; c < nk; ++c) {
         const int cur = c & 1;
         const bool more = c + 1 < nk;
+#ifdef MM_X6_TUNE
+        if (!(p.tune & 64))
+#endif
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) fa[1][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + 32 * X6_REC + pc * 32);
         affine();                                                       // (PW) chunk c+1's BatchNorm + activation, with the coefficients its gload fetched
         const float x[8] = {sa[0].x, sa[0].y, sa[0].z, sa[0].w, sa[1].x, sa[1].y, sa[1].z, sa[1].w};
         u32x4 p1, p2, p3;
+#ifdef MM_X6_TUNE
+        if (c + 2 < nk && !(p.tune & 128)) gload();
+#else
         if (c + 2 < nk) gload();                                        // chunk c+2 (x[] holds copies of chunk c+1)
+#endif
+#ifdef MM_X6_TUNE
+        const unsigned bnext = (p.tune & 1) ? 0u : (more ? bso + bchunk : bso);
+#else
         const unsigned bnext = more ? bso + bchunk : bso;               // the last chunk re-reads itself (into registers nobody uses)
+#endif
         bf16x8 fn0, fn1, fn2;                                           // row tile 0 of chunk c+1
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -457,25 +473,42 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
             X6_TILE(0)
             X6_TILE(1)
 #undef X6_TILE
+#ifdef MM_X6_TUNE
+            if (!(p.tune & 2))
+#endif
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bnext);      // same registers, next chunk
             if (u < 2) {
 #pragma unroll
                 for (int e = 2 * u; e < 2 * u + 2; ++e) {
                     const float a0 = x[2 * e], a1 = x[2 * e + 1];
+#ifdef MM_X6_TUNE
+                    if (p.tune & 4) { p1[e] = x6_top(a0, a1); p2[e] = p1[e]; p3[e] = p1[e]; continue; }
+#endif
                     const float b0 = x6_rest(a0), b1 = x6_rest(a1);
                     p1[e] = x6_top(a0, a1);
                     p2[e] = x6_top(b0, b1);
                     p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
                 }
+#ifdef MM_X6_TUNE
+                if (u == 1 && more && !(p.tune & 32)) {
+#else
                 if (u == 1 && more) {
+#endif
                     *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto) = p1;
                     *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 32) = p2;
                     *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 64) = p3;
                 }
             } else if (u == 2) {
+#ifdef MM_X6_TUNE
+                if (!(p.tune & 32))
+#endif
                 __syncthreads();
+#ifdef MM_X6_TUNE
+                if (more && !(p.tune & 64)) {
+#else
                 if (more) {
+#endif
                     fn0 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr);
                     fn1 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 32);
                     fn2 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 64);
@@ -549,6 +582,9 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
             }
         return;
     }
+#ifdef MM_X6_TUNE
+    if ((p.tune & 8) && acc[0][0][0] != 12345.678f) return;
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -581,6 +617,7 @@ int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nr
     }
     MMArgs a{};
     a.A = A; a.Bt = Bt; a.C = C; a.K = K; a.N = N; a.nt = g_myolo_opt.wino_nt ? 1 : 0;
+    a.tune = g_myolo_opt.tune0;
     long long tiles = 0;
     for (int r = 0; r < nruns; ++r) {
         if (rows[r] <= 0 || nq[r] <= 0) continue;

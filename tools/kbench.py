@@ -13,8 +13,11 @@ import torch         # noqa: E402
 from myolo import _ext as X   # noqa: E402
 
 
-def timeit(fn, iters, warm=2):
-    for _ in range(warm):
+WARM = 2
+
+
+def timeit(fn, iters, warm=None):
+    for _ in range(WARM if warm is None else warm):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,9 +33,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--warm", type=int, default=2, help="untimed launches first; an MFMA-bound kernel needs ~30 to get through the clock transient after idle")
     ap.add_argument("--rois", type=int, default=32 * 147)
     ap.add_argument("--cout", type=int, default=256)
     a = ap.parse_args()
+    global WARM
+    WARM = a.warm
     dev = "cuda:0"
     g = torch.Generator(device=dev).manual_seed(0)
     rn = lambda *s: torch.randn(*s, device=dev, generator=g)   # noqa: E731
@@ -114,9 +120,9 @@ def main():
         print("torch copy_: %.3f ms  %.0f GB/s" % (ms, 2 * nbytes / ms / 1e6))
     elif a.which == "mfma":
         # matrix-pipe ceiling: myolo_mfma_probe (register operands, eight independent accumulator blocks per wave) over waves per SIMD
-        for kind, name, flop in ((0, "bf16 32x32x16", 32768.0), (1, "f32 32x32x2", 4096.0)):
-            for blocks in (256, 512, 1024):
-                it = 20000 if kind == 0 else 10000
+        for kind, name, flop in ((0, "bf16 32x32x16", 32768.0), (1, "f32 32x32x2", 4096.0), (2, "bf16 2 chains", 32768.0), (3, "bf16 1 chain", 32768.0)):
+            for blocks in ((256, 512, 1024) if kind < 2 else (512,)):
+                it = 10000 if kind == 1 else 20000
                 out = torch.zeros(blocks * 256, device=dev)
                 fn = lambda: X.call("myolo_mfma_probe", kind, it, blocks, out.data_ptr(), st)   # noqa: E731
                 ms = timeit(fn, 3)
