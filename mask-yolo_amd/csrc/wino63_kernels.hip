@@ -298,8 +298,7 @@ __device__ __forceinline__ W63CropAxis w63_crop_axis(float b0, float b1, int siz
 enum { W63_FROM_M = 0, W63_FROM_ACT = 1, W63_FROM_LAZY = 2, W63_FROM_CROP = 3 };
 enum { W63_TO_V = 0, W63_TO_NONE = 1, W63_TO_Q = 2, W63_TO_VQ = 3 };      // TO_VQ: both transforms of ONE tile fill (V -> a.Vn, Q -> a.Qn)
 
-// one (image, 64-channel slice) unit of the layer boundary; INL = false: an out-of-line call from the persistent form of the kernel (a loop
-// around the inlined body makes the compiler keep the 64 plane offsets live across iterations: 168 VGPRs and 600+ bytes of scratch per lane)
+// one (image, 64-channel slice) unit of the layer boundary
 template <int FRONT, int BACK>
 __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, long long unit)
 {
@@ -416,9 +415,6 @@ __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, 
     else         { if (tx == 0) w63_back_v<4, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<4, 4>(a, pl, act_lds, py0, px0, lane); }
 }
 template <int FRONT, int BACK>
-__device__ __attribute__((noinline)) void w63_unit_call(const W63Args& a, float* act_lds, long long unit) { w63_unit_body<FRONT, BACK>(a, act_lds, unit); }
-
-template <int FRONT, int BACK>
 __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float act_lds[];         // [14][14][64]
@@ -426,19 +422,9 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args
     w63_unit_body<FRONT, BACK>(a, act_lds, blockIdx.x);
 }
 
-// persistent form (option "w63_persist" = workgroups per CU): a fixed number of workgroups walks the units.  Tuning experiment: a stream-copy
-// kernel runs ~20 % faster with ONE workgroup per CU than with the 8+ an ordinary launch keeps resident (tools/kbench.py copy); whether that
-// carries over to this kernel is recorded in profiles/r3_notes.md.  The unit body is an out-of-line call here (see w63_unit_body).
-template <int FRONT, int BACK>
-__global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_persist_kernel(W63Args a)
-{
-    extern __shared__ __attribute__((aligned(16))) float act_lds[];
-    const long long nunits = a.NR * (a.C / W63_CS);
-    for (long long unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
-        if (unit != (long long)blockIdx.x) __syncthreads();          // the previous unit's readers of the LDS tile are done
-        w63_unit_call<FRONT, BACK>(a, act_lds, unit);
-    }
-}
+// (A persistent form -- a few workgroups per CU walking the units in a loop, the unit body an out-of-line call because the inlined loop made the
+// compiler keep the 64 plane offsets live across iterations: 168 VGPRs + scratch -- was measured in round 3: 1.25 against 0.81 ms.  One workgroup
+// serialises load -> transform -> store; the one-unit-per-workgroup launch overlaps them across workgroups.  Removed; profiles/r3_notes.md.)
 
 // dU [64][Ci][Co] -> dw [3,3,Ci,Co] = G8^T dU G8
 __global__ __launch_bounds__(256) void wino63_dw_kernel(const float* __restrict__ dU, float* __restrict__ dw, int Ci, int Co)
@@ -525,12 +511,6 @@ static int w63_launch(const W63Args& a, hipStream_t s)
     W63Args b = a;
     b.order = g_myolo_opt.w63_order ? 0 : 1;
     const long long grid = a.NR * (a.C / W63_CS);
-    if (g_myolo_opt.w63_persist > 0 && grid > 256ll * g_myolo_opt.w63_persist) {
-        static bool attr2 = false;
-        if (!attr2) { (void)hipFuncSetAttribute((const void*)wino63_boundary_persist_kernel<FRONT, BACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr2 = true; }
-        hipLaunchKernelGGL((wino63_boundary_persist_kernel<FRONT, BACK>), dim3((unsigned)(256ll * g_myolo_opt.w63_persist)), dim3(W63_TILES * 64), lds, s, b);
-        return MYOLO_OK;
-    }
     hipLaunchKernelGGL((wino63_boundary_kernel<FRONT, BACK>), dim3((unsigned)grid), dim3(W63_TILES * 64), lds, s, b);
     return MYOLO_OK;
 }
