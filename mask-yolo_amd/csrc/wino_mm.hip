@@ -298,14 +298,18 @@ __device__ __forceinline__ float mm_act(float v, int act)
     return v;
 }
 
-template <int EPI, bool PW = false, int AG = MM_A_PLAIN>
+// NU = 32-column blocks per wave: 4 (tile 128 x 256) or 2 (tile 128 x 128, twice the workgroups: for the products whose 128 x 256 tiles
+// do not fill the chip -- the 14x14 / 7x7 pointwise layers of the trunk; each A element is then split by two workgroups instead of one)
+template <int EPI, bool PW = false, int AG = MM_A_PLAIN, int NU = 4>
 __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 {
+    static_assert(NU == 4 || (NU == 2 && EPI == MM_EP_PLAIN && AG == MM_A_PLAIN), "the 128-column tile exists for the plain product only");
+    constexpr int BN = 64 * NU;
     __shared__ __attribute__((aligned(16))) unsigned char As[2][MM_BM * X6_REC];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
-    const int ntn = p.N / MM_BN;
+    const int ntn = p.N / BN;
     long long bid;
     {
         const long long nwg = gridDim.x, orig = blockIdx.x;
@@ -321,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     const long long per_plane = (long long)R.mtiles * ntn;
     const int z = (int)(local / per_plane);
     const long long rem = local - z * per_plane;
-    const int n0 = (int)(rem % ntn) * MM_BN;
+    const int n0 = (int)(rem % ntn) * BN;
     const long long m0 = (rem / ntn) * MM_BM;
     const long long M = R.rows;
     const int nk = p.K / MM_BK;
@@ -406,22 +410,22 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     const int afr = (wm * 64 + l31) * X6_REC + half * 16;          // + t * 32 rows, + piece * 32 bytes
     // B fragments: tile (n0 + wn*128)/32 + u, piece pc, this lane's k half and column: 16 bytes at
     //   ((chunk * N/32 + tile) * 6 + pc * 2 + half) * 512 + l31 * 16
-    const unsigned bvo = (unsigned)(((n0 + wn * 128) >> 5) * 6 + half) * 512u + (unsigned)l31 * 16u;     // + u * 3072 + pc * 1024
+    const unsigned bvo = (unsigned)(((n0 + wn * 32 * NU) >> 5) * 6 + half) * 512u + (unsigned)l31 * 16u;     // + u * 3072 + pc * 1024
     const unsigned bchunk = (unsigned)(p.N >> 5) * 3072u;
     unsigned bso = 0;                                                                                    // chunk offset (scalar)
-    bf16x8 bq[4][3];
+    bf16x8 bq[NU][3];
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NU];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
     gload();
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NU; ++u)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bso);
     sstore(0);
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 #endif
         bf16x8 fn0, fn1, fn2;                                           // row tile 0 of chunk c+1
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < NU; ++u) {
             // smallest terms first
 #define X6_TILE(t)                                                                                                 \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][2], acc[t][u], 0, 0, 0);           \
@@ -478,9 +482,9 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 #endif
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bnext);      // same registers, next chunk
-            if (u < 2) {
+            if (u < NU / 2) {                                           // the split of chunk c+1 in NU/2 slices
 #pragma unroll
-                for (int e = 2 * u; e < 2 * u + 2; ++e) {
+                for (int e = (8 / NU) * u; e < (8 / NU) * (u + 1); ++e) {
                     const float a0 = x[2 * e], a1 = x[2 * e + 1];
 #ifdef MM_X6_TUNE
                     if (p.tune & 4) { p1[e] = x6_top(a0, a1); p2[e] = p1[e]; p3[e] = p1[e]; continue; }
@@ -491,15 +495,15 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
                     p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
                 }
 #ifdef MM_X6_TUNE
-                if (u == 1 && more && !(p.tune & 32)) {
+                if (u == NU / 2 - 1 && more && !(p.tune & 32)) {
 #else
-                if (u == 1 && more) {
+                if (u == NU / 2 - 1 && more) {
 #endif
                     *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto) = p1;
                     *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 32) = p2;
                     *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 64) = p3;
                 }
-            } else if (u == 2) {
+            } else if (u == NU / 2) {
 #ifdef MM_X6_TUNE
                 if (!(p.tune & 32))
 #endif
@@ -528,9 +532,9 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         if (p.stat) {
             // column sums of the tile (BatchNorm statistics of the conv's output): lane -> its 32 row slots, the other half-wave, the two
             // waves sharing the columns through LDS (free after the loop); one row of partials per row tile: fixed-order finish
-            float s1[4], s2[4];
+            float s1[NU], s2[NU];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+            for (int u = 0; u < NU; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -538,23 +542,23 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
                     const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (row >= M) continue;
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const float v = acc[t][u][r]; s1[u] += v; s2[u] = fmaf(v, v, s2[u]); }
+                    for (int u = 0; u < NU; ++u) { const float v = acc[t][u][r]; s1[u] += v; s2[u] = fmaf(v, v, s2[u]); }
                 }
             __syncthreads();                                     // (every wave is past its last fragment read)
             float* sred = reinterpret_cast<float*>(&As[0][0]);   // [2 (wm)][2 (sum, sumsq)][256]
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 s1[u] += __shfl_xor(s1[u], 32, 64);
                 s2[u] += __shfl_xor(s2[u], 32, 64);
                 if (half == 0) {
-                    sred[(wm * 2 + 0) * MM_BN + wn * 128 + u * 32 + l31] = s1[u];
-                    sred[(wm * 2 + 1) * MM_BN + wn * 128 + u * 32 + l31] = s2[u];
+                    sred[(wm * 2 + 0) * BN + wn * 32 * NU + u * 32 + l31] = s1[u];
+                    sred[(wm * 2 + 1) * BN + wn * 32 * NU + u * 32 + l31] = s2[u];
                 }
             }
             __syncthreads();
-            for (int e = tid; e < 2 * MM_BN; e += 256) {
-                const int v = e / MM_BN, cc = e - v * MM_BN;
-                p.stat[((m0 / MM_BM) * 2 + v) * p.N + n0 + cc] = (double)sred[(0 * 2 + v) * MM_BN + cc] + (double)sred[(1 * 2 + v) * MM_BN + cc];
+            for (int e = tid; e < 2 * BN; e += 256) {
+                const int v = e / BN, cc = e - v * BN;
+                p.stat[((m0 / MM_BM) * 2 + v) * p.N + n0 + cc] = (double)sred[(0 * 2 + v) * BN + cc] + (double)sred[(1 * 2 + v) * BN + cc];
             }
         }
     }
@@ -565,7 +569,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         const int cb = n0 - tap * p.Co + wn * 128 + l31;
         float bv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) bv[u] = p.bias ? p.bias[cb + 32 * u] : 0.f;
+        for (int u = 0; u < NU; ++u) bv[u] = p.bias ? p.bias[cb + 32 * u] : 0.f;
         const long long hw = (long long)p.H * p.W;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
                 const int y = rem / p.W, x = rem - y * p.W;
                 float* dst = p.C + (n_img * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1)) * p.Co + cb;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) dst[32 * u] = mm_act(acc[t][u][r] + bv[u], p.a_act);
+                for (int u = 0; u < NU; ++u) dst[32 * u] = mm_act(acc[t][u][r] + bv[u], p.a_act);
             }
         return;
     }
@@ -591,9 +595,9 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         for (int r = 0; r < 16; ++r) {
             const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (row >= M) continue;
-            float* dst = Cp + row * p.N + n0 + wn * 128 + l31;
+            float* dst = Cp + row * p.N + n0 + wn * 32 * NU + l31;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NU; ++u) {
                 if (p.nt) __builtin_nontemporal_store(acc[t][u][r], dst + 32 * u);
                 else dst[32 * u] = acc[t][u][r];
             }
@@ -601,6 +605,9 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 }
 
 /* whether the Winograd multiply of a (K = Cin, N = Cout) layer runs here (and the filters are therefore stored transposed) */
+// fewer 128 x 256 tiles than CUs: 128 x 128 tiles (twice the workgroups) instead; option x6_no_half_tiles = 1 is the ablation
+static bool x6_half_tiles(long long tiles) { return !g_myolo_opt.x6_no_half_tiles && tiles < 256; }
+
 bool myolo_gemm_nt_batched_ok(int K, int N) { return !g_myolo_opt.wino_no_bt && K >= MM_BK && (K % MM_BK) == 0 && (N % MM_BN) == 0; }
 /* ... and whether it runs as six bf16 piece products per fp32 product (option "wino_x6"; the filters are stored split then) */
 bool myolo_gemm_nt_batched_x6(int K, int N) { return g_myolo_opt.wino_x6 && myolo_gemm_nt_batched_ok(K, N); }
@@ -724,7 +731,8 @@ extern "C" int myolo_matmul_f32(const float* A, const float* B, float* C, int64_
         const long long total = (long long)K * N;
         hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, B, (__bf16*)ws, K, N, b_is_nk ? 0 : 1);
         a.Bt = (const float*)ws;
-        hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+        if (x6_half_tiles(tiles)) hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, false, MM_A_PLAIN, 2>), dim3((unsigned)(2 * tiles)), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);
     } else {
         if (!b_is_nk) {
             hipLaunchKernelGGL(mm_transpose_kn_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, B, (float*)ws, K, N);
@@ -1055,7 +1063,8 @@ int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift
     const long long total = (long long)K * N;
     hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 1);
     a.Bt = (const float*)split;
-    hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
+    if (x6_half_tiles(tiles)) hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true, MM_A_PLAIN, 2>), dim3((unsigned)(2 * tiles)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
 }
 
