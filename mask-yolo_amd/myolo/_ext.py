@@ -254,7 +254,8 @@ def measure_mfma_tflops(iters=20000, reps=3, device="cuda:0"):
     out_buf = torch.zeros(blocks * 256, device=device)
     res = {}
     for name, kind, flop, it in (("bf16_32x32x16", 0, 32768.0, iters), ("f32_32x32x2", 1, 4096.0, iters // 2)):
-        call("myolo_mfma_probe", kind, 200, blocks, out_buf.data_ptr(), stream())
+        for _ in range(3):                                  # the clock ramps up over the first ~10 ms of MFMA work after idle
+            call("myolo_mfma_probe", kind, it, blocks, out_buf.data_ptr(), stream())
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):

@@ -614,6 +614,7 @@ class Net(object):
         n, h, w, c = c4shape
         Cf = cfg.TOP_FEATURE_MAP_DEPTH
         Fm = self._new(n * h * w, Cf)
+        # (running this conv on a side stream underneath the YOLO head's forward blocks was measured in round 3: 21.55 vs 21.55 / 21.67 ms, nothing)
         self.conv3x3_fwd(C4, "feature_map", Fm, n, h, w, c, Cf)
         for f, s in YOLO_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)

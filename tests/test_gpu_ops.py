@@ -1132,3 +1132,21 @@ def test_conv1_bnstats_fwd(N, H, W, Co, nofuse):
                X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv), N, H, W, Co, 3, wsb.data_ptr(), wsb.numel(), X.stream())
     check(y, ref, what="fused conv1 fwd")
     _check_bn_outputs(ref.reshape(-1, Co).astype(np.float32), g, b, mm, mv, mean, var, scale, shift, tmm, tmv)
+
+
+def test_measurement_probes_run_and_are_plausible():
+    """the two ceiling probes bench.py prints beside the nominal peaks (myolo_stream_copy, myolo_mfma_probe): they run, reject bad
+    arguments, and land in a plausible range on an MI355X (a tenth of the nominal peaks at least -- the point is that they execute)."""
+    r = X.measure_mfma_tflops(iters=4000, reps=2, device=DEV)
+    assert r["bf16_32x32x16"] > 250.0 and r["f32_32x32x2"] > 15.0, r
+    out = torch.zeros(512 * 256, device=DEV)
+    with pytest.raises(RuntimeError):
+        X.call("myolo_mfma_probe", 7, 10, 512, out.data_ptr(), X.stream())
+    with pytest.raises(RuntimeError):
+        X.call("myolo_mfma_probe", 0, 0, 512, out.data_ptr(), X.stream())
+    for kind in (2, 3):                                    # the dependent-chain variants
+        assert X.call("myolo_mfma_probe", kind, 10, 512, out.data_ptr(), X.stream()) in (0, None)
+    torch.cuda.synchronize()
+    assert float(out.abs().sum()) == 0.0                   # the probe never writes (its store is behind an impossible condition)
+    hb = X.measure_hbm_copy_gbs(nbytes=256 << 20, iters=2, device=DEV)
+    assert hb["float4"] > 500.0 and hb["read_only_1wg_per_cu"] > 500.0, hb

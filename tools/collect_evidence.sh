@@ -15,23 +15,27 @@ bash tools/profile_step.sh ${TAG}native --fp32-matmul native > /dev/null 2>&1
 cp gpurun_out/prof_${TAG}native/${TAG}native_bench_kernel_stats.csv gpurun_out/prof_${TAG}native/${TAG}native_bench_kernel_by_grid.csv gpurun_out/prof_${TAG}native/${TAG}native_timeline.txt $OUT/
 {
   for k in wino_fwd wino63_fwd wino63_mm wino63_wgrad wino63_boundary wino_bwd_data wino_bwd_weight conv3x3_fwd deconv_mask_fwd roialign_fwd roialign_bwd dw; do
-    python tools/kbench.py $k --iters 10 2>&1 | grep -vE "amdgpu.ids|^$" | tail -16
+    python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -16      # steady state: 30 untimed launches first (clock transient after idle, r3_notes.md)
   done
   echo "--- KBENCH_OPTIONS=wino_x6=1"
   for k in wino_fwd wino63_fwd wino63_mm wino63_wgrad wino_bwd_data deconv_mask_fwd; do
-    KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --iters 10 2>&1 | grep -vE "amdgpu.ids|^$" | tail -1
+    KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -1
   done
   echo "--- bf16 inference kernels (default; bf16_no_c3=1 = the nine-fetch implicit GEMM; bf16_no256=1 = the 128^2 kernels; bf16_no_loopn=1)"
-  python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no_c3=1 python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py conv3x3_bf16_fwd --iters 20 2>&1 | tail -1
-  python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no_loopn=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py deconv_mask_bf16_fwd --iters 20 2>&1 | tail -1
+  python tools/kbench.py conv3x3_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no_c3=1 python tools/kbench.py conv3x3_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py conv3x3_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
+  python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no_loopn=1 python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
+  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
   echo "--- tools/overlap_mm_boundary.py"
   python tools/overlap_mm_boundary.py 2>&1 | tail -1
   echo "--- HBM stream copy (hand-written float4 kernel, grid sweep) beside torch copy_"
   python tools/kbench.py copy --iters 5 2>&1 | grep -v amdgpu
+  echo "--- matrix-pipe ceiling (myolo_mfma_probe: register operands, no memory traffic)"
+  python tools/kbench.py mfma --warm 5 2>&1 | grep -v amdgpu
+  echo "--- wino_mm_x6_kernel as a plain GEMM at constant FLOPs over K (tools/experiments/x6_k_sweep.py)"
+  python tools/experiments/x6_k_sweep.py 2>&1 | grep -v amdgpu
   echo "--- tools/pw_layers.py"
   python tools/pw_layers.py 2>&1 | grep -E "total"
 } > $OUT/${TAG}_kbench.txt

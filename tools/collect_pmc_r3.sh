@@ -11,25 +11,29 @@ mkdir -p $OUT
 SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"
 for k in wino63_mm wino63_wgrad wino63_boundary; do
   for c in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${k}_$c -o p -- env KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --iters 3 > /dev/null 2>&1
+    rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/${k}_$c -o p -- env KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 6 > /dev/null 2>&1
   done
-  rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/${k}_sq -o p -- env KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --iters 3 > /dev/null 2>&1
+  rocprofv3 --pmc $SQ --kernel-trace --output-format csv -d $OUT/${k}_sq -o p -- env KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 6 > /dev/null 2>&1
 done
 python - "$OUT" "$TAG" <<'PY'
 import csv, collections, json, sys
 out, tag = sys.argv[1], sys.argv[2]
 def per_launch(d, kname):
-    rows = [r for r in csv.DictReader(open("%s/%s/p_counter_collection.csv" % (out, d))) if kname in r["Kernel_Name"]]
+    # steady state only: the LAST five launches of the kernel (the first ~25 after idle run through a clock transient)
+    kt = [r for r in csv.DictReader(open("%s/%s/p_kernel_trace.csv" % (out, d))) if kname in r["Kernel_Name"]]
+    kt = sorted(kt, key=lambda r: int(r["Start_Timestamp"]))[-5:]
+    keep = set(r["Dispatch_Id"] for r in kt)
+    rows = [r for r in csv.DictReader(open("%s/%s/p_counter_collection.csv" % (out, d))) if kname in r["Kernel_Name"] and r["Dispatch_Id"] in keep]
     acc = collections.defaultdict(float); disp = set()
     for r in rows:
         acc[r["Counter_Name"]] += float(r["Counter_Value"]); disp.add(r["Dispatch_Id"])
-    kt = [r for r in csv.DictReader(open("%s/%s/p_kernel_trace.csv" % (out, d))) if kname in r["Kernel_Name"]]
     dur = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in kt)
     n = max(1, len(disp))
     return {k: v / n for k, v in acc.items()}, dur / max(1, len(kt)), n
 NR, C = 4704, 256
 pe = 400 * NR * C
 res = {"shape": "NR = 4704 ROIs (32 x 147), 14x14, 256 -> 256 channels, F(6,3)/F(4,3) tiling: 400 point-tiles per ROI, 64 planes; KBENCH_OPTIONS=wino_x6=1",
+       "steady_state": "30 untimed launches first; counters and durations of the last five launches only (round 3: the earlier passes measured launches 3-5 after idle, inside the clock transient)",
        "method": "separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ set), --kernel-trace only; traffic = 2 x FETCH_SIZE + WRITE_SIZE "
                  "(gfx950: FETCH_SIZE counts half of a wide streaming read, MI355X_MICROARCH.md), KB -> bytes x 1024"}
 for target, kname, key, alg_bytes, alg_flop in (
