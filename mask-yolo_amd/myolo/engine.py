@@ -170,6 +170,7 @@ class Net(object):
         self._wgrad_stream = torch.cuda.Stream(device=self.dev)
         self._ws_wgrad = Workspace(self.dev)
         self.overlap_conv1_wgrad = True
+        self.overlap_compact_wgrad = True  # ... and the weight / bias gradients of the compacted conv2-4 / deconv backward in front of it on that stream
         # the trunk's weight-gradient kernels (no consumer but the optimiser) on their own stream and scratch, beside the
         # BatchNorm-backward -> data-gradient chain that is the critical path of the trunk backward
         self._twg_stream = torch.cuda.Stream(device=self.dev)
@@ -1158,9 +1159,34 @@ class Net(object):
         dd = self._new(Md, MASK_FILTERS)
         X.call("myolo_mask_head_out_bwd", X.ptr(d_p), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(dz_p), X.ptr(dd),
                X.ptr(self.g["myolo_mask/kernel"]), X.ptr(self.g["myolo_mask/bias"]), Md, MASK_FILTERS, C, *self._wsargs(), X.stream())
-        X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_p), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
-               MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
-        self.colsum(dd, self.g["myolo_mask_deconv/bias"])
+        # The compacted part is a chain of data gradients (deconv -> conv4 -> conv3 -> conv2 -> bn1's coefficients) that conv1's dense backward
+        # waits for; the weight / bias gradients hanging off it have no consumer before the bucket's all-reduce.  They go to the stream (and
+        # scratch) conv1's weight gradient uses later: queued in front of it, finished before the bucket is released there.
+        side_wg = bool(self.overlap_compact_wgrad and self.overlap_conv1_wgrad)
+
+        def off_chain(fn, tensors):
+            if not side_wg:
+                return fn()
+            cur = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._wgrad_stream.wait_event(ev)
+            saved = self._ws_active
+            self._ws_active = self._ws_wgrad
+            try:
+                with torch.cuda.stream(self._wgrad_stream):
+                    fn()
+            finally:
+                self._ws_active = saved
+            for t in tensors:
+                t.record_stream(self._wgrad_stream)
+            self._wgrad_pending = True
+
+        def deconv_wgrad():
+            X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_p), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
+                   MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+            self.colsum(dd, self.g["myolo_mask_deconv/bias"])
+        off_chain(deconv_wgrad, (a4_p, dd))
         da = self._new(NP * q, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NP, ps, ps,
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
@@ -1189,11 +1215,14 @@ class Net(object):
                 c_p = gather(self.tape[bn][0], q)
                 dy = self.bn_act_bwd(bn, da, y_override=c_p)
             a_next = xin                  # conv_i's input = post-activation of layer i-1
-            self.conv3x3_bwd_weight(xin, None, dy, cn, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
-            self.colsum(dy, self.g[cn + "/bias"])
+            def conv_wgrad(xin=xin, dy=dy, cn=cn):
+                self.conv3x3_bwd_weight(xin, None, dy, cn, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
+                self.colsum(dy, self.g[cn + "/bias"])
+            off_chain(conv_wgrad, (xin, dy))
             da = self._new(NP * q, MASK_FILTERS)
             self.conv3x3_bwd_data(dy, cn, da, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
         # bn1: batch statistics -> dense dx from the row-sparse upstream gradient
+        released = [False]                      # the mask-head bucket handed to the all-reduce hook on the side stream (fork_wgrad)
         c1, act, _ = self.tape["myolo_mask_bn1"]
         buf = self.bnbuf["myolo_mask_bn1"]
         M1 = NR * q
@@ -1235,6 +1264,7 @@ class Net(object):
             wg_bytes = (X.wino63_bwd_weight_from_q_ws_bytes(NR, cin, MASK_FILTERS) if merged else
                         X.wino63_bwd_weight_ws_bytes(NR, cin, MASK_FILTERS) if v63 else X.wino_ws_bytes(NR, ps, ps, cin, MASK_FILTERS, 2))
             def fork_wgrad():
+                released[0] = bool(self.on_bucket_ready)
                 self._ws_wgrad.ensure(wg_bytes)
                 cur = torch.cuda.current_stream()
                 self._wgrad_stream.wait_stream(cur)
@@ -1276,7 +1306,8 @@ class Net(object):
             self.conv3x3_bwd_data(dc1, "myolo_mask_conv1", dp0, NR, ps, ps, cin, MASK_FILTERS)
         dF = self._new(n * h * w, cf)
         X.call("myolo_roialign_bwd_grouped", X.ptr(dp0), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
-        if self.on_bucket_ready and not self._wgrad_pending:
+        if self.on_bucket_ready and not released[0]:
+            self.join_conv1_wgrad()       # the compacted weight gradients on the side stream, if any
             self.on_bucket_ready(2)       # (otherwise the bucket was released on the weight gradient's stream, behind that kernel)
         return dF
 

@@ -97,6 +97,21 @@ def main():
         fn = lambda: X.call("myolo_wino63_input_transform", X.ptr(y), X.ptr(sc), X.ptr(sh), 1, None, None, X.ptr(Vn), NR, C, st)   # noqa: E731
         ms = timeit(fn, a.iters)
         print("wino63_boundary<act,V> NR=%d: %.3f ms  %.0f GB/s" % (NR, ms, (pe + M * C) * 4 / ms / 1e6))
+    elif a.which == "wino63_lazy":
+        # conv1's backward transforms: bn1's lazily formed input gradient (y_pre + the positive ROIs' compact dy) -> LDS tile -> V (data gradient operand) and
+        # Q (weight gradient operand) in ONE pass: reads 0.94 GB, writes 2 x 1.93 GB
+        pe = X.wino63_plane_elems(NR, C)
+        y = rn(M, C)
+        npos = 8
+        dyc = rn(npos * ps * ps, C)
+        inv = torch.full((NR,), -1, dtype=torch.int32, device=dev)
+        inv[:npos] = torch.arange(npos, dtype=torch.int32, device=dev)
+        sc, sh, ka, kb = rn(C), rn(C), rn(C) * 1e-3, rn(C) * 1e-3
+        V, Q = torch.empty(pe, device=dev), torch.empty(pe, device=dev)
+        fn = lambda: X.call("myolo_wino63_lazybn_transforms", X.ptr(y), X.ptr(dyc), X.ptr(inv), X.ptr(sc), X.ptr(sh), X.ptr(ka), X.ptr(kb), 1, X.ptr(V), X.ptr(Q), NR, C, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        by = (M * C + 2 * pe) * 4.0
+        print("wino63_boundary<lazy,VQ> NR=%d: %.3f ms  %.0f GB/s (%.2f GB read + written)" % (NR, ms, by / ms / 1e6, by / 1e9))
     elif a.which == "wino63_mm":
         pe = X.wino63_plane_elems(NR, C)
         V, Mp, w = rn(pe), torch.empty(pe, device=dev), rn(3, 3, C, C) * 0.02
