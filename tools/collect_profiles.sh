@@ -95,7 +95,7 @@ PY
 head -8 $OUT/${TAG}_bench_kernel_by_grid.csv | cut -c1-170
 cat $OUT/${TAG}_kbench.txt | grep -v "^dw  \|^dw 1"
 cat $OUT/${TAG}_bench.json | cut -c1-400
-python tools/bench_infer.py --batch 4 > $OUT/${TAG}_bench_infer.json 2>/dev/null; cat $OUT/${TAG}_bench_infer.json
+python bench.py --config rice416-bf16 --steps 20 2>/dev/null | tail -1 > $OUT/${TAG}_bench_infer.json; cut -c1-300 $OUT/${TAG}_bench_infer.json
 # the repository-HEAD head (N_BOX=5, R=245) and the direct-convolution form, for BASELINE.md
 python bench.py --steps 10 --warmup 3 --cpu-images 0 --nbox 5 2> /dev/null | tail -1 > $OUT/${TAG}_bench_nbox5.json; cut -c1-260 $OUT/${TAG}_bench_nbox5.json
 python bench.py --steps 10 --warmup 3 --cpu-images 0 --conv3x3 direct --no-variant 2> /dev/null | tail -1 > $OUT/${TAG}_bench_direct.json; cut -c1-260 $OUT/${TAG}_bench_direct.json
