@@ -40,7 +40,18 @@ def _case(world=2):
     return cfg, P, batches
 
 
-def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch"):
+def _force_positives(net, cfg, k=3):
+    """the first k proposals of every image are replaced by a ground-truth box (IoU 1 -> positive): the compacted mask-head backward, conv1's
+    dense backward on its side stream and the release of the mask-head bucket BEHIND that stream's work all run under the reducer"""
+    def hook(proposals, db):
+        gt = db["gt_boxes"].to(torch.float32)                       # [B,T,4] px, x1 y1 x2 y2
+        H, W = float(cfg.IMAGE_SHAPE[0]), float(cfg.IMAGE_SHAPE[1])
+        norm = (gt - torch.tensor([0., 0., 1., 1.], device=gt.device)) / torch.tensor([W - 1, H - 1, W - 1, H - 1], device=gt.device)
+        proposals[:, :k, :] = norm[:, :1, :].expand(-1, k, -1)
+    net.proposals_hook = hook
+
+
+def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch", positives=False):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -56,10 +67,14 @@ def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch"):
         cfg, P, batches = _case(world)
         # ---- single-rank gradients of EVERY shard (no communication) -> their mean is the expected exchanged gradient
         solo = MaskYOLO(mode="training", config=cfg, device=dev)
+        if positives:
+            _force_positives(solo.net, cfg)
         expect = None
+        npos_seen = 0
         for b in batches:
             solo.load_state_dict(P)
-            solo.net.forward_backward(solo.net.to_device_batch(b))
+            out = solo.net.forward_backward(solo.net.to_device_batch(b))
+            npos_seen += int(out["n_pos"].sum())
             solo.net.join_conv1_wgrad()
             torch.cuda.synchronize()
             expect = solo.net.flat_g.double() if expect is None else expect + solo.net.flat_g.double()
@@ -68,6 +83,9 @@ def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch"):
         # ---- the data-parallel step: own shard, bucketed overlapped all-reduce, 1/world inside Adam
         model = MaskYOLO(mode="training", config=cfg, device=dev)
         model.load_state_dict(P)
+        if positives:
+            _force_positives(model.net, cfg)
+            assert npos_seen >= 3 * len(batches), "forcing positives did not produce positives (%d)" % npos_seen
         model._reducer = GradReducer(model.net.flat_g, model.net.bucket_ranges, timing=True, backend=reducer).attach(model.net)
         assert model._reducer.world == world and model._reducer.ranks_seen() == world
         if freeze:
@@ -108,12 +126,12 @@ def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch"):
         dist.destroy_process_group()
 
 
-def _run_ranks(world, freeze, backend="gloo", reducer="torch"):
+def _run_ranks(world, freeze, backend="gloo", reducer="torch", positives=False):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, freeze, backend, reducer)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, freeze, backend, reducer, positives)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=900) for _ in range(world))
@@ -132,6 +150,13 @@ def _run_ranks(world, freeze, backend="gloo", reducer="torch"):
 def test_n_rank_step_real_engine_gloo_on_one_gpu(world, freeze):
     """SURVEY 8(e)'s parity test as worded, for 2 / 4 / 8 ranks (the ranks share the one GPU of the box; the transport is gloo)."""
     _run_ranks(world, freeze)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_n_rank_step_with_positive_rois(world):
+    """the same parity check with positive ROIs in every image (a random-init net proposes almost none): the mask-head bucket is then complete
+    only behind the side stream that carries the compacted weight gradients and conv1's dense weight gradient, and is released there."""
+    _run_ranks(world, False, positives=True)
 
 
 @pytest.mark.parametrize("reducer", ["torch", "capi"])
