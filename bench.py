@@ -711,7 +711,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=1.0)
     ap.add_argument("--nbox", type=int, default=3, choices=[3, 5],
                     help="3 = self-consistent Shapes head (R=147, primary); 5 = repository-HEAD head (R=245)")
-    ap.add_argument("--in-flight", type=int, default=2, help="--config rice416-bf16: inference batches in flight (Net.predict_stream); 1 = strictly serial")
+    ap.add_argument("--in-flight", type=int, default=3, help="--config rice416-bf16: inference batches in flight (Net.predict_stream); 1 = strictly serial")
     ap.add_argument("--config", choices=["shapes224-train", "rice416-bf16"], default="shapes224-train",
                     help="shapes224-train = BASELINE configs[1] (the metric); rice416-bf16 = configs[3] inference throughput")
     ap.add_argument("--cpu-images", type=int, default=32, help="images in the CPU-baseline step (0 = skip; halved while host memory is short)")

@@ -32,7 +32,7 @@ new = '''## 6. Results (round 3, measured on 1x MI355X by ONE `python bench.py -
 | `variants.mask_head_forward_on_positives_only` | %(po_v).1f | %(po_ms).2f | opt-in; never the headline |
 | `variants.n_pos_sweep` k = 5 / 10 / 20 | %(s5v).0f / %(s10v).0f / %(s20v).0f | %(s5).2f / %(s10).2f / %(s20).2f | first k proposals of every image forced onto a ground-truth box: the band of a trained net |
 | `secondary_nbox5` | %(n5v).1f | %(n5ms).2f | repository-HEAD head, N_BOX=5, R=245 |
-| `inference_rice416_bf16` | %(iv).1f | %(ims).2f | BASELINE configs[3]: Rice 416x416, batch 4, bf16 mask head, hipGraph replays, two batches in flight (`Net.predict_stream`) |
+| `inference_rice416_bf16` | %(iv).1f | %(ims).2f | BASELINE configs[3]: Rice 416x416, batch 4, bf16 mask head, hipGraph replays, `config.in_flight` batches in flight (`Net.predict_stream`; three by default) |
 | `inference_rice416_bf16.one_in_flight` | %(i1v).1f | %(i1ms).2f | the same forwards strictly one after the other (what rounds 1-2 reported) |
 | `cpu_baseline` | %(cpu).2f | | torch-CPU fp32 restatement, %(cores)d threads, 32-image training step |
 
