@@ -173,8 +173,12 @@ class Net(object):
         self.overlap_compact_wgrad = True  # ... and the weight / bias gradients of the compacted conv2-4 / deconv backward in front of it on that stream
         # the trunk's weight-gradient kernels (no consumer but the optimiser) on their own stream and scratch, beside the
         # BatchNorm-backward -> data-gradient chain that is the critical path of the trunk backward
-        self._twg_stream = torch.cuda.Stream(device=self.dev)
-        self._ws_twg = Workspace(self.dev)
+        self._twg_stream_own = torch.cuda.Stream(device=self.dev)
+        self._ws_twg_own = Workspace(self.dev)
+        # 1 (default): they share conv1's weight-gradient stream and scratch -- ONE weight-gradient stream, its launches strictly in order.
+        # Measured (profiles/r3_notes.md, "hardware queues"): with the two streams really concurrent the step is 1.6 ms SLOWER; HIP's default
+        # of four hardware queues happened to alias them, a mapping that depends on stream creation order -- so the order is made explicit
+        self.single_wgrad_stream = 1
         self.overlap_trunk_wgrad = True
         self._twg_pending = False
         # ... and started only when conv1's data gradient (the other matrix-pipe-bound kernel of that window) has been issued: two MFMA-bound
@@ -532,6 +536,14 @@ class Net(object):
         ap = self.bn_act_fwd(pwn + "_bn", y2, ACT_RELU6, train)
         self.tape["blk%d" % bid] = (a, shape, stride, ad)
         return ap, (N, Ho, Wo, Co)
+
+    @property
+    def _twg_stream(self):
+        return self._wgrad_stream if self.single_wgrad_stream else self._twg_stream_own
+
+    @property
+    def _ws_twg(self):
+        return self._ws_wgrad if self.single_wgrad_stream else self._ws_twg_own
 
     def _on_wgrad_stream(self, fn, tensors):
         """run fn(ws_ptr, ws_size) -- a weight-gradient launch sequence whose inputs are complete on the current stream -- on the trunk's
