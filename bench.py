@@ -23,6 +23,11 @@ import subprocess
 import sys
 import time
 
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); the inference lanes (Net.predict_stream) only overlap when each has a
+# queue of its own (+3 % at Rice 416), and the training step is laid out so that it does not depend on the mapping (profiles/r3_notes.md,
+# "hardware queues").  Read by the HIP runtime when it initialises, i.e. before the first device call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "mask-yolo_amd")):
     if p not in sys.path:
@@ -774,7 +779,7 @@ def main():
             torch.cuda.empty_cache()
             try:
                 a5 = copy.copy(args)
-                a5.nbox, a5.no_variant, a5.no_extras, a5.cpu_images, a5.warmup = 5, True, True, 0, 3
+                a5.nbox, a5.no_variant, a5.no_extras, a5.cpu_images, a5.warmup = 5, True, True, 0, max(5, args.warmup)
                 r5 = bench_train(a5, rank, world, local)
                 res["secondary_nbox5"] = {k: r5[k] for k in ("metric", "value", "unit", "ms_per_step", "step_ms")}
                 res["secondary_nbox5"].update(workload="the same step with the repository-HEAD head: N_BOX=5, config.py:28 anchors, R=245 ROIs/img (SURVEY 8(d) 'report both')",

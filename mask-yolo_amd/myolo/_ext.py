@@ -7,7 +7,13 @@ call returns a negative status, a RuntimeError is raised."""
 import ctypes
 import os
 
-import torch
+# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A side stream that lands on the COMPUTE stream's queue serialises
+# against it in submission order (measured: +4 ... +8 ms per training step, profiles/r3_notes.md "hardware queues"), and inference lanes only
+# overlap with a queue each: eight queues leave room for the engine's streams (engine._shared_stream) beside what else the process creates.
+# Effective when set before the process's first device call; a value the user set wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+import torch      # noqa: E402
 
 _LIB = None
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -86,6 +86,21 @@ def init_state_dict(cfg, seed=0):
     return sd
 
 
+_SHARED_STREAMS = {}
+
+
+def _shared_stream(dev, name, **kw):
+    """The engine's side streams are created ONCE per device and process and shared by every Net.  Which hardware queue a HIP stream is multiplexed
+    onto is decided when it is created (least-used of GPU_MAX_HW_QUEUES queues, the compute stream's included); a second Net's fresh streams were
+    measured landing on the compute stream's queue (step 21.0 -> 29.3 ms with the YOLO-head stream there, 24.8 ms with the weight-gradient stream),
+    the first Net's never do.  Nets of one process do not run concurrently, so sharing costs nothing."""
+    key = (str(torch.device(dev)), name)
+    st = _SHARED_STREAMS.get(key)
+    if st is None:
+        st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev, **kw)
+    return st
+
+
 class Workspace(object):
     """One growable scratch buffer shared by every call on the compute stream."""
 
@@ -162,18 +177,18 @@ class Net(object):
         self._ws_main = Workspace(self.dev, on_realloc=self._graphs.clear)
         self._ws_side = Workspace(self.dev)    # scratch of the YOLO-head backward running on the side stream
         self._ws_active = self._ws_main
-        self._yolo_stream = torch.cuda.Stream(device=self.dev)
+        self._yolo_stream = _shared_stream(self.dev, "yolo_head_bwd")
         self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
         self.yolo_bwd_early = 0           # 1 = launched right behind the YOLO loss (under the mask head's FORWARD) instead of at the start of its backward
         # conv1's weight gradient (MFMA-bound, 2.7 ms, nothing downstream but the optimiser) on a third stream with its own
         # scratch, underneath conv1's data gradient -> ROIAlign backward -> backbone backward (launch- / HBM-bound small kernels)
-        self._wgrad_stream = torch.cuda.Stream(device=self.dev)
+        self._wgrad_stream = _shared_stream(self.dev, "weight_gradients")
         self._ws_wgrad = Workspace(self.dev)
         self.overlap_conv1_wgrad = True
         self.overlap_compact_wgrad = True  # ... and the weight / bias gradients of the compacted conv2-4 / deconv backward in front of it on that stream
         # the trunk's weight-gradient kernels (no consumer but the optimiser) on their own stream and scratch, beside the
         # BatchNorm-backward -> data-gradient chain that is the critical path of the trunk backward
-        self._twg_stream_own = torch.cuda.Stream(device=self.dev)
+        self._twg_stream_own_ = None           # (created on demand: the two-stream ablation only)
         self._ws_twg_own = Workspace(self.dev)
         # 1 (default): they share conv1's weight-gradient stream and scratch -- ONE weight-gradient stream, its launches strictly in order.
         # Measured (profiles/r3_notes.md, "hardware queues"): with the two streams really concurrent the step is 1.6 ms SLOWER; HIP's default
@@ -219,7 +234,7 @@ class Net(object):
         # the positive ROIs.  Same loss, gradients and BN state; the training graph's unused myolo_mask rows of the
         # non-positive ROIs are not produced.  Off by default (cfg.TRAIN_MASK_HEAD_ROIS = "all").
         self.sparse_mask_fwd = getattr(cfg, "TRAIN_MASK_HEAD_ROIS", "all") == "positives"
-        self._copy_stream = torch.cuda.Stream(device=self.dev)
+        self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
         self._bind_cache = {}
@@ -539,7 +554,11 @@ class Net(object):
 
     @property
     def _twg_stream(self):
-        return self._wgrad_stream if self.single_wgrad_stream else self._twg_stream_own
+        if self.single_wgrad_stream:
+            return self._wgrad_stream
+        if self._twg_stream_own_ is None:
+            self._twg_stream_own_ = _shared_stream(self.dev, "trunk_weight_gradients")
+        return self._twg_stream_own_
 
     @property
     def _ws_twg(self):
@@ -1567,7 +1586,7 @@ class Net(object):
         if st is None:
             if self._fz_table is None:
                 self._frozen_affine_all()            # builds the (read-only) slot table every lane shares
-            st = {"stream": torch.cuda.Stream(device=self.dev)}
+            st = {"stream": _shared_stream(self.dev, "lane%d" % lane)}
             if lane > 0:
                 st["ws"] = Workspace(self.dev, on_realloc=self._graphs.clear)
                 st["bnbuf"] = {k: torch.zeros_like(v) for k, v in self.bnbuf.items()}
@@ -1611,14 +1630,14 @@ class Net(object):
             # overlaps with another stream's work when replayed, on whichever stream -- two lanes then run strictly one after the
             # other.  Captured with a side stream current, the same graph overlaps (and may still be replayed on the default stream).
             if self._cap_stream is None:
-                self._cap_stream = torch.cuda.Stream(device=self.dev)
+                self._cap_stream = _shared_stream(self.dev, "capture")
             self._cap_stream.wait_stream(cur)
             with torch.cuda.stream(self._cap_stream):
                 ent = self._capture_predict(images)
             cur.wait_stream(self._cap_stream)
             return ent
         static_in = images.clone()
-        side = torch.cuda.Stream(device=self.dev)
+        side = _shared_stream(self.dev, "capture_warmup")
         side.wait_stream(cur)
         with torch.cuda.stream(side):            # warm-up off the capture stream: workspace growth, caches, allocator pools
             for _ in range(2):
