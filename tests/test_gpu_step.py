@@ -579,6 +579,30 @@ def test_predict_stream_matches_predict(in_flight, dtype):
     assert len(net._graphs) == in_flight
 
 
+def test_side_streams_are_shared_by_every_net_of_the_process():
+    """engine._shared_stream: the side streams exist once per device (a later Net's fresh streams could land on the compute stream's hardware
+    queue, profiles/r3_notes.md "hardware queues"), and two Nets used alternately still produce what each produces alone."""
+    import os
+    from myolo.engine import Net
+    assert os.environ.get("GPU_MAX_HW_QUEUES"), "myolo._ext sets a default for the hardware-queue count"
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=2)
+    a, b = Net(cfg, device="cuda:0", seed=1), Net(cfg, device="cuda:0", seed=2)
+    for name in ("_yolo_stream", "_wgrad_stream", "_copy_stream"):
+        assert getattr(a, name) is getattr(b, name), name
+    assert a._twg_stream is a._wgrad_stream                       # one weight-gradient stream
+    samples = make_shapes_samples(2, cfg)
+    batch, _ = BatchGenerator(samples, cfg, 'training', shuffle=False, norm=True)[0]
+    da, db = a.to_device_batch(batch), b.to_device_batch(batch)
+    a.forward_backward(da)
+    ga = a.grads_dict()
+    b.forward_backward(db)
+    gb = b.grads_dict()
+    a.forward_backward(da)
+    b.forward_backward(db)                                       # interleaved on the shared streams
+    ga2, gb2 = a.grads_dict(), b.grads_dict()
+    assert all(np.array_equal(ga[k], ga2[k]) for k in ga) and all(np.array_equal(gb[k], gb2[k]) for k in gb)
+
+
 def test_inference_folded_frozen_bn_equals_unfolded():
     """Net.fold_frozen_bn (BatchNorm on moving statistics + ReLU6 in the epilogue of the depthwise / pointwise conv in train=False
     forwards) changes the launch count, not one bit of the outputs."""
