@@ -191,27 +191,39 @@ class KernelTimer(object):
 def timed_steps(net, dbs, steps, lr, barrier, per_step=None):
     """K steps between two barriers (host wall clock = the reported time).  per_step (a list): filled with the K step durations in ms
     from HIP events recorded on the compute stream at the step boundaries (no synchronisation inside the region)."""
+    import gc
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
-    barrier()
-    t0 = time.perf_counter()
-    out = None
-    for i in range(steps):
+    # the host runs about one step (~20 ms) ahead of the GPU and cannot run further ahead (it reads n_pos every step): a collector pause inside
+    # the region comes straight out of that lead, so the cyclic collector is parked for the K steps (reference counting still frees everything)
+    gc.collect()
+    gc_was = gc.isenabled()
+    gc.disable()
+    try:
+        barrier()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            if evs:
+                evs[i].record()
+            out = net.train_step(dbs[i % len(dbs)], lr)
         if evs:
-            evs[i].record()
-        out = net.train_step(dbs[i % len(dbs)], lr)
-    if evs:
-        evs[steps].record()
-    barrier()
-    el = time.perf_counter() - t0
+            evs[steps].record()
+        barrier()
+        el = time.perf_counter() - t0
+    finally:
+        if gc_was:
+            gc.enable()
     if evs:
         per_step.extend(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     return el, out
 
 
 def percentiles(ms):
-    a = np.sort(np.asarray(ms, np.float64))
+    raw = np.asarray(ms, np.float64)
+    a = np.sort(raw)
     return {"p10": float(np.percentile(a, 10)), "p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)),
-            "min": float(a[0]), "max": float(a[-1]), "n": int(a.size), "source": "HIP events on the compute stream at the step boundaries, inside the timed region"}
+            "min": float(a[0]), "max": float(a[-1]), "max_at_step": int(np.argmax(raw)) if raw.size else -1, "n": int(a.size),
+            "source": "HIP events on the compute stream at the step boundaries, inside the timed region"}
 
 
 def bench_train(args, rank, world, local):
