@@ -40,6 +40,7 @@ struct Bf16Args {
     const float* w2;         // EP_DECONV_MASK: 1x1 mask conv kernel [Co][ncls] (fp32)
     float* part;             // EP_DECONV_MASK: partial logits [slab][4*M][ncls]
     int ncls;
+    int tune;                // BF16_TUNE builds only (tools/experiments/bf16_tune.sh): timing-only ablations, results are wrong
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t mk_rsrc(const void* base, long long nbytes)
@@ -765,8 +766,15 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
         if constexpr (LOOPN) {
             const int kk = kt + 1;
             if (kk % nk == 0) {                       // a column block is complete: its epilogue, then the accumulators start over
+#ifdef BF16_TUNE
+                if (!(p.tune & 1))
+#endif
                 mask_epilogue((kk / nk - 1) * T2N);
+#ifdef BF16_TUNE
+                if constexpr (EPI == EP_DECONV_MASK) { if (!(p.tune & 2)) acc_start((kk / nk) * T2N < p.N ? (kk / nk) * T2N : 0); }
+#else
                 if constexpr (EPI == EP_DECONV_MASK) acc_start((kk / nk) * T2N < p.N ? (kk / nk) * T2N : 0);
+#endif
                 else {
 #pragma unroll
                     for (int t = 0; t < 4; ++t)
@@ -1162,6 +1170,7 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
     Bf16Args a = {};
     a.A = x; a.Wt = wt; a.bias = bias; a.M = M; a.N = 4 * Cout; a.K = Cin; a.H = H; a.W = W; a.Co = Cout; a.act = MYOLO_ACT_RELU;
     a.w2 = w2; a.part = (float*)ws; a.ncls = ncls;
+    a.tune = g_myolo_opt.tune0;
     const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
     const long long tiles256 = cdiv64(M, T2M) * (a.N / T2N);
     const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
