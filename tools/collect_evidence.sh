@@ -30,6 +30,7 @@ cp gpurun_out/prof_${TAG}native/${TAG}native_bench_kernel_stats.csv gpurun_out/p
   KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
   echo "--- tools/overlap_mm_boundary.py"
   python tools/overlap_mm_boundary.py 2>&1 | tail -1
+  KBENCH_OPTIONS=wino_x6=1 python tools/overlap_mm_boundary.py 2>&1 | tail -1
   echo "--- HBM stream copy (hand-written float4 kernel, grid sweep) beside torch copy_"
   python tools/kbench.py copy --iters 5 2>&1 | grep -v amdgpu
   echo "--- matrix-pipe ceiling (myolo_mfma_probe: register operands, no memory traffic)"
