@@ -106,6 +106,12 @@ int myolo_wino63_output_input_transform(const float* M, const float* bias, const
                                         const int32_t* flags, float* Vn, int N, int C, int act, void* stream);
 int myolo_wino63_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y, int N, int C, int act,
                                   void* stream);
+/* ... with the conv's PRE-BatchNorm output (A^T m A + bias) kept for the flagged ROIs (ypre written where flags[img] != 0, NULL: everywhere; y of
+ * output_transform_keep_pre -- the activation -- written for every ROI, may be NULL): the exact-sparsity backward reads bn2-4's backward off it */
+int myolo_wino63_output_input_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* ypre,
+                                                 const int32_t* flags, float* Vn, int N, int C, int act, void* stream);
+int myolo_wino63_output_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* y, float* ypre,
+                                           const int32_t* flags, int N, int C, int act, void* stream);
 /* conv1 of the mask head on this tiling: ROIAlign fused into the input transform (myolo_wino_input_transform_roialign), the output
  * transform that also yields the training-mode BatchNorm statistics (myolo_wino_output_transform_bn_stats), and the weight gradient
  * from the kept V planes and the lazily formed output gradient (myolo_conv3x3_wino_bwd_weight_lazybn) */

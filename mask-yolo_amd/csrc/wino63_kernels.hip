@@ -170,6 +170,10 @@ struct W63Args {
     double* stats;
     float* Qn;               // TO_VQ: the adjoint-output-transformed planes (TO_Q alone writes them to Vn)
     int order;               // workgroup order, see the kernel (set by w63_launch from option "w63_order")
+    // FROM_M: the value BEFORE the affine + activation (A^T m A + bias = the conv's pre-BatchNorm output) written where flags[img] != 0 (NULL:
+    // everywhere); with ypre set, `flags` governs ypre and y (if any) is written everywhere.  The exact-sparsity backward reads the frozen BatchNorms'
+    // backward off THIS tensor for the positive ROIs: no (a - beta) / gamma reconstruction from the post-activation value
+    float* ypre;
 };
 
 __device__ __forceinline__ float w63_act(float v, int act)
@@ -199,16 +203,20 @@ __device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& p
     const float b = a.bias ? a.bias[c] : 0.f;
     const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
     float* ybase = wr ? a.y + (img * W63_HW * W63_HW) * a.C + c : nullptr;
+    const bool wrp = a.ypre && (!a.flags || a.flags[img] != 0);
+    float* pbase = wrp ? a.ypre + (img * W63_HW * W63_HW) * a.C + c : nullptr;
 #pragma unroll
     for (int i = 0; i < MY; ++i) {
         float r[6];
         w63_at<CX>(tmp[i], r);
 #pragma unroll
         for (int j = 0; j < MX; ++j) {
-            const float v = w63_act(fmaf(r[j] + b, sc, sh), a.act);
+            const float pre = r[j] + b;
+            const float v = w63_act(fmaf(pre, sc, sh), a.act);
             const int pix = (oy + i) * W63_HW + ox + j;
             act_lds[pix * W63_CS + lane] = v;
             if (wr) ybase[(long long)pix * a.C] = v;
+            if (wrp) pbase[(long long)pix * a.C] = pre;
             s1 += v;
             s2 = fmaf(v, v, s2);
         }
@@ -309,7 +317,7 @@ __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, 
     const int c = slice * W63_CS + lane;
     const int ty = wave / 3, tx = wave - ty * 3;
     const W63Planes pl = w63_planes(a.NR, img, ty, tx, a.C, c);
-    const bool wr = a.y && (!a.flags || a.flags[img] != 0);
+    const bool wr = a.y && (a.ypre || !a.flags || a.flags[img] != 0);
     if (FRONT == W63_FROM_M) {
         const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;           // output origin: 0, 6, 10
         float s1 = 0.f, s2 = 0.f;
@@ -570,6 +578,30 @@ int myolo_wino63_output_input_transform(const float* M, const float* bias, const
     MYOLO_REQUIRE(M && Vn && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_input_transform: bad arguments (C %% 64 == 0)");
     W63Args a{M, Vn, y, flags, bias, scale, shift, N, C, act};
     w63_launch<W63_FROM_M, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* the two calls above with the conv's PRE-BatchNorm output (A^T m A + bias) kept for the flagged ROIs: ypre written where flags[img] != 0 (NULL:
+ * everywhere); y (output_transform_keep_pre: the activation every ROI's consumer reads; may be NULL) is written everywhere */
+int myolo_wino63_output_input_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* ypre,
+                                                 const int32_t* flags, float* Vn, int N, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && Vn && ypre && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_input_transform_keep_pre: bad arguments (C %% 64 == 0)");
+    W63Args a{M, Vn, nullptr, flags, bias, scale, shift, N, C, act};
+    a.ypre = ypre;
+    w63_launch<W63_FROM_M, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_wino63_output_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* y, float* ypre,
+                                           const int32_t* flags, int N, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && ypre && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_transform_keep_pre: bad arguments (C %% 64 == 0)");
+    W63Args a{M, nullptr, y, flags, bias, scale, shift, N, C, act};
+    a.ypre = ypre;
+    w63_launch<W63_FROM_M, W63_TO_NONE>(a, (hipStream_t)stream);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

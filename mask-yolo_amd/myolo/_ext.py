@@ -67,6 +67,8 @@ SIGS = {
     "myolo_wino63_input_transform": [P, P, P, I, P, P, P, I, I, P],
     "myolo_wino63_output_input_transform": [P, P, P, P, P, P, P, I, I, I, P],
     "myolo_wino63_output_transform": [P, P, P, P, P, I, I, I, P],
+    "myolo_wino63_output_input_transform_keep_pre": [P, P, P, P, P, P, P, I, I, I, P],
+    "myolo_wino63_output_transform_keep_pre": [P, P, P, P, P, P, P, I, I, I, P],
     "myolo_wino63_input_transform_roialign": [P, P, P, P, I, I, I, I, I, P],
     "myolo_wino63_output_transform_bn_stats": [P, P, P, I, I, P, P, P, P, P, P, P, P, P, Z, P],
     "myolo_wino63_bwd_weight_lazybn": [P, P, P, P, P, P, P, P, I, P, I, I, I, P, Z, P],

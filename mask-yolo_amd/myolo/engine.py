@@ -201,6 +201,7 @@ class Net(object):
         # backward costs neither much (0 = start it together with the data gradient, as in round 2)
         self.conv1_wgrad_after_dgrad = 0
         self._wgrad_pending = False
+        self.mask_keep_pre = True         # F(6,3) chain in training: the positive ROIs' PRE-BatchNorm conv outputs are kept (exact bn2-4 backward); False: post-activation + (a - beta) / gamma
         self.lazy_bn1_bwd = True          # conv1's gradients read bn1's input gradient lazily (never materialised)
         self.fused_frozen_bn = True       # bn_act_fwd on moving statistics: one launch instead of coefficients + apply
         self.fold_frozen_bn = True        # train=False forwards: that BatchNorm + ReLU6 in the epilogue of the depthwise / pointwise conv
@@ -860,21 +861,36 @@ class Net(object):
                 self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
             if fold and i < 4 and use63 == next63:
                 ykeep = self._new(NR * q, MASK_FILTERS) if train else None
+                keep_pre = bool(train and use63 and self.mask_keep_pre)     # what is kept for the positive ROIs is the conv's PRE-BatchNorm output (exact backward, any gamma)
                 if use63:
                     Vn = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
-                    self._call_timed("wino_out_in", "myolo_wino63_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
-                                     X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, MASK_FILTERS,
-                                     ACT_RELU, X.stream())
+                    if keep_pre:
+                        self._call_timed("wino_out_in", "myolo_wino63_output_input_transform_keep_pre", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
+                                         X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags), X.ptr(Vn), NR, MASK_FILTERS, ACT_RELU, X.stream())
+                    else:
+                        self._call_timed("wino_out_in", "myolo_wino63_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
+                                         X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, MASK_FILTERS,
+                                         ACT_RELU, X.stream())
                 else:
                     Vn = self._new(36, T, MASK_FILTERS)
                     self._call_timed("wino_out_in", "myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
                                      X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS,
                                      ACT_RELU, X.stream())
-                x, Vcur = ykeep, Vn
+                if keep_pre:
+                    # the next conv's input and this BatchNorm's backward are both formed from the kept pre-BN rows (mask_head_bwd_sparse: "lazy_bn")
+                    self.tape[bn] = (ykeep, ACT_RELU, False)
+                    x, Vcur = ("lazy_bn", ykeep, bn), Vn
+                else:
+                    x, Vcur = ykeep, Vn
             else:
                 y = self._new(NR * q, MASK_FILTERS)
                 if fold:
-                    if use63:
+                    if use63 and train and pos_flags is not None and self.mask_keep_pre:
+                        ypre = self._new(NR * q, MASK_FILTERS)
+                        X.call("myolo_wino63_output_transform_keep_pre", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), X.ptr(ypre),
+                               X.ptr(pos_flags), NR, MASK_FILTERS, ACT_RELU, X.stream())
+                        self.tape[bn] = (ypre, ACT_RELU, False)
+                    elif use63:
                         X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, MASK_FILTERS,
                                ACT_RELU, X.stream())
                     else:

@@ -245,6 +245,15 @@ def _relu_flips(P, cap_a, cap_b, pos, n_all):
     return flips
 
 
+def _force_first_proposals_onto_gt(net, cfg, k):
+    def hook(proposals, db):
+        gt = db["gt_boxes"].to(torch.float32)                       # [B,T,4] px, x1 y1 x2 y2
+        H, W = float(cfg.IMAGE_SHAPE[0]), float(cfg.IMAGE_SHAPE[1])
+        norm = (gt - torch.tensor([0., 0., 1., 1.], device=gt.device)) / torch.tensor([W - 1, H - 1, W - 1, H - 1], device=gt.device)
+        proposals[:, :k, :] = norm[:, :1, :].expand(-1, k, -1)
+    net.proposals_hook = hook
+
+
 def test_sparse_mask_backward_equals_dense():
     """The positive-ROI-only backward of conv2-4/deconv/myolo_mask is an exact-zero elimination:
     gradients agree with the dense path to fp32 summation-order noise, on the same device inputs.
@@ -270,6 +279,38 @@ def test_sparse_mask_backward_equals_dense():
             continue
         worst = max(worst, rel(grads[1][k], d))
     assert worst < 1e-4 + 5e-3 * flips, (worst, flips)
+
+
+def test_sparse_mask_backward_with_zero_and_tiny_frozen_bn_gammas():
+    """bn2-4 of the mask head are frozen affine maps; the exact-sparsity backward reads their backward off the conv's PRE-BatchNorm output, kept
+    for the positive ROIs by the Winograd layer boundary -- not off (a - beta) / gamma of the post-activation value, which is undefined for
+    gamma == 0 and ill-conditioned for tiny gamma (round-2 advisor finding).  Channels with gamma = 0 / 1e-6 / -1e-5 and beta > 0 (ReLU open):
+    every gradient, dgamma of those channels included, equals the dense backward's."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    P = dict(P)
+    for i, bn in enumerate(("myolo_mask_bn2", "myolo_mask_bn3", "myolo_mask_bn4")):
+        g, b = P[bn + "/gamma"].copy(), P[bn + "/beta"].copy()
+        g[3 + i], g[40 + i], g[100 + i] = 0.0, 1e-6, -1e-5
+        b[3 + i], b[40 + i], b[100 + i] = 0.7, 0.4, 0.9
+        P[bn + "/gamma"], P[bn + "/beta"] = g, b
+    grads = []
+    for sparse in (False, True):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        model.net.sparse_mask_bwd = sparse
+        _force_first_proposals_onto_gt(model.net, cfg, 3)
+        out = model.train_on_batch(batch, learning_rate=0.0)
+        grads.append(model.net.grads_dict())
+    assert int(np.sum(out["n_pos"])) >= 3 * len(out["n_pos"])
+    for bn in ("myolo_mask_bn2", "myolo_mask_bn3", "myolo_mask_bn4"):
+        d, s_ = grads[0][bn + "/gamma"], grads[1][bn + "/gamma"]
+        assert np.abs(d).max() > 0
+        assert np.abs(s_ - d).max() <= 2e-3 * np.abs(d).max(), (bn, float(np.abs(s_ - d).max()), float(np.abs(d).max()))
+        for c in (3, 4, 5):                      # the gamma == 0 channels: a real, non-zero gradient
+            if abs(P[bn + "/gamma"][c]) == 0.0:
+                assert abs(d[c]) > 0 and abs(s_[c] - d[c]) <= 2e-2 * abs(d[c]), (bn, c, float(d[c]), float(s_[c]))
+    worst = max(rel(grads[1][k], grads[0][k]) for k in grads[0] if np.abs(grads[0][k]).max() > 1e-12 and k != "myolo_mask_conv1/bias")
+    assert worst < 2e-2, worst
 
 
 def test_positives_only_forward_equals_full_forward():
@@ -488,7 +529,7 @@ def test_inference_forward_matches_oracle():
 
 def test_overfitting_one_batch_drives_the_mask_loss_down():
     """No oracle here: 500 Adam steps on one fixed batch must take the mask loss from chance level (0.69 once boxes start to
-    match) below 0.15 while the YOLO loss falls too -- the forward, both losses, every gradient and the optimiser pull in
+    match) below 0.15 (median of the last 100 steps) while the YOLO loss falls too -- the forward, both losses, every gradient and the optimiser pull in
     the same direction.  tools/overfit_check.py is the full-size version (224x224, 1500 steps): mask loss 0.01, and detect()
     on the training images returns ground-truth classes with pasted-mask IoU 0.83-0.90."""
     B = 4
@@ -499,14 +540,18 @@ def test_overfitting_one_batch_drives_the_mask_loss_down():
     m.set_trainable(".*")
     m.compile(1e-3, 0.9)
     db = m.net.to_device_batch(batch)
-    early, y0 = 0.0, None                         # no positive ROI (mask loss 0) until the boxes start to fit
+    early, y0, tail = 0.0, None, []               # no positive ROI (mask loss 0) until the boxes start to fit
     for i in range(500):
         out = m.net.train_step(db, 1e-3 if i < 350 else 3e-4)
         if i == 0:
             y0 = float(out["yolo_terms"][0])
         if i < 150:
             early = max(early, float(out["mask_terms"][0]))
-    last, y1 = float(out["mask_terms"][0]), float(out["yolo_terms"][0])
+        if i >= 400:
+            tail.append(float(out["mask_terms"][0]))
+    # the median of the last 100 steps, not the last step: whenever a moving box makes another ROI positive the loss of that one step jumps
+    # (0.002 -> 0.17 -> 0.03 within a hundred steps is typical)
+    last, y1 = float(np.median(tail)), float(out["yolo_terms"][0])
     assert early > 0.5 and last < 0.15, (early, last)
     assert y1 < 0.5 * y0, (y0, y1)
 
