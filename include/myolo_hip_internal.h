@@ -90,6 +90,9 @@ int myolo_conv3x3_wino_bwd_weight_lazybn(const float* v_saved, const float* y_pr
  * Needs C % 32 == 0 and ceil(H/4)*ceil(W/4) <= 32 (14x14: 16 tiles). */
 int myolo_wino_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
                                       const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream);
+/* ... writing the conv's PRE-BatchNorm output (A^T m A + bias) to ypre where flags[img] != 0 (NULL: everywhere) instead of the activation */
+int myolo_wino_output_input_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* ypre,
+                                               const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream);
 
 /* ---- F(6,3)/F(4,3) tiling of 14x14 maps: buffer sizes and stages (csrc/wino63_kernels.hip) ---- */
 size_t myolo_wino63_plane_elems(int N, int C);

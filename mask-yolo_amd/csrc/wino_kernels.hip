@@ -575,8 +575,9 @@ __global__ __launch_bounds__(256) void wino_dw_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restrict__ M, float* __restrict__ Vn, float* __restrict__ y,
                                                           const int32_t* __restrict__ flags, const float* __restrict__ bias,
                                                           const float* __restrict__ scale, const float* __restrict__ shift, TileGeom g,
-                                                          int C, int act)
+                                                          int C, int act, int keep_pre)
 {
+    // keep_pre: what is written to y is the value BEFORE the affine + activation (the conv's pre-BatchNorm output), see wino63_kernels.hip W63Args::ypre
     extern __shared__ __attribute__((aligned(16))) float ysm[];       // [H][W][WOI_CS]
     const int img = blockIdx.x;
     const int c = blockIdx.y * WOI_CS + (threadIdx.x & 7) * 4;
@@ -610,13 +611,14 @@ __global__ __launch_bounds__(256) void wino_out_in_kernel(const float* __restric
                 const int xx = 4 * tx + j;
                 if (xx >= g.W) continue;
                 float4 v = r[j] + b;
+                const float4 pre = v;
                 if (scale) v = make_float4(v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w);
                 if (act == MYOLO_ACT_RELU) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
                 else if (act == MYOLO_ACT_RELU6)
                     v = make_float4(fminf(fmaxf(v.x, 0.f), 6.f), fminf(fmaxf(v.y, 0.f), 6.f), fminf(fmaxf(v.z, 0.f), 6.f),
                                     fminf(fmaxf(v.w, 0.f), 6.f));
                 *reinterpret_cast<float4*>(&ysm[(yy * g.W + xx) * WOI_CS + (threadIdx.x & 7) * 4]) = v;
-                if (wr) stg4(obase + ((long long)yy * g.W + xx) * C, v);
+                if (wr) stg4(obase + ((long long)yy * g.W + xx) * C, keep_pre ? pre : v);
             }
         }
     }
@@ -856,7 +858,23 @@ int myolo_wino_output_input_transform(const float* M, const float* bias, const f
     MYOLO_REQUIRE((C % WOI_CS) == 0 && g.TH * g.TW * 8 <= 256 && (size_t)H * W * WOI_CS * sizeof(float) <= 65536,
                   "wino_output_input_transform: needs C %% 32 == 0 and at most 32 tiles per image (got C=%d, %dx%d)", C, H, W);
     hipLaunchKernelGGL(wino_out_in_kernel, dim3(N, C / WOI_CS), dim3(g.TH * g.TW * 8), (size_t)H * W * WOI_CS * sizeof(float),
-                       (hipStream_t)stream, M, V_next, y, flags, bias, scale, shift, g, C, act);
+                       (hipStream_t)stream, M, V_next, y, flags, bias, scale, shift, g, C, act, 0);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* the same boundary with the conv's PRE-BatchNorm output (A^T m A + bias) written to ypre where flags[img] != 0 (NULL: everywhere) instead of the
+ * activation: what the exact-sparsity backward reads bn2-4's backward off (csrc/wino63_kernels.hip: myolo_wino63_output_input_transform_keep_pre) */
+int myolo_wino_output_input_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* ypre,
+                                               const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && V_next && ypre && N > 0 && H > 0 && W > 0 && C > 0, "wino_output_input_transform_keep_pre: bad arguments");
+    MYOLO_REQUIRE(!scale == !shift, "wino_output_input_transform_keep_pre: scale and shift go together");
+    const TileGeom g = geom(N, H, W);
+    MYOLO_REQUIRE((C % WOI_CS) == 0 && g.TH * g.TW * 8 <= 256 && (size_t)H * W * WOI_CS * sizeof(float) <= 65536,
+                  "wino_output_input_transform_keep_pre: needs C %% 32 == 0 and at most 32 tiles per image (got C=%d, %dx%d)", C, H, W);
+    hipLaunchKernelGGL(wino_out_in_kernel, dim3(N, C / WOI_CS), dim3(g.TH * g.TW * 8), (size_t)H * W * WOI_CS * sizeof(float),
+                       (hipStream_t)stream, M, V_next, ypre, flags, bias, scale, shift, g, C, act, 1);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -87,6 +87,7 @@ SIGS = {
     "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_transform": [P, P, P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_input_transform": [P, P, P, P, P, P, P, I, I, I, I, I, P],
+    "myolo_wino_output_input_transform_keep_pre": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "myolo_wino_input_transform_affine": [P, P, P, I, P, I, I, I, I, P],
     "myolo_wino_output_transform_bn_stats": [P, P, P, I, I, I, I, P, P, P, P, P, P, P, P, P, Z, P],
     "myolo_bn_bwd_rowsparse_coeffs": [P, P, P, P, P, P, P, P, P, P, P, L, I, I, I, I, P, Z, P],

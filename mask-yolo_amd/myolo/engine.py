@@ -861,7 +861,7 @@ class Net(object):
                 self.tape[bn] = (None, ACT_RELU, False)       # pre-BN tensor never materialised
             if fold and i < 4 and use63 == next63:
                 ykeep = self._new(NR * q, MASK_FILTERS) if train else None
-                keep_pre = bool(train and use63 and self.mask_keep_pre)     # what is kept for the positive ROIs is the conv's PRE-BatchNorm output (exact backward, any gamma)
+                keep_pre = bool(train and self.mask_keep_pre)     # what is kept for the positive ROIs is the conv's PRE-BatchNorm output (exact backward, any gamma)
                 if use63:
                     Vn = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
                     if keep_pre:
@@ -873,9 +873,9 @@ class Net(object):
                                          ACT_RELU, X.stream())
                 else:
                     Vn = self._new(36, T, MASK_FILTERS)
-                    self._call_timed("wino_out_in", "myolo_wino_output_input_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
-                                     X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn), NR, ps, ps, MASK_FILTERS,
-                                     ACT_RELU, X.stream())
+                    self._call_timed("wino_out_in", "myolo_wino_output_input_transform_keep_pre" if keep_pre else "myolo_wino_output_input_transform",
+                                     X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags) if train else None, X.ptr(Vn),
+                                     NR, ps, ps, MASK_FILTERS, ACT_RELU, X.stream())
                 if keep_pre:
                     # the next conv's input and this BatchNorm's backward are both formed from the kept pre-BN rows (mask_head_bwd_sparse: "lazy_bn")
                     self.tape[bn] = (ykeep, ACT_RELU, False)
@@ -896,6 +896,12 @@ class Net(object):
                     else:
                         X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, ps, ps,
                                MASK_FILTERS, ACT_RELU, X.stream())
+                        if train and self.mask_keep_pre and self.sparse_mask_bwd:
+                            # (the F(4,3)-tiling output transform has no flagged second output: a second pass writes the pre-BatchNorm rows of every ROI.
+                            #  Non-default tiling; the F(6,3) boundary above writes the flagged ROIs' rows in the same pass)
+                            ypre = self._new(NR * q, MASK_FILTERS)
+                            X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), None, None, X.ptr(ypre), NR, ps, ps, MASK_FILTERS, ACT_NONE, X.stream())
+                            self.tape[bn] = (ypre, ACT_RELU, False)
                     x = y
                     Vcur = None                      # (a tiling change at this boundary: the next conv transforms y itself)
                 elif 256 % (MASK_FILTERS // 4) == 0 and i < 4:
