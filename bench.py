@@ -557,6 +557,23 @@ def bench_train(args, rank, world, local):
                        "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
                                "on the comm stream as soon as backward completes it"}
     res.update(extras)
+    if world == 1 and not args.no_extras and x6 and traffic is not None and not args.no_live_pmc:
+        # HBM traffic of the dominant kernel measured IN THIS RUN: two separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE) on the same launch
+        # shape in a child process (tools/pmc_traffic.py; this process keeps its memory and is idle meanwhile).  Falls back to the committed
+        # profiles/r3_pmc_x6.json figure (kept as roofline.traffic_from_profiles) when rocprofv3 is missing or fails.
+        try:
+            cp = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_traffic.py"), "wino63_mm", "wino_mm_x6_kernel", "wino_x6=1"],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300)
+            live = json.loads(cp.stdout.decode().strip().splitlines()[-1])
+        except Exception as e:
+            live = {"error": "%s: %s" % (type(e).__name__, e)}
+        res["roofline"]["traffic_live"] = live
+        if "traffic_bytes_per_launch_corrected" in live:
+            res["roofline"]["traffic_from_profiles"] = res["roofline"]["traffic"]
+            res["roofline"]["traffic"] = live["traffic_bytes_per_launch_corrected"]
+            res["roofline"]["traffic_source"] = ("measured in this run: tools/pmc_traffic.py (two separate rocprofv3 --pmc passes, FETCH_SIZE x2 + WRITE_SIZE, on "
+                                                 "tools/kbench.py wino63_mm at the launch shape of the timed kernel, last five of 36 launches) = %.2fx the algorithmic bytes"
+                                                 % (live["traffic_bytes_per_launch_corrected"] / res["roofline"]["algorithmic_bytes"]))
     if variants:
         res["variants"] = variants
     if args.cpu_images > 0 and world == 1:
@@ -735,6 +752,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-3)
     ap.add_argument("--mask-head-rois", choices=["all", "positives"], default="all",
                     help="cfg.TRAIN_MASK_HEAD_ROIS of the run that produces `value` (default: all ROIs, as the reference graph)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure the dominant kernel's HBM traffic with rocprofv3 --pmc in a child process (default line only)")
     ap.add_argument("--no-extras", action="store_true", help="skip the extra objects of the default line (HBM copy bandwidth, comm probe, N_BOX=5 and Rice-416 bf16 runs)")
     ap.add_argument("--no-variant", action="store_true", help="skip the extra timed runs (dense backward, positives-only forward, n_pos sweep)")
     ap.add_argument("--conv3x3", choices=["auto", "direct", "winograd"], default="auto", help="cfg.CONV3X3_ALGO")
