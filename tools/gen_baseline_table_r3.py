@@ -22,7 +22,7 @@ rows = "\n".join("| %s | %s | %.1f | %.0f | %.1f | %s | %.2f | %.1f | %.2f |" % 
                  for l in r.get("trunk_layers", []))
 new = '''## 6. Results (round 3, measured on 1x MI355X by ONE `python bench.py --steps 20 --warmup 5`; evidence `profiles/%(tag)s_*`, notes `profiles/r3_notes.md`)
 
-(generated from `profiles/%(tag)s_bench.json` by `tools/gen_baseline_table_r3.py`; box-to-box spread of the headline at the end of the round: 21.0-21.5 ms)
+(generated from `profiles/%(tag)s_bench.json` by `tools/gen_baseline_table_r3.py`; box-to-box spread of the headline at the end of the round: 21.0-21.7 ms)
 
 | Object of the line | img/s | ms | what it is |
 |---|---|---|---|
