@@ -56,9 +56,13 @@ def bbox_iou(box1, box2):
 
 
 def bbox_iou_2(box1, box2, image_shape):
+    """myolo_utils.py:201-228.  The rows detect() passes are float32 (model.py:1304) and the reference multiplies their
+    elements by the Python ints of image_shape: a float64 product under the scalar promotion of every numpy before 2.0
+    (the ones the reference ran with), a float32 one from 2.0 on.  float() pins the former, whatever numpy runs this
+    (tests/golden/ref_host_boxes.npz holds the reference's own outputs)."""
     w, h = image_shape[0], image_shape[1]
-    a = BoundBox(box1[0] * w, box1[1] * h, box1[2] * w, box1[3] * h)
-    b = BoundBox(box2[0] * w, box2[1] * h, box2[2] * w, box2[3] * h)
+    a = BoundBox(float(box1[0]) * w, float(box1[1]) * h, float(box1[2]) * w, float(box1[3]) * h)
+    b = BoundBox(float(box2[0]) * w, float(box2[1]) * h, float(box2[2]) * w, float(box2[3]) * h)
     return bbox_iou(a, b)
 
 
@@ -192,8 +196,15 @@ def _softmax(x, axis=-1, t=-100.):
 
 
 def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_threshold=0.3):
-    """myolo_utils.py:36-85: per-class greedy NMS on the decoded YOLO grid."""
-    netout = np.array(netout, dtype=np.float64)
+    """myolo_utils.py:36-85: per-class greedy NMS on the decoded YOLO grid.  -> list of BoundBox.
+
+    Arithmetic types as the reference had them (pinned by tests/golden/ref_host_decode.npz, outputs of the reference's own
+    function): the whole-array steps (:42-44) stay in the dtype of `netout` -- float32 for a network output (model.py:1224) --
+    and so do the exp() calls on its elements; everything done to those elements one at a time with Python scalars
+    (:56-60, the IoUs, the final `> obj_threshold`) is float64, which is what numpy < 2.0 promotes
+    `np.float32 <op> Python float` to.  float() below spells that out so that numpy >= 2.0 (which would stay in float32) gives
+    the same boxes.  Unlike the reference (:42-44 write into the caller's array) the input is left untouched."""
+    netout = np.array(netout, dtype=netout.dtype if getattr(netout, "dtype", None) in (np.float32, np.float64) else np.float64)
     grid_h, grid_w, nb_box = netout.shape[:3]
     boxes = []
     netout[..., 4] = _sigmoid(netout[..., 4])
@@ -205,10 +216,10 @@ def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_thr
                 classes = netout[row, col, b, 5:]
                 if np.sum(classes) > 0:
                     x, y, w, h = netout[row, col, b, :4]
-                    x = (col + _sigmoid(x)) / grid_w
-                    y = (row + _sigmoid(y)) / grid_h
-                    w = anchors[2 * b + 0] * np.exp(w) / grid_w
-                    h = anchors[2 * b + 1] * np.exp(h) / grid_h
+                    x = (col + 1. / (1. + float(np.exp(-x)))) / grid_w
+                    y = (row + 1. / (1. + float(np.exp(-y)))) / grid_h
+                    w = float(anchors[2 * b + 0]) * float(np.exp(w)) / grid_w
+                    h = float(anchors[2 * b + 1]) * float(np.exp(h)) / grid_h
                     boxes.append(BoundBox(x - w / 2, y - h / 2, x + w / 2, y + h / 2, netout[row, col, b, 4], classes))
     for c in range(nb_class):
         order = list(reversed(np.argsort([box.classes[c] for box in boxes])))
@@ -220,7 +231,7 @@ def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_thr
                 bj = order[j]
                 if bbox_iou(boxes[bi], boxes[bj]) >= nms_threshold:
                     boxes[bj].classes[c] = 0
-    return [box for box in boxes if box.get_score() > obj_threshold]
+    return [box for box in boxes if float(box.get_score()) > obj_threshold]
 
 
 def NMB(boxes, class_ids, indices, image_shape, nms_threshold=0.3):

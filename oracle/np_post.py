@@ -32,16 +32,22 @@ def bbox_iou(b1, b2):
 
 
 def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_threshold=0.3):
-    """-> list of (xmin, ymin, xmax, ymax, confidence, classes[nb_class]) after per-class greedy NMS."""
-    netout = np.array(netout, dtype=np.float64)
+    """-> list of (xmin, ymin, xmax, ymax, confidence, classes[nb_class]) after per-class greedy NMS.
+    PINNED by tests/golden/ref_host_decode.npz (outputs of the reference's own function, numpy 1.26.4): array steps in the
+    input's dtype (float32 network output, model.py:1224), per-element steps in float64 -- the scalar promotion of the numpy
+    generation the reference ran with (round 4 finding: rounds 1-3 converted everything to float64 first, which kept 1-2 boxes
+    more or fewer near the NMS threshold)."""
+    netout = np.asarray(netout)
+    netout = np.array(netout, dtype=netout.dtype if netout.dtype in (np.float32, np.float64) else np.float64)
     gh, gw, nb = netout.shape[:3]
-    netout[..., 4] = 1. / (1. + np.exp(-netout[..., 4]))
+    one = netout.dtype.type(1)
+    netout[..., 4] = one / (one + np.exp(-netout[..., 4]))
     x = netout[..., 5:] - np.max(netout[..., 5:])
     if np.min(x) < -100.:
-        x = x / np.min(x) * -100.
+        x = x / np.min(x) * netout.dtype.type(-100.)
     e = np.exp(x)
     netout[..., 5:] = netout[..., 4][..., None] * (e / e.sum(-1, keepdims=True))
-    netout[..., 5:] *= netout[..., 5:] > obj_threshold
+    netout[..., 5:] *= netout[..., 5:] > netout.dtype.type(obj_threshold)
     boxes = []
     for row in range(gh):
         for col in range(gw):
@@ -49,11 +55,12 @@ def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_thr
                 classes = netout[row, col, b, 5:]
                 if np.sum(classes) > 0:
                     tx, ty, tw, th = netout[row, col, b, :4]
-                    cx = (col + 1. / (1. + np.exp(-tx))) / gw
-                    cy = (row + 1. / (1. + np.exp(-ty))) / gh
-                    w = anchors[2 * b + 0] * np.exp(tw) / gw
-                    h = anchors[2 * b + 1] * np.exp(th) / gh
-                    boxes.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, netout[row, col, b, 4], classes.copy()])
+                    ex, ey, ew, eh = (np.float64(np.exp(-tx)), np.float64(np.exp(-ty)), np.float64(np.exp(tw)), np.float64(np.exp(th)))
+                    cx = (col + 1. / (1. + ex)) / gw
+                    cy = (row + 1. / (1. + ey)) / gh
+                    w = np.float64(anchors[2 * b + 0]) * ew / gw
+                    h = np.float64(anchors[2 * b + 1]) * eh / gh
+                    boxes.append([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2, netout[row, col, b, 4], classes])
     for c in range(nb_class):
         order = list(reversed(np.argsort([bx[5][c] for bx in boxes])))
         for i in range(len(order)):
@@ -64,18 +71,20 @@ def decode_one_yolo_output(netout, anchors, nb_class, obj_threshold=0.3, nms_thr
                 bj = order[j]
                 if bbox_iou(boxes[bi][:4], boxes[bj][:4]) >= nms_threshold:
                     boxes[bj][5][c] = 0
-    return [bx for bx in boxes if bx[5][int(np.argmax(bx[5]))] > obj_threshold]
+    return [bx for bx in boxes if np.float64(bx[5][int(np.argmax(bx[5]))]) > obj_threshold]
 
 
 def nmb(boxes, class_ids, indices, image_shape, nms_threshold=0.3):
     """myolo_utils.py:88-113 -- suppress later same-class boxes overlapping an earlier one (every pair is tested,
-    also pairs whose first member was itself suppressed, as in the reference)."""
+    also pairs whose first member was itself suppressed, as in the reference).  PINNED by tests/golden/ref_host_nmb.npz;
+    float32 box elements times the Python ints of image_shape are float64 products (numpy < 2.0 scalar promotion)."""
     w, h = image_shape[0], image_shape[1]
     remove = []
+    B = np.asarray(boxes, dtype=np.float64)
     for i in range(len(indices)):
         for j in range(i + 1, len(indices)):
-            a = [boxes[i][0] * w, boxes[i][1] * h, boxes[i][2] * w, boxes[i][3] * h]
-            b = [boxes[j][0] * w, boxes[j][1] * h, boxes[j][2] * w, boxes[j][3] * h]
+            a = [B[i][0] * w, B[i][1] * h, B[i][2] * w, B[i][3] * h]
+            b = [B[j][0] * w, B[j][1] * h, B[j][2] * w, B[j][3] * h]
             if bbox_iou(a, b) >= nms_threshold and class_ids[i] == class_ids[j]:
                 remove.append(j)
     return np.delete(indices, remove)
