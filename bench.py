@@ -226,6 +226,44 @@ def percentiles(ms):
             "source": "HIP events on the compute stream at the step boundaries, inside the timed region"}
 
 
+def bench_train_api(model, cfg, args, dev, n_images=512, epochs=4, stream_steps=48):
+    """img/s of the reference's public training calls on this build (world 1):
+      train():               MaskYOLO.train(ShapesDataset of n_images, ...) -- host BatchGenerator.__getitem__ on a prefetch thread, pinned
+                             staging, async H2D on the upload stream, lazy StepResult; timed between the on_epoch_end callbacks of epochs
+                             2..E (epoch 1 warms the staging buffers), each callback after a device synchronise
+      train_shapes_stream(): inputs rasterised / encoded on the device (ShapesProducer); whole call timed, losses read at the end"""
+    from myolo.shapes import ShapesDataset
+    B = cfg.BATCH_SIZE
+    ds = ShapesDataset(1234)
+    ds.load_shapes(n_images, cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1])
+    ds.prepare()
+    stamps = []
+
+    def cb(ep, logs):
+        torch.cuda.synchronize()
+        stamps.append(time.perf_counter())
+    t0 = time.perf_counter()
+    hist = model.train(ds, None, args.lr, epochs=epochs, layers="all", verbose=0, custom_callbacks=[cb])
+    t_total = time.perf_counter() - t0
+    steps_per_epoch = (n_images + B - 1) // B
+    el = stamps[-1] - stamps[0]
+    train_ips = B * steps_per_epoch * (len(stamps) - 1) / el
+    assert all(np.isfinite(h) for h in hist)
+    model.train_shapes_stream(4, learning_rate=args.lr)          # warm-up (producer buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    losses = model.train_shapes_stream(stream_steps, learning_rate=args.lr, start_index=4 * B)
+    torch.cuda.synchronize()
+    el2 = time.perf_counter() - t0
+    assert all(np.isfinite(l) for l in losses)
+    return {"train": {"images_per_sec": train_ips, "ms_per_step": 1e3 * el / (steps_per_epoch * (len(stamps) - 1)),
+                      "images": n_images, "epochs_timed": len(stamps) - 1, "steps_per_epoch": steps_per_epoch,
+                      "setup_and_first_epoch_s": t_total - el, "epoch_mean_loss": hist},
+            "train_shapes_stream": {"images_per_sec": B * stream_steps / el2, "ms_per_step": 1e3 * el2 / stream_steps, "steps": stream_steps},
+            "note": "public calls of myolo.model.MaskYOLO (reference surface model.py:943-1060), single GPU; compare with `value` "
+                    "(Net.train_step on device-resident batches)"}
+
+
 def bench_train(args, rank, world, local):
     from myolo import dist as mdist
     from myolo.config import make_config, ShapesConfig, ShapesHeadConfig
@@ -395,6 +433,13 @@ def bench_train(args, rank, world, local):
             extras["comm_overlap_probe_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
             net.on_bucket_ready, net.before_optimizer, net.grad_scale = reducer.bucket_ready, reducer.wait, reducer.grad_scale
+        # (c) the DROP-IN surface (model.py:943-1060): MaskYOLO.train() on a ShapesDataset through BatchGenerator + the pinned
+        #     prefetch/upload path, and train_shapes_stream() with the inputs produced on the device -- img/s of the public calls, to be
+        #     read against `value` (Net.train_step on batches already resident in HBM)
+        try:
+            extras["train_api"] = bench_train_api(model, cfg, args, dev)
+        except Exception as e:
+            extras["train_api"] = {"error": "%s: %s" % (type(e).__name__, e)}
         extras["host_wait_on_n_pos_ms_per_step"] = {
             "value": npos_wait_ms, "note": "wall time the HOST thread is blocked on the per-image positive counts (the step's one device-to-host "
             "read, issued mid-forward on a copy stream): the host runs a whole step ahead of the GPU, so this is host idle time while the GPU "
@@ -547,8 +592,20 @@ def bench_train(args, rank, world, local):
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
                    "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "net_attrs": list(args.net_attr), "share_gpu": bool(args.share_gpu), "forced_positives": args.force_pos,
                    "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
-        "roofline": roofline,
+        "roofline": None,
     }
+    res["roofline"] = roofline
+    if "train_api" in extras and "train" in extras["train_api"]:
+        ta = extras["train_api"]
+        res["config"]["train_api_images_per_sec"] = {"MaskYOLO.train": ta["train"]["images_per_sec"],
+                                                     "MaskYOLO.train_shapes_stream": ta["train_shapes_stream"]["images_per_sec"],
+                                                     "Net.train_step(value)": res["value"]}
+    if variants.get("n_pos_sweep"):
+        sw = variants["n_pos_sweep"]
+        res["config"]["n_pos_sweep_ms"] = dict([("%.2f" % npos_mean, res["ms_per_step"])] +
+                                               [(k.replace("n_pos_", ""), v["ms_per_step"]) for k, v in sw.items()])
+        res["config"]["n_pos_sweep_note"] = ("ms per step at <key> positive ROIs per image: the first key is this run's own batch (random-init net), the others "
+                                             "force the first k proposals of every image onto a ground-truth box; a trained Shapes net sits at 5-20")
     if world > 1:
         res["comm"] = {"backend": ("gloo (--share-gpu test mode: all ranks on one GPU)" if args.share_gpu else
                                    "RCCL via %s" % ("the C-ABI (myolo_comm_*)" if args.comm == "capi" else "torch.distributed (nccl)")),

@@ -238,6 +238,7 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self._stage = None                # to_device_batch: ring of pinned staging sets + upload stream (created on first use)
         self._bind_cache = {}
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
         self.timings = {}                 # tag -> [(start_event, end_event), ...]
@@ -726,8 +727,19 @@ class Net(object):
             join()
             X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
         if self.on_bucket_ready:
-            self.join_trunk_wgrad()       # bucket 1 = YOLO head + feature_map: their weight gradients ran on the weight-gradient stream
-            self.on_bucket_ready(1)
+            # bucket 1 = YOLO head + feature_map.  Its last pieces are on two streams: the YOLO head's chain (joined into the compute
+            # stream just above) and the weight-gradient stream (feature_map's and the YOLO blocks' weight gradients).  The bucket is
+            # released ON the weight-gradient stream, behind an event of the compute stream -- the compute stream itself does not wait
+            # (round 3 joined the whole weight-gradient stream here, conv1's 2.7 ms weight gradient included, in front of the
+            # backbone backward: +3 ms per step whenever a reducer was attached).
+            if self.overlap_trunk_wgrad and self._twg_pending:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._twg_stream.wait_event(ev)
+                with torch.cuda.stream(self._twg_stream):
+                    self.on_bucket_ready(1)
+            else:
+                self.on_bucket_ready(1)
         da = dC4
         for _ in BACKBONE_BLOCKS:
             da = self.dw_block_bwd(bid, da)
@@ -1372,27 +1384,68 @@ class Net(object):
 
     # ------------------------------------------------------------------ steps
     def to_device_batch(self, batch):
-        """host batch (the six arrays of model.py:896-897) -> device tensors in C-ABI dtypes."""
+        """host batch (the six arrays of model.py:896-897, or the three of 'yolo' mode, myolo_utils.py:849-851) -> device
+        tensors in C-ABI dtypes.  Upload path: each array is converted into a PINNED staging buffer (a ring of
+        `_STAGE_SETS` sets, so a prefetching caller can stage batch i+1 while batch i's copies are in flight) and copied
+        with an asynchronous H2D on the engine's upload stream into FRESH device tensors; the dict carries the event
+        (`_ready`) that the consuming step makes its stream wait on (`_await_batch`).  Nothing here blocks the host except
+        re-use of a staging set whose previous copy is still running."""
         dev = self.dev
         T = self.cfg.TRUE_BOX_BUFFER
-        if len(batch) == 3:              # 'yolo' mode generator output (myolo_utils.py:849-851)
+        if len(batch) == 3:
             images, true_boxes, y_true = batch
-            return dict(
-                images=torch.as_tensor(np.ascontiguousarray(images, np.float32), device=dev),
-                true_boxes=torch.as_tensor(np.ascontiguousarray(np.asarray(true_boxes, np.float32).reshape(-1, T, 4)), device=dev),
-                y_true=torch.as_tensor(np.ascontiguousarray(y_true, np.float32), device=dev))
-        images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
-        return dict(
-            images=torch.as_tensor(np.ascontiguousarray(images, np.float32), device=dev),
-            true_boxes=torch.as_tensor(np.ascontiguousarray(np.asarray(true_boxes, np.float32).reshape(-1, T, 4)), device=dev),
-            y_true=torch.as_tensor(np.ascontiguousarray(y_true, np.float32), device=dev),
-            gt_ids=torch.as_tensor(np.ascontiguousarray(gt_ids, np.int32), device=dev),
-            gt_boxes=torch.as_tensor(np.ascontiguousarray(gt_boxes, np.int32), device=dev),
-            gt_masks=torch.as_tensor(np.ascontiguousarray(gt_masks).view(np.uint8), device=dev))
+            items = [("images", images, np.float32, None), ("true_boxes", true_boxes, np.float32, (-1, T, 4)),
+                     ("y_true", y_true, np.float32, None)]
+        else:
+            images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
+            items = [("images", images, np.float32, None), ("true_boxes", true_boxes, np.float32, (-1, T, 4)),
+                     ("y_true", y_true, np.float32, None), ("gt_ids", gt_ids, np.int32, None),
+                     ("gt_boxes", gt_boxes, np.int32, None),
+                     ("gt_masks", gt_masks, np.uint8, None)]              # bool -> 0/1 bytes
+        if self._stage is None:
+            self._stage = [dict(bufs={}, ev=None) for _ in range(self._STAGE_SETS)]
+            self._stage_i = 0
+            self._upload_stream = _shared_stream(dev, "batch_upload")
+        st = self._stage[self._stage_i]
+        self._stage_i = (self._stage_i + 1) % self._STAGE_SETS
+        if st["ev"] is not None:
+            st["ev"].synchronize()                    # the staging set's previous H2D (two batches ago): long finished
+        out = {}
+        tdt = {np.float32: torch.float32, np.int32: torch.int32, np.uint8: torch.uint8}
+        with torch.cuda.stream(self._upload_stream):
+            for key, arr, dt, shape in items:
+                a = np.asarray(arr)
+                if shape is not None:
+                    a = a.reshape(shape)
+                pin = st["bufs"].get(key)
+                if pin is None or tuple(pin.shape) != a.shape:
+                    pin = st["bufs"][key] = torch.empty(a.shape, dtype=tdt[dt], pin_memory=True)
+                np.copyto(pin.numpy(), a, casting="unsafe")          # dtype conversion + the one host copy, into pinned memory
+                t = torch.empty(a.shape, dtype=tdt[dt], device=dev)
+                t.copy_(pin, non_blocking=True)
+                out[key] = t
+            st["ev"] = torch.cuda.Event()
+            st["ev"].record(self._upload_stream)
+        out["_ready"] = st["ev"]
+        return out
+
+    _STAGE_SETS = 3
+
+    def _await_batch(self, db):
+        """make the current stream wait for a staged batch's H2D copies (and tell the allocator the tensors are used here)."""
+        ev = db.get("_ready") if isinstance(db, dict) else None
+        if ev is not None and not db.get("_awaited"):
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            for v in db.values():
+                if isinstance(v, torch.Tensor) and v.is_cuda:
+                    v.record_stream(cur)
+            db["_awaited"] = True
 
     def forward_backward(self, db):
         """One training forward + backward on a device batch.  Gradients land in self.flat_g."""
         self._activate()
+        self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
         images = db["images"]
@@ -1477,6 +1530,7 @@ class Net(object):
         BatchNormalization on its moving statistics, no gradient, no state change.  Returns the loss terms as device
         tensors (yolo_terms[8], mask_terms[2]); 'yolo' mode batches (three arrays) give the YOLO loss only."""
         self._activate()
+        self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
         images = db["images"]
@@ -1517,6 +1571,7 @@ class Net(object):
         """'yolo' mode training step (model.py:906-920: outputs [yolo_output, yolo_sum_loss]): backbone + YOLO head
         + yolo_custom_loss, no feature_map / ROIAlign / mask head.  db needs images, true_boxes, y_true."""
         self._activate()
+        self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
         images = db["images"]

@@ -19,9 +19,14 @@ pure-Python HDF5 reader (no h5py in this image) as well as ``.npz``; ``train`` r
 reference, model.py:1037-1038) are honoured as plain callables ``cb(epoch, logs)``; checkpoints are ``.npz`` keyed by Keras layer names
 (and Keras ``.h5`` files are read too); weights are cached by (path, mtime) instead of reloaded per call.
 """
+import collections.abc
+import contextlib
 import datetime
+import gc
 import os
+import queue
 import re
+import threading
 
 import numpy as np
 import torch
@@ -52,6 +57,117 @@ class _KerasModelShim(object):
         txt = "\n".join(lines) + "\ntrainable parameters: %d" % self._o.net.nparam
         print(txt)
         return txt
+
+
+class StepResult(collections.abc.Mapping):
+    """What one training step hands back, without stopping the pipeline.
+
+    Keras' train_on_batch / fit_generator return loss values, not tensors (model.py:1047-1059); rounds 1-3 copied every
+    output of the training graph (model.py:899: ~100 MB at config 2) to the host after every step.  Here a step ends with ONE
+    small asynchronous device->pinned copy (the loss terms + the per-image positive counts) and an event; the scalar keys
+    ('loss', 'yolo_sum_loss', 'mask_loss', 'loss_xy', 'loss_wh', 'loss_conf', 'loss_class', 'recall') wait for that event
+    when first read, and the tensor keys ('yolo_output', 'yolo_proposals', 'output_rois', 'myolo_mask', 'target_class_ids',
+    'target_mask', 'n_pos', 'feature_map') are downloaded only when indexed (the device tensors stay referenced here, so
+    reading them later still gives this step's values).  A read-only Mapping: out['loss'], out.get(...), dict(out) all work."""
+
+    SCALARS = ("loss", "yolo_sum_loss", "mask_loss", "loss_xy", "loss_wh", "loss_conf", "loss_class", "recall")
+
+    def __init__(self, tensors, yolo_terms, mask_terms, loss_weights):
+        self._t = dict(tensors)                       # key -> device tensor | None
+        self._host = {}
+        self._w = loss_weights
+        ny = int(yolo_terms.numel())
+        self._ny = ny
+        self._pin = torch.empty(ny + 2, dtype=torch.float32, pin_memory=True)
+        self._pin[:ny].copy_(yolo_terms, non_blocking=True)
+        if mask_terms is not None:
+            self._pin[ny:ny + 2].copy_(mask_terms, non_blocking=True)
+        self._has_mask = mask_terms is not None
+        self._ev = torch.cuda.Event()
+        self._ev.record(torch.cuda.current_stream())
+        self._sc = None
+
+    def _scalars(self):
+        if self._sc is None:
+            self._ev.synchronize()
+            v = self._pin.numpy()
+            yt = v[:self._ny]
+            m0 = float(v[self._ny]) if self._has_mask else 0.0
+            w1, w2 = self._w
+            self._sc = dict(yolo_sum_loss=float(yt[0]), mask_loss=m0, loss=float(yt[0] * w1 + m0 * w2) if self._has_mask
+                            else float(yt[0] * w1), loss_xy=float(yt[1]), loss_wh=float(yt[2]), loss_conf=float(yt[3]),
+                            loss_class=float(yt[4]), recall=float(yt[5]))
+        return self._sc
+
+    def ready(self):
+        """True when the loss scalars can be read without waiting for the GPU."""
+        return self._sc is not None or self._ev.query()
+
+    def __getitem__(self, k):
+        if k in self.SCALARS:
+            return self._scalars()[k]
+        if k not in self._t:
+            raise KeyError(k)
+        if k not in self._host:
+            t = self._t[k]
+            self._host[k] = None if t is None else t.cpu().numpy()
+        return self._host[k]
+
+    def device(self, k):
+        """the device tensor behind a tensor key (no copy)."""
+        return self._t[k]
+
+    def __iter__(self):
+        return iter(list(self._t.keys()) + list(self.SCALARS))
+
+    def __len__(self):
+        return len(self._t) + len(self.SCALARS)
+
+
+@contextlib.contextmanager
+def _gc_parked():
+    """the cyclic collector parked for the duration of a training loop (a gen-2 pass over torch's object graph is a
+    multi-ms host stall in the middle of the launch sequence); collected once on the way out."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+        gc.collect()
+
+
+class _Prefetcher(object):
+    """Runs `make(i)` for the items of `schedule` one step ahead on a thread (Keras' fit_generator does the same with its
+    generator queue, model.py:1055-1058: max_queue_size 3, one worker).  make = BatchGenerator.__getitem__ + the pinned
+    staging + the asynchronous upload (Net.to_device_batch): numpy's copies and the event waits release the GIL, so this
+    overlaps the main thread's kernel launches."""
+
+    def __init__(self, schedule, make, device, depth=2):
+        self._q = queue.Queue(maxsize=depth)
+        self._err = None
+
+        def run():
+            try:
+                torch.cuda.set_device(device)
+                for i in schedule:
+                    self._q.put((i, make(i)))
+            except BaseException as e:                # surfaced in the consumer
+                self._err = e
+            finally:
+                self._q.put(None)
+        self._th = threading.Thread(target=run, name="myolo-batch-prefetch", daemon=True)
+        self._th.start()
+
+    def __iter__(self):
+        while True:
+            item = self._q.get()
+            if item is None:
+                if self._err is not None:
+                    raise self._err
+                return
+            yield item
 
 
 class MaskYOLO(object):
@@ -166,24 +282,15 @@ class MaskYOLO(object):
             net.flat_g.mul_(self._train_mask)          # torch used as a memory op on a flag vector only
         net.adam_step(lr)
         if yolo_only:
-            yt = out["yolo_terms"].cpu().numpy()
-            return dict(yolo_output=out["yolo_output"].cpu().numpy(), yolo_sum_loss=float(yt[0]), mask_loss=0.0,
-                        loss=float(yt[0] * out["loss_weights"][0]), loss_xy=float(yt[1]), loss_wh=float(yt[2]),
-                        loss_conf=float(yt[3]), loss_class=float(yt[4]), recall=float(yt[5]))
+            return StepResult(dict(yolo_output=out["yolo_output"]), out["yolo_terms"], None, out["loss_weights"])
         return self._host_outputs(out)
 
     @staticmethod
     def _host_outputs(out):
-        yt = out["yolo_terms"].cpu().numpy()
-        mt = out["mask_terms"].cpu().numpy()
-        w1, w2 = out["loss_weights"]
-        res = {k: (None if out[k] is None else out[k].cpu().numpy())
-               for k in ("yolo_output", "yolo_proposals", "output_rois", "myolo_mask", "target_class_ids", "target_mask", "n_pos",
-                         "feature_map")}
-        res.update(yolo_sum_loss=float(yt[0]), mask_loss=float(mt[0]), loss=float(yt[0] * w1 + mt[0] * w2),
-                   loss_xy=float(yt[1]), loss_wh=float(yt[2]), loss_conf=float(yt[3]), loss_class=float(yt[4]),
-                   recall=float(yt[5]))
-        return res
+        """-> StepResult: the loss scalars from one small async copy, the graph's tensors on demand."""
+        return StepResult({k: out[k] for k in ("yolo_output", "yolo_proposals", "output_rois", "myolo_mask", "target_class_ids",
+                                               "target_mask", "n_pos", "feature_map")},
+                          out["yolo_terms"], out["mask_terms"], out["loss_weights"])
 
     def _data_parallel(self):
         """(rank, world): when torch.distributed is initialised with more than one rank (myolo.dist.init_from_env under
@@ -243,15 +350,29 @@ class MaskYOLO(object):
         schedule = dp_batch_indices(len(train_info), cfg.BATCH_SIZE, rank, world, len(train_gen))   # raises if < one batch
         history = []
         self.history = {"loss": [], "val_loss": []}
+        n_steps = len(train_gen)
+
+        def make(i):                                   # runs on the prefetch thread, one batch ahead of the step
+            inputs, _ = train_gen[i]                   # the wrapped last batch is full-size (myolo_utils.py:730-735)
+            return self.net.to_device_batch(inputs)
+
+        def report(ep, i, out):
+            losses.append(out["loss"])
+            if verbose:
+                print("epoch %d step %d/%d loss %.4f (yolo %.4f mask %.4f recall %.3f)" %
+                      (ep + 1, i + 1, n_steps, out["loss"], out["yolo_sum_loss"], out["mask_loss"], out["recall"]))
+
         for ep in range(epochs):
             losses = []
-            for i in schedule:
-                inputs, _ = train_gen[i]               # the wrapped last batch is full-size (myolo_utils.py:730-735)
-                out = self.train_on_batch(inputs)
-                losses.append(out["loss"])
-                if verbose:
-                    print("epoch %d step %d/%d loss %.4f (yolo %.4f mask %.4f recall %.3f)" %
-                          (ep + 1, i + 1, len(train_gen), out["loss"], out["yolo_sum_loss"], out["mask_loss"], out["recall"]))
+            with _gc_parked():
+                pending = None
+                for i, db in _Prefetcher(schedule, make, self.net.dev):
+                    out = self.train_on_batch(db)
+                    if pending is not None:            # step i-1's numbers are read once step i is queued behind it: the
+                        report(ep, *pending)           # host never waits for the step it has just launched
+                    pending = (i, out)
+                if pending is not None:
+                    report(ep, *pending)
             history.append(float(np.mean(losses)))
             logs = {"loss": history[-1]}
             if val_gen is not None and len(val_info) >= cfg.BATCH_SIZE:
@@ -282,13 +403,18 @@ class MaskYOLO(object):
         self.set_trainable(".*")
         self.compile(cfg.LEARNING_RATE if learning_rate is None else learning_rate, cfg.LEARNING_MOMENTUM)
         rank, world = self._data_parallel()          # rank r takes images [r*B, (r+1)*B) of each global batch of world*B
-        losses = []
-        for i in range(steps):
-            lo = start_index + (i * world + rank) * cfg.BATCH_SIZE
-            out = self.train_on_batch(prod.batch(list(range(lo, lo + cfg.BATCH_SIZE))))
-            losses.append(out["loss"])
-            if verbose:
-                print("step %d loss %.4f" % (i + 1, out["loss"]))
+        results = []
+        with _gc_parked():
+            for i in range(steps):
+                lo = start_index + (i * world + rank) * cfg.BATCH_SIZE
+                results.append(self.train_on_batch(prod.batch(list(range(lo, lo + cfg.BATCH_SIZE)))))
+                if verbose and i:
+                    print("step %d loss %.4f" % (i, results[i - 1]["loss"]))      # one step behind: no wait on the step in flight
+                if i >= 2:
+                    results[i - 2] = results[i - 2]["loss"]                          # long finished: keep the number, drop the tensors
+        losses = [r if isinstance(r, float) else r["loss"] for r in results]
+        if verbose and steps:
+            print("step %d loss %.4f" % (steps, losses[-1]))
         return losses
 
     # ------------------------------------------------------------------ inference
