@@ -9,6 +9,7 @@
 // a shared-memory tree combines the row lanes, per-block partials go to the caller's workspace
 // in double and a second tiny kernel finishes -- deterministic, no atomics.
 #include "myolo_common.h"
+#include <type_traits>
 #include <stdlib.h>
 #include <stdarg.h>
 #include <string.h>
@@ -39,7 +40,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -844,6 +845,286 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// depthwise 3x3, row-sliding LDS-staged form (round 4; shapes with C % 32 == 0 -- every layer of the alpha-1 net).
+//
+// A workgroup owns PX = 224 / CQB output columns x CQB channel quads (CQB x 16 B = 128 / 256 / 512 contiguous bytes per pixel) of ONE
+// image and walks DOWN a chunk of rows.  Per input row: every thread loads ONE float4 (two for stride 2) -- issued PF rows ahead, so
+// PF x 16 B per thread are in flight -- applies the producing layer's BatchNorm + ReLU6 to it once, puts it into a double-buffered LDS
+// row and, behind ONE barrier, reads its left / right neighbours from there.  The row then feeds the three output rows it belongs to
+// (rotating accumulators: ky = 2 of row iy-1 -> emitted, ky = 1 of row iy, ky = 0 of row iy+1; for stride 2 an even input row closes
+// one output row and opens the next).  So an input element is fetched from global memory exactly once per workgroup (the round-3
+// kernel: (TH+2)/TH x (TW+2)/TW = 2.25 times from L1/L2), the only re-fetch is the halo between neighbouring workgroups: one column
+// either side of a strip (32 spare threads of the 256 load it) and the rows between two row chunks -- and neighbours are adjacent in
+// the (XCD-contiguous) workgroup order, i.e. they find those lines in their XCD's L2.
+// FMA order per output = the round-3 kernel's (ky outer, kx inner, from +0): bit-identical results.
+// `fu.stat`: per-workgroup partial sums of the output, row = (image, strip, chunk), this workgroup's channel slice of it.
+// ---------------------------------------------------------------------------------------
+struct DwRowsGeom { int cqb, px, strips, chunks, rc, ncb, nblk; long long tiles; };
+
+static bool dw_rows_ok(int H, int W, int C) { return (C % 32) == 0 && (long long)H * W * C * 4 < (1ll << 30) && !g_myolo_opt.dw_legacy; }
+
+static DwRowsGeom dw_rows_geom(int N, int H, int W, int C, int S)
+{
+    DwRowsGeom g;
+    const int Ho = H / S, Wo = W / S, cq = C / 4;
+    g.cqb = (Wo <= 7 && (cq % 32) == 0) ? 32 : ((cq % 16) == 0 ? 16 : 8);
+    g.px = 224 / g.cqb;
+    g.strips = (Wo + g.px - 1) / g.px;
+    g.ncb = cq / g.cqb;
+    const long long base = (long long)N * g.ncb * g.strips;
+    const long long want = g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 1024;     // ~4 workgroups per CU, all resident at once
+    int chunks = 1;
+    while (base * chunks < want && Ho / (chunks * 2) >= 7) chunks *= 2;
+    g.rc = (Ho + chunks - 1) / chunks;
+    g.chunks = (Ho + g.rc - 1) / g.rc;
+    g.tiles = base * g.chunks;
+    g.nblk = N * g.strips * g.chunks;
+    return g;
+}
+
+typedef unsigned int dw_u32x4 __attribute__((ext_vector_type(4)));
+#define DW_OOB 0x7fffff00u           // buffer offset beyond every image (images are < 2^30 bytes, checked by the launcher): load gives 0, store is dropped
+__device__ __forceinline__ float4 dw_bufld(__amdgpu_buffer_rsrc_t r, unsigned off)
+{
+    const dw_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void dw_bufst(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v)
+{
+    const dw_u32x4 t = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)off, 0, 0);
+}
+// branch-free act(v * sc + sh): lo / hi are the clamps of the activation (-inf / +inf where it has none), `none` keeps the unclamped value
+__device__ __forceinline__ float4 dw_affine(float4 v, float4 sc, float4 sh, float lo, float hi, bool none)
+{
+    float4 a = make_float4(fmaf(v.x, sc.x, sh.x), fmaf(v.y, sc.y, sh.y), fmaf(v.z, sc.z, sh.z), fmaf(v.w, sc.w, sh.w));
+    float4 c = make_float4(fminf(fmaxf(a.x, lo), hi), fminf(fmaxf(a.y, lo), hi), fminf(fmaxf(a.z, lo), hi), fminf(fmaxf(a.w, lo), hi));
+    return none ? a : c;
+}
+
+typedef float dw_f2 __attribute__((ext_vector_type(2)));
+struct dw_f4p { dw_f2 lo, hi; };                 // a float4 as two packed pairs: v_pk_fma_f32 / v_pk_add_f32 do two lanes' worth per instruction
+__device__ __forceinline__ dw_f4p dw_pk(float4 v) { dw_f4p r; r.lo = dw_f2{v.x, v.y}; r.hi = dw_f2{v.z, v.w}; return r; }
+__device__ __forceinline__ float4 dw_unpk(dw_f4p v) { return make_float4(v.lo.x, v.lo.y, v.hi.x, v.hi.y); }
+__device__ __forceinline__ dw_f4p dw_fma(dw_f4p a, dw_f4p b, dw_f4p c)
+{
+    dw_f4p r;
+    r.lo = __builtin_elementwise_fma(a.lo, b.lo, c.lo);
+    r.hi = __builtin_elementwise_fma(a.hi, b.hi, c.hi);
+    return r;
+}
+__device__ __forceinline__ dw_f4p dw_zero() { dw_f4p r; r.lo = dw_f2{0.f, 0.f}; r.hi = dw_f2{0.f, 0.f}; return r; }
+// act(v * sc + sh): R6 = ReLU6 as one v_med3_f32 per element; otherwise the clamps lo / hi (-inf / +inf where the activation has none)
+template <bool R6>
+__device__ __forceinline__ dw_f4p dw_affine_pk(dw_f4p v, dw_f4p sc, dw_f4p sh, float lo, float hi)
+{
+    dw_f4p a = dw_fma(v, sc, sh);
+    if (R6) {
+        a.lo.x = __builtin_amdgcn_fmed3f(a.lo.x, 0.f, 6.f); a.lo.y = __builtin_amdgcn_fmed3f(a.lo.y, 0.f, 6.f);
+        a.hi.x = __builtin_amdgcn_fmed3f(a.hi.x, 0.f, 6.f); a.hi.y = __builtin_amdgcn_fmed3f(a.hi.y, 0.f, 6.f);
+    } else {
+        a.lo.x = fminf(fmaxf(a.lo.x, lo), hi); a.lo.y = fminf(fmaxf(a.lo.y, lo), hi);
+        a.hi.x = fminf(fmaxf(a.hi.x, lo), hi); a.hi.y = fminf(fmaxf(a.hi.y, lo), hi);
+    }
+    return a;
+}
+
+// What bounds this kernel is the VALU, not HBM: with every load and store pointed out of range (no memory traffic at all) the first form
+// of it still took 21.7 of its 30.4 us on the 112x112x32 layer -- ~125 wave64 fp32 instructions per row at 4 cycles each (16 lanes per
+// cycle; the 157 TFLOP/s vector peak is PACKED fp32).  Hence: packed FMAs / adds (v_pk_fma_f32: the 36 FMAs of a row are 18 instructions),
+// ReLU6 as one v_med3_f32, the producing BatchNorm applied ONCE per element before it goes to LDS (not on each of its three reads), padding
+// columns handled by a zero scale / shift instead of per-element selects, the first two rows of a chunk peeled so that no emitted row
+// needs a mask, out-of-image rows by a uniform branch.
+// Every global access is a raw buffer access on a per-image descriptor: rows above / below the image, padding columns, dead lanes and
+// the rows a prefetch runs past its chunk are "offset out of range" -- the load returns 0 without a memory request, the store is dropped --
+// so there is no branch around a load (a load inside an exec-masked branch makes hipcc wait vmcnt(0) at every use: an earlier form drained
+// its prefetch queue once per row).
+// MODE 0: plain; 1: the producing layer's BatchNorm + activation on load, statistics of the output when fu.stat; 2: folded frozen
+// BatchNorm + activation on the way out (inference).
+template <int S, int CQB, int MODE, bool R6>
+__global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                         int H, int W, int C, int Ho, int Wo, int strips, int chunks, int rc, int ncb,
+                                                         unsigned xcd_tiles, int flags, DwAffine af, DwFuse fu)
+{
+    constexpr int PX = 224 / CQB;                 // output columns of this workgroup
+    constexpr int NE = (S == 1) ? PX + 2 : PX + 1;      // LDS row entries: S=1 input cols x0-1 .. x0+PX; S=2 even input cols 2*x0 .. 2*(x0+PX)
+    constexpr int NHALO = (S == 1) ? 2 : 1;
+    constexpr int NL = (S == 1) ? 1 : 2;           // float4 loads per thread and input row
+    constexpr int PF = (S == 1) ? 3 : 2;           // input rows in flight per thread
+    __shared__ float4 rowbuf[2][NE * CQB];
+    __shared__ float4 red[224];
+    const int tid = threadIdx.x;
+    unsigned b = blockIdx.x;
+    if (xcd_tiles) b = (b & 7u) * xcd_tiles + (b >> 3);          // workgroup b runs on XCD b % 8: give every XCD a contiguous run of tiles
+    const int ch = b % (unsigned)chunks;
+    unsigned t = b / (unsigned)chunks;
+    const int sx = t % (unsigned)strips;
+    t /= (unsigned)strips;
+    const int cb = t % (unsigned)ncb;
+    const int n = t / (unsigned)ncb;
+    const int x0 = sx * PX;
+    const int y0 = ch * rc, y1 = min(y0 + rc, Ho);
+    // roles: threads 0..223 = (output column, channel quad); 224.. = halo columns
+    const bool comp = tid < 224;
+    int px, q, e_w, col;                           // LDS entry this thread writes, (first) input column it loads
+    bool loader;
+    if (comp) {
+        px = tid / CQB; q = tid % CQB;
+        if (S == 1) { e_w = px + 1; col = x0 + px; } else { e_w = px; col = 2 * (x0 + px); }
+        loader = true;
+    } else {
+        const int k = tid - 224;
+        px = 0; q = k % CQB;
+        const int side = k / CQB;                  // S=1: 0 left, 1 right; S=2: 0 = the one (right) halo column
+        loader = side < NHALO && CQB < 32;         // (CQB = 32: only chosen when the strip spans the row -- both halo columns are padding, zeroed once below)
+        if (S == 1) { e_w = side ? PX + 1 : 0; col = side ? x0 + PX : x0 - 1; } else { e_w = PX; col = 2 * (x0 + PX); }
+    }
+    const int c = (cb * CQB + q) * 4;
+    const bool colin = loader && col >= 0 && col < W;
+    const bool col2in = comp && (S == 2) && (col + 1) < W;
+    const int ox = x0 + px;
+    const bool live = comp && ox < Wo;
+    dw_f4p wv[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wv[k] = dw_pk(ld4g(w + k * C + c));
+    // MODE 1: input map (scale / shift zeroed for a padding column: act(0 * v + 0) = 0); MODE 2: output map
+    dw_f4p sc0 = dw_pk(make_float4(1.f, 1.f, 1.f, 1.f)), sh0 = dw_zero(), sc1 = sc0, sh1 = sh0;
+    float lo = -INFINITY, hi = INFINITY;
+    if (MODE != 0) {
+        const DwAffine a = (MODE == 1) ? fu.in : af;
+        if (a.scale) {                              // (MODE 1 without an input map: statistics only; the identity is exact)
+            sc0 = dw_pk(ld4g(a.scale + c)); sh0 = dw_pk(ld4g(a.shift + c));
+            lo = a.act == MYOLO_ACT_NONE ? -INFINITY : 0.f;
+            hi = a.act == MYOLO_ACT_RELU6 ? 6.f : INFINITY;
+        }
+        sc1 = sc0; sh1 = sh0;
+        if (MODE == 1) {
+            if (!colin) { sc0 = dw_zero(); sh0 = dw_zero(); }
+            if (!col2in) { sc1 = dw_zero(); sh1 = dw_zero(); }
+        }
+    }
+    if (CQB == 32 && !comp) {                      // constant zero halo entries of both buffers
+        const int k = tid - 224;
+        rowbuf[0][k] = f4zero(); rowbuf[1][k] = f4zero();
+        rowbuf[0][(NE - 1) * CQB + k] = f4zero(); rowbuf[1][(NE - 1) * CQB + k] = f4zero();
+    }
+    // input rows of this chunk: S=1: y0-1 .. y1 (pad 1 above / below); S=2: 2*y0 .. 2*y1 (pad below / right only)
+    const int row0 = (S == 1) ? y0 - 1 : 2 * y0;
+    const int nrows = (S == 1) ? (y1 - y0 + 2) : (2 * (y1 - y0) + 1);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)n * H * W * C), 0, H * W * C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + (long long)n * Ho * Wo * C), 0, Ho * Wo * C * 4, 0x00020000);
+    const unsigned off0 = (colin && !(flags & 2)) ? (unsigned)(col * C + c) * 4u : DW_OOB;
+    const unsigned off1 = col2in ? off0 + (unsigned)C * 4u : DW_OOB;
+    const int rstride = W * C * 4;                 // bytes; a row index outside [0, H) drives the offset out of the descriptor's range
+    float4 pf[PF][NL];
+    auto fetch = [&](int r, float4* dst) {
+        const int iy = row0 + r;
+        const bool ok = r < nrows && iy >= 0 && iy < H;         // uniform
+        const unsigned ro = ok ? (unsigned)(iy * rstride) : DW_OOB;     // (DW_OOB + DW_OOB wraps to 0xfffffe00: still out of range)
+        dst[0] = dw_bufld(rx, off0 + ro);
+        if (NL == 2) dst[NL - 1] = dw_bufld(rx, off1 + ro);
+    };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) fetch(j, pf[j]);
+    dw_f4p a1 = dw_zero(), a2 = dw_zero();          // S=1: outputs iy / iy-1 in the making; S=2: a1 = current output row
+    dw_f4p s1 = dw_zero(), s2 = dw_zero();
+    const unsigned yoff = (live && !(flags & 4)) ? (unsigned)(ox * C + c) * 4u : DW_OOB;
+    const int ystride = Wo * C * 4;
+    auto emit = [&](dw_f4p o, int oy) {             // (only called for rows that exist: y0 <= oy < y1; dead lanes are zeroed out of the sums at the end)
+        if (MODE == 1) {
+            s1.lo += o.lo; s1.hi += o.hi;
+            s2 = dw_fma(o, o, s2);
+        }
+        if (MODE == 2) o = dw_affine_pk<R6>(o, sc0, sh0, lo, hi);
+        dw_bufst(ry, yoff + (unsigned)(oy * ystride), dw_unpk(o));
+    };
+    // one input row: value(s) -> (input map) -> LDS -> barrier -> neighbours; PEEL = 0: an ordinary row; 1 / 2: the first / second row of the
+    // chunk, which only open accumulators (S=2: only 1 exists)
+    auto row = [&](int r, float4* cur, auto peel) {
+        constexpr int PEEL = decltype(peel)::value;
+        dw_f4p v0 = dw_pk(cur[0]), v1 = dw_pk(cur[NL - 1]);
+        fetch(r + PF, cur);
+        const int iy = row0 + r;
+        if (MODE == 1) {
+            if (iy >= 0 && iy < H) {                // uniform; a row outside the image stays zero (the load returned zeros)
+                v0 = dw_affine_pk<R6>(v0, sc0, sh0, lo, hi);
+                if (NL == 2) v1 = dw_affine_pk<R6>(v1, sc1, sh1, lo, hi);
+            }
+        }
+        float4* buf = rowbuf[r & 1];
+        if (loader) buf[e_w * CQB + q] = dw_unpk(v0);
+        __syncthreads();
+        if (S == 1) {
+            const dw_f4p l = dw_pk(buf[px * CQB + q]), rt = dw_pk(buf[(px + 2) * CQB + q]);
+            // this input row is ky = 2 of output iy-1 (a2, complete after it), ky = 1 of output iy (a1), ky = 0 of output iy+1
+            if (PEEL == 0) {
+                a2 = dw_fma(l, wv[6], a2); a2 = dw_fma(v0, wv[7], a2); a2 = dw_fma(rt, wv[8], a2);
+                emit(a2, iy - 1);
+            }
+            if (PEEL != 1) { a1 = dw_fma(l, wv[3], a1); a1 = dw_fma(v0, wv[4], a1); a1 = dw_fma(rt, wv[5], a1); }
+            dw_f4p a0 = dw_fma(l, wv[0], dw_zero()); a0 = dw_fma(v0, wv[1], a0); a0 = dw_fma(rt, wv[2], a0);
+            a2 = a1; a1 = a0;
+        } else {
+            const dw_f4p rt = dw_pk(buf[(px + 1) * CQB + q]);
+            if ((r & 1) == 0) {                     // even input row 2m: ky = 2 of output m-1 (then emitted), ky = 0 of output m
+                if (PEEL == 0) {
+                    a1 = dw_fma(v0, wv[6], a1); a1 = dw_fma(v1, wv[7], a1); a1 = dw_fma(rt, wv[8], a1);
+                    emit(a1, (iy >> 1) - 1);
+                }
+                a1 = dw_fma(v0, wv[0], dw_zero()); a1 = dw_fma(v1, wv[1], a1); a1 = dw_fma(rt, wv[2], a1);
+            } else {
+                a1 = dw_fma(v0, wv[3], a1); a1 = dw_fma(v1, wv[4], a1); a1 = dw_fma(rt, wv[5], a1);
+            }
+        }
+    };
+    // rows 0 .. NPEEL-1 open the accumulators; the others each complete one output row (S=1) / one per pair (S=2).  The loop is unrolled by
+    // the least common multiple of PF (static prefetch register) and 2 (static LDS buffer / S=2 row parity).
+    constexpr int NPEEL = (S == 1) ? 2 : 1;
+    constexpr int UN = (S == 1) ? 6 : 2;
+    row(0, pf[0], std::integral_constant<int, 1>{});
+    if (S == 1) row(1, pf[1], std::integral_constant<int, 2>{});
+    for (int it = NPEEL; it < nrows; it += UN) {
+#pragma unroll
+        for (int j = 0; j < UN; ++j) {
+            const int r = it + j;
+            if (r < nrows) row(r, pf[(NPEEL + j) % PF], std::integral_constant<int, 0>{});       // uniform
+        }
+    }
+    if (MODE == 1 && fu.stat) {
+        // reduction over the PX threads that share a channel quad, in double; this workgroup's slice of partial row (n, strip, chunk)
+        const long long blk = ((long long)n * strips + sx) * chunks + ch;
+        if (!live) { s1 = dw_zero(); s2 = dw_zero(); }
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            __syncthreads();
+            if (comp) red[tid] = dw_unpk(v == 0 ? s1 : s2);
+            __syncthreads();
+            if (tid < CQB) {
+                double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                for (int j = 0; j < PX; ++j) {
+                    const float4 tt = red[j * CQB + tid];
+                    d0 += tt.x; d1 += tt.y; d2 += tt.z; d3 += tt.w;
+                }
+                double* o = fu.stat + (blk * 2 + v) * C + (cb * CQB + tid) * 4;
+                o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
+            }
+        }
+    }
+}
+
+template <int S, int CQB>
+static void dw_rows_launch(const DwRowsGeom& g, const float* x, const float* w, float* y, int H, int W, int C, DwAffine af, DwFuse fu, hipStream_t s)
+{
+    const unsigned xcd = (g.tiles % 8 == 0 && g.tiles >= 64 && !(g_myolo_opt.tune0 & 8)) ? (unsigned)(g.tiles / 8) : 0u;
+    const int flags = ((g_myolo_opt.tune0 & 16) ? 2 : 0) | ((g_myolo_opt.tune0 & 32) ? 4 : 0);      // timing-only ablations: no loads / no stores
+#define DW_ROWS_GO(MODE, R6) hipLaunchKernelGGL((dw_rows_kernel<S, CQB, MODE, R6>), dim3((unsigned)g.tiles), dim3(256), 0, s, x, w, y, H, W, C, H / S, W / S, g.strips, g.chunks, g.rc, g.ncb, xcd, flags, af, fu)
+    if (fu.in.scale || fu.stat) { if (fu.in.scale && fu.in.act == MYOLO_ACT_RELU6) DW_ROWS_GO(1, true); else DW_ROWS_GO(1, false); }
+    else if (af.scale) { if (af.act == MYOLO_ACT_RELU6) DW_ROWS_GO(2, true); else DW_ROWS_GO(2, false); }
+    else DW_ROWS_GO(0, false);
+#undef DW_ROWS_GO
 }
 
 // dx[iy,ix] = sum_{ky,kx} dy[(iy+pt-ky)/S, (ix+pl-kx)/S] * w[ky,kx]   (when divisible and in range)
@@ -1862,23 +2143,33 @@ int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, in
     return MYOLO_OK;
 }
 
-// workgroups of the depthwise forward launch for this shape (= rows of statistics partials of the fused form)
-static void dw_fwd_grid(int N, int H, int W, int C, int stride, int& which, dim3& grid)
+// workgroups of the depthwise forward launch for this shape; nblk = rows of statistics partials of the fused form
+static void dw_fwd_grid(int N, int H, int W, int C, int stride, int& which, dim3& grid, int& nblk)
 {
+    if (dw_rows_ok(H, W, C)) {
+        const DwRowsGeom g = dw_rows_geom(N, H, W, C, stride);
+        which = 10;
+        grid = dim3((unsigned)g.tiles, 1, 1);
+        nblk = g.nblk;
+        return;
+    }
     const int Ho = H / stride, Wo = W / stride;
     if (stride == 1) {
         const int per_row = ((Wo + 3) / 4) * (C / 4);
         // strips of 4 output rows where that still leaves >= ~1000 workgroups; the small late layers keep more, shorter strips
         const long long wg4 = (long long)((per_row + 255) / 256) * ((Ho + 3) / 4) * N;
-        if (Ho >= 4 && wg4 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1) { which = 0; grid = dim3((per_row + 255) / 256, (Ho + 3) / 4, N); }
+        const int minwg = 400;
+        if (Ho >= 4 && wg4 >= minwg && !g_myolo_opt.dw_rows1) { which = 0; grid = dim3((per_row + 255) / 256, (Ho + 3) / 4, N); }
         else if (Ho >= 2 && !g_myolo_opt.dw_rows1) { which = 1; grid = dim3((per_row + 255) / 256, (Ho + 1) / 2, N); }
         else { which = 2; grid = dim3((per_row + 255) / 256, Ho, N); }
     } else {
         const int per_row = ((Wo + 1) / 2) * (C / 4);
         const long long wg2 = (long long)((per_row + 255) / 256) * ((Ho + 1) / 2) * N;
-        if (Ho >= 2 && wg2 >= (g_myolo_opt.dw_min_wg ? g_myolo_opt.dw_min_wg : 400) && !g_myolo_opt.dw_rows1) { which = 3; grid = dim3((per_row + 255) / 256, (Ho + 1) / 2, N); }
+        const int minwg = 400;
+        if (Ho >= 2 && wg2 >= minwg && !g_myolo_opt.dw_rows1) { which = 3; grid = dim3((per_row + 255) / 256, (Ho + 1) / 2, N); }
         else { which = 4; grid = dim3((per_row + 255) / 256, Ho, N); }
     }
+    nblk = (int)(grid.x * grid.y * grid.z);
 }
 
 static int dw_fwd_launch(const float* x, const float* w, float* y, int N, int H, int W, int C, int stride, DwAffine af, void* stream,
@@ -1888,9 +2179,25 @@ static int dw_fwd_launch(const float* x, const float* w, float* y, int N, int H,
     MYOLO_REQUIRE(stride == 1 || ((H & 1) == 0 && (W & 1) == 0), "dwconv3x3[_affine_act]_fwd: stride 2 needs even H, W");
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / stride, Wo = W / stride;
-    int which;
+    int which, nblk;
     dim3 grid;
-    dw_fwd_grid(N, H, W, C, stride, which, grid);
+    dw_fwd_grid(N, H, W, C, stride, which, grid, nblk);
+    if (which == 10) {
+        MYOLO_REQUIRE(!(af.scale && (fu.in.scale || fu.stat)), "dwconv3x3_fwd: input map / statistics and an output map in one launch are not supported");
+        const DwRowsGeom g = dw_rows_geom(N, H, W, C, stride);
+        MYOLO_REQUIRE(g.tiles < (1ll << 31), "dwconv3x3_fwd: too many tiles");
+        if (stride == 1) {
+            if (g.cqb == 32) dw_rows_launch<1, 32>(g, x, w, y, H, W, C, af, fu, s);
+            else if (g.cqb == 16) dw_rows_launch<1, 16>(g, x, w, y, H, W, C, af, fu, s);
+            else dw_rows_launch<1, 8>(g, x, w, y, H, W, C, af, fu, s);
+        } else {
+            if (g.cqb == 32) dw_rows_launch<2, 32>(g, x, w, y, H, W, C, af, fu, s);
+            else if (g.cqb == 16) dw_rows_launch<2, 16>(g, x, w, y, H, W, C, af, fu, s);
+            else dw_rows_launch<2, 8>(g, x, w, y, H, W, C, af, fu, s);
+        }
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     switch (which) {
     case 0: hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 4>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
     case 1: hipLaunchKernelGGL((dw_fwd_kernel<1, 4, 2>), grid, dim3(256), 0, s, x, w, y, N, H, W, C, Ho, Wo, af, fu); break;
@@ -1922,10 +2229,10 @@ int myolo_dwconv3x3_affine_act_fwd(const float* x, const float* w, const float* 
  * it is.  The normalised input is never written and y is not re-read for its statistics. */
 size_t myolo_dwconv3x3_bnstats_ws_bytes(int N, int H, int W, int C, int stride)
 {
-    int which;
+    int which, nblk;
     dim3 grid;
-    dw_fwd_grid(N, H, W, C, stride, which, grid);
-    const size_t fused = align256((size_t)grid.x * grid.y * grid.z * 2 * C * sizeof(double)) + 2 * C * sizeof(double);
+    dw_fwd_grid(N, H, W, C, stride, which, grid, nblk);
+    const size_t fused = align256((size_t)nblk * 2 * C * sizeof(double)) + 2 * C * sizeof(double);
     const long long M = (long long)N * (H / stride) * (W / stride);
     const size_t plain = align256(col_ws_bytes(M, C, 2)) + 2 * C * sizeof(double);
     return fused > plain ? fused : plain;
@@ -1944,11 +2251,10 @@ int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const flo
     const int cq = C / 4;
     const DwAffine in{in_scale, in_shift, in_act};
     const FinBnStats fin{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance};
-    if (cq <= 256 && (256 % cq) == 0 && !g_myolo_opt.no_trunk_fusion) {
-        int which;
+    if ((dw_rows_ok(H, W, C) || (cq <= 256 && (256 % cq) == 0)) && !g_myolo_opt.no_trunk_fusion) {
+        int which, nblk;
         dim3 grid;
-        dw_fwd_grid(N, H, W, C, stride, which, grid);
-        const int nblk = (int)(grid.x * grid.y * grid.z);
+        dw_fwd_grid(N, H, W, C, stride, which, grid, nblk);
         double* part = (double*)ws;
         double* tot = (double*)((char*)ws + align256((size_t)nblk * 2 * C * sizeof(double)));
         if (phases & 1) {

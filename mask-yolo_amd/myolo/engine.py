@@ -238,6 +238,9 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.bucket1_on_wgrad_stream = 1  # data-parallel: bucket 1 released on the weight-gradient stream (0: round 3's join of that stream into the compute stream)
+        self.pinned_upload = 1            # to_device_batch through pinned staging + the upload stream (0: synchronous torch.as_tensor copies, rounds 1-3)
+        self.upload_own_stream = 0        # EXPERIMENT
         self._stage = None                # to_device_batch: ring of pinned staging sets + upload stream (created on first use)
         self._bind_cache = {}
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
@@ -732,13 +735,14 @@ class Net(object):
             # released ON the weight-gradient stream, behind an event of the compute stream -- the compute stream itself does not wait
             # (round 3 joined the whole weight-gradient stream here, conv1's 2.7 ms weight gradient included, in front of the
             # backbone backward: +3 ms per step whenever a reducer was attached).
-            if self.overlap_trunk_wgrad and self._twg_pending:
+            if self.bucket1_on_wgrad_stream and self.overlap_trunk_wgrad and self._twg_pending:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 self._twg_stream.wait_event(ev)
                 with torch.cuda.stream(self._twg_stream):
                     self.on_bucket_ready(1)
             else:
+                self.join_trunk_wgrad()
                 self.on_bucket_ready(1)
         da = dC4
         for _ in BACKBONE_BLOCKS:
@@ -1392,6 +1396,12 @@ class Net(object):
         re-use of a staging set whose previous copy is still running."""
         dev = self.dev
         T = self.cfg.TRUE_BOX_BUFFER
+        if not self.pinned_upload:
+            keys = ("images", "true_boxes", "y_true", "gt_ids", "gt_boxes", "gt_masks")[:len(batch)]
+            dts = dict(images=np.float32, true_boxes=np.float32, y_true=np.float32, gt_ids=np.int32, gt_boxes=np.int32, gt_masks=np.uint8)
+            out = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(a).reshape(-1, T, 4) if k == "true_boxes" else a, dts[k]), device=dev)
+                   for k, a in zip(keys, batch)}
+            return out
         if len(batch) == 3:
             images, true_boxes, y_true = batch
             items = [("images", images, np.float32, None), ("true_boxes", true_boxes, np.float32, (-1, T, 4)),
@@ -1405,7 +1415,7 @@ class Net(object):
         if self._stage is None:
             self._stage = [dict(bufs={}, ev=None) for _ in range(self._STAGE_SETS)]
             self._stage_i = 0
-            self._upload_stream = _shared_stream(dev, "batch_upload")
+            self._upload_stream = _shared_stream(dev, "batch_upload") if self.upload_own_stream else self._copy_stream
         st = self._stage[self._stage_i]
         self._stage_i = (self._stage_i + 1) % self._STAGE_SETS
         if st["ev"] is not None:

@@ -244,6 +244,95 @@ def main():
             tot_b += nb
             print("dw %3dx%3dx%4d s%d: %.4f ms %6.0f GB/s" % (H, H, Cc, s, ms, nb / ms / 1e6))
         print("dw total: %.3f ms, %.0f GB/s (%.1f%% of 8000)" % (tot_ms, tot_b / tot_ms / 1e6, tot_b / tot_ms / 1e6 / 80))
+    elif a.which == "dw_fused":
+        # the depthwise layers AS THE TRAINING STEP RUNS THEM: producer's BatchNorm + ReLU6 applied on load, this conv's BatchNorm statistics from
+        # its epilogue (phase 1 of myolo_dwconv3x3_bnstats_fwd; the finish launch is timed separately), inputs rotated through enough
+        # buffers (> 600 MB) that no launch finds its input in the 256 MB Infinity Cache
+        layers = [(112, 32, 1), (112, 64, 2), (56, 64, 1), (56, 128, 2), (28, 256, 1), (28, 256, 1), (28, 512, 2),
+                  (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 1), (14, 512, 2), (7, 1024, 1)]
+        if os.environ.get("KBENCH_DW_MIN_WG"):
+            X.set_option("dw_min_wg", int(os.environ["KBENCH_DW_MIN_WG"]))
+        tot_ms, tot_b = 0.0, 0.0
+        import ctypes
+        for H, Cc, s in layers:
+            nbytes = 32 * H * H * Cc * 4
+            nbuf = max(2, int(640e6 // nbytes) + 1) if os.environ.get("KBENCH_COLD", "1") == "1" else 1
+            xs = [rn(32, H, H, Cc) for _ in range(nbuf)]
+            w = rn(3, 3, Cc)
+            sc, sh = torch.rand(Cc, device=dev) + 0.5, rn(Cc) * 0.1
+            ys = [torch.empty(32, H // s, H // s, Cc, device=dev) for _ in range(min(nbuf, 4))]
+            gam, bet = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev)
+            outs = [torch.empty(Cc, device=dev) for _ in range(6)]
+            wsb = X.dw_bnstats_ws_bytes(32, H, H, Cc, s)
+            wsd = torch.empty(wsb, dtype=torch.uint8, device=dev)
+            it = [0]
+
+            def fn(phases=1):
+                i = it[0]
+                it[0] += 1
+                X.call("myolo_dwconv3x3_bnstats_fwd", X.ptr(xs[i % nbuf]), X.ptr(sc), X.ptr(sh), 2, X.ptr(w), X.ptr(ys[i % len(ys)]),
+                       X.ptr(gam), X.ptr(bet), *[X.ptr(o) for o in outs], 32, H, H, Cc, s, phases, wsd.data_ptr(), wsb, st)
+            ms = timeit(lambda: fn(1), a.iters)
+            ms_fin = timeit(lambda: fn(2), a.iters)
+            nb = (xs[0].numel() + ys[0].numel()) * 4
+            tot_ms += ms
+            tot_b += nb
+            print("dw_fused %3dx%3dx%4d s%d: %.4f ms %6.0f GB/s   (finish launch %.4f ms)" % (H, H, Cc, s, ms, nb / ms / 1e6, ms_fin))
+        print("dw_fused total: %.3f ms, %.0f GB/s (%.1f%% of 8000)" % (tot_ms, tot_b / tot_ms / 1e6, tot_b / tot_ms / 1e6 / 80))
+    elif a.which in ("dw_bwd", "pw_fused"):
+        # the trunk's other launches as the training step runs them, inputs rotated through > 600 MB of buffers (no Infinity-Cache hits):
+        #   dw_bwd:   depthwise data gradient and weight gradient (input re-normalised on load) of the 14 layers
+        #   pw_fused: the 14 pointwise layers (A operand normalised on load, BatchNorm partial sums in the epilogue; phase 1 only)
+        layers = [(112, 32, 1, 64), (112, 64, 2, 64), (56, 64, 1, 128), (56, 128, 2, 256), (28, 256, 1, 256), (28, 256, 1, 512), (28, 512, 2, 512),
+                  (14, 512, 1, 512), (14, 512, 1, 512), (14, 512, 1, 512), (14, 512, 1, 512), (14, 512, 1, 512), (14, 512, 2, 1024), (7, 1024, 1, 1024)]
+        tot = {}
+        for li, (H, Cc, s, Co) in enumerate(layers, 1):
+            Ho = H // s
+            nb_in = 32 * H * H * Cc * 4
+            nbuf = max(2, int(640e6 // nb_in) + 1)
+            sc, sh = torch.rand(Cc, device=dev) + 0.5, rn(Cc) * 0.1
+            it = [0]
+            if a.which == "dw_bwd":
+                xs = [rn(32, H, H, Cc) for _ in range(nbuf)]
+                dys = [rn(32, Ho, Ho, Cc) for _ in range(max(2, min(nbuf, int(640e6 // (32 * Ho * Ho * Cc * 4)) + 1)))]
+                w, dx, dwg = rn(3, 3, Cc), torch.empty(32, H, H, Cc, device=dev), torch.empty(3, 3, Cc, device=dev)
+
+                def f_data():
+                    i = it[0]; it[0] += 1
+                    X.call("myolo_dwconv3x3_bwd_data", X.ptr(dys[i % len(dys)]), X.ptr(w), X.ptr(dx), 32, H, H, Cc, s, st)
+
+                def f_wgrad():
+                    i = it[0]; it[0] += 1
+                    X.call("myolo_dwconv3x3_bwd_weight_affine_in", X.ptr(xs[i % nbuf]), X.ptr(sc), X.ptr(sh), 2, X.ptr(dys[i % len(dys)]), X.ptr(dwg),
+                           32, H, H, Cc, s, ws.data_ptr(), ws.numel(), st)
+                for name, fn, nb in (("bwd_data", f_data, (32 * Ho * Ho + 32 * H * H) * Cc * 4), ("bwd_weight", f_wgrad, (32 * Ho * Ho + 32 * H * H) * Cc * 4)):
+                    ms = timeit(fn, a.iters)
+                    tot.setdefault(name, [0.0, 0.0])
+                    tot[name][0] += ms; tot[name][1] += nb
+                    print("dw%-2d %-10s %3dx%3dx%4d s%d: %.4f ms %6.0f GB/s" % (li, name, H, H, Cc, s, ms, nb / ms / 1e6))
+            else:
+                Mr = 32 * Ho * Ho
+                nbuf = max(2, int(640e6 // (Mr * Cc * 4)) + 1)
+                xs = [rn(Mr, Cc) for _ in range(nbuf)]
+                w, y = rn(Cc, Co) * 0.05, torch.empty(Mr, Co, device=dev)
+                gam, bet = torch.ones(Co, device=dev), torch.zeros(Co, device=dev)
+                outs = [torch.empty(Co, device=dev) for _ in range(6)]
+                wsb = X.pw_bnstats_ws_bytes(Mr, Cc, Co)
+                wsd = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+
+                def f_pw(phases=1):
+                    i = it[0]; it[0] += 1
+                    X.call("myolo_pwconv1x1_bnstats_fwd", X.ptr(xs[i % nbuf]), X.ptr(sc), X.ptr(sh), 2, X.ptr(w), X.ptr(y), X.ptr(gam), X.ptr(bet),
+                           *[X.ptr(o) for o in outs], Mr, Cc, Co, phases, wsd.data_ptr(), wsb, st)
+                ms = timeit(lambda: f_pw(1), a.iters)
+                ms2 = timeit(lambda: f_pw(2), a.iters)
+                fl, nb = 2.0 * Mr * Cc * Co, 4.0 * (Mr * Cc + Mr * Co + Cc * Co)
+                tot.setdefault("pw", [0.0, 0.0, 0.0])
+                tot["pw"][0] += ms; tot["pw"][1] += nb; tot["pw"][2] += fl
+                print("pw%-2d M=%6d %4d->%4d: %.4f ms %6.1f TF/s %6.0f GB/s   (finish launch %.4f ms)" % (li, Mr, Cc, Co, ms, fl / ms / 1e9, nb / ms / 1e6, ms2))
+        for k, v in tot.items():
+            print("%s %s total: %.3f ms, %.0f GB/s (%.1f%% of 8000)%s" % (a.which, k, v[0], v[1] / v[0] / 1e6, v[1] / v[0] / 1e6 / 80,
+                                                                         "  %.1f TF/s" % (v[2] / v[0] / 1e9) if len(v) > 2 else ""))
 
 
 if __name__ == "__main__":
