@@ -243,8 +243,13 @@ def bench_train_api(model, cfg, args, dev, n_images=512, epochs=4, stream_steps=
         torch.cuda.synchronize()
         stamps.append(time.perf_counter())
     t0 = time.perf_counter()
+    model.net.host_wait_s = 0.0
     hist = model.train(ds, None, args.lr, epochs=epochs, layers="all", verbose=0, custom_callbacks=[cb])
     t_total = time.perf_counter() - t0
+    ht = dict(model.host_times)
+    nst = max(1, ht["steps"])
+    host_ms = {"wait_for_batch_ms_per_step": 1e3 * ht["wait_for_batch_s"] / nst, "launch_step_ms_per_step": 1e3 * ht["launch_step_s"] / nst,
+               "of_which_wait_on_n_pos_ms_per_step": 1e3 * model.net.host_wait_s / nst}
     steps_per_epoch = (n_images + B - 1) // B
     el = stamps[-1] - stamps[0]
     train_ips = B * steps_per_epoch * (len(stamps) - 1) / el
@@ -258,7 +263,7 @@ def bench_train_api(model, cfg, args, dev, n_images=512, epochs=4, stream_steps=
     assert all(np.isfinite(l) for l in losses)
     return {"train": {"images_per_sec": train_ips, "ms_per_step": 1e3 * el / (steps_per_epoch * (len(stamps) - 1)),
                       "images": n_images, "epochs_timed": len(stamps) - 1, "steps_per_epoch": steps_per_epoch,
-                      "setup_and_first_epoch_s": t_total - el, "epoch_mean_loss": hist},
+                      "setup_and_first_epoch_s": t_total - el, "epoch_mean_loss": hist, "launch_thread": host_ms},
             "train_shapes_stream": {"images_per_sec": B * stream_steps / el2, "ms_per_step": 1e3 * el2 / stream_steps, "steps": stream_steps},
             "note": "public calls of myolo.model.MaskYOLO (reference surface model.py:943-1060), single GPU; compare with `value` "
                     "(Net.train_step on device-resident batches)"}

@@ -308,6 +308,9 @@ int myolo_matmul_f32(const float* A, const float* B, float* C, int64_t M, int K,
 /* ---- small elementwise helpers ---- */
 int myolo_add_inplace(float* a, const float* b, int64_t n, void* stream);      /* a += b */
 int myolo_fill(float* a, float value, int64_t n, void* stream);
+/* y[i] = (float)(x[i] / 255.0): the generator's `image / 255.` (myolo_utils.py:824) done on the device, so that a training batch crosses
+ * PCIe as bytes (a quarter of the float32 image) -- same bits as the host expression. */
+int myolo_u8_to_unit_f32(const uint8_t* x, float* y, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1847,6 +1847,21 @@ __global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, l
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (; i < n; i += stride) a[i] += b[i];
 }
+__global__ __launch_bounds__(256) void u8_unit_kernel(const uint8_t* __restrict__ x, float* __restrict__ y, long long n)
+{
+    __shared__ float lut[256];
+    lut[threadIdx.x] = (float)((double)threadIdx.x / 255.0);      // correctly rounded float32 of the float64 quotient
+    __syncthreads();
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i * 4 < n; i += stride) {
+        if (i * 4 + 4 <= n && ((((size_t)x) | ((size_t)y)) & 15) == 0) {
+            const unsigned v = *reinterpret_cast<const unsigned*>(x + i * 4);
+            st4g(y + i * 4, make_float4(lut[v & 255u], lut[(v >> 8) & 255u], lut[(v >> 16) & 255u], lut[v >> 24]));
+        } else {
+            for (long long j = i * 4; j < n && j < i * 4 + 4; ++j) y[j] = lut[x[j]];
+        }
+    }
+}
 __global__ void fill_kernel(float* __restrict__ a, float v, long long n)
 {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2496,6 +2511,18 @@ int myolo_add_inplace(float* a, const float* b, int64_t n, void* stream)
 {
     MYOLO_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
     hipLaunchKernelGGL(add_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, a, b, (long long)n);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* y[i] = x[i] / 255 as the correctly rounded float32 of the float64 quotient -- what `image / 255.` stored into a float32 batch gives
+ * (myolo_utils.py:824): a 256-entry table built once per launch in LDS from exactly that expression.  n % 4 == 0 (an image row of
+ * pixels x 3 channels always is for the even image sizes of this path; the tail is done bytewise otherwise). */
+int myolo_u8_to_unit_f32(const uint8_t* x, float* y, int64_t n, void* stream)
+{
+    MYOLO_REQUIRE(x && y && n > 0, "u8_to_unit_f32: bad arguments");
+    const long long quads = (long long)((n + 3) / 4);
+    hipLaunchKernelGGL(u8_unit_kernel, dim3(ew_blocks(quads)), dim3(256), 0, (hipStream_t)stream, x, y, (long long)n);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

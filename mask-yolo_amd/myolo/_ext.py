@@ -113,6 +113,7 @@ SIGS = {
     "myolo_pwconv1x1_bwd_weight_affine_in": [P, P, P, I, P, P, L, I, I, P, Z, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],
+    "myolo_u8_to_unit_f32": [P, P, L, P],
     "myolo_set_option": [ctypes.c_char_p, I],
     "myolo_get_option": [ctypes.c_char_p, P],
     "myolo_comm_unique_id": [P],

@@ -12,6 +12,7 @@ yolo_branch_graph :249-278; feature_map :848; DecodeYOLOLayer :1442-1473; Detect
 :605-661; build_mask_graph :668-715; yolo_custom_loss :86-242; myolo_mask_loss_graph :718-754;
 compile :1062-1094 (loss sum + Adam).
 """
+import threading
 import time
 
 import numpy as np
@@ -241,6 +242,7 @@ class Net(object):
         self.bucket1_on_wgrad_stream = 1  # data-parallel: bucket 1 released on the weight-gradient stream (0: round 3's join of that stream into the compute stream)
         self.pinned_upload = 1            # to_device_batch through pinned staging + the upload stream (0: synchronous torch.as_tensor copies, rounds 1-3)
         self.upload_own_stream = 0        # EXPERIMENT
+        self._stage_lock = threading.Lock()
         self._stage = None                # to_device_batch: ring of pinned staging sets + upload stream (created on first use)
         self._bind_cache = {}
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
@@ -1402,38 +1404,52 @@ class Net(object):
             out = {k: torch.as_tensor(np.ascontiguousarray(np.asarray(a).reshape(-1, T, 4) if k == "true_boxes" else a, dts[k]), device=dev)
                    for k, a in zip(keys, batch)}
             return out
-        if len(batch) == 3:
-            images, true_boxes, y_true = batch
-            items = [("images", images, np.float32, None), ("true_boxes", true_boxes, np.float32, (-1, T, 4)),
-                     ("y_true", y_true, np.float32, None)]
-        else:
-            images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
-            items = [("images", images, np.float32, None), ("true_boxes", true_boxes, np.float32, (-1, T, 4)),
-                     ("y_true", y_true, np.float32, None), ("gt_ids", gt_ids, np.int32, None),
-                     ("gt_boxes", gt_boxes, np.int32, None),
-                     ("gt_masks", gt_masks, np.uint8, None)]              # bool -> 0/1 bytes
+        n = int(np.asarray(batch[0]).shape[0])
+
+        def fill(arrays):
+            for dst, src in zip(arrays, batch):
+                np.copyto(dst, np.asarray(src).reshape(dst.shape), casting="unsafe")     # dtype conversion + the one host copy, into pinned memory
+        return self.stage_batch(fill, n, yolo=len(batch) == 3, u8_images=False)    # (the arrays are used as they are: no normalisation here)
+
+    def stage_batch(self, fill, n, yolo=False, u8_images=True):
+        """fill(arrays) writes a host batch of n images into the pinned staging arrays -- [images, true_boxes [n,T,4] f32, y_true f32
+        (, gt_ids i32, gt_boxes i32, gt_masks u8)]; images uint8 [n,H,W,3] (the raw bytes: `/ 255.` of myolo_utils.py:824 then happens on
+        the device, myolo_u8_to_unit_f32, and a quarter of the bytes cross PCIe) or float32 -- then the asynchronous upload is queued.
+        MaskYOLO.train() lets BatchGenerator.fill encode straight into these arrays on its prefetch thread.  -> device batch dict."""
+        cfg, dev = self.cfg, self.dev
+        H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+        G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+        spec = [("images", (n, H, W, 3), torch.uint8 if u8_images else torch.float32), ("true_boxes", (n, T, 4), torch.float32),
+                ("y_true", (n, cfg.GRID_H, G, A, 5 + C), torch.float32)]
+        if not yolo:
+            spec += [("gt_ids", (n, T), torch.int32), ("gt_boxes", (n, T, 4), torch.int32), ("gt_masks", (n, H, W, cfg.MAX_GT_INSTANCES), torch.uint8)]
         if self._stage is None:
             self._stage = [dict(bufs={}, ev=None) for _ in range(self._STAGE_SETS)]
             self._stage_i = 0
             self._upload_stream = _shared_stream(dev, "batch_upload") if self.upload_own_stream else self._copy_stream
-        st = self._stage[self._stage_i]
-        self._stage_i = (self._stage_i + 1) % self._STAGE_SETS
+        with self._stage_lock:
+            st = self._stage[self._stage_i]
+            self._stage_i = (self._stage_i + 1) % self._STAGE_SETS
         if st["ev"] is not None:
-            st["ev"].synchronize()                    # the staging set's previous H2D (two batches ago): long finished
+            st["ev"].synchronize()                    # the staging set's previous H2D (a few batches ago): long finished
+        arrays = []
+        for key, shape, dt in spec:
+            pin = st["bufs"].get(key)
+            if pin is None or tuple(pin.shape) != shape or pin.dtype != dt:
+                pin = st["bufs"][key] = torch.empty(shape, dtype=dt, pin_memory=True)
+            arrays.append(pin.numpy())
+        fill(arrays)
         out = {}
-        tdt = {np.float32: torch.float32, np.int32: torch.int32, np.uint8: torch.uint8}
         with torch.cuda.stream(self._upload_stream):
-            for key, arr, dt, shape in items:
-                a = np.asarray(arr)
-                if shape is not None:
-                    a = a.reshape(shape)
-                pin = st["bufs"].get(key)
-                if pin is None or tuple(pin.shape) != a.shape:
-                    pin = st["bufs"][key] = torch.empty(a.shape, dtype=tdt[dt], pin_memory=True)
-                np.copyto(pin.numpy(), a, casting="unsafe")          # dtype conversion + the one host copy, into pinned memory
-                t = torch.empty(a.shape, dtype=tdt[dt], device=dev)
-                t.copy_(pin, non_blocking=True)
+            for key, shape, dt in spec:
+                t = torch.empty(shape, dtype=dt, device=dev)
+                t.copy_(st["bufs"][key], non_blocking=True)
                 out[key] = t
+            if u8_images:
+                raw = out["images"]
+                out["images"] = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
+                X.call("myolo_u8_to_unit_f32", X.ptr(raw), X.ptr(out["images"]), raw.numel(), X.stream())
+                out["_raw_images"] = raw              # (kept until the conversion has run)
             st["ev"] = torch.cuda.Event()
             st["ev"].record(self._upload_stream)
         out["_ready"] = st["ev"]

@@ -27,6 +27,7 @@ import os
 import queue
 import re
 import threading
+import time
 
 import numpy as np
 import torch
@@ -127,15 +128,24 @@ class StepResult(collections.abc.Mapping):
 @contextlib.contextmanager
 def _gc_parked():
     """the cyclic collector parked for the duration of a training loop (a gen-2 pass over torch's object graph is a
-    multi-ms host stall in the middle of the launch sequence); collected once on the way out."""
+    multi-ms host stall in the middle of the launch sequence); collected once on the way out.  The interpreter's thread switch
+    interval is shortened meanwhile: the launch thread and the batch-prefetch thread share the GIL, and the default 5 ms is a
+    quarter of a step."""
+    import sys
     was = gc.isenabled()
-    gc.disable()
+    gc.collect()
+    gc.freeze()                   # everything alive now (the model, the dataset) is long-lived: keep it out of the closing collection,
+    gc.disable()                  # which then only walks what the loop itself left behind (a full pass cost ~40 ms per epoch of 16 steps)
+    sw = sys.getswitchinterval()
+    sys.setswitchinterval(min(sw, 0.0005))
     try:
         yield
     finally:
+        sys.setswitchinterval(sw)
         if was:
             gc.enable()
         gc.collect()
+        gc.unfreeze()
 
 
 class _Prefetcher(object):
@@ -185,6 +195,7 @@ class MaskYOLO(object):
         self.net = self.build(mode=mode, config=self.config)
         self.keras_model = _KerasModelShim(self)
         self.epoch = 0
+        self.host_times = {"wait_for_batch_s": 0.0, "launch_step_s": 0.0, "steps": 0}    # train(): where the launch thread's wall time goes
 
     # ------------------------------------------------------------------ build
     def build(self, mode, config):
@@ -352,9 +363,13 @@ class MaskYOLO(object):
         self.history = {"loss": [], "val_loss": []}
         n_steps = len(train_gen)
 
+        bytes_ok = bool(train_info) and all(inst[0].dtype == np.uint8 for inst in train_info)
+
         def make(i):                                   # runs on the prefetch thread, one batch ahead of the step
-            inputs, _ = train_gen[i]                   # the wrapped last batch is full-size (myolo_utils.py:730-735)
-            return self.net.to_device_batch(inputs)
+            # BatchGenerator.__getitem__'s arrays (the wrapped last batch is full-size, myolo_utils.py:730-735) encoded straight into
+            # the engine's pinned staging buffers; images travel as bytes and are normalised on the device
+            lo, hi = train_gen.batch_bounds(i)
+            return self.net.stage_batch(lambda arrays: train_gen.fill(i, arrays), hi - lo, yolo=(mode == 'yolo'), u8_images=bytes_ok)
 
         def report(ep, i, out):
             losses.append(out["loss"])
@@ -362,34 +377,46 @@ class MaskYOLO(object):
                 print("epoch %d step %d/%d loss %.4f (yolo %.4f mask %.4f recall %.3f)" %
                       (ep + 1, i + 1, n_steps, out["loss"], out["yolo_sum_loss"], out["mask_loss"], out["recall"]))
 
-        for ep in range(epochs):
-            losses = []
-            with _gc_parked():
+        # ONE prefetcher for the whole run (Keras' generator queue also keeps running across epoch ends): the first batches of epoch e+1
+        # are encoded and uploaded while epoch e finishes
+        stream = iter(_Prefetcher([(e, i) for e in range(epochs) for i in schedule], lambda it: make(it[1]), self.net.dev))
+        with _gc_parked():                          # for the whole run: a full collection at every epoch end cost ~50 ms per epoch
+            for ep in range(epochs):
+                losses = []
                 pending = None
-                for i, db in _Prefetcher(schedule, make, self.net.dev):
+                for _ in schedule:
+                    t0 = time.perf_counter()
+                    (_, i), db = next(stream)
+                    t1 = time.perf_counter()
                     out = self.train_on_batch(db)
+                    self.host_times["wait_for_batch_s"] += t1 - t0      # the launch thread blocked on the prefetch queue
+                    self.host_times["launch_step_s"] += time.perf_counter() - t1
+                    self.host_times["steps"] += 1
                     if pending is not None:            # step i-1's numbers are read once step i is queued behind it: the
                         report(ep, *pending)           # host never waits for the step it has just launched
                     pending = (i, out)
                 if pending is not None:
                     report(ep, *pending)
-            history.append(float(np.mean(losses)))
-            logs = {"loss": history[-1]}
-            if val_gen is not None and len(val_info) >= cfg.BATCH_SIZE:
-                # validation_data=val_generator, validation_steps=len(val_generator) (model.py:1053-1054): forward only, BN on
-                # moving statistics, batch-mean of the total loss.  Every rank evaluates the same (small) set.
-                vl = [self.evaluate_on_batch(val_gen[j][0])["loss"] for j in range(len(val_gen))]
-                logs["val_loss"] = float(np.mean(vl))
-                if verbose:
-                    print("epoch %d val_loss %.4f" % (ep + 1, logs["val_loss"]))
-            self.history["loss"].append(logs["loss"])
-            self.history["val_loss"].append(logs.get("val_loss", float("nan")))
-            if self.model_dir and rank == 0:
-                os.makedirs(self.model_dir, exist_ok=True)
-                stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
-                self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
-            for cb in (custom_callbacks or []):
-                (cb.on_epoch_end if hasattr(cb, "on_epoch_end") else cb)(ep, dict(logs))
+                gc.collect(0)                          # the young generation only (cheap): what this epoch's steps left behind
+                history.append(float(np.mean(losses)))
+                logs = {"loss": history[-1]}
+                if val_gen is not None and len(val_info) >= cfg.BATCH_SIZE:
+                    # validation_data=val_generator, validation_steps=len(val_generator) (model.py:1053-1054): forward only, BN on
+                    # moving statistics, batch-mean of the total loss.  Every rank evaluates the same (small) set.
+                    vl = [self.evaluate_on_batch(val_gen[j][0])["loss"] for j in range(len(val_gen))]
+                    logs["val_loss"] = float(np.mean(vl))
+                    if verbose:
+                        print("epoch %d val_loss %.4f" % (ep + 1, logs["val_loss"]))
+                self.history["loss"].append(logs["loss"])
+                self.history["val_loss"].append(logs.get("val_loss", float("nan")))
+                if self.model_dir and rank == 0:
+                    os.makedirs(self.model_dir, exist_ok=True)
+                    stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
+                    self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
+                for cb in (custom_callbacks or []):
+                    (cb.on_epoch_end if hasattr(cb, "on_epoch_end") else cb)(ep, dict(logs))
+        for _ in stream:                               # (drains the prefetch thread: nothing is left when every epoch ran)
+            pass
         self.epoch = max(self.epoch, epochs)
         return history
 

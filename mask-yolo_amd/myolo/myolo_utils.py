@@ -132,13 +132,19 @@ class BatchGenerator(object):
         iou = inter / (w * h + self.anchor_w * self.anchor_h - inter)
         return int(np.argmax(iou))
 
-    def __getitem__(self, idx):
+    def batch_bounds(self, idx):
+        """[l_bound, r_bound) of batch idx; the last batch is wrapped back to full size (myolo_utils.py:728-735)."""
         cfg = self.config
         l_bound = idx * cfg.BATCH_SIZE
         r_bound = (idx + 1) * cfg.BATCH_SIZE
         if r_bound > len(self.all_info):
             r_bound = len(self.all_info)
             l_bound = max(0, r_bound - cfg.BATCH_SIZE)
+        return l_bound, r_bound
+
+    def __getitem__(self, idx):
+        cfg = self.config
+        l_bound, r_bound = self.batch_bounds(idx)
         n = r_bound - l_bound
         H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
         T = cfg.TRUE_BOX_BUFFER
@@ -148,6 +154,31 @@ class BatchGenerator(object):
         gt_ids = np.zeros((n, T), dtype=np.int32)
         gt_boxes_b = np.zeros((n, T, 4), dtype=np.int32)
         gt_masks_b = np.zeros((n, H, W, cfg.MAX_GT_INSTANCES), dtype=bool)
+        self._encode(l_bound, r_bound, images, true_boxes, y_true, gt_ids, gt_boxes_b, gt_masks_b)
+        if self.mode == 'yolo':
+            return [images, true_boxes, y_true], []
+        return [images, true_boxes, y_true, gt_ids, gt_boxes_b, gt_masks_b], []
+
+    def fill(self, idx, out):
+        """__getitem__(idx)'s arrays written INTO caller-provided buffers `out` (same order; any float dtype for the three float
+        arrays, uint8 or bool masks; true_boxes may be [n,T,4]) -- MaskYOLO.train() hands in the engine's pinned staging buffers, so a
+        batch is encoded straight into the memory the H2D copy reads (no 35 MB of fresh arrays and no second host copy per step).
+        Same values as __getitem__ after the cast the upload applies anyway."""
+        l_bound, r_bound = self.batch_bounds(idx)
+        for a in out[1:]:
+            a.fill(0)                                # (images are overwritten completely)
+        tb = out[1].reshape(r_bound - l_bound, 1, 1, 1, -1, 4)
+        if self.mode == 'yolo':
+            self._encode(l_bound, r_bound, out[0], tb, out[2], None, None, None)
+        else:
+            self._encode(l_bound, r_bound, out[0], tb, out[2], out[3], out[4], out[5])
+        return out
+
+    def _encode(self, l_bound, r_bound, images, true_boxes, y_true, gt_ids, gt_boxes_b, gt_masks_b):
+        """the body of myolo_utils.py:748-844 on zero-initialised outputs."""
+        cfg = self.config
+        H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
+        T = cfg.TRUE_BOX_BUFFER
         cell_w = float(W) / cfg.GRID_W
         cell_h = float(H) / cfg.GRID_H
         for k, inst in enumerate(self.all_info[l_bound:r_bound]):
@@ -171,13 +202,24 @@ class BatchGenerator(object):
                     y_true[k, gy, gx, a, 5 + class_ids[i]] = 1
                     true_boxes[k, 0, 0, 0, tbi] = box
                     tbi = (tbi + 1) % T
-            images[k] = image / 255. if self.norm else image
-            gt_ids[k, :class_ids.shape[0]] = class_ids
-            gt_boxes_b[k, :boxes.shape[0]] = boxes
-            gt_masks_b[k, :, :, :masks.shape[-1]] = masks
-        if self.mode == 'yolo':
-            return [images, true_boxes, y_true], []
-        return [images, true_boxes, y_true, gt_ids, gt_boxes_b, gt_masks_b], []
+            if images.dtype == np.uint8:
+                # a byte batch (Net.stage_batch): the `/ 255.` happens on the device (myolo_u8_to_unit_f32, same bits)
+                assert self.norm and image.dtype == np.uint8, "byte staging needs uint8 images and norm=True"
+                images[k] = image
+            elif self.norm and image.dtype == np.uint8 and images.dtype == np.float32:
+                # image / 255. (float64) stored into the float32 batch (myolo_utils.py:824) = one correctly rounded float32 per byte
+                # value: a 256-entry table gives the same bits without the float64 temporary
+                np.take(_U8_OVER_255, image, out=images[k])
+            else:
+                images[k] = image / 255. if self.norm else image
+            if gt_ids is not None:
+                gt_ids[k, :class_ids.shape[0]] = class_ids
+                gt_boxes_b[k, :boxes.shape[0]] = boxes
+                for j in range(masks.shape[-1]):         # (channel by channel: load_mask stacks the instances channel-major, one
+                    gt_masks_b[k, :, :, j] = masks[:, :, j]   #  contiguous plane each -- twice as fast as the strided block assignment)
+
+
+_U8_OVER_255 = (np.arange(256) / 255.).astype(np.float32)
 
 
 # ---------------------------------------------------------------------------

@@ -962,3 +962,76 @@ def test_device_stream_training_equals_host_fed_training():
         batch, _ = BatchGenerator(samples, cfg, "training", shuffle=False, norm=True)[0]
         l2.append(m2.train_on_batch(batch)["loss"])
     assert l1 == l2 and np.isfinite(l1).all()
+
+
+# ------------------------------------------------------------------ round 4: the drop-in surface without host round trips
+def test_u8_to_unit_f32_is_the_generators_division():
+    """myolo_u8_to_unit_f32 == (image / 255.) stored into a float32 batch (myolo_utils.py:824), every byte value, ragged tail too."""
+    from myolo import _ext as X
+    for n in (256, 4 * 1001, 4 * 1001 + 3, 32 * 224 * 224 * 3):
+        x = torch.arange(n, device="cuda:0", dtype=torch.int64).mul_(2654435761).remainder_(256).to(torch.uint8)
+        y = torch.empty(n, device="cuda:0")
+        X.call("myolo_u8_to_unit_f32", X.ptr(x), X.ptr(y), n, X.stream())
+        want = (x.cpu().numpy() / 255.).astype(np.float32)
+        assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_stage_batch_fill_equals_to_device_batch_of_getitem():
+    """BatchGenerator.fill into the engine's pinned staging arrays (bytes for the images, normalised on the device) gives the
+    device batch that to_device_batch(gen[i]) gives -- every tensor bit-identical, last (wrapped) batch included."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=8)
+    samples = make_shapes_samples(20, cfg)
+    gen = BatchGenerator(samples, cfg, "training", shuffle=False, norm=True)
+    model = MaskYOLO(mode="training", config=cfg, seed=0)
+    net = model.net
+    for i in (0, 1, 2, 0, 1):                                    # more batches than staging sets: the ring is reused
+        a = net.to_device_batch(gen[i][0])
+        lo, hi = gen.batch_bounds(i)
+        b = net.stage_batch(lambda arrays: gen.fill(i, arrays), hi - lo)
+        torch.cuda.synchronize()
+        for k in ("images", "true_boxes", "y_true", "gt_ids", "gt_boxes", "gt_masks"):
+            assert a[k].dtype == b[k].dtype and torch.equal(a[k], b[k]), (i, k)
+    ygen = BatchGenerator(samples, cfg, "yolo", shuffle=False, norm=True)
+    a = net.to_device_batch(ygen[1][0])
+    b = net.stage_batch(lambda arrays: ygen.fill(1, arrays), 8, yolo=True)
+    torch.cuda.synchronize()
+    assert set(k for k in b if not k.startswith("_")) == {"images", "true_boxes", "y_true"}
+    for k in ("images", "true_boxes", "y_true"):
+        assert torch.equal(a[k], b[k])
+
+
+def test_step_result_is_lazy_and_train_equals_a_hand_loop():
+    """train_on_batch returns a Mapping whose scalars come from one small async copy and whose tensors are fetched on demand;
+    MaskYOLO.train (prefetch thread, pinned byte staging, results read one step late) produces the same weights and losses as
+    the plain loop gen[i] -> train_on_batch -> float(loss) it replaces."""
+    import collections.abc
+    from myolo.shapes import ShapesDataset
+    from myolo import myolo_utils as mutils
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=8)
+    ds = ShapesDataset(seed=7)
+    ds.load_shapes(24, 128, 128)
+    ds.prepare()
+    m1 = MaskYOLO(mode="training", config=cfg, seed=1)
+    hist = m1.train(ds, None, learning_rate=5e-4, epochs=2, layers="all", verbose=0, shuffle_seed=3)
+    m2 = MaskYOLO(mode="training", config=cfg, seed=1)
+    info = [list(mutils.load_image_gt(ds, cfg, i)) for i in ds.image_ids]
+    gen = mutils.BatchGenerator(info, cfg, mode="training", shuffle=True, norm=True, rng=np.random.RandomState(3))
+    m2.set_trainable(".*")
+    m2.compile(5e-4, cfg.LEARNING_MOMENTUM)
+    ref = []
+    for ep in range(2):
+        losses = []
+        for i in range(len(gen)):
+            out = m2.train_on_batch(gen[i][0])
+            assert isinstance(out, collections.abc.Mapping) and not isinstance(out, dict)
+            losses.append(out["loss"])
+        ref.append(float(np.mean(losses)))
+    assert hist == ref
+    s1, s2 = m1.state_dict(), m2.state_dict()
+    assert all(np.array_equal(s1[k], s2[k]) for k in s1)
+    # the Mapping: scalar keys, tensor keys on demand, the usual dict protocol
+    assert set(out.SCALARS) <= set(out.keys()) and "myolo_mask" in out and out.get("nope") is None
+    assert abs(out["loss"] - (out["yolo_sum_loss"] + out["mask_loss"])) < 1e-5
+    mm = out["myolo_mask"]
+    assert isinstance(mm, np.ndarray) and mm.shape[:2] == (8, cfg.TRAIN_ROIS_PER_IMAGE) and out["myolo_mask"] is mm
+    assert out.device("myolo_mask").is_cuda and dict(out)["loss"] == out["loss"]
