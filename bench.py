@@ -329,6 +329,20 @@ def bench_train(args, rank, world, local):
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
     mul_ms, mul_n = net.kernel_ms("wino_multiply")
     bucket_ms = reducer.bucket_ms() if world > 1 else None
+    weights_same = None
+    if world > 1:
+        # every rank must hold bit-identical weights after the K averaged updates: an integer digest of the flat parameter buffer, MIN == MAX over ranks
+        net.join_conv1_wgrad()
+        net.join_trunk_wgrad()
+        dig = net.flat_p.view(torch.int32).to(torch.int64).sum().reshape(1)
+        dig2 = (net.flat_p.view(torch.int32).to(torch.int64) * torch.arange(1, net.flat_p.numel() + 1, device=dev, dtype=torch.int64).remainder_(8191)).sum().reshape(1)
+        d = torch.cat([dig, dig2])
+        lo_, hi_ = d.clone(), d.clone()
+        if args.share_gpu:
+            lo_, hi_ = lo_.cpu(), hi_.cpu()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        weights_same = bool(torch.equal(lo_, hi_))
 
     # ---- second pass (not part of `value`): per-launch timings of the kernels north_star names
     net.timed_tags = {"roialign_fwd", "wino_in", "wino_out_in"} | {"dw%d_fwd" % i for i in range(1, 15)} | {"pw%d_fwd" % i for i in range(1, 15)}
@@ -614,7 +628,7 @@ def bench_train(args, rank, world, local):
     if world > 1:
         res["comm"] = {"backend": ("gloo (--share-gpu test mode: all ranks on one GPU)" if args.share_gpu else
                                    "RCCL via %s" % ("the C-ABI (myolo_comm_*)" if args.comm == "capi" else "torch.distributed (nccl)")),
-                       "rccl_ranks_seen": ranks_seen, "bucket_allreduce_ms": bucket_ms,
+                       "rccl_ranks_seen": ranks_seen, "bucket_allreduce_ms": bucket_ms, "weights_identical_across_ranks": weights_same,
                        "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
                        "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
                                "on the comm stream as soon as backward completes it"}

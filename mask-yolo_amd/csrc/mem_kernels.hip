@@ -40,7 +40,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_bwd_legacy", &MyoloOptions::dw_bwd_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
     const bool live = comp && ox < Wo;
     dw_f4p wv[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wv[k] = dw_pk(ld4g(w + k * C + c));
+    for (int k = 0; k < 9; ++k) wv[k] = dw_pk(ld4g(w + ((flags & 8) ? 8 - k : k) * C + c));     // flags & 8: the kernel rotated by 180 degrees (data gradient)
     // MODE 1: input map (scale / shift zeroed for a padding column: act(0 * v + 0) = 0); MODE 2: output map
     dw_f4p sc0 = dw_pk(make_float4(1.f, 1.f, 1.f, 1.f)), sh0 = dw_zero(), sc1 = sc0, sh1 = sh0;
     float lo = -INFINITY, hi = INFINITY;
@@ -1116,10 +1116,11 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
 }
 
 template <int S, int CQB>
-static void dw_rows_launch(const DwRowsGeom& g, const float* x, const float* w, float* y, int H, int W, int C, DwAffine af, DwFuse fu, hipStream_t s)
+static void dw_rows_launch(const DwRowsGeom& g, const float* x, const float* w, float* y, int H, int W, int C, DwAffine af, DwFuse fu, hipStream_t s,
+                           bool flip = false)
 {
     const unsigned xcd = (g.tiles % 8 == 0 && g.tiles >= 64 && !(g_myolo_opt.tune0 & 8)) ? (unsigned)(g.tiles / 8) : 0u;
-    const int flags = ((g_myolo_opt.tune0 & 16) ? 2 : 0) | ((g_myolo_opt.tune0 & 32) ? 4 : 0);      // timing-only ablations: no loads / no stores
+    const int flags = ((g_myolo_opt.tune0 & 16) ? 2 : 0) | ((g_myolo_opt.tune0 & 32) ? 4 : 0) | (flip ? 8 : 0);      // 2 / 4: timing-only ablations (no loads / no stores)
 #define DW_ROWS_GO(MODE, R6) hipLaunchKernelGGL((dw_rows_kernel<S, CQB, MODE, R6>), dim3((unsigned)g.tiles), dim3(256), 0, s, x, w, y, H, W, C, H / S, W / S, g.strips, g.chunks, g.rc, g.ncb, xcd, flags, af, fu)
     if (fu.in.scale || fu.stat) { if (fu.in.scale && fu.in.act == MYOLO_ACT_RELU6) DW_ROWS_GO(1, true); else DW_ROWS_GO(1, false); }
     else if (af.scale) { if (af.act == MYOLO_ACT_RELU6) DW_ROWS_GO(2, true); else DW_ROWS_GO(2, false); }
@@ -1446,17 +1447,39 @@ __global__ __launch_bounds__(256) void crop_bwd_grouped_kernel(const float* __re
 // per (pixel, box): with C = 256 a 256-thread workgroup is 4 consecutive pixels of ONE image (H*W % 4 == 0), so its
 // R boxes are shared.  The candidate window only has to be conservative (the exact floor/ceil test inside uses the
 // forward kernel's expressions), so multiplying by a reciprocal instead of dividing changes no result.
-__global__ __launch_bounds__(256) void crop_bwd_grouped_lds_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
-                                                                   float* __restrict__ dimg, int H, int W, int R, int ch, int cw)
+template <int TP>        // the workgroup's pixel tile is TP x TP (one wave per pixel): 2 -> 256 threads, 4 -> 1024 threads
+__global__ __launch_bounds__(64 * TP * TP) void crop_bwd_grouped_lds_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                                   float* __restrict__ dimg, int H, int W, int R, int ch, int cw,
+                                                                   unsigned xcd_tiles, int quad)
 {
     extern __shared__ __attribute__((aligned(16))) float sp[];      // [R][8]: y1 x1 y2 x2 | y0 1/sy x0 1/sx  (1/s = 0: degenerate)
     constexpr int C = 256, cq = 64;
-    const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Which four pixels a workgroup owns decides how often a crop sample is fetched: a sample touches up to 2 x 2 feature pixels.  With four
+    // CONSECUTIVE pixels of a row per workgroup and workgroup b on XCD b % 8, the two feature rows of a sample were served by different
+    // XCDs' L2s: rocprofv3 counted 2.6 GB of fetches for 0.94 GB of gradient crops (profiles/r4_pmc_trunk.json).  Now: a 2 x 2 pixel quad
+    // per workgroup (the four waves share most samples through L1) and XCD-contiguous workgroup order (every XCD owns whole images, so
+    // vertically adjacent quads share its L2).  The sums themselves are unchanged (each wave still walks its pixel's boxes in order).
+    unsigned bid = blockIdx.x;
+    if (xcd_tiles) bid = (bid & 7u) * xcd_tiles + (bid >> 3);
+    long long pix;
+    int b, y, x;
+    if (quad) {
+        const unsigned qw = (unsigned)W / TP, qpi = ((unsigned)H / TP) * qw;
+        b = (int)(bid / qpi);
+        const unsigned qr = bid - (unsigned)b * qpi;
+        const unsigned qy = qr / qw, qx = qr - qy * qw;
+        const int wv = threadIdx.x >> 6;
+        y = TP * (int)qy + (wv / TP);
+        x = TP * (int)qx + (wv % TP);
+        pix = ((long long)b * H + y) * W + x;
+    } else {
+        pix = (long long)bid * 4 + (threadIdx.x >> 6);
+        b = (int)(pix / ((long long)H * W));
+        const int rem = (int)(pix - (long long)b * H * W);
+        y = rem / W; x = rem - y * W;
+    }
     const int c = (threadIdx.x & 63) * 4;
-    const int b = (int)(pix / ((long long)H * W));
-    const int rem = (int)(pix - (long long)b * H * W);
-    const int y = rem / W, x = rem - y * W;
-    for (int r = threadIdx.x; r < R; r += 256) {
+    for (int r = threadIdx.x; r < R; r += 64 * TP * TP) {
         const float4 bx = ld4g(boxes + ((long long)b * R + r) * 4);
         const float sy = (ch > 1) ? (bx.z - bx.x) * (float)(H - 1) / (float)(ch - 1) : 0.f;
         const float sx = (cw > 1) ? (bx.w - bx.y) * (float)(W - 1) / (float)(cw - 1) : 0.f;
@@ -2299,7 +2322,16 @@ int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, 
     hipStream_t s = (hipStream_t)stream;
     const int Ho = H / stride, Wo = W / stride;
     const int per_row = W * (C / 4);
-    if (stride == 1)
+    if (stride == 1 && dw_rows_ok(H, W, C) && !g_myolo_opt.dw_bwd_legacy) {
+        // stride 1: dx = dy (*) w rotated by 180 degrees, SAME padding -- the forward's row-sliding kernel (the round-3 gather kernel fetched
+        // 1.5-2.2x the algorithmic bytes, profiles/r4_pmc_trunk.json)
+        const DwRowsGeom g = dw_rows_geom(N, H, W, C, 1);
+        const DwAffine none{nullptr, nullptr, MYOLO_ACT_NONE};
+        const DwFuse nof{none, nullptr};
+        if (g.cqb == 32) dw_rows_launch<1, 32>(g, dy, w, dx, H, W, C, none, nof, s, true);
+        else if (g.cqb == 16) dw_rows_launch<1, 16>(g, dy, w, dx, H, W, C, none, nof, s, true);
+        else dw_rows_launch<1, 8>(g, dy, w, dx, H, W, C, none, nof, s, true);
+    } else if (stride == 1)
         hipLaunchKernelGGL((dw_bwd_data_kernel<1>), dim3((per_row + 255) / 256, H, N), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
     else
         hipLaunchKernelGGL((dw_bwd_data_kernel<2>), dim3((per_row + 255) / 256, H, N), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
@@ -2406,8 +2438,17 @@ int myolo_roialign_bwd_grouped(const float* dout, const float* boxes, float* dim
     MYOLO_REQUIRE(dout && boxes && dimage && B > 0 && R > 0 && (C & 3) == 0, "roialign_bwd_grouped: bad arguments");
     const long long total = (long long)B * H * W * (C / 4);
     if (C == 256 && ((long long)H * W) % 4 == 0 && R <= 1536 && !g_myolo_opt.crop_bwd_nolds) {
-        hipLaunchKernelGGL(crop_bwd_grouped_lds_kernel, dim3((unsigned)(total / 256)), dim3(256), (size_t)R * 8 * sizeof(float),
-                           (hipStream_t)stream, dout, boxes, dimage, H, W, R, crop_h, crop_w);
+        const int mode = g_myolo_opt.tune0;            // ablation (kbench): 1 = round-3 pixel order, 3 = tiles without the XCD-contiguous order, 4 = 4 x 4 tiles
+        const bool t4 = (H % 4) == 0 && (W % 4) == 0 && mode == 4;      // (4 x 4 tiles, 1024 threads: measured slower than 2 x 2 -- 0.368 against 0.346 ms)
+        const int quad = ((H | W) & 1) == 0 && mode != 1;
+        const unsigned wgs = (unsigned)(total / (t4 ? 1024 : 256));
+        const unsigned xcd = (wgs % 8 == 0 && wgs >= 64 && mode != 3 && mode != 1) ? wgs / 8 : 0u;
+        if (t4)
+            hipLaunchKernelGGL(crop_bwd_grouped_lds_kernel<4>, dim3(wgs), dim3(1024), (size_t)R * 8 * sizeof(float),
+                               (hipStream_t)stream, dout, boxes, dimage, H, W, R, crop_h, crop_w, xcd, 1);
+        else
+            hipLaunchKernelGGL(crop_bwd_grouped_lds_kernel<2>, dim3(wgs), dim3(256), (size_t)R * 8 * sizeof(float),
+                               (hipStream_t)stream, dout, boxes, dimage, H, W, R, crop_h, crop_w, xcd, quad);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }

@@ -25,6 +25,7 @@ struct MyoloOptions {
     int tune0;            // scratch integer for kernel-tuning experiments (0 = off); never set by the product
     int dw_min_wg;        // depthwise forward (row-sliding kernel): workgroups wanted before rows stop being split into chunks (0 = default 1024)
     int dw_rows1;         // depthwise forward (round-3 kernel): one output row per thread (no vertical strip)
+    int dw_bwd_legacy;    // depthwise data gradient, stride 1: the round-3 gather kernel instead of the row-sliding one (ablation)
     int dw_legacy;        // depthwise forward: the round-3 register-tiled kernel also where the row-sliding LDS-staged one applies (ablation)
     int wino_x6;          // winograd multiply on the bf16 matrix pipe: 6 piece products per fp32 product, fp32 accumulation (csrc/wino_mm.hip)
     int wino_no_bt;       // winograd multiply: gemm_nn_fast on [K][N] filters instead of wino_mm_kernel on transposed ones

@@ -233,3 +233,26 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert d["comm"]["rccl_ranks_seen"] == 2 and len(d["comm"]["bucket_allreduce_ms"]) == 3 and all(v > 0 for v in d["comm"]["bucket_allreduce_ms"])
     assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert "variants" in d and "dense_mask_backward" in d["variants"]            # the variants ran in lockstep on both ranks
+
+
+def test_bench_eight_ranks_at_full_config2_size_on_one_gpu():
+    """BASELINE configs[2] minus the wire: `bench.py --gpus 8` at the FULL per-GPU size (224 x 224, batch 32 per rank, alpha 1, R = 147) with
+    the eight ranks sharing this box's one GPU (gloo transport; RCCL needs a device per rank).  Eight ranks are seen by the reducer, the global
+    batch is 256, every rank holds bit-identical weights after the averaged updates, the line is well-formed.  Not a throughput claim."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "3", "--warmup", "1", "--cpu-images", "0",
+                        "--no-variant", "--no-extras"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp8" and d["config"]["share_gpu"] is True
+    assert d["comm"]["rccl_ranks_seen"] == 8 and len(d["comm"]["bucket_allreduce_ms"]) == 3
+    assert d["comm"]["weights_identical_across_ranks"] is True
+    assert "224x224" in d["config"]["workload"] and "batch 32/GPU" in d["config"]["workload"] and np.isfinite(d["config"]["final_loss"])
