@@ -85,6 +85,7 @@ int myolo_dwconv3x3_affine_act_fwd(const float* x, const float* w, const float* 
                                    int N, int H, int W, int C, int stride, void* stream);
 int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx,
                              int N, int H, int W, int C, int stride, void* stream);
+size_t myolo_dwconv3x3_bwd_weight_ws_bytes(int N, int H, int W, int C, int stride);   /* scratch every path of the call below accepts */
 int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw,
                                int N, int H, int W, int C, int stride, void* ws, size_t ws_bytes, void* stream);
 

@@ -1115,6 +1115,155 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
     }
 }
 
+// Depthwise WEIGHT gradient in the same row-sliding form: dw[ky][kx][c] = sum over output pixels of x[oy*S+ky-pt][ox*S+kx-pl][c] * dy[oy][ox][c].
+// A thread (output column, channel quad) walks down the input rows of its chunk; an input row meets the dy rows it feeds (S=1: oy = iy+1-ky,
+// three of them, kept in a sliding register window; S=2: row 2m -> ky=0 of oy=m and ky=2 of oy=m-1, row 2m+1 -> ky=1 of oy=m), the
+// neighbouring columns come through the LDS row.  Each chunk counts exactly its own output rows (dy of other rows is loaded as zero).
+// The producing BatchNorm + activation is applied to x once per element on the way in (MODE-1 form of the forward).  Nine packed
+// accumulators per thread, reduced over the workgroup's columns in double into ONE row of partials per (image, strip, chunk),
+// finished by colreduce_finish<FinD2F> in a fixed order (deterministic).
+template <int S, int CQB, bool R6>
+__global__ __launch_bounds__(256, 4) void dw_rows_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
+                                                               int H, int W, int C, int Ho, int Wo, int strips, int chunks, int rc, int ncb,
+                                                               unsigned xcd_tiles, DwAffine in)
+{
+    constexpr int PX = 224 / CQB;
+    constexpr int NE = (S == 1) ? PX + 2 : PX + 1;
+    constexpr int NHALO = (S == 1) ? 2 : 1;
+    constexpr int NL = (S == 1) ? 1 : 2;
+    constexpr int PF = 2;
+    __shared__ float4 rowbuf[2][NE * CQB];
+    __shared__ float4 red[224];
+    const int tid = threadIdx.x;
+    unsigned b = blockIdx.x;
+    if (xcd_tiles) b = (b & 7u) * xcd_tiles + (b >> 3);
+    const int ch = b % (unsigned)chunks;
+    unsigned t = b / (unsigned)chunks;
+    const int sx = t % (unsigned)strips;
+    t /= (unsigned)strips;
+    const int cb = t % (unsigned)ncb;
+    const int n = t / (unsigned)ncb;
+    const int x0 = sx * PX;
+    const int y0 = ch * rc, y1 = min(y0 + rc, Ho);
+    const bool comp = tid < 224;
+    int px, q, e_w, col;
+    bool loader;
+    if (comp) {
+        px = tid / CQB; q = tid % CQB;
+        if (S == 1) { e_w = px + 1; col = x0 + px; } else { e_w = px; col = 2 * (x0 + px); }
+        loader = true;
+    } else {
+        const int k = tid - 224;
+        px = 0; q = k % CQB;
+        const int side = k / CQB;
+        loader = side < NHALO && CQB < 32;
+        if (S == 1) { e_w = side ? PX + 1 : 0; col = side ? x0 + PX : x0 - 1; } else { e_w = PX; col = 2 * (x0 + PX); }
+    }
+    const int c = (cb * CQB + q) * 4;
+    const bool colin = loader && col >= 0 && col < W;
+    const bool col2in = comp && (S == 2) && (col + 1) < W;
+    const int ox = x0 + px;
+    const bool live = comp && ox < Wo;
+    dw_f4p sc0 = dw_pk(make_float4(1.f, 1.f, 1.f, 1.f)), sh0 = dw_zero(), sc1 = sc0, sh1 = sh0;
+    float lo = -INFINITY, hi = INFINITY;
+    const bool inaff = in.scale != nullptr;
+    if (inaff) {
+        sc0 = dw_pk(ld4g(in.scale + c)); sh0 = dw_pk(ld4g(in.shift + c));
+        lo = in.act == MYOLO_ACT_NONE ? -INFINITY : 0.f;
+        hi = in.act == MYOLO_ACT_RELU6 ? 6.f : INFINITY;
+        sc1 = sc0; sh1 = sh0;
+        if (!colin) { sc0 = dw_zero(); sh0 = dw_zero(); }
+        if (!col2in) { sc1 = dw_zero(); sh1 = dw_zero(); }
+    }
+    if (CQB == 32 && !comp) {
+        const int k = tid - 224;
+        rowbuf[0][k] = f4zero(); rowbuf[1][k] = f4zero();
+        rowbuf[0][(NE - 1) * CQB + k] = f4zero(); rowbuf[1][(NE - 1) * CQB + k] = f4zero();
+    }
+    const int row0 = (S == 1) ? y0 - 1 : 2 * y0;
+    const int nrows = (S == 1) ? (y1 - y0 + 2) : (2 * (y1 - y0) + 1);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + (long long)n * H * W * C), 0, H * W * C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(dy + (long long)n * Ho * Wo * C), 0, Ho * Wo * C * 4, 0x00020000);
+    const unsigned off0 = colin ? (unsigned)(col * C + c) * 4u : DW_OOB;
+    const unsigned off1 = col2in ? off0 + (unsigned)C * 4u : DW_OOB;
+    const unsigned goff = live ? (unsigned)(ox * C + c) * 4u : DW_OOB;
+    const int rstride = W * C * 4, gstride = Wo * C * 4;
+    // what input row r brings with it: its x value(s) and the ONE new dy row it needs (S=1: oy = iy+1; S=2: even rows 2m -> oy = m)
+    auto fetch = [&](int r, float4* dx_, float4& dg) {
+        const int iy = row0 + r;
+        const bool ok = r < nrows && iy >= 0 && iy < H;
+        const unsigned ro = ok ? (unsigned)(iy * rstride) : DW_OOB;
+        dx_[0] = dw_bufld(rx, off0 + ro);
+        if (NL == 2) dx_[NL - 1] = dw_bufld(rx, off1 + ro);
+        const int oy = (S == 1) ? iy + 1 : (iy >> 1);
+        const bool need = (S == 1) || ((r & 1) == 0);
+        const bool gok = need && r < nrows && oy >= y0 && oy < y1;        // only this chunk's own output rows are counted
+        dg = dw_bufld(rg, gok ? goff + (unsigned)(oy * gstride) : DW_OOB);
+    };
+    float4 pfx[PF][NL], pfg[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) fetch(j, pfx[j], pfg[j]);
+    dw_f4p acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = dw_zero();
+    dw_f4p gA = dw_zero(), gB = dw_zero();          // S=1: dy[iy-1], dy[iy] (own column); S=2: gB = dy[m] of the current pair, gA = dy[m-1]
+    auto row = [&](int r, float4* curx, float4& curg) {
+        dw_f4p v0 = dw_pk(curx[0]), v1 = dw_pk(curx[NL - 1]);
+        const dw_f4p gC = dw_pk(curg);
+        fetch(r + PF, curx, curg);
+        const int iy = row0 + r;
+        if (inaff) {
+            if (iy >= 0 && iy < H) {
+                v0 = dw_affine_pk<R6>(v0, sc0, sh0, lo, hi);
+                if (NL == 2) v1 = dw_affine_pk<R6>(v1, sc1, sh1, lo, hi);
+            }
+        }
+        float4* buf = rowbuf[r & 1];
+        if (loader) buf[e_w * CQB + q] = dw_unpk(v0);
+        __syncthreads();
+        if (S == 1) {
+            const dw_f4p l = dw_pk(buf[px * CQB + q]), rt = dw_pk(buf[(px + 2) * CQB + q]);
+            // input row iy is tap ky of output row iy+1-ky: ky = 0 -> dy[iy+1] (just loaded), 1 -> dy[iy], 2 -> dy[iy-1]
+            acc[0] = dw_fma(l, gC, acc[0]); acc[1] = dw_fma(v0, gC, acc[1]); acc[2] = dw_fma(rt, gC, acc[2]);
+            acc[3] = dw_fma(l, gB, acc[3]); acc[4] = dw_fma(v0, gB, acc[4]); acc[5] = dw_fma(rt, gB, acc[5]);
+            acc[6] = dw_fma(l, gA, acc[6]); acc[7] = dw_fma(v0, gA, acc[7]); acc[8] = dw_fma(rt, gA, acc[8]);
+            gA = gB; gB = gC;
+        } else {
+            const dw_f4p rt = dw_pk(buf[(px + 1) * CQB + q]);
+            if ((r & 1) == 0) {                     // row 2m: ky = 0 of output m (dy just loaded), ky = 2 of output m-1
+                gA = gB; gB = gC;
+                acc[0] = dw_fma(v0, gB, acc[0]); acc[1] = dw_fma(v1, gB, acc[1]); acc[2] = dw_fma(rt, gB, acc[2]);
+                acc[6] = dw_fma(v0, gA, acc[6]); acc[7] = dw_fma(v1, gA, acc[7]); acc[8] = dw_fma(rt, gA, acc[8]);
+            } else {                                // row 2m+1: ky = 1 of output m
+                acc[3] = dw_fma(v0, gB, acc[3]); acc[4] = dw_fma(v1, gB, acc[4]); acc[5] = dw_fma(rt, gB, acc[5]);
+            }
+        }
+    };
+    for (int it = 0; it < nrows; it += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            const int r = it + j;
+            if (r < nrows) row(r, pfx[j], pfg[j]);
+        }
+    }
+    const long long blk = ((long long)n * strips + sx) * chunks + ch;
+#pragma unroll
+    for (int v = 0; v < 9; ++v) {
+        __syncthreads();
+        if (comp) red[tid] = dw_unpk(acc[v]);       // (dead and halo lanes only ever multiplied by dy = 0)
+        __syncthreads();
+        if (tid < CQB) {
+            double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            for (int j = 0; j < PX; ++j) {
+                const float4 tt = red[j * CQB + tid];
+                d0 += tt.x; d1 += tt.y; d2 += tt.z; d3 += tt.w;
+            }
+            double* o = part + (blk * 9 + v) * C + (cb * CQB + tid) * 4;
+            o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
+        }
+    }
+}
+
 template <int S, int CQB>
 static void dw_rows_launch(const DwRowsGeom& g, const float* x, const float* w, float* y, int H, int W, int C, DwAffine af, DwFuse fu, hipStream_t s,
                            bool flip = false)
@@ -2342,6 +2491,20 @@ int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, 
 static int dw_bwd_weight_impl(const float* x, DwAffine in, const float* dy, float* dw, int N, int H, int W, int C, int stride, void* ws,
                               size_t ws_bytes, void* stream);
 
+size_t myolo_dwconv3x3_bwd_weight_ws_bytes(int N, int H, int W, int C, int stride)
+{
+    if (N <= 0 || (C & 3) || (stride != 1 && stride != 2)) return 0;
+    const long long M = (long long)N * (H / stride) * (W / stride);
+    size_t need = align256(col_ws_bytes(M, C, 9)) + 9 * (size_t)C * sizeof(double);          // the generic column reduction (always accepted)
+    if (dw_rows_ok(H, W, C)) {
+        const DwRowsGeom g = dw_rows_geom(N, H, W, C, stride);
+        const size_t rows = align256((size_t)g.nblk * 9 * C * sizeof(double)) + 9 * (size_t)C * sizeof(double);
+        if (rows > need) need = rows;
+    }
+    const size_t tiled = align256((size_t)768 * 9 * C * sizeof(double)) + 9 * (size_t)C * sizeof(double);
+    return need > tiled ? need : tiled;
+}
+
 int myolo_dwconv3x3_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int C, int stride, void* ws,
                                size_t ws_bytes, void* stream)
 {
@@ -2367,6 +2530,25 @@ static int dw_bwd_weight_impl(const float* x, DwAffine in, const float* dy, floa
     const long long M = (long long)N * Ho * Wo;
     hipStream_t s = (hipStream_t)stream;
     const int cq = C / 4;
+    if (dw_rows_ok(H, W, C) && !g_myolo_opt.dw_wgrad_generic && !g_myolo_opt.dw_bwd_legacy) {
+        const DwRowsGeom g = dw_rows_geom(N, H, W, C, stride);
+        const size_t pb2 = align256((size_t)g.nblk * 9 * C * sizeof(double));
+        if (pb2 + 9 * C * sizeof(double) <= ws_bytes && ws && g.tiles < (1ll << 31)) {
+            double* part2 = (double*)ws;
+            double* tot2 = (double*)((char*)ws + pb2);
+            const unsigned xcd = (g.tiles % 8 == 0 && g.tiles >= 64) ? (unsigned)(g.tiles / 8) : 0u;
+            const bool r6 = in.scale && in.act == MYOLO_ACT_RELU6;
+#define DW_WG_GO(S_, CQB_) do { if (r6) hipLaunchKernelGGL((dw_rows_wgrad_kernel<S_, CQB_, true>), dim3((unsigned)g.tiles), dim3(256), 0, s, x, dy, part2, H, W, C, Ho, Wo, g.strips, g.chunks, g.rc, g.ncb, xcd, in); \
+                               else hipLaunchKernelGGL((dw_rows_wgrad_kernel<S_, CQB_, false>), dim3((unsigned)g.tiles), dim3(256), 0, s, x, dy, part2, H, W, C, Ho, Wo, g.strips, g.chunks, g.rc, g.ncb, xcd, in); } while (0)
+            if (stride == 1) { if (g.cqb == 32) DW_WG_GO(1, 32); else if (g.cqb == 16) DW_WG_GO(1, 16); else DW_WG_GO(1, 8); }
+            else { if (g.cqb == 32) DW_WG_GO(2, 32); else if (g.cqb == 16) DW_WG_GO(2, 16); else DW_WG_GO(2, 8); }
+#undef DW_WG_GO
+            const int nvc = 9 * C;
+            hipLaunchKernelGGL((colreduce_finish<FinD2F>), dim3((nvc + 7) / 8), dim3(256), 0, s, part2, tot2, g.nblk, nvc, C, FinD2F{dw});
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+    }
     if (cq <= 256 && (256 % cq) == 0 && !g_myolo_opt.dw_wgrad_generic) {
         // tiled kernel: 2 rows x 4 columns (stride 1) / 2 x 2 (stride 2) of output pixels per thread
         const int TW = stride == 1 ? 4 : 2, TH = 2;

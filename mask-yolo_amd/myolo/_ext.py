@@ -149,6 +149,8 @@ def load():
     lib.myolo_conv3x3s2_c3_bnstats_ws_bytes.restype = Z
     lib.myolo_dwconv3x3_bnstats_ws_bytes.argtypes = [I, I, I, I, I]
     lib.myolo_dwconv3x3_bnstats_ws_bytes.restype = Z
+    lib.myolo_dwconv3x3_bwd_weight_ws_bytes.argtypes = [I, I, I, I, I]
+    lib.myolo_dwconv3x3_bwd_weight_ws_bytes.restype = Z
     lib.myolo_pwconv1x1_bnstats_ws_bytes.argtypes = [L, I, I]
     lib.myolo_pwconv1x1_bnstats_ws_bytes.restype = Z
     lib.myolo_pwconv1x1_bnstats_ok.argtypes = [I, I]
@@ -183,7 +185,7 @@ def load():
 
 
 def exported_symbols():
-    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes", "myolo_conv3x3s2_c3_bnstats_ws_bytes", "myolo_dwconv3x3_bnstats_ws_bytes",
+    return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes", "myolo_conv3x3s2_c3_bnstats_ws_bytes", "myolo_dwconv3x3_bnstats_ws_bytes", "myolo_dwconv3x3_bwd_weight_ws_bytes",
                               "myolo_pwconv1x1_bnstats_ws_bytes", "myolo_pwconv1x1_bnstats_ok",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
 
@@ -294,6 +296,10 @@ def conv1_bnstats_ws_bytes(n, h, w, cout):
 
 def dw_bnstats_ws_bytes(n, h, w, c, stride):
     return int(load().myolo_dwconv3x3_bnstats_ws_bytes(int(n), int(h), int(w), int(c), int(stride)))
+
+
+def dw_bwd_weight_ws_bytes(n, h, w, c, stride):
+    return int(load().myolo_dwconv3x3_bwd_weight_ws_bytes(int(n), int(h), int(w), int(c), int(stride)))
 
 
 def pw_bnstats_ws_bytes(m, cin, cout):

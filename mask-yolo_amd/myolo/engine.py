@@ -583,6 +583,8 @@ class Net(object):
         with torch.cuda.stream(self._twg_stream):
             fn(self._ws_twg.ptr, self._ws_twg.size)
         for t in tensors:
+            if isinstance(t, tuple) and len(t) == 3 and t[0] == "lazy":       # ("lazy", pre-BN tensor, bn): the tensor inside is what the kernels read
+                t = t[1]
             if torch.is_tensor(t):
                 t.record_stream(self._twg_stream)
         self._twg_pending = True
@@ -601,7 +603,8 @@ class Net(object):
         Co = self.p[pwn + "/kernel"].shape[3]
         M = N * Ho * Wo
         dy2 = self.bn_act_bwd(pwn + "_bn", da)
-        self._ws_twg.ensure(X.workspace_bytes(M, C, Co))
+        # the scratch the weight gradients will really run on (their own stream's, or the main one without the overlap), sized for both of them
+        (self._ws_twg if self.overlap_trunk_wgrad else self.ws).ensure(max(X.workspace_bytes(M, C, Co), X.dw_bwd_weight_ws_bytes(N, H, W, C, stride)))
 
         def pw_wgrad(wsp, wsz):
             if self._is_lazy(ad):       # the forward normalised the depthwise output on load: so does the weight gradient
