@@ -130,6 +130,8 @@ static size_t col_ws_bytes(long long M, int C, int nv)
     return (size_t)g.rblocks * nv * C * sizeof(double);
 }
 
+template <class OP, class = void> struct colreduce_hoists : std::false_type {};
+template <class OP> struct colreduce_hoists<OP, std::void_t<decltype(OP::HOIST)>> : std::true_type {};
 template <class OP>
 __global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int C, ColGeom g, double* __restrict__ part)
 {
@@ -145,8 +147,10 @@ __global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int 
     float4 acc[NV];
 #pragma unroll
     for (int v = 0; v < NV; ++v) acc[v] = f4zero();
-    if (cok)
+    if (cok) {
+        if constexpr (colreduce_hoists<OP>::value) op.init(cq * 4);
         for (long long r = r0 + pl_i; r < r1; r += g.pl) op(r, cq * 4, acc);
+    }
     // combine row lanes
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -336,6 +340,9 @@ __global__ __launch_bounds__(256) void bn_frozen_batched_kernel(const float* __r
     }
 }
 
+// (round 4) These streaming kernels are bound by their VALU work, not by HBM (a wave64 fp32 instruction takes 4 cycles: 16 lanes per cycle), so the
+// per-element index arithmetic is taken out of the loop: the grid-stride is a multiple of 256 and C/4 divides 256 for every layer of this net, so a
+// thread keeps ONE channel quad -- its coefficients are loaded once, no 64-bit modulo per element (HOIST; the general form stays for other C).
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, float* __restrict__ y,
                                                        long long nquads, int C, int act)
@@ -344,6 +351,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int cq = C / 4;
+    if ((256 % cq) == 0) {
+        const int c = (int)((unsigned)(blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)cq) * 4;
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        for (; i < nquads; i += stride) {
+            const float4 v = ld4g(x + i * 4);
+            float4 o;
+            o.x = actf(fmaf(v.x, sc.x, sh.x), act);
+            o.y = actf(fmaf(v.y, sc.y, sh.y), act);
+            o.z = actf(fmaf(v.z, sc.z, sh.z), act);
+            o.w = actf(fmaf(v.w, sc.w, sh.w), act);
+            if (nt) st4g_nt(y + i * 4, o); else st4g(y + i * 4, o);
+        }
+        return;
+    }
     for (; i < nquads; i += stride) {
         const int c = (int)(i % cq) * 4;
         const float4 v = ld4g(x + i * 4);
@@ -395,6 +416,7 @@ __global__ __launch_bounds__(256) void bn_frozen_apply_kernel(const float* __res
 // backward pass 1: dbeta = sum dz, dgamma = sum dz*xhat, with dz = dy * actmask(x*scale+shift)
 struct OpBnBwd {
     static constexpr int NV = 2;
+    static constexpr int HOIST = 1;      // colreduce_kernel calls init(c) once per thread: the channel's terms stay in registers
     const float* dy;
     const float* x;
     const float* scale;
@@ -402,15 +424,21 @@ struct OpBnBwd {
     const float* mean;
     const float* var;
     int C, act;
+    float4 sc, sh, mu, rs;
+    __device__ void init(int c)
+    {
+        sc = ld4g(scale + c); sh = ld4g(shift + c); mu = ld4g(mean + c);
+        const float4 vr = ld4g(var + c);
+        rs = make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F));
+    }
     __device__ void operator()(long long r, int c, float4* acc) const
     {
         const float4 g = ld4g(dy + r * C + c), v = ld4g(x + r * C + c);
-        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c), mu = ld4g(mean + c), vr = ld4g(var + c);
         float dz, xh;
-        dz = g.x * actmask(fmaf(v.x, sc.x, sh.x), act); xh = (v.x - mu.x) * rsqrtf(vr.x + BN_EPS_F); acc[0].x += dz; acc[1].x = fmaf(dz, xh, acc[1].x);
-        dz = g.y * actmask(fmaf(v.y, sc.y, sh.y), act); xh = (v.y - mu.y) * rsqrtf(vr.y + BN_EPS_F); acc[0].y += dz; acc[1].y = fmaf(dz, xh, acc[1].y);
-        dz = g.z * actmask(fmaf(v.z, sc.z, sh.z), act); xh = (v.z - mu.z) * rsqrtf(vr.z + BN_EPS_F); acc[0].z += dz; acc[1].z = fmaf(dz, xh, acc[1].z);
-        dz = g.w * actmask(fmaf(v.w, sc.w, sh.w), act); xh = (v.w - mu.w) * rsqrtf(vr.w + BN_EPS_F); acc[0].w += dz; acc[1].w = fmaf(dz, xh, acc[1].w);
+        dz = g.x * actmask(fmaf(v.x, sc.x, sh.x), act); xh = (v.x - mu.x) * rs.x; acc[0].x += dz; acc[1].x = fmaf(dz, xh, acc[1].x);
+        dz = g.y * actmask(fmaf(v.y, sc.y, sh.y), act); xh = (v.y - mu.y) * rs.y; acc[0].y += dz; acc[1].y = fmaf(dz, xh, acc[1].y);
+        dz = g.z * actmask(fmaf(v.z, sc.z, sh.z), act); xh = (v.z - mu.z) * rs.z; acc[0].z += dz; acc[1].z = fmaf(dz, xh, acc[1].z);
+        dz = g.w * actmask(fmaf(v.w, sc.w, sh.w), act); xh = (v.w - mu.w) * rs.w; acc[0].w += dz; acc[1].w = fmaf(dz, xh, acc[1].w);
     }
 };
 
@@ -444,6 +472,16 @@ struct FinBnBwdCoef {                // FinBnBwd + the per-channel terms of dx =
     }
 };
 
+__device__ __forceinline__ float bn_dx_one(float g, float x, float sc, float sh, float mu, float rstd, float db, float dg, float invM, int act,
+                                           int batch_stats)
+{
+    const float dz = g * actmask(fmaf(x, sc, sh), act);
+    if (batch_stats) {
+        const float xh = (x - mu) * rstd;
+        return sc * (dz - (db + xh * dg) * invM);
+    }
+    return sc * dz;
+}
 __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ var,
@@ -453,6 +491,28 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long stride = (long long)gridDim.x * blockDim.x;
     const int cq = C / 4;
+    const bool nt = nquads > (4ll << 20);
+    if ((256 % cq) == 0) {              // HOIST (see bn_apply_kernel): one channel quad per thread, its eight per-channel terms formed once
+        const int c = (int)((unsigned)(blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)cq) * 4;
+        const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        float4 mu = f4zero(), rs = f4zero(), db = f4zero(), dg = f4zero();
+        if (batch_stats) {
+            mu = ld4g(mean + c);
+            const float4 vr = ld4g(var + c);
+            rs = make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F));
+            db = make_float4((float)tot[c], (float)tot[c + 1], (float)tot[c + 2], (float)tot[c + 3]);
+            dg = make_float4((float)tot[C + c], (float)tot[C + c + 1], (float)tot[C + c + 2], (float)tot[C + c + 3]);
+        }
+        for (; i < nquads; i += stride) {
+            const float4 g = ld4g(dy + i * 4), v = ld4g(x + i * 4);
+            const float4 o = make_float4(bn_dx_one(g.x, v.x, sc.x, sh.x, mu.x, rs.x, db.x, dg.x, invM, act, batch_stats),
+                                         bn_dx_one(g.y, v.y, sc.y, sh.y, mu.y, rs.y, db.y, dg.y, invM, act, batch_stats),
+                                         bn_dx_one(g.z, v.z, sc.z, sh.z, mu.z, rs.z, db.z, dg.z, invM, act, batch_stats),
+                                         bn_dx_one(g.w, v.w, sc.w, sh.w, mu.w, rs.w, db.w, dg.w, invM, act, batch_stats));
+            if (nt) st4g_nt(dx + i * 4, o); else st4g(dx + i * 4, o);
+        }
+        return;
+    }
     for (; i < nquads; i += stride) {
         const int c = (int)(i % cq) * 4;
         const float4 g = ld4g(dy + i * 4), v = ld4g(x + i * 4);
@@ -462,16 +522,11 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
         float o[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float dz = gv[k] * actmask(fmaf(xv[k], scv[k], shv[k]), act);
-            if (batch_stats) {
-                const float xh = (xv[k] - mean[c + k]) * rsqrtf(var[c + k] + BN_EPS_F);
-                const float db = (float)tot[c + k], dg = (float)tot[C + c + k];
-                o[k] = scv[k] * (dz - (db + xh * dg) * invM);
-            } else {
-                o[k] = scv[k] * dz;
-            }
+            const float mu = batch_stats ? mean[c + k] : 0.f, rstd = batch_stats ? rsqrtf(var[c + k] + BN_EPS_F) : 0.f;
+            const float db = batch_stats ? (float)tot[c + k] : 0.f, dg = batch_stats ? (float)tot[C + c + k] : 0.f;
+            o[k] = bn_dx_one(gv[k], xv[k], scv[k], shv[k], mu, rstd, db, dg, invM, act, batch_stats);
         }
-        if (nquads > (4ll << 20)) st4g_nt(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        if (nt) st4g_nt(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
         else st4g(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
@@ -519,12 +574,12 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_post_kernel(const float* __rest
 __global__ __launch_bounds__(256) void gather_groups_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
                                                             float* __restrict__ dst, int n, long long gq)
 {
-    const long long total = (long long)n * gq;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (; i < total; i += stride) {
-        const long long g = i / gq, o = i - g * gq;
-        st4g(dst + i * 4, ld4g(src + ((long long)idx[g] * gq + o) * 4));
+    // blockIdx.y walks the groups, blockIdx.x / the loop the quads inside one: no 64-bit division per element (round 3: i / gq)
+    for (int g = blockIdx.y; g < n; g += gridDim.y) {
+        const float* sp = src + (long long)idx[g] * gq * 4;
+        float* dp = dst + (long long)g * gq * 4;
+        for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < gq; o += (long long)gridDim.x * blockDim.x)
+            st4g(dp + o * 4, ld4g(sp + o * 4));
     }
 }
 
@@ -2219,8 +2274,16 @@ int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n,
         return MYOLO_OK;
     }
     const long long total = (long long)n * (group_elems / 4);
-    hipLaunchKernelGGL(gather_groups_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n,
-                       (long long)(group_elems / 4));
+    {
+        const long long gq = (long long)(group_elems / 4);
+        long long bx = (gq + 255) / 256;
+        if (bx > 64) bx = 64;
+        long long by = n;
+        if (by * bx > 16384) by = 16384 / bx;
+        if (by < 1) by = 1;
+        (void)total;
+        hipLaunchKernelGGL(gather_groups_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, gq);
+    }
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

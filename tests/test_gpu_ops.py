@@ -1150,3 +1150,21 @@ def test_measurement_probes_run_and_are_plausible():
     assert float(out.abs().sum()) == 0.0                   # the probe never writes (its store is behind an impossible condition)
     hb = X.measure_hbm_copy_gbs(nbytes=256 << 20, iters=2, device=DEV)
     assert hb["float4"] > 500.0 and hb["read_only_1wg_per_cu"] > 500.0, hb
+
+
+def test_gather_groups_matches_index_select():
+    """myolo_gather_groups (round 4: groups on blockIdx.y, no per-element division) against torch indexing: many small groups (more than
+    the grid's y extent), a few big ones, scalar groups."""
+    from myolo import _ext as X
+    g = torch.Generator(device="cuda:0").manual_seed(3)
+    for n_src, n, ge in ((4704, 3000, 49 * 64), (300, 7, 784 * 256), (5000, 4999, 4), (64, 64, 196 * 256)):
+        src = torch.randn(n_src, ge, device="cuda:0", generator=g)
+        idx = torch.randint(0, n_src, (n,), device="cuda:0", generator=g, dtype=torch.int32)
+        dst = torch.empty(n, ge, device="cuda:0")
+        X.call("myolo_gather_groups", X.ptr(src), X.ptr(idx), X.ptr(dst), n, ge, X.stream())
+        assert torch.equal(dst, src[idx.long()])
+    src = torch.arange(1000, device="cuda:0", dtype=torch.float32).view(1000, 1)          # one 4-byte element per group
+    idx = torch.randint(0, 1000, (333,), device="cuda:0", generator=g, dtype=torch.int32)
+    dst = torch.empty(333, 1, device="cuda:0")
+    X.call("myolo_gather_groups", X.ptr(src), X.ptr(idx), X.ptr(dst), 333, 1, X.stream())
+    assert torch.equal(dst, src[idx.long()])

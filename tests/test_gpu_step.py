@@ -259,26 +259,36 @@ def test_sparse_mask_backward_equals_dense():
     gradients agree with the dense path to fp32 summation-order noise, on the same device inputs.
     The dense path keeps the deconv output of the forward, the sparse one rebuilds it for the positives with a launch of a different
     size (different split-K): an element that is ~1e-7 from zero can come out on the other side of the ReLU, and with 4 positive
-    ROIs one such flip moves a gradient tensor by ~1e-3 of its norm -- the bound scales with the number of flips found."""
-    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
-    grads, cap = [], []
-    for sparse in (False, True):
-        model = MaskYOLO(mode="training", config=cfg)
-        model.load_state_dict(P)
-        model.net.sparse_mask_bwd = sparse
-        model.net.tape_hook = _capture_mask_tape(cap)
-        out = model.train_on_batch(batch, learning_rate=0.0)
-        grads.append(model.net.grads_dict())
-    R = out["myolo_mask"].shape[1]
-    pos = np.concatenate([np.arange(b * R, b * R + n) for b, n in enumerate(out["n_pos"])])
-    flips = _relu_flips(P, cap[0], cap[1], pos, len(out["n_pos"]) * R) if len(pos) else 0
-    worst = 0.0
-    for k in grads[0]:
-        d = grads[0][k]
-        if np.abs(d).max() < 1e-12 or k == "myolo_mask_conv1/bias":
-            continue
-        worst = max(worst, rel(grads[1][k], d))
-    assert worst < 1e-4 + 5e-3 * flips, (worst, flips)
+    ROIs one such flip switches a whole gradient term on or off (measured: up to 1.5e-2 of a tensor's maximum for ONE flip).  Which
+    element sits that close to zero is rounding luck of the kernels in front, so the tight bound is asserted on the first of a few seeded
+    cases in which NO decision flipped (round 4: seed 0 had one flip after the depthwise kernels changed their statistics' summation
+    order; with the round-3 kernels the same case has none and agrees to 3e-5)."""
+    seen = []
+    for seed in (0, 1, 2, 3, 4):
+        cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4, seed=seed)
+        grads, cap = [], []
+        for sparse in (False, True):
+            model = MaskYOLO(mode="training", config=cfg)
+            model.load_state_dict(P)
+            model.net.sparse_mask_bwd = sparse
+            model.net.tape_hook = _capture_mask_tape(cap)
+            out = model.train_on_batch(batch, learning_rate=0.0)
+            grads.append(model.net.grads_dict())
+        R = out["myolo_mask"].shape[1]
+        pos = np.concatenate([np.arange(b * R, b * R + n) for b, n in enumerate(out["n_pos"])])
+        flips = _relu_flips(P, cap[0], cap[1], pos, len(out["n_pos"]) * R) if len(pos) else 0
+        worst = 0.0
+        for k in grads[0]:
+            d = grads[0][k]
+            if np.abs(d).max() < 1e-12 or k == "myolo_mask_conv1/bias":
+                continue
+            worst = max(worst, rel(grads[1][k], d))
+        seen.append((seed, flips, worst))
+        assert len(pos) > 0
+        assert worst < 1e-4 + 3e-2 * flips, seen
+        if flips == 0:
+            return
+    raise AssertionError("no seeded case without a ReLU flip between the two forwards: %r" % (seen,))
 
 
 @pytest.mark.parametrize("tiles", ["f63", "f43"])
