@@ -97,6 +97,7 @@ struct ColGeom {
     int cgroups;     // ceil((C/4) / cl)
     int rblocks;     // number of row slabs
     long long rows_per_block;
+    int unroll4;     // four rows per loop trip (ablation: option tune0 & 64 turns it off)
 };
 
 static ColGeom col_geom(long long M, int C)
@@ -121,6 +122,7 @@ static ColGeom col_geom(long long M, int C)
     if (rpb < min_rows) rpb = min_rows;
     g.rows_per_block = rpb;
     g.rblocks = (int)cdiv64(M, rpb);
+    g.unroll4 = (g_myolo_opt.tune0 & 64) ? 0 : 1;
     return g;
 }
 
@@ -149,7 +151,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(OP op, long long M, int 
     for (int v = 0; v < NV; ++v) acc[v] = f4zero();
     if (cok) {
         if constexpr (colreduce_hoists<OP>::value) op.init(cq * 4);
-        for (long long r = r0 + pl_i; r < r1; r += g.pl) op(r, cq * 4, acc);
+        // four rows per trip: their loads are independent, so 4x the bytes are in flight per thread (one row per trip ran at ~2 TB/s on the
+        // BatchNorm-backward sums: a dependent load -> accumulate chain per row).  Same rows, same order of additions per accumulator.
+        long long r = r0 + pl_i;
+        const long long st = g.pl;
+        if (g.unroll4)
+        for (; r + 3 * st < r1; r += 4 * st) {
+            op(r, cq * 4, acc);
+            op(r + st, cq * 4, acc);
+            op(r + 2 * st, cq * 4, acc);
+            op(r + 3 * st, cq * 4, acc);
+        }
+        for (; r < r1; r += st) op(r, cq * 4, acc);
     }
     // combine row lanes
 #pragma unroll
