@@ -367,13 +367,18 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if ((256 % cq) == 0) {
         const int c = (int)((unsigned)(blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)cq) * 4;
         const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+        auto one = [&](float4 v) {
+            return make_float4(actf(fmaf(v.x, sc.x, sh.x), act), actf(fmaf(v.y, sc.y, sh.y), act), actf(fmaf(v.z, sc.z, sh.z), act),
+                               actf(fmaf(v.w, sc.w, sh.w), act));
+        };
+        for (; i + 3 * stride < nquads; i += 4 * stride) {          // four independent quads per trip
+            const float4 v0 = ld4g(x + i * 4), v1 = ld4g(x + (i + stride) * 4), v2 = ld4g(x + (i + 2 * stride) * 4), v3 = ld4g(x + (i + 3 * stride) * 4);
+            const float4 o0 = one(v0), o1 = one(v1), o2 = one(v2), o3 = one(v3);
+            if (nt) { st4g_nt(y + i * 4, o0); st4g_nt(y + (i + stride) * 4, o1); st4g_nt(y + (i + 2 * stride) * 4, o2); st4g_nt(y + (i + 3 * stride) * 4, o3); }
+            else { st4g(y + i * 4, o0); st4g(y + (i + stride) * 4, o1); st4g(y + (i + 2 * stride) * 4, o2); st4g(y + (i + 3 * stride) * 4, o3); }
+        }
         for (; i < nquads; i += stride) {
-            const float4 v = ld4g(x + i * 4);
-            float4 o;
-            o.x = actf(fmaf(v.x, sc.x, sh.x), act);
-            o.y = actf(fmaf(v.y, sc.y, sh.y), act);
-            o.z = actf(fmaf(v.z, sc.z, sh.z), act);
-            o.w = actf(fmaf(v.w, sc.w, sh.w), act);
+            const float4 o = one(ld4g(x + i * 4));
             if (nt) st4g_nt(y + i * 4, o); else st4g(y + i * 4, o);
         }
         return;
@@ -516,12 +521,23 @@ __global__ __launch_bounds__(256) void bn_bwd_dx_kernel(const float* __restrict_
             db = make_float4((float)tot[c], (float)tot[c + 1], (float)tot[c + 2], (float)tot[c + 3]);
             dg = make_float4((float)tot[C + c], (float)tot[C + c + 1], (float)tot[C + c + 2], (float)tot[C + c + 3]);
         }
+        auto one = [&](float4 g, float4 v) {
+            return make_float4(bn_dx_one(g.x, v.x, sc.x, sh.x, mu.x, rs.x, db.x, dg.x, invM, act, batch_stats),
+                               bn_dx_one(g.y, v.y, sc.y, sh.y, mu.y, rs.y, db.y, dg.y, invM, act, batch_stats),
+                               bn_dx_one(g.z, v.z, sc.z, sh.z, mu.z, rs.z, db.z, dg.z, invM, act, batch_stats),
+                               bn_dx_one(g.w, v.w, sc.w, sh.w, mu.w, rs.w, db.w, dg.w, invM, act, batch_stats));
+        };
+        for (; i + 3 * stride < nquads; i += 4 * stride) {          // four independent quads per trip: eight loads in flight per thread
+            const float4 g0 = ld4g(dy + i * 4), v0 = ld4g(x + i * 4);
+            const float4 g1 = ld4g(dy + (i + stride) * 4), v1 = ld4g(x + (i + stride) * 4);
+            const float4 g2 = ld4g(dy + (i + 2 * stride) * 4), v2 = ld4g(x + (i + 2 * stride) * 4);
+            const float4 g3 = ld4g(dy + (i + 3 * stride) * 4), v3 = ld4g(x + (i + 3 * stride) * 4);
+            const float4 o0 = one(g0, v0), o1 = one(g1, v1), o2 = one(g2, v2), o3 = one(g3, v3);
+            if (nt) { st4g_nt(dx + i * 4, o0); st4g_nt(dx + (i + stride) * 4, o1); st4g_nt(dx + (i + 2 * stride) * 4, o2); st4g_nt(dx + (i + 3 * stride) * 4, o3); }
+            else { st4g(dx + i * 4, o0); st4g(dx + (i + stride) * 4, o1); st4g(dx + (i + 2 * stride) * 4, o2); st4g(dx + (i + 3 * stride) * 4, o3); }
+        }
         for (; i < nquads; i += stride) {
-            const float4 g = ld4g(dy + i * 4), v = ld4g(x + i * 4);
-            const float4 o = make_float4(bn_dx_one(g.x, v.x, sc.x, sh.x, mu.x, rs.x, db.x, dg.x, invM, act, batch_stats),
-                                         bn_dx_one(g.y, v.y, sc.y, sh.y, mu.y, rs.y, db.y, dg.y, invM, act, batch_stats),
-                                         bn_dx_one(g.z, v.z, sc.z, sh.z, mu.z, rs.z, db.z, dg.z, invM, act, batch_stats),
-                                         bn_dx_one(g.w, v.w, sc.w, sh.w, mu.w, rs.w, db.w, dg.w, invM, act, batch_stats));
+            const float4 o = one(ld4g(dy + i * 4), ld4g(x + i * 4));
             if (nt) st4g_nt(dx + i * 4, o); else st4g(dx + i * 4, o);
         }
         return;
@@ -2116,6 +2132,15 @@ static inline int ew_blocks(long long n)
     if (b < 1) b = 1;
     return (int)b;
 }
+// for the kernels whose loop takes four quads per trip and keeps per-thread channel terms: at least four quads per thread, at most 16 workgroups per CU
+static inline int ew_blocks4(long long nquads)
+{
+    if (g_myolo_opt.tune0 & 128) return ew_blocks(nquads);       // ablation: round-3 launch shape (one quad per thread up to 2 M threads)
+    long long b = (nquads + 1023) / 1024;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (int)b;
+}
 
 template <int CC>
 static int mask_out_bwd_impl(const float* x, const float* w, const float* dz, float* dx, float* dw, float* db, int64_t M, int Cin,
@@ -2218,7 +2243,7 @@ int myolo_bn_apply_act(const float* x, const float* scale, const float* shift, f
 {
     MYOLO_REQUIRE(x && scale && shift && y && M > 0 && (C & 3) == 0, "bn_apply_act: bad arguments");
     const long long nq = (long long)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks(nq)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, nq, C, act);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_blocks4(nq)), dim3(256), 0, (hipStream_t)stream, x, scale, shift, y, nq, C, act);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -2250,7 +2275,7 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
     OpBnBwd op{dy, x, scale, shift, mean, var, C, act};
     run_colreduce(op, M, C, part, tot, s, FinBnBwd{dgamma, dbeta});
     const long long nq = (long long)M * C / 4;
-    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq,
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks4(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq,
                        C, act, batch_stats, 1.0f / (float)M);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
