@@ -549,7 +549,7 @@ def bench_train(args, rank, world, local):
                             "avg_ms": conv_ms, "ops_timed": conv_n, "direct_conv_flop": flop_direct,
                             "direct_equivalent_tflops": flop_direct / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
                             "winograd_flop_frac_of_peak": wflop / (conv_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK if conv_ms > 0 else 0.0},
-                "depthwise": hbm_obj("dw_fwd_kernel, the 14 depthwise 3x3 layers of backbone + YOLO head (sum over the layers, one step)",
+                "depthwise": hbm_obj("dw_rows_kernel (row-sliding LDS-staged, round 4), the 14 depthwise 3x3 layers of backbone + YOLO head (sum over the layers, one step)",
                                      dwb, dw_ms, note="SURVEY 8(d): activation in + out once, 20.97 MB/img at 224^2 alpha 1"),
                 "roialign": hbm_obj("ROIAlign forward (fused into conv1's Winograd input transform when CONV3X3_ALGO != direct)", roi_bytes, roi_ms,
                                     note="SURVEY 8(d) bytes: the [B*R,14,14,256] crops + one read of the feature map; the fused kernel of the default "
@@ -633,6 +633,16 @@ def bench_train(args, rank, world, local):
                        "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
                                "on the comm stream as soon as backward completes it"}
     res.update(extras)
+    # the dominant kernel is co-bound: at K = 256 with fp32 in / out its algorithmic bytes at the measured copy rate take as long as its products on the
+    # matrix pipe -- both fractions are reported: frac_mfma = flop / peak / time, frac_composite = max(flop / peak, bytes / copy rate) / time
+    cp = extras.get("hbm_copy_measured_gbs") if isinstance(extras.get("hbm_copy_measured_gbs"), dict) else None
+    copy_gbs = max([v for k, v in cp.items() if k.startswith("float4") and isinstance(v, (int, float))] or [5600.0]) if cp else 5600.0
+    if kms > 0:
+        t_mfma, t_hbm = kflop / (peak * 1e12), kbytes / (copy_gbs * 1e9)
+        res["roofline"]["frac_mfma"] = t_mfma / (kms * 1e-3)
+        res["roofline"]["frac_composite"] = max(t_mfma, t_hbm) / (kms * 1e-3)
+        res["roofline"]["composite_note"] = ("bound = max(flop / %.0f TFLOP/s, algorithmic bytes / %.0f GB/s [the read+write copy rate %s]) = %.3f ms against %.3f ms measured"
+                                             % (peak, copy_gbs, "measured in this run" if cp else "of profiles/r3_notes.md", 1e3 * max(t_mfma, t_hbm), kms))
     if world == 1 and not args.no_extras and x6 and traffic is not None and not args.no_live_pmc:
         # HBM traffic of the dominant kernel measured IN THIS RUN: two separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE) on the same launch
         # shape in a child process (tools/pmc_traffic.py; this process keeps its memory and is idle meanwhile).  Falls back to the committed

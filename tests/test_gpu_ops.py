@@ -324,7 +324,11 @@ def test_deconv_mask_fused(N, H, W, Cin, Cout, C, x6, request):
 
 
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 32, 2), (3, 7, 7, 128, 1), (1, 14, 10, 64, 2),
-                                            (2, 9, 13, 16, 1)])
+                                            (2, 9, 13, 16, 1),
+                                            # round 4, the row-sliding kernels on ragged shapes: several strips with a partial last one, row chunks
+                                            # that do not divide the height, channel counts of 3 / 5 blocks, the 32-quad form on rows of 7 and fewer
+                                            (2, 46, 40, 64, 1), (2, 46, 40, 96, 2), (1, 30, 58, 160, 1), (4, 9, 7, 1024, 1), (2, 18, 14, 1024, 2),
+                                            (3, 5, 3, 128, 1), (40, 28, 28, 32, 1)])
 def test_dwconv3x3(N, H, W, C, stride):
     rng = np.random.default_rng(4)
     x, w = rnd(rng, N, H, W, C), rnd(rng, 3, 3, C)
@@ -1047,7 +1051,8 @@ def _check_bn_outputs(y_ref2d, g, b, mm, mv, mean, var, scale, shift, tmm, tmv):
 @pytest.mark.parametrize("nofuse", [0, 1])
 @pytest.mark.parametrize("N,H,W,C,stride,lazy", [(2, 16, 16, 32, 1, True), (2, 16, 16, 32, 2, True), (3, 14, 14, 512, 1, True), (3, 14, 14, 512, 2, False),
                                                  (2, 8, 8, 1024, 1, True), (1, 14, 10, 64, 2, True), (2, 12, 12, 16, 1, True), (2, 6, 6, 24, 1, True),
-                                                 (32, 28, 28, 256, 1, True)])
+                                                 (32, 28, 28, 256, 1, True), (2, 46, 40, 96, 1, True), (2, 46, 40, 64, 2, True), (4, 9, 7, 1024, 1, False),
+                                                 (1, 30, 58, 160, 2, True)])
 def test_dwconv3x3_bnstats_fwd_and_affine_in_weight_gradient(N, H, W, C, stride, lazy, nofuse):
     """depthwise conv whose input is relu6(x * in_scale + in_shift) formed on load, with the batch statistics of its output from the
     conv's own epilogue; and its weight gradient re-normalising x on load.  (C = 24: a channel count the in-kernel reduction does
