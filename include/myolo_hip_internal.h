@@ -35,6 +35,10 @@ int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const flo
  *   for the n_groups row groups idx[] (compact dy [n_groups*group_rows, C]; inv[group] = slot or -1);
  *   results are identical to bn_act_bwd on the zero-padded dense gradient. */
 int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n, int64_t group_elems, void* stream);
+/* the same gather of n groups of group_rows x C floats, fused with the per-channel affine map + activation that follows it in the compacted mask-head
+ * backward: dst_pre (NULL: not written) = the gathered rows, dst_act = act(row * scale + shift) as myolo_bn_apply_act gives.  C / 4 must divide 256. */
+int myolo_gather_groups_affine_act(const float* src, const int32_t* idx, const float* scale, const float* shift, int act, float* dst_pre,
+                                   float* dst_act, int n, int64_t group_rows, int C, void* stream);
 int myolo_bn_act_bwd_rowsparse(const float* dy_compact, const float* x, const int32_t* idx, const int32_t* inv,
                                const float* mean, const float* var, const float* scale, const float* shift,
                                float* dx, float* dgamma, float* dbeta,

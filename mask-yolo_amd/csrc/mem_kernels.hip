@@ -460,6 +460,39 @@ struct OpBnBwd {
     }
 };
 
+// Frozen BatchNorm (+ activation) backward in ONE pass: dx = scale * dz does not depend on the sums, so the pass that forms the sums for
+// dgamma / dbeta writes it as well (the two-kernel form read dy and x twice).  Same expressions as OpBnBwd + bn_bwd_dx_kernel(batch_stats = 0).
+struct OpBnBwdFrozenDx {
+    static constexpr int NV = 2;
+    static constexpr int HOIST = 1;
+    const float* dy;
+    const float* x;
+    const float* scale;
+    const float* shift;
+    const float* mean;
+    const float* var;
+    float* dx;
+    int C, act;
+    float4 sc, sh, mu, rs;
+    __device__ void init(int c)
+    {
+        sc = ld4g(scale + c); sh = ld4g(shift + c); mu = ld4g(mean + c);
+        const float4 vr = ld4g(var + c);
+        rs = make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F));
+    }
+    __device__ void operator()(long long r, int c, float4* acc) const
+    {
+        const float4 g = ld4g(dy + r * C + c), v = ld4g(x + r * C + c);
+        float4 o;
+        float dz, xh;
+        dz = g.x * actmask(fmaf(v.x, sc.x, sh.x), act); xh = (v.x - mu.x) * rs.x; acc[0].x += dz; acc[1].x = fmaf(dz, xh, acc[1].x); o.x = sc.x * dz;
+        dz = g.y * actmask(fmaf(v.y, sc.y, sh.y), act); xh = (v.y - mu.y) * rs.y; acc[0].y += dz; acc[1].y = fmaf(dz, xh, acc[1].y); o.y = sc.y * dz;
+        dz = g.z * actmask(fmaf(v.z, sc.z, sh.z), act); xh = (v.z - mu.z) * rs.z; acc[0].z += dz; acc[1].z = fmaf(dz, xh, acc[1].z); o.z = sc.z * dz;
+        dz = g.w * actmask(fmaf(v.w, sc.w, sh.w), act); xh = (v.w - mu.w) * rs.w; acc[0].w += dz; acc[1].w = fmaf(dz, xh, acc[1].w); o.w = sc.w * dz;
+        st4g(dx + r * C + c, o);
+    }
+};
+
 // tot = {dbeta[C], dgamma[C]} (double) -> write float grads
 struct FinBnBwd {                    // dbeta = sum(dz), dgamma = sum(dz * xhat)
     static constexpr int PAIR = 1;
@@ -609,6 +642,27 @@ __global__ __launch_bounds__(256) void gather_groups_kernel(const float* __restr
         float* dp = dst + (long long)g * gq * 4;
         for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < gq; o += (long long)gridDim.x * blockDim.x)
             st4g(dp + o * 4, ld4g(sp + o * 4));
+    }
+}
+
+// gather of row groups fused with the BatchNorm apply + activation that followed it in the compacted mask-head backward: dst_pre (optional) =
+// the gathered rows as they are, dst_act = act(row * scale + shift) -- the expressions of bn_apply_kernel, one read of the source instead of two
+__global__ __launch_bounds__(256) void gather_groups_affine_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                                   const float* __restrict__ scale, const float* __restrict__ shift, int act,
+                                                                   float* __restrict__ dst_pre, float* __restrict__ dst_act, int n, long long gq, int cq)
+{
+    // gq (quads per group) is a multiple of cq (quads per row) and the x-stride of the loop a multiple of 256: with 256 % cq == 0 a thread keeps one channel quad
+    const int c = (int)((unsigned)(blockIdx.x * blockDim.x + threadIdx.x) % (unsigned)cq) * 4;
+    const float4 sc = ld4g(scale + c), sh = ld4g(shift + c);
+    for (int g = blockIdx.y; g < n; g += gridDim.y) {
+        const float* sp = src + (long long)idx[g] * gq * 4;
+        const long long base = (long long)g * gq * 4;
+        for (long long o = (long long)blockIdx.x * blockDim.x + threadIdx.x; o < gq; o += (long long)gridDim.x * blockDim.x) {
+            const float4 v = ld4g(sp + o * 4);
+            if (dst_pre) st4g(dst_pre + base + o * 4, v);
+            st4g(dst_act + base + o * 4, make_float4(actf(fmaf(v.x, sc.x, sh.x), act), actf(fmaf(v.y, sc.y, sh.y), act),
+                                                     actf(fmaf(v.z, sc.z, sh.z), act), actf(fmaf(v.w, sc.w, sh.w), act)));
+        }
     }
 }
 
@@ -2272,6 +2326,12 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
     double* part = (double*)ws;
     double* tot = (double*)((char*)ws + align256(pb));
     hipStream_t s = (hipStream_t)stream;
+    if (!batch_stats && !(g_myolo_opt.tune0 & 256)) {           // frozen: one pass (tune0 & 256: the two-kernel form, ablation)
+        OpBnBwdFrozenDx op{dy, x, scale, shift, mean, var, dx, C, act};
+        run_colreduce(op, M, C, part, tot, s, FinBnBwd{dgamma, dbeta});
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     OpBnBwd op{dy, x, scale, shift, mean, var, C, act};
     run_colreduce(op, M, C, part, tot, s, FinBnBwd{dgamma, dbeta});
     const long long nq = (long long)M * C / 4;
@@ -2322,6 +2382,23 @@ int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n,
         (void)total;
         hipLaunchKernelGGL(gather_groups_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n, gq);
     }
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+int myolo_gather_groups_affine_act(const float* src, const int32_t* idx, const float* scale, const float* shift, int act, float* dst_pre,
+                                   float* dst_act, int n, int64_t group_rows, int C, void* stream)
+{
+    MYOLO_REQUIRE(src && idx && scale && shift && dst_act && n > 0 && group_rows > 0 && C > 0 && (C & 3) == 0 && (256 % (C / 4)) == 0,
+                  "gather_groups_affine_act: bad arguments (C / 4 must divide 256)");
+    const long long gq = (long long)group_rows * (C / 4);
+    long long bx = (gq + 255) / 256;
+    if (bx > 64) bx = 64;
+    long long by = n;
+    if (by * bx > 16384) by = 16384 / bx;
+    if (by < 1) by = 1;
+    hipLaunchKernelGGL(gather_groups_affine_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), 0, (hipStream_t)stream, src, idx, scale, shift, act,
+                       dst_pre, dst_act, n, gq, C / 4);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -7,12 +7,7 @@ call returns a negative status, a RuntimeError is raised."""
 import ctypes
 import os
 
-# HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A side stream that lands on the COMPUTE stream's queue serialises
-# against it in submission order (measured: +4 ... +8 ms per training step, profiles/r3_notes.md "hardware queues"), and inference lanes only
-# overlap with a queue each: eight queues leave room for the engine's streams (engine._shared_stream) beside what else the process creates.
-# Effective when set before the process's first device call; a value the user set wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
+# (GPU_MAX_HW_QUEUES is handled by myolo.engine._ensure_hw_queues at the first Net, not at import: ADVICE r3)
 import torch      # noqa: E402
 
 _LIB = None
@@ -111,6 +106,7 @@ SIGS = {
     "myolo_dwconv3x3_bwd_weight_affine_in": [P, P, P, I, P, P, I, I, I, I, I, P, Z, P],
     "myolo_pwconv1x1_bnstats_fwd": [P, P, P, I, P, P, P, P, P, P, P, P, P, P, L, I, I, I, P, Z, P],
     "myolo_pwconv1x1_bwd_weight_affine_in": [P, P, P, I, P, P, L, I, I, P, Z, P],
+    "myolo_gather_groups_affine_act": [P, P, P, P, I, P, P, I, L, I, P],
     "myolo_add_inplace": [P, P, L, P],
     "myolo_fill": [P, F, L, P],
     "myolo_u8_to_unit_f32": [P, P, L, P],

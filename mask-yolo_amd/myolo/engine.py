@@ -12,6 +12,7 @@ yolo_branch_graph :249-278; feature_map :848; DecodeYOLOLayer :1442-1473; Detect
 :605-661; build_mask_graph :668-715; yolo_custom_loss :86-242; myolo_mask_loss_graph :718-754;
 compile :1062-1094 (loss sum + Adam).
 """
+import os
 import threading
 import time
 
@@ -126,8 +127,25 @@ class Workspace(object):
         return self.buf.numel()
 
 
+def _ensure_hw_queues(want=8):
+    """HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A side stream that lands on the COMPUTE stream's queue
+    serialises against it in submission order (measured: +4 ... +8 ms per training step, profiles/r3_notes.md "hardware queues"; an extra
+    stream cost 6.6 ms in round 4), and inference lanes only overlap with a queue each.  The variable is read when the HIP runtime initialises:
+    it is set here -- at the first Net, not at import -- when the user did not set it and HIP is not up yet; otherwise a warning says so."""
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if cur is not None:
+        return
+    if not torch.cuda.is_initialized():
+        os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+    else:
+        import warnings
+        warnings.warn("myolo: HIP was initialised before the first Net without GPU_MAX_HW_QUEUES set (default 4 hardware queues): side streams may share "
+                      "the compute stream's queue (+4..8 ms per training step measured).  Export GPU_MAX_HW_QUEUES=8 before the first device call.")
+
+
 class Net(object):
     def __init__(self, cfg, device="cuda:0", seed=0):
+        _ensure_hw_queues()
         X.load()
         self.cfg = cfg
         self.dev = torch.device(device)
@@ -175,7 +193,7 @@ class Net(object):
         self._lanes = {}                  # predict_stream: lane -> its stream / scratch / coefficient buffers
         self._cap_stream = None           # graph capture never happens with the default stream current (see _capture_predict)
         # a captured graph bakes in pointers to the scratch buffer: growing it (a bigger launch on the same Net) drops the graphs
-        self._ws_main = Workspace(self.dev, on_realloc=self._graphs.clear)
+        self._ws_main = Workspace(self.dev, on_realloc=lambda: self._drop_graphs(0))
         self._ws_side = Workspace(self.dev)    # scratch of the YOLO-head backward running on the side stream
         self._ws_active = self._ws_main
         self._yolo_stream = _shared_stream(self.dev, "yolo_head_bwd")
@@ -239,6 +257,7 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.fuse_compact_gather = 1      # compacted mask-head backward: gather + BatchNorm apply in one kernel, each pre-BN tensor gathered once (0: round 3's sequence)
         self.bucket1_on_wgrad_stream = 1  # data-parallel: bucket 1 released on the weight-gradient stream (0: round 3's join of that stream into the compute stream)
         self.pinned_upload = 1            # to_device_batch through pinned staging + the upload stream (0: synchronous torch.as_tensor copies, rounds 1-3)
         self.upload_own_stream = 0        # EXPERIMENT
@@ -1264,15 +1283,22 @@ class Net(object):
         da = self._new(NP * q, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NP, ps, ps,
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
+        pre_rows = {}                         # id(pre-BN tensor) -> its positive rows: layer i's input tensor is layer i-1's BatchNorm input, gathered ONCE
         for i in range(4, 1, -1):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             src = convs[i - 1]
             if isinstance(src, tuple):        # ("lazy_bn", pre-BN tensor, bn layer): the forward normalised on load
                 _, ypre, bsrc = src
-                yp = gather(ypre, q)
                 xin = self._new(NP * q, MASK_FILTERS)
-                X.call("myolo_bn_apply_act", X.ptr(yp), X.ptr(self.bnbuf[bsrc][2]), X.ptr(self.bnbuf[bsrc][3]), X.ptr(xin), NP * q,
-                       MASK_FILTERS, ACT_RELU, X.stream())
+                if compact or not self.fuse_compact_gather:
+                    yp = gather(ypre, q)
+                    X.call("myolo_bn_apply_act", X.ptr(yp), X.ptr(self.bnbuf[bsrc][2]), X.ptr(self.bnbuf[bsrc][3]), X.ptr(xin), NP * q,
+                           MASK_FILTERS, ACT_RELU, X.stream())
+                else:                         # one kernel: the gathered pre-BN rows (kept for bn_{i-1}'s backward below) and their normalised form
+                    yp = self._new(NP * q, MASK_FILTERS)
+                    X.call("myolo_gather_groups_affine_act", X.ptr(ypre), X.ptr(idx_d), X.ptr(self.bnbuf[bsrc][2]), X.ptr(self.bnbuf[bsrc][3]), ACT_RELU,
+                           X.ptr(yp), X.ptr(xin), NP, q, MASK_FILTERS, X.stream())
+                pre_rows[id(ypre)] = yp
             else:
                 xin = gather(src, q)
             if self.tape[bn][0] is None:
@@ -1286,7 +1312,9 @@ class Net(object):
                        X.ptr(buf[2]), X.ptr(dy), X.ptr(self.g[bn + "/gamma"]), X.ptr(self.g[bn + "/beta"]), NP * q, MASK_FILTERS,
                        self.tape[bn][1], *self._wsargs(), X.stream())
             else:
-                c_p = gather(self.tape[bn][0], q)
+                c_p = pre_rows.get(id(self.tape[bn][0])) if self.fuse_compact_gather else None
+                if c_p is None:
+                    c_p = gather(self.tape[bn][0], q)
                 dy = self.bn_act_bwd(bn, da, y_override=c_p)
             a_next = xin                  # conv_i's input = post-activation of layer i-1
             def conv_wgrad(xin=xin, dy=dy, cn=cn):
@@ -1694,11 +1722,17 @@ class Net(object):
                 self._frozen_affine_all()            # builds the (read-only) slot table every lane shares
             st = {"stream": _shared_stream(self.dev, "lane%d" % lane)}
             if lane > 0:
-                st["ws"] = Workspace(self.dev, on_realloc=self._graphs.clear)
+                # a lane's scratch growth invalidates only THAT lane's captured graphs (key[-1] == lane); sized like lane 0's so that it
+                # does not regrow during warm-up (every lane's graphs used to be dropped, each recapture a device synchronise)
+                st["ws"] = Workspace(self.dev, nbytes=max(self._ws_main.size, 256 << 20), on_realloc=lambda lane=lane: self._drop_graphs(lane))
                 st["bnbuf"] = {k: torch.zeros_like(v) for k, v in self.bnbuf.items()}
                 st["fz"] = torch.empty_like(self._fz_coeffs)
             self._lanes[lane] = st
         return st
+
+    def _drop_graphs(self, lane):
+        for k in [k for k in self._graphs if k[-1] == lane]:
+            del self._graphs[k]
 
     def predict_graphed(self, images, lane=0):
         """predict() replayed from a captured hipGraph (one per input shape and lane): the ~150 launches of an inference forward

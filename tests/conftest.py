@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the product sets this at the first Net when HIP is not up yet (myolo.engine._ensure_hw_queues); the GPU tests touch the device through bare
+# operator calls before any Net exists, so the harness sets it for the whole session (read by the HIP runtime when it initialises)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "mask-yolo_amd")):
     if p not in sys.path:
