@@ -284,7 +284,8 @@ def bench_train(args, rank, world, local):
         name, _, val = kv.partition("=")
         assert hasattr(net, name), "unknown engine attribute %s" % name
         setattr(net, name, type(getattr(net, name))(int(val)))
-    reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1)
+    comm_stream = None if args.comm_own_stream else net._copy_stream        # (see GradReducer: a fresh HIP stream is not free)
+    reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1, stream=comm_stream)
     reducer.attach(net)
     ranks_seen = reducer.ranks_seen() if world > 1 else 1
 
@@ -435,7 +436,7 @@ def bench_train(args, rank, world, local):
         # (b) what the three real gradient buckets cost as RCCL collectives on the comm stream while backward runs: a 1-rank
         #     communicator through the C-ABI (launch + stream + kernel cost of the exchange, not the wire), and the step with it
         try:
-            probe = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], always=True, backend="capi", timing=True)
+            probe = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], always=True, backend="capi", timing=True, stream=comm_stream)
             probe.attach(net)
             for i in range(2):
                 net.train_step(dbs[i % nb], args.lr)
@@ -609,7 +610,7 @@ def bench_train(args, rank, world, local):
                                "; Winograd multiply products: " + ("native fp32 MFMA" if net.fp32_matmul == "native" else
                                "FP32_MATMUL='bf16x6' (each fp32 product = six exact bf16 piece products, fp32 accumulation)"),
                    "global_batch": args.batch * world, "parallelism": "dp%d" % world, "final_loss": loss,
-                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "net_attrs": list(args.net_attr), "share_gpu": bool(args.share_gpu), "forced_positives": args.force_pos,
+                   "n_pos_mean": npos_mean, "rois_per_image": R, "lib_options": list(args.lib_option), "net_attrs": list(args.net_attr), "comm_own_stream": bool(args.comm_own_stream), "share_gpu": bool(args.share_gpu), "forced_positives": args.force_pos,
                    "peak_hbm_allocated_gb": torch.cuda.max_memory_allocated() / 2.0 ** 30},
         "roofline": None,
     }
@@ -849,6 +850,7 @@ def main():
     ap.add_argument("--force-pos", type=int, default=0, metavar="K",
                     help="replace the first K proposals of every image by a ground-truth box for the WHOLE run (the n_pos sweep's hook): the step "
                          "at the positive counts a trained net produces; recorded in config.forced_positives")
+    ap.add_argument("--comm-own-stream", action="store_true", help="ablation: the gradient all-reduces on a fresh HIP stream of their own (rounds 1-3) instead of the engine's copy stream")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST ONLY: every rank uses cuda:0 and the ranks rendezvous over gloo (RCCL needs one GPU per rank) -- exercises the whole "
                          "N > 1 code path of this script on a one-GPU box; recorded in config.share_gpu, never a throughput claim")

@@ -63,7 +63,7 @@ class GradReducer(object):
     wait() is called before the optimiser (Net.before_optimizer).  With world_size 1 both are no-ops,
     so the single-GPU path is bit-identical to running without a reducer."""
 
-    def __init__(self, flat_grad, bucket_ranges, group=None, always=False, backend="torch", timing=False):
+    def __init__(self, flat_grad, bucket_ranges, group=None, always=False, backend="torch", timing=False, stream=None):
         """backend "torch": torch.distributed.all_reduce (nccl = RCCL on GPU tensors, gloo otherwise).
         backend "capi": the library's own myolo_comm_* entry points (include/myolo_hip.h) -- RCCL driven through the C-ABI,
         torch.distributed only carries the 128-byte unique id to the other ranks.  GPU tensors only.
@@ -82,7 +82,10 @@ class GradReducer(object):
         # always=True issues the collectives even in a 1-rank group (used to test the RCCL/stream path on one GPU)
         self.active = self.world > 1 or (always and (dist.is_initialized() or backend == "capi"))
         if self.cuda and self.active:
-            self.comm_stream = torch.cuda.Stream(device=flat_grad.device)
+            # stream: an existing side stream to issue the collectives on (MaskYOLO passes the engine's copy stream, idle during backward).  A NEW
+            # HIP stream is not free on this runtime: streams are multiplexed onto a few hardware queues and one more can put a side stream on
+            # the compute stream's queue -- measured +3.4 ms per step with a fresh comm stream (bench comm probe 24.7 vs 21.3 ms), round 4.
+            self.comm_stream = stream if stream is not None else torch.cuda.Stream(device=flat_grad.device, priority=-1)    # (high priority: engine._shared_stream)
             self.done = [torch.cuda.Event() for _ in self.ranges]
             # timing: one (start, end) event pair per collective, kept until bucket_ms() reads them -- nothing synchronises inside a step
             self._pairs = [[] for _ in self.ranges]

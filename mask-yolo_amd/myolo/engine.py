@@ -92,13 +92,18 @@ _SHARED_STREAMS = {}
 
 
 def _shared_stream(dev, name, **kw):
-    """The engine's side streams are created ONCE per device and process and shared by every Net.  Which hardware queue a HIP stream is multiplexed
-    onto is decided when it is created (least-used of GPU_MAX_HW_QUEUES queues, the compute stream's included); a second Net's fresh streams were
-    measured landing on the compute stream's queue (step 21.0 -> 29.3 ms with the YOLO-head stream there, 24.8 ms with the weight-gradient stream),
-    the first Net's never do.  Nets of one process do not run concurrently, so sharing costs nothing."""
+    """The engine's side streams are created ONCE per device and process, shared by every Net, and are HIGH-PRIORITY streams.
+    HIP multiplexes streams onto a few hardware queues, decided by the runtime as streams come into use; a side stream that ends up sharing the
+    compute stream's queue / pipe serialises against it.  Measured: 21.0 -> 29.3 ms with the YOLO-head stream there (round 3); round 4: 20.5 ->
+    26.3 ms when a torch.distributed NCCL process group had been created BEFORE the Net -- i.e. in every data-parallel run -- and +3.6 ms for a
+    fresh stream for the gradient all-reduces; neither GPU_MAX_HW_QUEUES = 4 / 8 / 16 / 24 nor probing candidate streams for concurrency changed
+    that (tools/experiments/pg_stream_cost.py).  High-priority streams are served from a queue pool of their own, apart from every
+    normal-priority stream torch, RCCL or the user create: 20.63 / 20.67 / 20.68 ms without a process group / with one created before / after the
+    Net.  (MYOLO_STREAM_PRIORITY=0 restores normal priority for that experiment.)  Nets of one process do not run concurrently, so sharing costs nothing."""
     key = (str(torch.device(dev)), name)
     st = _SHARED_STREAMS.get(key)
     if st is None:
+        kw.setdefault("priority", int(os.environ.get("MYOLO_STREAM_PRIORITY", "-1")))
         st = _SHARED_STREAMS[key] = torch.cuda.Stream(device=dev, **kw)
     return st
 

@@ -313,7 +313,7 @@ class MaskYOLO(object):
             return 0, 1
         if getattr(self, "_reducer", None) is None:
             from .dist import GradReducer
-            self._reducer = GradReducer(self.net.flat_g, self.net.bucket_ranges).attach(self.net)
+            self._reducer = GradReducer(self.net.flat_g, self.net.bucket_ranges, stream=self.net._copy_stream).attach(self.net)
         return tdist.get_rank(), tdist.get_world_size()
 
     def evaluate_on_batch(self, batch):
