@@ -1,0 +1,36 @@
+#!/bin/bash
+# Round-4 evidence in one gpurun call:   gpurun --timeout 3000 -- 'bash tools/collect_evidence_r4.sh r4'
+#   the full default bench line, the step profile (default and 20 forced positives), the kernel micro-benchmarks on cold inputs.
+TAG=${1:-r4}
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/evidence_$TAG
+mkdir -p $OUT
+python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/${TAG}_bench.json
+bash tools/profile_step.sh $TAG --steps 10 > /dev/null 2>&1
+cp gpurun_out/prof_$TAG/${TAG}_bench_kernel_stats.csv gpurun_out/prof_$TAG/${TAG}_bench_kernel_by_grid.csv gpurun_out/prof_$TAG/${TAG}_timeline.txt gpurun_out/prof_$TAG/${TAG}_step_sequence.txt $OUT/
+bash tools/profile_step.sh ${TAG}_pos20 --steps 10 --force-pos 20 > /dev/null 2>&1
+cp gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_stats.csv gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_by_grid.csv gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_timeline.txt gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_step_sequence.txt $OUT/
+{
+  echo "--- depthwise forward as the step runs it (cold inputs); then with the round-3 kernel (dw_legacy=1)"
+  python tools/kbench.py dw_fused --iters 20 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=dw_legacy=1 python tools/kbench.py dw_fused --iters 20 2>&1 | grep -v amdgpu | tail -1
+  echo "--- depthwise data / weight gradients (cold inputs); then with the round-3 kernels (dw_bwd_legacy=1)"
+  python tools/kbench.py dw_bwd --iters 20 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=dw_bwd_legacy=1 python tools/kbench.py dw_bwd --iters 20 2>&1 | grep -v amdgpu | grep total
+  echo "--- pointwise layers (fp32 MFMA kernels; then wino_x6=1 = the product's FP32_MATMUL=bf16x6)"
+  python tools/kbench.py pw_fused --iters 20 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py pw_fused --iters 20 2>&1 | grep -v amdgpu
+  echo "--- ROIAlign forward / backward (backward: default, tune0=1 = round-3 pixel order, tune0=4 = 4x4 tiles)"
+  python tools/kbench.py roialign_fwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=tune0=1 python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=tune0=4 python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  echo "--- Winograd kernels (unchanged this round), steady state"
+  for k in wino63_mm wino63_wgrad wino63_boundary; do KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
+  echo "--- HBM stream copy"
+  python tools/kbench.py copy --iters 5 2>&1 | grep -v amdgpu | head -8
+  echo "--- stream / process-group experiment (tools/experiments/pg_stream_cost.py): default = high-priority side streams; MYOLO_STREAM_PRIORITY=0 = rounds 1-3"
+  for m in none pg_first pg; do HSA_ENABLE_IPC_MODE_LEGACY=0 python tools/experiments/pg_stream_cost.py $m 2>&1 | grep "ms per step"; done
+  for m in none pg_first pg; do MYOLO_STREAM_PRIORITY=0 HSA_ENABLE_IPC_MODE_LEGACY=0 python tools/experiments/pg_stream_cost.py $m 2>&1 | grep "ms per step"; done
+} > $OUT/${TAG}_kbench.txt
+head -c 600 $OUT/${TAG}_bench.json; echo; grep wall $OUT/${TAG}_timeline.txt; grep wall $OUT/${TAG}_pos20_timeline.txt; tail -8 $OUT/${TAG}_kbench.txt
