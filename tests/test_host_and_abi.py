@@ -304,3 +304,33 @@ def test_bench_algorithmic_work_matches_survey():
     assert abs(bench.dw_bytes(224, 1.0, 1) / 1e6 - 20.97) < 0.01          # 20.97 MB / image over the 14 dw layers
     fl, _ = bench.pw_flops_bytes(224, 1.0, 1)
     assert abs(fl / 1e6 - (488.2 + 770.8)) < 1.0                          # backbone + YOLO-head pointwise MFLOP / image
+
+
+def test_batch_generator_fill_equals_getitem_and_byte_images():
+    """BatchGenerator.fill (round 4: what MaskYOLO.train() hands the engine's pinned staging arrays to) writes __getitem__'s arrays in place: float32
+    images bit-identical (the 256-entry table = image / 255. stored into float32), byte images = the raw pixels (normalised later by
+    myolo_u8_to_unit_f32), the other arrays equal after the cast the upload applies anyway; the wrapped last batch and 'yolo' mode included."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], BATCH_SIZE=4)
+    samples = make_shapes_samples(6, cfg)
+    gen = mutils.BatchGenerator(samples, cfg, "training", shuffle=False, norm=True)
+    assert np.array_equal(mutils._U8_OVER_255, (np.arange(256, dtype=np.uint8) / 255.).astype(np.float32))
+    T = cfg.TRUE_BOX_BUFFER
+    for idx in (0, 1):
+        ref, _ = gen[idx]
+        for img_dt in (np.float32, np.uint8):
+            out = [np.full(ref[0].shape, 7, img_dt), np.full((4, T, 4), 7, np.float32), np.full(ref[2].shape, 7, np.float32),
+                   np.full(ref[3].shape, 7, np.int32), np.full(ref[4].shape, 7, np.int32), np.full(ref[5].shape, 7, np.uint8)]
+            gen.fill(idx, out)
+            if img_dt == np.uint8:
+                assert np.array_equal(mutils._U8_OVER_255[out[0]], ref[0])
+            else:
+                assert np.array_equal(out[0], ref[0])
+            assert np.array_equal(out[1].reshape(-1), ref[1].astype(np.float32).reshape(-1))
+            assert np.array_equal(out[2], ref[2].astype(np.float32))
+            assert np.array_equal(out[3], ref[3]) and np.array_equal(out[4], ref[4]) and np.array_equal(out[5].astype(bool), ref[5])
+    assert gen.batch_bounds(1) == (2, 6)                               # wrapped back to a full batch (myolo_utils.py:730-735)
+    ygen = mutils.BatchGenerator(samples, cfg, "yolo", shuffle=False, norm=True)
+    ref, _ = ygen[0]
+    out = [np.zeros(ref[0].shape, np.float32), np.ones((4, T, 4), np.float32), np.ones(ref[2].shape, np.float32)]
+    ygen.fill(0, out)
+    assert np.array_equal(out[0], ref[0]) and np.array_equal(out[2], ref[2].astype(np.float32))
