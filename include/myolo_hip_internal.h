@@ -35,6 +35,10 @@ int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const flo
  *   for the n_groups row groups idx[] (compact dy [n_groups*group_rows, C]; inv[group] = slot or -1);
  *   results are identical to bn_act_bwd on the zero-padded dense gradient. */
 int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n, int64_t group_elems, void* stream);
+/* the index those helpers take, built on the device from the per-image positive counts of myolo_mask_targets (an image's positives are its first
+ * n_pos[b] ROIs, model.py:593): flags [B*R] (NULL: not written) = 1 for a positive ROI, inv [B*R] = its compact slot or -1, idx [slot] = flat ROI
+ * (the first sum(n_pos) entries of a [B*R] buffer are written), total [1] (NULL: not written) = sum(n_pos).  No host round trip. */
+int myolo_positive_index(const int32_t* n_pos, int B, int R, int32_t* flags, int32_t* idx, int32_t* inv, int32_t* total, void* stream);
 /* the same gather of n groups of group_rows x C floats, fused with the per-channel affine map + activation that follows it in the compacted mask-head
  * backward: dst_pre (NULL: not written) = the gathered rows, dst_act = act(row * scale + shift) as myolo_bn_apply_act gives.  C / 4 must divide 256. */
 int myolo_gather_groups_affine_act(const float* src, const int32_t* idx, const float* scale, const float* shift, int act, float* dst_pre,

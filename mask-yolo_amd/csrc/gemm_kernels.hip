@@ -1691,8 +1691,28 @@ size_t myolo_deconv2x2s2_mask_ws_bytes(int N, int H, int W, int Cin, int Cout, i
            (size_t)(Cout / BN) * 2 * 4 * N * H * W * ncls * sizeof(float);
 }
 
+static int deconv2x2s2_mask_fwd_impl(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
+                                     int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream,
+                                     const int32_t* keep_inv, float* keep_d, int keep_cap);
+
 int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
                                int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream)
+{
+    return deconv2x2s2_mask_fwd_impl(x, w, bias, w2, b2, p_out, N, H, W, Cin, Cout, ncls, ws, ws_bytes, stream, nullptr, nullptr, 0);
+}
+
+int myolo_deconv2x2s2_mask_fwd_keep(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
+                                    int N, int H, int W, int Cin, int Cout, int ncls, const int32_t* keep_inv, float* keep_d, int keep_cap,
+                                    void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(keep_inv && keep_d && keep_cap > 0, "deconv2x2s2_mask_fwd_keep: keep_inv / keep_d / keep_cap missing");
+    MYOLO_REQUIRE(myolo_deconv_mask_mm_ok(Cin, Cout), "deconv2x2s2_mask_fwd_keep: needs Cin %% 16 == 0 and Cout %% 256 == 0 (got %d, %d)", Cin, Cout);
+    return deconv2x2s2_mask_fwd_impl(x, w, bias, w2, b2, p_out, N, H, W, Cin, Cout, ncls, ws, ws_bytes, stream, keep_inv, keep_d, keep_cap);
+}
+
+static int deconv2x2s2_mask_fwd_impl(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
+                                     int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream,
+                                     const int32_t* keep_inv, float* keep_d, int keep_cap)
 {
     MYOLO_REQUIRE(x && w && bias && w2 && b2 && p_out && N > 0 && H > 0 && W > 0, "deconv2x2s2_mask_fwd: bad arguments");
     MYOLO_REQUIRE(Cout % BN == 0 && Cin % BK == 0 && (Cin & 3) == 0 && ncls >= 1 && ncls <= 4,
@@ -1703,7 +1723,7 @@ int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias
     MYOLO_REQUIRE(((uintptr_t)x & 15) == 0, "deconv2x2s2_mask_fwd: x must be 16-byte aligned");
     if (myolo_deconv_mask_mm_ok(Cin, Cout)) {          // csrc/wino_mm.hip: 128x256 tiles, b128 fragments; bf16x6 with option "wino_x6"
         float* part = (float*)((char*)ws + wb);
-        const int rc = myolo_deconv_mask_mm(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s);
+        const int rc = myolo_deconv_mask_mm(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s, keep_inv, keep_d, keep_cap);
         if (rc != MYOLO_OK) return rc;
         myolo_launch_deconv_mask_finish(part, b2, p_out, 4ll * N * H * W, ncls, Cout / 128, s);      // a wave covers 128 channels there
         MYOLO_CHECK_LAUNCH();

@@ -40,7 +40,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
-        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_bwd_legacy", &MyoloOptions::dw_bwd_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_bwd_legacy", &MyoloOptions::dw_bwd_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"tn_wgs", &MyoloOptions::tn_wgs}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)
@@ -2357,6 +2357,41 @@ int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const flo
     run_colreduce(op, M, C, part, tot, s, FinBnBwd{dgamma, dbeta});
     const long long nq = (long long)M * C / 4;
     hipLaunchKernelGGL(bn_bwd_dx_post_kernel, dim3(ew_blocks(nq)), dim3(256), 0, s, dy, a_post, scale, dx, nq, C, act);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+// Index of the positive ROIs built on the device (detect_mask_target_graph puts an image's positives first, model.py:593): ROI (b, r) is positive iff
+// r < n_pos[b]; its compact slot = (positives of images < b) + r.  One workgroup: an exclusive scan of the B counts in LDS, then every ROI's three entries.
+__global__ __launch_bounds__(256) void positive_index_kernel(const int32_t* __restrict__ npos, int B, int R, int32_t* __restrict__ flags,
+                                                             int32_t* __restrict__ idx, int32_t* __restrict__ inv, int32_t* __restrict__ total)
+{
+    extern __shared__ int32_t pfx[];              // [B + 1]
+    if (threadIdx.x == 0) {
+        int32_t run = 0;
+        for (int b = 0; b < B; ++b) {
+            int32_t c = npos[b];
+            c = c < 0 ? 0 : c > R ? R : c;
+            pfx[b] = run;
+            run += c;
+        }
+        pfx[B] = run;
+        if (total) *total = run;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B * R; i += 256) {
+        const int b = i / R, r = i - b * R;
+        const bool pos = r < pfx[b + 1] - pfx[b];
+        if (flags) flags[i] = pos ? 1 : 0;
+        inv[i] = pos ? pfx[b] + r : -1;
+        if (pos) idx[pfx[b] + r] = i;
+    }
+}
+
+int myolo_positive_index(const int32_t* n_pos, int B, int R, int32_t* flags, int32_t* idx, int32_t* inv, int32_t* total, void* stream)
+{
+    MYOLO_REQUIRE(n_pos && idx && inv && B > 0 && R > 0 && B <= 8192, "positive_index: bad arguments (1 <= B <= 8192)");
+    hipLaunchKernelGGL(positive_index_kernel, dim3(1), dim3(256), (size_t)(B + 1) * sizeof(int32_t), (hipStream_t)stream, n_pos, B, R, flags, idx, inv, total);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -37,6 +37,7 @@ struct MyoloOptions {
     int dw_wgrad_generic; // depthwise weight gradient: the generic 9-accumulator column reduction instead of the tiled kernel (ablation)
     int pw_no_x6;         // pointwise convs with >= 256 channels: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)
+    int tn_wgs;           // wino_tn_x6_kernel: at most this many workgroups walking the work units (0 = one workgroup per unit); one fits a CU, so 224 leaves 32 CUs free
     int no_trunk_fusion;  // *_bnstats_fwd: the conv, then a separate statistics pass (ablation of the producer-fused BatchNorm statistics)
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
     // 1 = Keras 2.2.x on TF-1.x through tf.nn.fused_batch_norm (Bessel-corrected batch variance, then Keras' n/(n-(1+eps)));
@@ -85,7 +86,8 @@ bool myolo_gemm_nt_batched_x6(int K, int N);
 bool myolo_deconv_mask_mm_ok(int Cin, int Cout);
 size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout);
 int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
-                         long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s);
+                         long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s,
+                         const int32_t* keep_inv = nullptr, float* keep_d = nullptr, int keep_cap = 0);
 int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nruns, const long long* rows, const long long* a_off,
                                const long long* b_off, const long long* c_off, const int* nq, int K, int N, hipStream_t s);
 // csrc/wino_mm.hip: C[z] = A[z]^T B[z] with six exact bf16 piece products per fp32 product (the Winograd weight gradient under "wino_x6")

@@ -49,6 +49,11 @@ struct MMArgs {
     const float* w2;       // [Co][ncls]: the 1x1 mask conv
     float* part;           // [Co/128 slabs][4*M pixels][ncls] partial logits
     int H, W, Co, ncls;
+    // ... and optionally the ReLU'd deconv output itself for the images (ROIs) the caller will differentiate: keep_inv[image] = slot (< keep_cap) or -1,
+    // keep_d [slot][2H][2W][Co] -- what MM_EP_DECONV would write for that image (the sparse mask-head backward reads it instead of re-running the deconv)
+    const int32_t* keep_inv;
+    float* keep_d;
+    int keep_cap;
     // PW (pointwise conv of the trunk in training mode, see gemm_kernels.hip myolo_pwconv1x1_bnstats_fwd): A := act(A * a_scale[k] + a_shift[k])
     // on load; stat: per row-tile partial sums of the output columns [M tiles][2][N] doubles
     const float* a_scale;
@@ -90,6 +95,29 @@ __device__ __forceinline__ void mm_deconv_mask_epilogue(const MMArgs& p, const f
 #pragma unroll
         for (int u = 0; u < 4; ++u) cbm[u] = p.bias[cbase + 32 * u];
         const long long hw = (long long)p.H * p.W;
+        if (p.keep_d) {
+            // images of this row tile (uniform): anything to keep at all?
+            const long long last = (m0 + MM_BM <= M ? m0 + MM_BM : M) - 1;
+            bool any = false;
+            for (long long g = m0 / hw; g <= last / hw; ++g) { const int sl = p.keep_inv[g]; any = any || (sl >= 0 && sl < p.keep_cap); }
+            if (any) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const long long row = m0 + wm * 64 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        if (row >= M) continue;
+                        const long long n_img = row / hw;
+                        const int sl = p.keep_inv[n_img];
+                        if (sl < 0 || sl >= p.keep_cap) continue;
+                        const int rem = (int)(row - n_img * hw);
+                        const int y = rem / p.W, x = rem - y * p.W;
+                        float* kd = p.keep_d + ((long long)sl * 4 * hw + (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1)) * p.Co + cbase;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) kd[32 * u] = fmaxf(acc[t][u][r] + cbm[u], 0.f);
+                    }
+            }
+        }
         const int rr = l31 & 15;          // after the butterfly lane l31 owns row slot rr of the 32-row block l31 >> 4
         const long long row = m0 + wm * 64 + (l31 >> 4) * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * half;
         float* dst = nullptr;
@@ -668,12 +696,13 @@ size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout) { return align256((si
  * transposed operand [N][K] the fp32 kernel wants), split = scratch of myolo_deconv_mask_mm_split_bytes (bf16x6 only),
  * part = [Cout/128][4*M][ncls] partial logits.  Option "wino_x6": six bf16 piece products per fp32 product. */
 int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
-                         long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s)
+                         long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s, const int32_t* keep_inv, float* keep_d, int keep_cap)
 {
     const int K = Cin, N = 4 * Cout;
     MMArgs a{};
     a.A = x; a.C = nullptr; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
     a.bias = bias; a.w2 = w2; a.part = part; a.H = H; a.W = W; a.Co = Cout; a.ncls = ncls;
+    a.keep_inv = keep_d ? keep_inv : nullptr; a.keep_d = keep_inv ? keep_d : nullptr; a.keep_cap = keep_cap;
     MMRun& R = a.run[0];
     R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
     R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
@@ -778,6 +807,7 @@ struct TNArgs {
     int Ka, N;
     int nruns;
     int tiles_k, tiles_n;      // Ka / 256, N / 256
+    long long nunits;          // (plane, split) pairs x tiles
     TNRun run[4];
 };
 
@@ -788,10 +818,14 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, half = lane >> 5, l31 = lane & 31;
-    // unit = ((plane, split) pair, tile): tiles of one pair are consecutive workgroups
+    // unit = ((plane, split) pair, tile): tiles of one pair are consecutive units.  One workgroup per unit, or (option "tn_wgs") a fixed number of
+    // workgroups walking the units: with 112 KB of LDS a CU holds ONE of these workgroups, so a grid of 224 leaves four CUs of every XCD to
+    // whatever runs beside this kernel (the trunk's backward chain: dozens of short dependent kernels that otherwise starve behind its
+    // half-millisecond workgroups)
     const int ntile = p.tiles_k * p.tiles_n;
-    const long long pair = blockIdx.x / ntile;
-    const int tile = (int)(blockIdx.x - pair * ntile);
+  for (long long bid = blockIdx.x; bid < p.nunits; bid += gridDim.x) {
+    const long long pair = bid / ntile;
+    const int tile = (int)(bid - pair * ntile);
     const int kat = tile / p.tiles_n, nt = tile - kat * p.tiles_n;
     int ri = 0;
 #pragma unroll
@@ -939,6 +973,7 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 #pragma unroll
             for (int u = 0; u < 2; ++u) Pp[(long long)row * p.N + u * 32] = acc[t][u][r];
         }
+  }
 }
 
 // C[plane] = sum over the plane's splits of part[(plane, split)], fixed order; grid (element quads / 256, planes)
@@ -979,7 +1014,7 @@ static long long tn_x6_plan(int nruns, const long long* rows, const int* nq, int
     const int ntile = (Ka / TN_T) * (N / TN_T);
     long long total_rows = 0;
     for (int r = 0; r < nruns; ++r) total_rows += rows[r] * nq[r];
-    const long long target_units = 3 * 256;
+    const long long target_units = 3 * (g_myolo_opt.tn_wgs > 0 ? g_myolo_opt.tn_wgs : 256);
     long long rps = ((total_rows * ntile + target_units - 1) / target_units + MM_BK - 1) / MM_BK * MM_BK;
     if (rps < 8 * MM_BK) rps = 8 * MM_BK;
     long long pairs = 0;
@@ -1005,6 +1040,8 @@ static long long tn_x6_plan(int nruns, const long long* rows, const int* nq, int
     }
     return pairs;
 }
+
+static long long tn_x6_grid(long long nunits) { return g_myolo_opt.tn_wgs > 0 && nunits > g_myolo_opt.tn_wgs ? g_myolo_opt.tn_wgs : nunits; }
 
 size_t myolo_gemm_tn_x6_ws_bytes(int nruns, const long long* rows, const int* nq, int Ka, int N)
 {
@@ -1038,7 +1075,8 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
         ++k;
     }
     if (pairs <= 0) return MYOLO_OK;
-    hipLaunchKernelGGL(wino_tn_x6_kernel<false>, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
+    a.nunits = pairs * a.tiles_k * a.tiles_n;
+    hipLaunchKernelGGL(wino_tn_x6_kernel<false>, dim3((unsigned)tn_x6_grid(a.nunits)), dim3(512), 0, s, a);
     const long long n4 = (long long)Ka * N / 4;
     hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), planes), dim3(256), 0, s, a);
     return MYOLO_OK;
@@ -1130,7 +1168,8 @@ int myolo_deconv_x6_bwd_weight(const float* x, const float* dy, float* dw, long 
         return MYOLO_EWORKSPACE;
     }
     a.run[0].a_off = 0; a.run[0].b_off = 0;
-    hipLaunchKernelGGL(wino_tn_x6_kernel<true>, dim3((unsigned)(pairs * a.tiles_k * a.tiles_n)), dim3(512), 0, s, a);
+    a.nunits = pairs * a.tiles_k * a.tiles_n;
+    hipLaunchKernelGGL(wino_tn_x6_kernel<true>, dim3((unsigned)tn_x6_grid(a.nunits)), dim3(512), 0, s, a);
     const long long n4 = (long long)Ka * N / 4;
     hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, a);
     return MYOLO_OK;

@@ -77,6 +77,8 @@ SIGS = {
     "myolo_conv3x3_wino_bwd_data": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_conv3x3_wino_bwd_weight": [P, P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_deconv2x2s2_mask_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, Z, P],
+    "myolo_deconv2x2s2_mask_fwd_keep": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, I, P, Z, P],
+    "myolo_positive_index": [P, I, I, P, P, P, P, P],
     "myolo_wino_weight_transform": [P, P, I, I, I, P],
     "myolo_wino_input_transform": [P, P, I, I, I, I, P],
     "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],

@@ -262,6 +262,7 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.keep_deconv_rows = 48        # training forward keeps the ReLU'd deconv output of up to this many positives PER IMAGE (batch total) for the sparse backward; 0 = re-run the deconv there (round 3); beyond the cap the backward re-runs it
         self.fuse_compact_gather = 1      # compacted mask-head backward: gather + BatchNorm apply in one kernel, each pre-BN tensor gathered once (0: round 3's sequence)
         self.bucket1_on_wgrad_stream = 1  # data-parallel: bucket 1 released on the weight-gradient stream (0: round 3's join of that stream into the compute stream)
         self.pinned_upload = 1            # to_device_batch through pinned staging + the upload stream (0: synchronous torch.as_tensor copies, rounds 1-3)
@@ -795,8 +796,9 @@ class Net(object):
         return t
 
     # ---- mask head -----------------------------------------------------------
-    def mask_head_fwd(self, Fm, fshape, rois, train, pos_flags=None):
-        """rois [B,R,4] (x1,y1,x2,y2).  Returns pred masks [B*R, mh*mw, C] (post-sigmoid)."""
+    def mask_head_fwd(self, Fm, fshape, rois, train, pos_flags=None, keep=None):
+        """rois [B,R,4] (x1,y1,x2,y2).  Returns pred masks [B*R, mh*mw, C] (post-sigmoid).  keep = (inv_d, cap): the fused deconv + mask pass
+        also writes the ReLU'd deconv output of the ROIs with a compact slot < cap (the sparse backward reads it instead of re-running the deconv)."""
         cfg = self.cfg
         B, R = rois.shape[:2]
         n, h, w, cf = fshape
@@ -832,10 +834,18 @@ class Net(object):
             # deconv + ReLU + 1x1 + sigmoid in one pass; the 28x28x256 tensor is never written.  The sparse backward
             # recomputes it for the positive ROIs (mask_head_bwd_sparse); the dense backward needs it whole.
             self.ws.ensure(X.deconv_mask_ws_bytes(NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C))
-            X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]),
-                   X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
-                   X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, *self._wsargs(), X.stream())
             d = None
+            if keep is not None and MASK_FILTERS % 256 == 0:
+                inv_d, cap = keep
+                dk = self._new(cap * 4 * q, MASK_FILTERS)
+                X.call("myolo_deconv2x2s2_mask_fwd_keep", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]),
+                       X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
+                       X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, X.ptr(inv_d), X.ptr(dk), cap, *self._wsargs(), X.stream())
+                d = ("kept", dk, cap)
+            else:
+                X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]),
+                       X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(self.p["myolo_mask/kernel"]), X.ptr(self.p["myolo_mask/bias"]),
+                       X.ptr(p), NR, ps, ps, MASK_FILTERS, MASK_FILTERS, C, *self._wsargs(), X.stream())
         else:
             d = self._new(NR * 4 * ps * ps, MASK_FILTERS)
             X.call("myolo_deconv2x2s2_fwd", X.ptr(x), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(self.p["myolo_mask_deconv/bias"]),
@@ -1119,6 +1129,9 @@ class Net(object):
         self._npos_ready.synchronize()          # the step's one host wait: the per-image positive counts (32 ints) from mid-forward
         self.host_wait_s += time.perf_counter() - t0
         npos_h = self._npos_pinned.numpy()
+        if "pos_index" in self.tape:            # built on the device in front of the forward (myolo_positive_index): only the total is needed here
+            NP = int(np.clip(npos_h[:B], 0, R).sum())
+            return (NP,) + (self.tape["pos_index"] if NP else (None, None))
         pos = np.concatenate([np.arange(b * R, b * R + int(npos_h[b]), dtype=np.int32) for b in range(B)]) if B else np.zeros(0, np.int32)
         NP = int(pos.shape[0])
         if NP == 0:
@@ -1246,7 +1259,14 @@ class Net(object):
         gather = (lambda t, rows: t) if compact else (lambda t, rows: self._gather(t, idx_d, NP, rows))
         dz_p = gather(dz, 4 * q)
         a4_p = gather(a4, q)
-        if d is None:          # fused forward (deconv + 1x1 in one pass): rebuild the deconv output of the positives
+        if isinstance(d, tuple):          # ("kept", rows, cap): the fused forward wrote the positives' deconv output in compact order
+            d_p = d[1] if NP <= d[2] else None
+            d = None
+        else:
+            d_p = None
+        if d_p is not None:
+            pass
+        elif d is None:          # fused forward (deconv + 1x1 in one pass): rebuild the deconv output of the positives
             d_p = self._new(NP * 4 * q, MASK_FILTERS)
             X.call("myolo_deconv2x2s2_fwd", X.ptr(a4_p), X.ptr(self.p["myolo_mask_deconv/kernel"]),
                    X.ptr(self.p["myolo_mask_deconv/bias"]), X.ptr(d_p), NP, ps, ps, MASK_FILTERS, MASK_FILTERS, ACT_RELU,
@@ -1558,8 +1578,18 @@ class Net(object):
         else:
             # the ROIs whose activations the sparse backward will gather: the first n_pos rows of each image (exactly the
             # index set of _positive_index, whatever their class id)
-            flags = (torch.arange(R, device=self.dev, dtype=torch.int32).view(1, R) < npos.view(B, 1)).to(torch.int32).contiguous()
-            pred = self.mask_head_fwd(Fm, fshape, rois, True, pos_flags=flags.view(-1) if self.sparse_mask_bwd else None)
+            flags = keep = None
+            if self.sparse_mask_bwd:
+                # flags / compact slots / slot -> ROI of the positives, built on the device from the counts (no host round trip: the forward
+                # below already uses them; the host only learns the TOTAL, to size the compacted backward's launches)
+                flags = self._new(B * R, dtype=torch.int32)
+                idx_d = self._new(B * R, dtype=torch.int32)
+                inv_d = self._new(B * R, dtype=torch.int32)
+                X.call("myolo_positive_index", X.ptr(npos), B, R, X.ptr(flags), X.ptr(idx_d), X.ptr(inv_d), None, X.stream())
+                self.tape["pos_index"] = (idx_d, inv_d)
+                if self.keep_deconv_rows:
+                    keep = (inv_d, max(1, min(B * R, int(self.keep_deconv_rows * B))))
+            pred = self.mask_head_fwd(Fm, fshape, rois, True, pos_flags=flags, keep=keep)
             tmask_l, tcls_l = tmask, tcls
         if pred is None:                  # positives-only forward without a positive ROI (model.py:750-752)
             mterms = torch.zeros(2, dtype=torch.float32, device=self.dev)

@@ -323,6 +323,65 @@ def test_deconv_mask_fused(N, H, W, Cin, Cout, C, x6, request):
     assert torch.equal(p, p3), "fused deconv+mask is not bit-reproducible"
 
 
+def test_positive_index_on_device():
+    """myolo_positive_index == the host construction the engine used through round 3 (an image's positives are its first n_pos ROIs, model.py:593),
+    counts clamped to [0, R]."""
+    rng = np.random.default_rng(5)
+    for B, R in ((1, 7), (32, 147), (5, 245), (300, 3)):
+        npos = rng.integers(0, R + 1, size=B).astype(np.int32)
+        npos[rng.integers(0, B)] = 0
+        if B > 2:
+            npos[1] = R
+        flags, idx, inv = (torch.full((B * R,), -7, dtype=torch.int32, device=DEV) for _ in range(3))
+        tot = torch.zeros(1, dtype=torch.int32, device=DEV)
+        X.call("myolo_positive_index", X.ptr(dt(npos)), B, R, X.ptr(flags), X.ptr(idx), X.ptr(inv), X.ptr(tot), X.stream())
+        pos = np.concatenate([np.arange(b * R, b * R + int(npos[b]), dtype=np.int32) for b in range(B)])
+        ref_inv = np.full(B * R, -1, np.int32)
+        ref_inv[pos] = np.arange(len(pos), dtype=np.int32)
+        assert int(tot.item()) == len(pos)
+        assert np.array_equal(inv.cpu().numpy(), ref_inv)
+        assert np.array_equal(idx.cpu().numpy()[:len(pos)], pos)
+        assert np.all(idx.cpu().numpy()[len(pos):] == -7), "entries beyond the total must stay untouched"
+        assert np.array_equal(flags.cpu().numpy(), (ref_inv >= 0).astype(np.int32))
+
+
+@pytest.mark.parametrize("x6", [0, 1])
+@pytest.mark.parametrize("N,H,W", [(9, 14, 14), (40, 5, 3), (66, 14, 14)])
+def test_deconv_mask_fused_keeps_the_positives_rows(N, H, W, x6, request):
+    """myolo_deconv2x2s2_mask_fwd_keep: the probabilities are those of the plain fused pass bit for bit, and the kept rows are bit for bit what
+    myolo_deconv2x2s2_fwd(ReLU) gives on the gathered inputs (what the sparse backward used to re-run), slots at / beyond the cap untouched."""
+    opt = X.option("wino_x6", x6)
+    opt.__enter__()
+    request.addfinalizer(lambda: opt.__exit__(None, None, None))
+    Cin = Cout = 256
+    C = 4
+    rng = np.random.default_rng(6)
+    x, w, b = rnd(rng, N, H, W, Cin), rnd(rng, 2, 2, Cout, Cin, scale=0.05), rnd(rng, Cout)
+    w2, b2 = rnd(rng, Cout, C, scale=0.1), rnd(rng, C)
+    wsb = torch.empty(X.deconv_mask_ws_bytes(N, H, W, Cin, Cout, C), dtype=torch.uint8, device=DEV)
+    _KEEP.append(wsb)
+    chosen = np.sort(rng.choice(N, size=max(2, N // 3), replace=False)).astype(np.int32)
+    inv = np.full(N, -1, np.int32)
+    inv[chosen] = np.arange(len(chosen), dtype=np.int32)
+    cap = len(chosen) - 1                                  # the last chosen image is beyond the cap: not kept
+    sentinel = -123.0
+    dk = torch.full((len(chosen), 2 * H, 2 * W, Cout), sentinel, dtype=torch.float32, device=DEV)
+    p0, p1 = new(N, 2 * H, 2 * W, C), new(N, 2 * H, 2 * W, C)
+    args = (X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(w2)), X.ptr(dt(b2)))
+    X.call("myolo_deconv2x2s2_mask_fwd", *args, X.ptr(p0), N, H, W, Cin, Cout, C, wsb.data_ptr(), wsb.numel(), X.stream())
+    X.call("myolo_deconv2x2s2_mask_fwd_keep", *args, X.ptr(p1), N, H, W, Cin, Cout, C, X.ptr(dt(inv)), X.ptr(dk), cap, wsb.data_ptr(), wsb.numel(), X.stream())
+    assert torch.equal(p0, p1)
+    xs = np.ascontiguousarray(x[chosen])
+    y = new(len(chosen), 2 * H, 2 * W, Cout)
+    X.call("myolo_deconv2x2s2_fwd", X.ptr(dt(xs)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(y), len(chosen), H, W, Cin, Cout, 1, *ws(), X.stream())
+    if x6 and len(chosen) * H * W >= 4096:      # the product's setting at >= 21 positives: both run wino_mm_x6_kernel, rows are independent of the launch's size
+        assert torch.equal(dk[:cap], y[:cap]), "kept rows differ from the re-run deconv"
+    else:                      # the stand-alone deconv is an fp32-MFMA kernel (below 4096 rows also under "wino_x6"): other summation order
+        assert float((dk[:cap] - y[:cap]).abs().max()) < 2e-5
+    assert bool((dk[cap:] == sentinel).all()), "a slot at / beyond the cap was written"
+    check(dk[:cap], O.relu(O.deconv2x2s2(xs[:cap], w, b)), 1e-5, "kept deconv rows")
+
+
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (2, 16, 16, 32, 2), (3, 7, 7, 128, 1), (1, 14, 10, 64, 2),
                                             (2, 9, 13, 16, 1),
                                             # round 4, the row-sliding kernels on ragged shapes: several strips with a partial last one, row chunks

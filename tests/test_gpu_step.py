@@ -222,7 +222,7 @@ def _capture_mask_tape(store):
     def hook(net):
         convs, a4, d = net.tape["mask"]
         store.append(([t.detach().clone() if torch.is_tensor(t) else None for t in convs], a4.detach().clone(),
-                      None if d is None else d.detach().clone()))
+                      d.detach().clone() if torch.is_tensor(d) else None))       # ("kept", rows, cap): the positives' rows, bit-identical to the rebuild (test_gpu_ops)
     return hook
 
 
