@@ -185,6 +185,14 @@ int myolo_yolo_loss(const float* y_true, const float* y_pred, const float* true_
                     float object_scale, float no_object_scale, float coord_scale, float class_scale,
                     float loss_weight, float* out_terms, float* grad,
                     int B, int G, int A, int C, int T, void* ws, size_t ws_bytes, void* stream);
+/* the same with the warm-up branch of model.py:193-207 selectable (warmup != 0: taken by the reference while its `seen` counter, incremented once per
+ * evaluation of the loss, is below config.WARM_UP_BATCHES): predictors without a box are pulled to their cell centre and anchor size, every
+ * predictor's coordinate terms count with weight 1.  myolo_yolo_loss == warmup 0. */
+int myolo_yolo_loss_warmup(const float* y_true, const float* y_pred, const float* true_boxes,
+                           const float* anchors, const float* class_weights,
+                           float object_scale, float no_object_scale, float coord_scale, float class_scale,
+                           float loss_weight, int warmup, float* out_terms, float* grad,
+                           int B, int G, int A, int C, int T, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- DetectMaskTargetLayer / detect_mask_target_graph model.py:457-661 (+norm_boxes_graph
  *      :1394-1408, trim_zeros_graph :1411-1420, overlaps_graph :420-454), one block per image ----

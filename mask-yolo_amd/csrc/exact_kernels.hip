@@ -205,6 +205,7 @@ struct LossArgs {
     float obj, noobj, coord, cls, lw;
     float* out; float* grad;
     int B, G, A, C, T;
+    int warm;                  // the warm-up branch of model.py:193-207
 };
 
 #define LOSS_NACC 9   // sum_xy, sum_wh, sum_conf, sum_cls, n_coord, n_conf, n_cls, nb_true, nb_pred
@@ -244,7 +245,18 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a)
                 const float v = iou_centre(px, py, pw, ph, q[0], q[1], q[2], q[3], nullptr);
                 if (v > best) best = v;
             }
-            const float coord_mask = t4 * a.coord;
+            float coord_mask = t4 * a.coord;
+            // warm-up (model.py:193-207, while seen < WARM_UP_BATCHES): a predictor without a box is pulled to its cell centre and its anchor's size,
+            // and every predictor's coordinate terms count with weight 1; the IoU / confidence / class terms above keep the plain targets
+            float txl = t[0], tyl = t[1], twl = t[2], thl = t[3];
+            if (a.warm) {
+                const float nob = (coord_mask < a.coord / 2.0f) ? 1.0f : 0.0f;
+                txl = t[0] + (0.5f + (float)col) * nob;
+                tyl = t[1] + (0.5f + (float)row) * nob;
+                twl = t[2] + 1.0f * a.anchors[2 * an] * nob;
+                thl = t[3] + 1.0f * a.anchors[2 * an + 1] * nob;
+                coord_mask = 1.0f;
+            }
             const float conf_mask = ((best < 0.6f) ? 1.0f : 0.0f) * (1.0f - t4) * a.noobj + t4 * a.obj;
             const float class_mask = t4 * a.cw[tcls] * a.cls;
             // softmax CE over class logits
@@ -254,7 +266,7 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a)
             for (int k = 0; k < a.C; ++k) se += expf(p[5 + k] - mx);
             const float lse = logf(se) + mx;
             if (pass == 0) {
-                const float ex = t[0] - px, ey = t[1] - py, ew = t[2] - pw, eh = t[3] - ph, ec = tconf - pc;
+                const float ex = txl - px, ey = tyl - py, ew = twl - pw, eh = thl - ph, ec = tconf - pc;
                 acc[0] += (double)((ex * ex + ey * ey) * coord_mask);
                 acc[1] += (double)((ew * ew + eh * eh) * coord_mask);
                 acc[2] += (double)(ec * ec * conf_mask);
@@ -267,8 +279,8 @@ __global__ __launch_bounds__(256) void yolo_loss_kernel(LossArgs a)
             } else {
                 const float ncoord = (float)tot[4] + 1e-6f, nconf = (float)tot[5] + 1e-6f, ncls = (float)tot[6] + 1e-6f;
                 float* g = a.grad + (long long)i * D;
-                float dpx = -(t[0] - px) * coord_mask / ncoord, dpy = -(t[1] - py) * coord_mask / ncoord;
-                float dpw = -(t[2] - pw) * coord_mask / ncoord, dph = -(t[3] - ph) * coord_mask / ncoord;
+                float dpx = -(txl - px) * coord_mask / ncoord, dpy = -(tyl - py) * coord_mask / ncoord;
+                float dpw = -(twl - pw) * coord_mask / ncoord, dph = -(thl - ph) * coord_mask / ncoord;
                 const float dtconf = (tconf - pc) * conf_mask / nconf;
                 const float dpc = -dtconf;
                 const float diou = dtconf * t4;
@@ -602,11 +614,20 @@ int myolo_yolo_loss(const float* y_true, const float* y_pred, const float* true_
                     float loss_weight, float* out_terms, float* grad, int B, int G, int A, int C, int T, void* ws, size_t ws_bytes,
                     void* stream)
 {
+    return myolo_yolo_loss_warmup(y_true, y_pred, true_boxes, anchors, class_weights, object_scale, no_object_scale, coord_scale, class_scale,
+                                  loss_weight, 0, out_terms, grad, B, G, A, C, T, ws, ws_bytes, stream);
+}
+
+int myolo_yolo_loss_warmup(const float* y_true, const float* y_pred, const float* true_boxes, const float* anchors,
+                           const float* class_weights, float object_scale, float no_object_scale, float coord_scale, float class_scale,
+                           float loss_weight, int warmup, float* out_terms, float* grad, int B, int G, int A, int C, int T, void* ws, size_t ws_bytes,
+                           void* stream)
+{
     (void)ws; (void)ws_bytes;
     MYOLO_REQUIRE(y_true && y_pred && true_boxes && anchors && class_weights && out_terms && grad, "yolo_loss: null pointer");
     MYOLO_REQUIRE(B > 0 && G > 0 && A > 0 && C > 0 && T > 0, "yolo_loss: bad sizes");
     LossArgs a{y_true, y_pred, true_boxes, anchors, class_weights, object_scale, no_object_scale, coord_scale, class_scale,
-               loss_weight, out_terms, grad, B, G, A, C, T};
+               loss_weight, out_terms, grad, B, G, A, C, T, warmup ? 1 : 0};
     hipLaunchKernelGGL(yolo_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

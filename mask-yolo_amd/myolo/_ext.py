@@ -52,6 +52,7 @@ SIGS = {
     "myolo_yolo_decode": [P, P, P, I, I, I, I, P],
     "myolo_yolo_detections": [P, P, P, I, I, I, I, P],
     "myolo_yolo_loss": [P, P, P, P, P, F, F, F, F, F, P, P, I, I, I, I, I, P, Z, P],
+    "myolo_yolo_loss_warmup": [P, P, P, P, P, F, F, F, F, F, I, P, P, I, I, I, I, I, P, Z, P],
     "myolo_shapes_batch": [P, I, P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, I, P, Z, P],
     "myolo_unmold_masks": [P, P, P, I, I, I, I, I, I, P, Z, P],
     "myolo_mask_targets": [P, P, P, P, P, P, P, P, I, I, I, I, I, I, I, P],

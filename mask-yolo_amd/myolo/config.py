@@ -134,8 +134,7 @@ class Config(object):
             "len(ANCHORS) must be 2*N_BOX (got %d anchors values, N_BOX=%d)" % (len(self.ANCHORS), self.N_BOX)
         assert self.TRUE_BOX_BUFFER == self.MAX_GT_INSTANCES, \
             "BatchGenerator sizes gt arrays by both (myolo_utils.py:742-745)"
-        assert getattr(self, "WARM_UP_BATCHES", 0) == 0, \
-            "WARM_UP_BATCHES > 0 is the dead warm-up branch of yolo_custom_loss (config.py:38, model.py:199-210): not built"
+        assert int(getattr(self, "WARM_UP_BATCHES", 0)) >= 0, "WARM_UP_BATCHES counts loss evaluations (model.py:194-196)"
         self.TRAIN_ROIS_PER_IMAGE = self.GRID_H * self.GRID_W * self.N_BOX
         cw = np.asarray(self.CLASS_WEIGHTS, dtype='float32')
         if cw.shape[0] != self.NUM_CLASSES:

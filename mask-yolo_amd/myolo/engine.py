@@ -262,6 +262,7 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.seen = 0                     # evaluations of the YOLO loss so far (the reference's `seen`, see _yolo_warm)
         self.keep_deconv_rows = 48        # training forward keeps the ReLU'd deconv output of up to this many positives PER IMAGE (batch total) for the sparse backward; 0 = re-run the deconv there (round 3); beyond the cap the backward re-runs it
         self.fuse_compact_gather = 1      # compacted mask-head backward: gather + BatchNorm apply in one kernel, each pre-BN tensor gathered once (0: round 3's sequence)
         self.bucket1_on_wgrad_stream = 1  # data-parallel: bucket 1 released on the weight-gradient stream (0: round 3's join of that stream into the compute stream)
@@ -1524,6 +1525,12 @@ class Net(object):
                     v.record_stream(cur)
             db["_awaited"] = True
 
+    def _yolo_warm(self):
+        """yolo_custom_loss's `seen` counter (model.py:113,194: a graph variable incremented by EVERY evaluation of the loss -- training and
+        validation batches alike -- and not part of the saved weights): 1 while the warm-up branch (model.py:196-207) is taken."""
+        self.seen += 1
+        return 1 if self.seen < int(self.cfg.WARM_UP_BATCHES) else 0
+
     def forward_backward(self, db):
         """One training forward + backward on a device batch.  Gradients land in self.flat_g."""
         self._activate()
@@ -1553,10 +1560,11 @@ class Net(object):
         w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
         yterms = self._new(8)
         dyolo = self._new(yo.shape[0], yo.shape[1])
+        warm = self._yolo_warm()
         def yolo_loss():
-            X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+            X.call("myolo_yolo_loss_warmup", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
                    X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
-                   float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+                   float(cfg.CLASS_SCALE), w1, warm, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
         if self.overlap_yolo_bwd:
             # the loss kernel (one workgroup row per image, ~0.17 ms) only feeds the YOLO head's backward, which runs on the side stream:
             # launch it there too (side scratch buffer), under the mask head's forward, instead of in front of it
@@ -1635,9 +1643,10 @@ class Net(object):
         w2 = float(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
         yterms = self._new(8)
         dyolo = self._new(yo.shape[0], yo.shape[1])          # the loss kernel always forms the gradient; unused here
-        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+        warm = self._yolo_warm()
+        X.call("myolo_yolo_loss_warmup", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
                X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
-               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+               float(cfg.CLASS_SCALE), w1, warm, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
         if "gt_masks" not in db:
             self.tape = {}
             return dict(yolo_terms=yterms, mask_terms=torch.zeros(2, dtype=torch.float32, device=self.dev), loss_weights=(w1, 0.0))
@@ -1673,9 +1682,10 @@ class Net(object):
         w1 = float(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
         yterms = self._new(8)
         dyolo = self._new(yo.shape[0], yo.shape[1])
-        X.call("myolo_yolo_loss", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
+        warm = self._yolo_warm()
+        X.call("myolo_yolo_loss_warmup", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
                X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
-               float(cfg.CLASS_SCALE), w1, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
+               float(cfg.CLASS_SCALE), w1, warm, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
         lo, hi = self.bucket_ranges[2]
         self.flat_g[lo:hi].zero_()
         if self.on_bucket_ready:

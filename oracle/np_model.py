@@ -230,16 +230,16 @@ class Tape(object):
         return O.crop_and_resize_bwd_image(dx, boxes, bidx, fshape)
 
 
-def train_step_fwd_bwd(P, batch, cfg):
+def train_step_fwd_bwd(P, batch, cfg, warmup=False):
     """One training forward+backward (no optimiser).  batch = the six arrays of model.py:896-897.
-    Returns dict(outputs..., loss, grads, moving)."""
+    Returns dict(outputs..., loss, grads, moving).  warmup: the loss's warm-up branch (np_ops.yolo_loss; the caller keeps `seen`)."""
     images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks = batch
     T = Tape(P, cfg, training=True)
     C4, Fm, yolo_out = T.trunk(images.astype(O.F32))
     proposals = O.yolo_decode(yolo_out, cfg.ANCHORS, cfg.GRID_W)
     rois, tcls, tmask, npos = O.mask_targets(proposals, gt_ids, gt_boxes, gt_masks, cfg)
     pred = T.mask_head(Fm, rois)
-    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=True)
+    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=True, warmup=warmup)
     ml, dpred = O.mask_bce(tmask, tcls, pred, want_grad=True)
     w1 = O.F32(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
     w2 = O.F32(cfg.LOSS_WEIGHTS.get("myolo_mask_loss", 1.))
@@ -253,7 +253,7 @@ def train_step_fwd_bwd(P, batch, cfg):
                 feature_map=Fm, C4=C4, grads=G, moving=T.moving, tape=T)
 
 
-def val_step_fwd(P, batch, cfg):
+def val_step_fwd(P, batch, cfg, warmup=False):
     """Validation forward of fit_generator (model.py:1053-1054: validation_data=val_generator): the training graph
     (model.py:872-904) evaluated in Keras' test phase -- K.learning_phase() = 0, so EVERY BatchNormalization, bn1 of the
     mask head included (model.py:690 has no training= argument and therefore follows the learning phase), normalises with
@@ -264,7 +264,7 @@ def val_step_fwd(P, batch, cfg):
     proposals = O.yolo_decode(yolo_out, cfg.ANCHORS, cfg.GRID_W)
     rois, tcls, tmask, npos = O.mask_targets(proposals, gt_ids, gt_boxes, gt_masks, cfg)
     pred = T.mask_head(Fm, rois)
-    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=False)
+    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=False, warmup=warmup)
     ml = O.mask_bce(tmask, tcls, pred, want_grad=False)
     ml = ml[0] if isinstance(ml, tuple) else ml
     w1 = O.F32(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
@@ -273,12 +273,12 @@ def val_step_fwd(P, batch, cfg):
                 yolo_sum_loss=yl["loss"], mask_loss=ml, loss=O.F32(yl["loss"] * w1 + ml * w2), yolo_terms=yl)
 
 
-def yolo_step_fwd_bwd(P, batch, cfg):
+def yolo_step_fwd_bwd(P, batch, cfg, warmup=False):
     """'yolo' mode training step (model.py:906-920, compile :1084-1085): loss = mean(yolo_sum_loss) only."""
     images, true_boxes, y_true = batch[:3]
     T = Tape(P, cfg, training=True)
     C4, Fm, yolo_out = T.trunk(images.astype(O.F32))
-    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=True)
+    yl = O.yolo_loss(y_true, yolo_out, true_boxes, cfg, want_grad=True, warmup=warmup)
     w1 = O.F32(cfg.LOSS_WEIGHTS.get("yolo_sum_loss", 1.))
     G = {}
     T.trunk_bwd(np.zeros_like(Fm), yl["grad"] * w1, G)

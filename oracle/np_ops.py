@@ -446,9 +446,12 @@ def _iou_centre(pxy, pwh, txy, twh):
     return iou, (pmin, pmax, tmin, tmax, d, iwh, inter, union)
 
 
-def yolo_loss(y_true, y_pred, true_boxes, cfg, want_grad=False):
-    """cfg needs ANCHORS, N_BOX, GRID_W, *_SCALE, CLASS_WEIGHTS.  WARM_UP_BATCHES=0 branch only
-    (config.py:38; the warm-up branch at model.py:199-207 is dead)."""
+def yolo_loss(y_true, y_pred, true_boxes, cfg, want_grad=False, warmup=False):
+    """cfg needs ANCHORS, N_BOX, GRID_W, *_SCALE, CLASS_WEIGHTS.  warmup=True is the tf.cond branch of model.py:193-207
+    (taken while `seen` -- incremented once per evaluation of the loss, model.py:194 -- is below WARM_UP_BATCHES; dead at the
+    default WARM_UP_BATCHES = 0, config.py:38): predictors without a ground-truth box are pulled to their cell centre and their
+    anchor's size, and EVERY predictor's coordinate terms count with weight 1 (tf.ones_like(coord_mask), not COORD_SCALE).  The
+    confidence / class terms and the IoU they use are formed before the branch and do not change."""
     y_true = y_true.astype(F32)
     y_pred = y_pred.astype(F32)
     tb = true_boxes.astype(F32)
@@ -472,6 +475,11 @@ def yolo_loss(y_true, y_pred, true_boxes, cfg, want_grad=False):
     conf_mask = (best < F32(0.6)).astype(F32) * (F32(1) - t4) * F32(cfg.NO_OBJECT_SCALE) + t4 * F32(cfg.OBJECT_SCALE)
     cw = np.asarray(cfg.CLASS_WEIGHTS, F32)
     class_mask = (t4 * cw[tcls] * F32(cfg.CLASS_SCALE)).astype(F32)
+    if warmup:                                                    # model.py:193-207
+        no_boxes = (coord_mask < F32(cfg.COORD_SCALE) / F32(2)).astype(F32)
+        txy = (txy + (F32(0.5) + cell_grid(G)) * no_boxes).astype(F32)
+        twh = (twh + np.ones_like(twh) * anc * no_boxes).astype(F32)
+        coord_mask = np.ones_like(coord_mask)
     n_coord = F32((coord_mask > 0).sum())
     n_conf = F32((conf_mask > 0).sum())
     n_cls = F32((class_mask > 0).sum())

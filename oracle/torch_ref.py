@@ -79,8 +79,8 @@ def crop_and_resize_t(img, boxes, bidx, ch, cw):
     return torch.where(valid, val, torch.zeros((), dtype=img.dtype))
 
 
-def yolo_loss_t(y_true, y_pred, true_boxes, cfg):
-    """model.py:86-242 in torch ops (autograd supplies the gradient)."""
+def yolo_loss_t(y_true, y_pred, true_boxes, cfg, warmup=False):
+    """model.py:86-242 in torch ops (autograd supplies the gradient); warmup: the branch of model.py:193-207 (see np_ops.yolo_loss)."""
     dt = y_pred.dtype
     B, G, _, A, D = y_pred.shape
     anc = torch.tensor(np.asarray(cfg.ANCHORS, np.float64).reshape(1, 1, 1, A, 2), dtype=dt)
@@ -105,6 +105,11 @@ def yolo_loss_t(y_true, y_pred, true_boxes, cfg):
     conf_mask = (best < 0.6).to(dt) * (1 - t4) * cfg.NO_OBJECT_SCALE + t4 * cfg.OBJECT_SCALE
     cw = torch.tensor(np.asarray(cfg.CLASS_WEIGHTS, np.float64), dtype=dt)
     class_mask = t4 * cw[tcls] * cfg.CLASS_SCALE
+    if warmup:
+        no_boxes = (coord_mask < cfg.COORD_SCALE / 2.).to(dt)
+        txy = txy + (0.5 + grid) * no_boxes
+        twh = twh + torch.ones_like(twh) * anc * no_boxes
+        coord_mask = torch.ones_like(coord_mask)
     n_coord = (coord_mask > 0).to(dt).sum()
     n_conf = (conf_mask > 0).to(dt).sum()
     n_cls = (class_mask > 0).to(dt).sum()

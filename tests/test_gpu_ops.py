@@ -607,6 +607,40 @@ def test_yolo_loss():
     check(grad, ref["grad"], 1e-4, "yolo loss grad")
 
 
+def test_yolo_loss_warmup_branch():
+    """myolo_yolo_loss_warmup(warmup=1) == the oracle's warm-up branch (model.py:193-207), terms and gradient; warmup=0 == myolo_yolo_loss bit for bit."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], COORD_SCALE=3.0, WARM_UP_BATCHES=4)
+    rng = np.random.default_rng(12)
+    B, G, A, C, T = 4, cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+    yp = rnd(rng, B, G, G, A, 5 + C)
+    yt = np.zeros_like(yp)
+    tb = np.zeros((B, 1, 1, 1, T, 4), np.float32)
+    for b in range(B):
+        for k in range(b + 1):
+            gy, gx, a = rng.integers(0, G, 2).tolist() + [int(rng.integers(0, A))]
+            box = [gx + rng.random(), gy + rng.random(), 0.5 + 3 * rng.random(), 0.5 + 3 * rng.random()]
+            yt[b, gy, gx, a, :4] = box
+            yt[b, gy, gx, a, 4] = 1
+            yt[b, gy, gx, a, 5 + rng.integers(1, C)] = 1
+            tb[b, 0, 0, 0, k] = box
+    args = (X.ptr(dt(yt)), X.ptr(dt(yp)), X.ptr(dt(tb.reshape(B, T, 4))), X.ptr(dt(np.asarray(cfg.ANCHORS, np.float32))),
+            X.ptr(dt(cfg.CLASS_WEIGHTS)), cfg.OBJECT_SCALE, cfg.NO_OBJECT_SCALE, cfg.COORD_SCALE, cfg.CLASS_SCALE, 1.0)
+    out = {}
+    for warm in (0, 1):
+        terms, grad = new(8), new(*yp.shape)
+        X.call("myolo_yolo_loss_warmup", *args, warm, X.ptr(terms), X.ptr(grad), B, G, A, C, T, *ws(), X.stream())
+        ref = O.yolo_loss(yt, yp, tb, cfg, want_grad=True, warmup=bool(warm))
+        t = terms.cpu().numpy()
+        for i, k in enumerate(["loss", "loss_xy", "loss_wh", "loss_conf", "loss_class", "recall", "n_coord", "n_conf"]):
+            assert abs(t[i] - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (warm, k, t[i], ref[k])
+        check(grad, ref["grad"], 1e-4, "yolo loss grad, warmup=%d" % warm)
+        out[warm] = (terms, grad)
+    assert float(out[1][0][6]) == B * G * G * A and float(out[0][0][6]) == sum(range(1, B + 1)) or float(out[0][0][6]) <= sum(range(1, B + 1))
+    terms, grad = new(8), new(*yp.shape)
+    X.call("myolo_yolo_loss", *args, X.ptr(terms), X.ptr(grad), B, G, A, C, T, *ws(), X.stream())
+    assert torch.equal(terms, out[0][0]) and torch.equal(grad, out[0][1])
+
+
 def test_mask_head_out_and_bce():
     rng = np.random.default_rng(11)
     NR, hw, Cin, C = 6, 28 * 28, 256, 4

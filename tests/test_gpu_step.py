@@ -142,6 +142,50 @@ def test_train_step_head_config_nbox5(fp32_matmul):
     assert not bad, bad
 
 
+def test_warm_up_batches_follow_the_seen_counter():
+    """config.WARM_UP_BATCHES (config.py:38, model.py:193-207): the loss's `seen` counter is incremented by every evaluation and the warm-up
+    branch is taken while seen < WARM_UP_BATCHES -- with 3, evaluations 1 and 2 (a training step and a validation forward count alike) are
+    warm, the third is not.  Learning rate 0 keeps the weights, so all three see the same network: terms and gradients against the oracle's
+    step with / without the branch."""
+    base, P, batch, ref_plain = make_case(ShapesConfig, 128, 0.5, 4)
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4, WARM_UP_BATCHES=3, COORD_SCALE=2.0)
+    ref_w = np_model.train_step_fwd_bwd(P, batch, cfg, warmup=True)
+    ref_p = np_model.train_step_fwd_bwd(P, batch, cfg, warmup=False)
+    assert abs(float(ref_w["yolo_sum_loss"]) - float(ref_p["yolo_sum_loss"])) > 1e-2
+    model = MaskYOLO(mode="training", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+
+    def check_step(out, ref, what):
+        for k in ("yolo_sum_loss", "loss_xy", "loss_wh", "loss_conf", "loss_class"):
+            r = float(ref["yolo_terms"][k] if k != "yolo_sum_loss" else ref["yolo_sum_loss"])
+            assert abs(float(out[k]) - r) <= 1e-4 * max(1.0, abs(r)), (what, k, float(out[k]), r)
+
+    out1 = model.train_on_batch(batch, learning_rate=0.0)            # seen = 1: warm
+    check_step(out1, ref_w, "step 1")
+    g1 = net.grads_dict()
+    db = net.to_device_batch(batch)
+    v = net.forward_loss(db)                                          # seen = 2: warm (Keras evaluates the same loss tensor on validation batches)
+    yt = v["yolo_terms"].cpu().numpy()
+    P2 = dict(P)                                                      # step 1 moved the moving statistics the validation forward normalises with
+    for name, (mm, mv) in ref_w["moving"].items():
+        P2[name + "/moving_mean"], P2[name + "/moving_variance"] = mm, mv
+    val_w = np_model.val_step_fwd(P2, batch, cfg, warmup=True)
+    assert abs(float(yt[0]) - float(val_w["yolo_sum_loss"])) <= 1e-4 * max(1.0, abs(float(val_w["yolo_sum_loss"])))
+    assert abs(float(val_w["yolo_sum_loss"]) - float(np_model.val_step_fwd(P2, batch, cfg)["yolo_sum_loss"])) > 1e-2
+    out3 = model.train_on_batch(batch, learning_rate=0.0)            # seen = 3: plain
+    check_step(out3, ref_p, "step 3")
+    g3 = net.grads_dict()
+    assert net.seen == 3
+    # the YOLO head's gradients follow the branch (the trunk's pick up ReLU6 flips: held to the end-to-end bound of compare_step)
+    for g, ref in ((g1, ref_w), (g3, ref_p)):
+        for k in ("conv_23/kernel", "conv_23/bias"):                  # the YOLO head's 1x1 conv (model.py:277-281)
+            e = float(np.linalg.norm(g[k].astype(np.float64) - ref["grads"][k]) / max(1e-30, np.linalg.norm(ref["grads"][k])))
+            assert e < 2e-2, (k, e)
+    k = "conv_23/kernel"
+    assert float(np.linalg.norm(g1[k] - g3[k])) > 1e-3 * float(np.linalg.norm(g3[k])), "warm-up did not change the YOLO head's gradient"
+
+
 @pytest.mark.parametrize("sparse", [False, True])
 def test_mask_head_teacher_forced(sparse):
     """Mask head forward + BCE + backward with the ORACLE's feature map and ROIs fed to the GPU

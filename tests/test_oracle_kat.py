@@ -226,6 +226,59 @@ def test_yolo_loss_gradient_matches_finite_difference():
         O.set_precision(np.float32)
 
 
+def test_yolo_loss_warmup_branch_closed_form_and_gradient():
+    """model.py:193-207 (taken while seen < WARM_UP_BATCHES): with sigmoid(0) = .5 and exp(0) * anchor every EMPTY predictor sits exactly on
+    its warm-up target (cell centre, anchor size), so only the one object predictor contributes to the coordinate terms -- with weight 1, not
+    COORD_SCALE, over ALL G*G*A predictors; confidence / class terms equal the plain branch's.  Then the analytic gradient of the branch
+    against finite differences in float64, and against torch autograd of the same graph (oracle/torch_ref.py)."""
+    cfg = _cfg(COORD_SCALE=4.0)
+    G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+    yt = np.zeros((1, G, G, A, 5 + C), F32)
+    yp = np.zeros((1, G, G, A, 5 + C), F32)
+    tb = np.zeros((1, 1, 1, 1, T, 4), F32)
+    row, col, a = 3, 2, 1
+    box = [col + 0.25, row + 0.5, cfg.ANCHORS[2 * a] * 2, cfg.ANCHORS[2 * a + 1]]
+    yt[0, row, col, a, :4] = box
+    yt[0, row, col, a, 4] = 1
+    yt[0, row, col, a, 5 + 2] = 1
+    tb[0, 0, 0, 0, 0] = box
+    plain = O.yolo_loss(yt, yp, tb, cfg)
+    warm = O.yolo_loss(yt, yp, tb, cfg, warmup=True)
+    n_all = G * G * A
+    assert plain["n_coord"] == 1 and warm["n_coord"] == n_all
+    assert abs(float(warm["loss_xy"]) - 0.25 ** 2 / (n_all + 1e-6) / 2) < 1e-9
+    assert abs(float(warm["loss_wh"]) - cfg.ANCHORS[2 * a] ** 2 / (n_all + 1e-6) / 2) < 1e-7
+    assert abs(float(plain["loss_xy"]) - 0.25 ** 2 * 4.0 / (1 + 1e-6) / 2) < 1e-7          # the plain branch weighs the object cell by COORD_SCALE
+    assert warm["loss_conf"] == plain["loss_conf"] and warm["loss_class"] == plain["loss_class"] and warm["n_conf"] == plain["n_conf"]
+    O.set_precision(np.float64)
+    try:
+        cfg = _cfg(IMAGE_SHAPE=[64, 64, 3], COORD_SCALE=2.0)
+        rng = np.random.default_rng(7)
+        G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
+        yp = rng.standard_normal((2, G, G, A, 5 + C)) * 0.5
+        yt = np.zeros_like(yp)
+        tb = np.zeros((2, 1, 1, 1, T, 4))
+        for b, (r, c, a) in enumerate([(0, 1, 2), (1, 0, 0)]):
+            box = [c + 0.4, r + 0.6, 1.5, 1.2]
+            yt[b, r, c, a, :4] = box
+            yt[b, r, c, a, 4] = 1
+            yt[b, r, c, a, 5 + 1 + b] = 1
+            tb[b, 0, 0, 0, 0] = box
+        g = O.yolo_loss(yt, yp, tb, cfg, want_grad=True, warmup=True)["grad"]
+        num = _numgrad(lambda: float(O.yolo_loss(yt, yp, tb, cfg, warmup=True)["loss"]), yp, eps=1e-6)
+        np.testing.assert_allclose(g, num, atol=2e-6)
+        import torch
+        from oracle import torch_ref as TR
+        ypt = torch.tensor(yp, dtype=torch.float64, requires_grad=True)
+        loss_t, _ = TR.yolo_loss_t(torch.tensor(yt), ypt, torch.tensor(tb), cfg, warmup=True)
+        loss_t.backward()
+        assert abs(float(loss_t) - float(O.yolo_loss(yt, yp, tb, cfg, warmup=True)["loss"])) < 1e-12
+        np.testing.assert_allclose(g, ypt.grad.numpy(), atol=1e-12)
+        assert abs(float(O.yolo_loss(yt, yp, tb, cfg, warmup=True)["loss"]) - float(O.yolo_loss(yt, yp, tb, cfg)["loss"])) > 1e-3
+    finally:
+        O.set_precision(np.float32)
+
+
 # ---------------------------------------------------------------- targets (model.py:457-602)
 def test_mask_targets_empty_gt_all_negative_and_padded_quirk():
     cfg = _cfg(IMAGE_SHAPE=[64, 64, 3])
