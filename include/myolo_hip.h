@@ -251,12 +251,7 @@ int myolo_adam_step(float* p, const float* g, float* m, float* v, int64_t n,
 size_t myolo_deconv2x2s2_mask_ws_bytes(int N, int H, int W, int Cin, int Cout, int ncls);
 int myolo_deconv2x2s2_mask_fwd(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
                                int N, int H, int W, int Cin, int Cout, int ncls, void* ws, size_t ws_bytes, void* stream);
-/* the same pass that ALSO writes relu(deconv + bias) -- exactly what myolo_deconv2x2s2_fwd(ACT_RELU) gives -- for the images (ROIs) the training step will
- * differentiate: keep_inv [N] = slot (0 <= slot < keep_cap) or -1 (myolo_positive_index), keep_d [keep_cap][2H][2W][Cout]; images whose slot is -1 or
- * >= keep_cap are not kept.  Needs Cout % 256 == 0 (the matrix-pipe kernels of csrc/wino_mm.hip). */
-int myolo_deconv2x2s2_mask_fwd_keep(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
-                                    int N, int H, int W, int Cin, int Cout, int ncls, const int32_t* keep_inv, float* keep_d, int keep_cap,
-                                    void* ws, size_t ws_bytes, void* stream);
+
 
 /* ---- Winograd F(4x4,3x3) form of the dense 3x3/s1/SAME convolutions (same contracts as myolo_conv3x3_* above:
  * myolo_mask_conv1-4 model.py:687-709 and their gradients); fp32 operands and accumulation, 4x fewer multiplications

@@ -39,6 +39,12 @@ int myolo_gather_groups(const float* src, const int32_t* idx, float* dst, int n,
  * n_pos[b] ROIs, model.py:593): flags [B*R] (NULL: not written) = 1 for a positive ROI, inv [B*R] = its compact slot or -1, idx [slot] = flat ROI
  * (the first sum(n_pos) entries of a [B*R] buffer are written), total [1] (NULL: not written) = sum(n_pos).  No host round trip. */
 int myolo_positive_index(const int32_t* n_pos, int B, int R, int32_t* flags, int32_t* idx, int32_t* inv, int32_t* total, void* stream);
+/* myolo_deconv2x2s2_mask_fwd (include/myolo_hip.h) that ALSO writes relu(deconv + bias) -- exactly what myolo_deconv2x2s2_fwd(ACT_RELU) gives -- for the images (ROIs) the training step will
+ * differentiate: keep_inv [N] = slot (0 <= slot < keep_cap) or -1 (myolo_positive_index), keep_d [keep_cap][2H][2W][Cout]; images whose slot is -1 or
+ * >= keep_cap are not kept.  Needs Cout % 256 == 0 (the matrix-pipe kernels of csrc/wino_mm.hip). */
+int myolo_deconv2x2s2_mask_fwd_keep(const float* x, const float* w, const float* bias, const float* w2, const float* b2, float* p_out,
+                                    int N, int H, int W, int Cin, int Cout, int ncls, const int32_t* keep_inv, float* keep_d, int keep_cap,
+                                    void* ws, size_t ws_bytes, void* stream);
 /* the same gather of n groups of group_rows x C floats, fused with the per-channel affine map + activation that follows it in the compacted mask-head
  * backward: dst_pre (NULL: not written) = the gathered rows, dst_act = act(row * scale + shift) as myolo_bn_apply_act gives.  C / 4 must divide 256. */
 int myolo_gather_groups_affine_act(const float* src, const int32_t* idx, const float* scale, const float* shift, int act, float* dst_pre,
