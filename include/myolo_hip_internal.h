@@ -28,6 +28,19 @@ int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const flo
                                  float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act,
                                  void* ws, size_t ws_bytes, void* stream);
 
+/* ---- prepared-weights registry: the weight-only re-layouts that entry points run in front of their kernels (transposes, bf16x6 piece splits, Winograd
+ * filter transforms) recorded once and re-run by the owner on a stream of its choice, off the training step's critical chain (csrc/myolo_common.h).
+ * arena: a 256-byte aligned device buffer the slots are carved from (entries that do not fit stay on the in-place path).  activate(h) makes h the
+ * registry the entry points consult (NULL: none); refresh re-runs entries [first, last) on `stream` for the current weight generation and returns
+ * how many it launched; invalidate: the weights changed.  One launch thread per process. ---- */
+int myolo_wprep_create(void* arena, size_t arena_bytes, void** handle);
+int myolo_wprep_destroy(void* h);
+int myolo_wprep_activate(void* h);
+int myolo_wprep_count(void* h);
+int myolo_wprep_invalidate(void* h);
+int myolo_wprep_refresh(void* h, int first, int last, int max_idle, void* stream);
+int myolo_wprep_stats(void* h, long long* hits, long long* misses, long long* bytes_used);
+
 /* Exact-sparsity helpers for the mask head backward (build_mask_graph model.py:690-708: bn1 is the only
  * batch-statistics layer, so behind it only ROIs with a positive target carry non-zero gradient):
  * gather_groups: dst[i] = src[idx[i]] for groups of group_elems floats (one ROI's rows);
@@ -71,6 +84,8 @@ size_t myolo_wino_u_elems(int Cin, int Cout);
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream);
 int myolo_wino_input_transform(const float* x, float* V, int N, int H, int W, int C, void* stream);
 int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
+/* weight_transform (flip 0) + multiply; U_scratch is written only when the filters are not already prepared for this step (myolo_wprep_*) */
+int myolo_wino_multiply_w(const float* V, const float* w, float* U_scratch, float* M, int N, int H, int W, int Cin, int Cout, void* stream);
 int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
                                 int N, int H, int W, int C, int act, void* stream);
 /* ROIAlign (myolo_crop_and_resize_fwd: same boxes / box_ind / sampling) fused into the input transform of the conv that
@@ -114,6 +129,9 @@ size_t myolo_wino63_u_elems(int Cin, int Cout);
 
 int myolo_wino63_weight_transform(const float* w, float* U, int Cin, int Cout, void* stream);
 int myolo_wino63_multiply(const float* V, const float* U, float* M, int N, int Cin, int Cout, void* stream);
+/* weight_transform + multiply in one call (w = the layer's [3,3,Cin,Cout] kernel): U_scratch (myolo_wino63_u_elems floats) is written only when the
+ * transformed filters are not already prepared for this step (prepared-weights registry, myolo_wprep_* above) */
+int myolo_wino63_multiply_w(const float* V, const float* w, float* U_scratch, float* M, int N, int Cin, int Cout, void* stream);
 /* x [N,14,14,C] -> act(x*scale + shift) (scale NULL: identity) -> V; the activation also goes to y (NULL: nowhere) where flags[img] != 0
  * (flags NULL: everywhere) */
 int myolo_wino63_input_transform(const float* x, const float* scale, const float* shift, int act, float* y, const int32_t* flags, float* V,

@@ -1431,11 +1431,13 @@ int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
         ws_bytes >= myolo_matmul_f32_ws_bytes(Cout, Cin, 1, MYOLO_PRODUCTS_BF16X6) && (((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0) {
         // FP32_MATMUL = "bf16x6": dx [M][Cin] = dy [M][Cout] * w^T, and w [Cin][Cout] IS the transposed operand [N][K] the NT kernel wants:
         // no transpose launch, six exact bf16 piece products per fp32 product on the bf16 matrix pipe (csrc/wino_mm.hip)
-        return myolo_matmul_f32(dy, w, dx, M, Cout, Cin, 1, MYOLO_PRODUCTS_BF16X6, ws, ws_bytes, stream);
+        return myolo_matmul_f32_impl(dy, w, dx, M, Cout, Cin, 1, MYOLO_PRODUCTS_BF16X6, ws, ws_bytes, stream, true);
     }
-    launch_transpose(w, (float*)ws, Cin, Cout, 1, 0, s);        // ws = w^T [Cout][Cin]
+    // w^T [Cout][Cin]: into ws, or already prepared for this step (prepared-weights registry, csrc/myolo_common.h)
+    const float* wt = (const float*)myolo_wprep_resolve(w, WP_TRANSPOSE, Cin, Cout, 10, (size_t)Cin * Cout * sizeof(float), ws, s,
+                                                        [=](void* d, hipStream_t st) { launch_transpose(w, (float*)d, Cin, Cout, 1, 0, st); });
     GemmArgs a = {};
-    a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = M; a.N = Cin; a.K = Cout;
+    a.A = dy; a.B = wt; a.C = dx; a.M = M; a.N = Cin; a.K = Cout;
     a.lda = Cout; a.ldb = Cin; a.ldc = Cin;
     const size_t wbytes = align256((size_t)Cin * Cout * sizeof(float));
     launch_nn<AM_PLAIN, EP_PLAIN>(a, s, (char*)ws + wbytes, ws_bytes > wbytes ? ws_bytes - wbytes : 0);
@@ -1627,9 +1629,10 @@ int myolo_conv3x3_bwd_data(const float* dy, const float* w, float* dx,
     MYOLO_NEED_WS((size_t)9 * Cin * Cout * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     // ws[tap][co][ci] = w[8-tap][ci][co]  : dx = conv3x3_same(dy, rot180(w)^T)
-    launch_transpose(w, (float*)ws, Cin, Cout, 9, 1, s);
+    const float* wt = (const float*)myolo_wprep_resolve(w, WP_TRANSPOSE, Cin, Cout, 91, (size_t)9 * Cin * Cout * sizeof(float), ws, s,
+                                                        [=](void* d, hipStream_t st) { launch_transpose(w, (float*)d, Cin, Cout, 9, 1, st); });
     GemmArgs a = {};
-    a.A = dy; a.B = (const float*)ws; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 9 * Cout;
+    a.A = dy; a.B = wt; a.C = dx; a.M = (long long)N * H * W; a.N = Cin; a.K = 9 * Cout;
     a.ldb = Cin; a.ldc = Cin; a.H = H; a.W = W; a.Cc = Cout;
     const size_t wbytes = align256((size_t)9 * Cin * Cout * sizeof(float));
     launch_nn<AM_CONV3, EP_PLAIN>(a, s, (char*)ws + wbytes, ws_bytes > wbytes ? ws_bytes - wbytes : 0);
@@ -1664,9 +1667,11 @@ int myolo_deconv2x2s2_fwd(const float* x, const float* w, const float* bias, flo
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
-    launch_transpose(w, (float*)ws, 4 * Cout, Cin, 1, 0, s);     // ws[ci][(ky,kx,co)]
+    // ws[ci][(ky,kx,co)]
+    const float* wt = (const float*)myolo_wprep_resolve(w, WP_TRANSPOSE, 4 * Cout, Cin, 10, (size_t)4 * Cin * Cout * sizeof(float), ws, s,
+                                                        [=](void* d, hipStream_t st) { launch_transpose(w, (float*)d, 4 * Cout, Cin, 1, 0, st); });
     GemmArgs a = {};
-    a.A = x; a.B = (const float*)ws; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
+    a.A = x; a.B = wt; a.C = y; a.bias = bias; a.M = (long long)N * H * W; a.N = 4 * Cout; a.K = Cin;
     a.lda = Cin; a.ldb = 4 * Cout; a.H = H; a.W = W; a.Co = Cout; a.act = act;
     launch_nn<AM_PLAIN, EP_DECONV>(a, s);
     MYOLO_CHECK_LAUNCH();

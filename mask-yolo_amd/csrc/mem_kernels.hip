@@ -62,6 +62,95 @@ extern "C" int myolo_get_option(const char* name, int* value)
     return MYOLO_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// prepared-weights registry (see myolo_common.h)
+// ---------------------------------------------------------------------------------------
+#include <vector>
+struct WPrepEntry {
+    const void* w; int kind; long long d0, d1, d2;
+    size_t off, bytes;
+    unsigned long long gen;            // weight generation its slot was refreshed for (0: never)
+    unsigned long long last_use;       // generation of the last resolve() that asked for it
+    std::function<void(void*, hipStream_t)> run;
+};
+struct WPrep {
+    char* arena; size_t cap, used;
+    unsigned long long gen;
+    std::vector<WPrepEntry> e;
+    long long hits, misses;
+};
+static WPrep* g_wprep = nullptr;       // the active registry (one launch thread)
+
+const void* myolo_wprep_resolve(const void* w, int kind, long long d0, long long d1, long long d2, size_t bytes, void* fallback, hipStream_t s,
+                                const std::function<void(void*, hipStream_t)>& run)
+{
+    WPrep* r = g_wprep;
+    if (r) {
+        for (auto& en : r->e)
+            if (en.w == w && en.kind == kind && en.d0 == d0 && en.d1 == d1 && en.d2 == d2 && en.bytes == bytes) {
+                en.last_use = r->gen;
+                if (en.gen == r->gen) { ++r->hits; return r->arena + en.off; }
+                ++r->misses;
+                run(fallback, s);
+                return fallback;
+            }
+        const size_t need = align256(bytes);
+        if (r->used + need <= r->cap) {            // new site: reserve a slot, prepared by the owner's next refresh
+            r->e.push_back(WPrepEntry{w, kind, d0, d1, d2, r->used, bytes, 0ull, r->gen, run});
+            r->used += need;
+        }
+        ++r->misses;
+    }
+    run(fallback, s);
+    return fallback;
+}
+
+extern "C" int myolo_wprep_create(void* arena, size_t arena_bytes, void** handle)
+{
+    MYOLO_REQUIRE(handle && arena && ((uintptr_t)arena & 255) == 0, "wprep_create: needs a 256-byte aligned device arena and a handle slot");
+    WPrep* r = new WPrep();
+    r->arena = (char*)arena; r->cap = arena_bytes; r->used = 0; r->gen = 1; r->hits = r->misses = 0;
+    *handle = r;
+    return MYOLO_OK;
+}
+extern "C" int myolo_wprep_destroy(void* h)
+{
+    if (g_wprep == (WPrep*)h) g_wprep = nullptr;
+    delete (WPrep*)h;
+    return MYOLO_OK;
+}
+extern "C" int myolo_wprep_activate(void* h) { g_wprep = (WPrep*)h; return MYOLO_OK; }
+extern "C" int myolo_wprep_count(void* h) { return h ? (int)((WPrep*)h)->e.size() : 0; }
+extern "C" int myolo_wprep_invalidate(void* h) { if (h) ++((WPrep*)h)->gen; return MYOLO_OK; }
+extern "C" int myolo_wprep_stats(void* h, long long* hits, long long* misses, long long* bytes_used)
+{
+    MYOLO_REQUIRE(h, "wprep_stats: null registry");
+    WPrep* r = (WPrep*)h;
+    if (hits) *hits = r->hits;
+    if (misses) *misses = r->misses;
+    if (bytes_used) *bytes_used = (long long)r->used;
+    return MYOLO_OK;
+}
+/* re-run the recorded preparations [first, last) into their slots on `stream` and mark them valid for the current weight generation; entries no
+ * resolve() has asked for during the last `max_idle` generations are skipped (they miss, and are prepared in place, when they come back).
+ * Returns the number of preparations launched (< 0: error). */
+extern "C" int myolo_wprep_refresh(void* h, int first, int last, int max_idle, void* stream)
+{
+    if (!h) { myolo_set_error("wprep_refresh: null registry"); return -1; }
+    WPrep* r = (WPrep*)h;
+    if (last > (int)r->e.size()) last = (int)r->e.size();
+    int n = 0;
+    for (int i = first < 0 ? 0 : first; i < last; ++i) {
+        WPrepEntry& en = r->e[i];
+        if (max_idle > 0 && r->gen - en.last_use > (unsigned long long)max_idle) continue;
+        en.run(r->arena + en.off, (hipStream_t)stream);
+        en.gen = r->gen;
+        ++n;
+    }
+    if (hipGetLastError() != hipSuccess) { myolo_set_error("wprep_refresh: a launch failed"); return -1; }
+    return n;
+}
+
 __device__ __forceinline__ float4 ld4g(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4g(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 typedef float f32x4n __attribute__((ext_vector_type(4)));

@@ -72,6 +72,21 @@ extern MyoloOptions g_myolo_opt;
         }                                                                            \
     } while (0)
 
+// ---------------------------------------------------------------------------------------
+// Prepared-weights registry (csrc/mem_kernels.hip).  Many entry points start by re-laying a WEIGHT tensor out for their kernel (a transpose, the
+// three-bf16-piece split of the bf16x6 products, a Winograd filter transform): 30-odd small launches per training step that depend on nothing
+// but the weights, all of them on the step's critical chain.  With a registry active (myolo_wprep_activate) such a site asks
+// myolo_wprep_resolve(): a known (weights, kind, dims) entry that was refreshed for the current weight generation returns its slot in the caller's
+// arena -- no launch; an unknown one is recorded (slot reserved) and prepared into the fallback scratch exactly as without a registry.  The owner
+// re-runs every recorded preparation with myolo_wprep_refresh() on a stream of its choice (the training step: a side stream at the step's start,
+// under the first layers) and orders its consumers behind that; myolo_wprep_invalidate() (the weights changed) makes every entry miss again.
+// One launch thread per process; no registry active = the previous behaviour, bit for bit (the prepared bytes are the same either way).
+// ---------------------------------------------------------------------------------------
+#include <functional>
+enum { WP_TRANSPOSE = 1, WP_X6_SPLIT = 2, WP_WINO63_U = 3, WP_WINO43_U = 4 };
+const void* myolo_wprep_resolve(const void* w, int kind, long long d0, long long d1, long long d2, size_t bytes, void* fallback, hipStream_t s,
+                                const std::function<void(void*, hipStream_t)>& run);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
@@ -104,6 +119,8 @@ int myolo_deconv_x6_bwd_data(const float* dy, const float* w, float* dx, long lo
 size_t myolo_deconv_x6_bwd_weight_ws_bytes(long long M, int Cin, int Co);
 int myolo_deconv_x6_bwd_weight(const float* x, const float* dy, float* dw, long long M, int H, int W, int Cin, int Co, void* part, size_t part_bytes,
                                hipStream_t s);
+int myolo_matmul_f32_impl(const float* A, const float* B, float* C, int64_t M, int K, int N, int b_is_nk, int products,
+                          void* ws, size_t ws_bytes, void* stream, bool b_is_weight);
 // pointwise convs with >= 256 channels under "wino_x6" (csrc/wino_mm.hip)
 bool myolo_pw_x6_ok(int K, int N);
 size_t myolo_pw_x6_split_bytes(int K, int N);

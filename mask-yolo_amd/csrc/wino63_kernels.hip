@@ -544,6 +544,25 @@ int myolo_wino63_weight_transform(const float* w, float* U, int Cin, int Cout, v
 }
 
 /* M[q] = V[q] * U[q] for the 64 points: one launch over the three runs of equal-height planes (csrc/wino_mm.hip) */
+// the transformed filters of a layer: into `scratch`, or the copy prepared for this step (prepared-weights registry, csrc/myolo_common.h).
+// flip = 1: rotated, (ci, co)-exchanged filters of the data gradient (Cin / Cout as the FORWARD conv has them, as wino63_w_kernel takes them)
+static const float* w63_filters(const float* w, float* scratch, int Cin, int Cout, int flip, hipStream_t s)
+{
+    const int layout = flip ? w63_layout(Cout, Cin) : w63_layout(Cin, Cout);
+    return (const float*)myolo_wprep_resolve(w, WP_WINO63_U, Cin, Cout, flip * 16 + layout, myolo_wino63_u_elems(Cin, Cout) * sizeof(float), scratch, s,
+                                             [=](void* d, hipStream_t st) {
+        hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, st, w, (float*)d, Cin, Cout, layout, flip);
+    });
+}
+
+/* weight_transform + multiply in one call: U_scratch (myolo_wino63_u_elems floats) is written only when the filters are not already prepared */
+int myolo_wino63_multiply_w(const float* V, const float* w, float* U_scratch, float* M, int N, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(V && w && U_scratch && M && N > 0 && myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "wino63_multiply_w: bad arguments");
+    const float* U = w63_filters(w, U_scratch, Cin, Cout, 0, (hipStream_t)stream);
+    return myolo_wino63_multiply(V, U, M, N, Cin, Cout, stream);
+}
+
 int myolo_wino63_multiply(const float* V, const float* U, float* M, int N, int Cin, int Cout, void* stream)
 {
     MYOLO_REQUIRE(V && U && M && N > 0 && myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "wino63_multiply: bad arguments");
@@ -733,10 +752,9 @@ int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, co
     MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cout, Cin), "wino63_bwd_data_lazybn: unsupported channel counts (%d -> %d)", Cin, Cout);
     MYOLO_NEED_WS(myolo_wino63_bwd_data_ws_bytes(N, Cin, Cout));
     hipStream_t s = (hipStream_t)stream;
-    float* U = (float*)ws;
     float* V = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
     float* Mp = (float*)((char*)V + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)));
-    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, w63_layout(Cout, Cin), 1);
+    const float* U = w63_filters(w, (float*)ws, Cin, Cout, 1, s);
     W63Args a{y_pre, V, nullptr, nullptr, nullptr, scale, shift, N, Cout, act, dy_compact, inv, ka, kb};
     w63_launch<W63_FROM_LAZY, W63_TO_V>(a, s);
     const int rc = myolo_wino63_multiply(V, U, Mp, N, Cout, Cin, stream);
@@ -773,9 +791,8 @@ int myolo_wino63_bwd_data_from_v(const float* V, const float* w, float* dx, int 
     MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cout, Cin), "wino63_bwd_data_from_v: unsupported channel counts (%d -> %d)", Cin, Cout);
     MYOLO_NEED_WS(myolo_wino63_bwd_data_from_v_ws_bytes(N, Cin, Cout));
     hipStream_t s = (hipStream_t)stream;
-    float* U = (float*)ws;
     float* Mp = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
-    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, w63_layout(Cout, Cin), 1);
+    const float* U = w63_filters(w, (float*)ws, Cin, Cout, 1, s);
     const int rc = myolo_wino63_multiply(V, U, Mp, N, Cout, Cin, stream);
     if (rc != MYOLO_OK) return rc;
     W63Args b{Mp, nullptr, dx, nullptr, nullptr, nullptr, nullptr, N, Cin, MYOLO_ACT_NONE};
@@ -826,10 +843,11 @@ int myolo_conv3x3_wino63_fwd(const float* x, const float* w, const float* bias, 
     MYOLO_REQUIRE(x && w && y && N > 0 && !scale == !shift, "conv3x3_wino63_fwd: bad arguments");
     MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "conv3x3_wino63_fwd: unsupported channel counts (%d -> %d)", Cin, Cout);
     MYOLO_NEED_WS(myolo_conv3x3_wino63_ws_bytes(N, Cin, Cout, 0));
-    float* U = (float*)ws;
     float* V = v_keep ? v_keep : (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
     float* Mp = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)) + align256(myolo_wino63_plane_elems(N, Cin) * sizeof(float)));
-    int rc = myolo_wino63_weight_transform(w, U, Cin, Cout, stream);
+    MYOLO_REQUIRE(w && myolo_wino63_ok(W63_HW, W63_HW, Cin, Cout), "conv3x3_wino63_fwd: unsupported channel counts (%d -> %d)", Cin, Cout);
+    const float* U = w63_filters(w, (float*)ws, Cin, Cout, 0, (hipStream_t)stream);
+    int rc = MYOLO_OK;
     if (rc == MYOLO_OK) rc = myolo_wino63_input_transform(x, nullptr, nullptr, MYOLO_ACT_NONE, nullptr, nullptr, V, N, Cin, stream);
     if (rc == MYOLO_OK) rc = myolo_wino63_multiply(V, U, Mp, N, Cin, Cout, stream);
     if (rc == MYOLO_OK) rc = myolo_wino63_output_transform(Mp, bias, scale, shift, y, N, Cout, act, stream);
@@ -843,10 +861,9 @@ int myolo_conv3x3_wino63_bwd_data(const float* dy, const float* w, float* dx, in
     MYOLO_REQUIRE(myolo_wino63_ok(W63_HW, W63_HW, Cout, Cin), "conv3x3_wino63_bwd_data: unsupported channel counts (%d -> %d)", Cin, Cout);
     MYOLO_NEED_WS(myolo_conv3x3_wino63_ws_bytes(N, Cin, Cout, 1));
     hipStream_t s = (hipStream_t)stream;
-    float* U = (float*)ws;
     float* V = (float*)((char*)ws + align256(myolo_wino63_u_elems(Cin, Cout) * sizeof(float)));
     float* Mp = (float*)((char*)V + align256(myolo_wino63_plane_elems(N, Cout) * sizeof(float)));
-    hipLaunchKernelGGL(wino63_w_kernel, dim3((Cin * Cout + 255) / 256), dim3(256), 0, s, w, U, Cin, Cout, w63_layout(Cout, Cin), 1);
+    const float* U = w63_filters(w, (float*)ws, Cin, Cout, 1, s);
     int rc = myolo_wino63_input_transform(dy, nullptr, nullptr, MYOLO_ACT_NONE, nullptr, nullptr, V, N, Cout, stream);
     if (rc == MYOLO_OK) rc = myolo_wino63_multiply(V, U, Mp, N, Cout, Cin, stream);
     if (rc == MYOLO_OK) rc = myolo_wino63_output_transform(Mp, nullptr, nullptr, nullptr, dx, N, Cin, MYOLO_ACT_NONE, stream);

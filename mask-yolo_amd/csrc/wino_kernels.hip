@@ -764,6 +764,15 @@ size_t myolo_wino_plane_elems(int N, int H, int W, int C) { return (size_t)geom(
 /* floats to allocate for the transformed filters U of myolo_wino_weight_transform (any layout the multiply may choose) */
 size_t myolo_wino_u_elems(int Cin, int Cout) { return u_bytes(Cin, Cout) / sizeof(float); }
 
+// transformed filters of a layer for the F(4,3) tiling: into `scratch`, or the copy prepared for this step (prepared-weights registry)
+static const float* w43_filters(const float* w, float* scratch, int Cin, int Cout, int flip, hipStream_t s)
+{
+    const int layout = wino_u_layout(flip ? Cout : Cin, flip ? Cin : Cout);
+    return (const float*)myolo_wprep_resolve(w, WP_WINO43_U, Cin, Cout, flip * 16 + layout, u_bytes(Cin, Cout), scratch, s, [=](void* d, hipStream_t st) {
+        hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, st, w, (float*)d, Cin, Cout, flip, layout);
+    });
+}
+
 /* ---- the four stages on their own (the engine times the multiply stage for bench.py's roofline) ---- */
 int myolo_wino_weight_transform(const float* w, float* U, int Cin, int Cout, int flip, void* stream)
 {
@@ -810,6 +819,14 @@ int myolo_wino_multiply(const float* V, const float* U, float* M, int N, int H, 
     if (rc != MYOLO_OK) return rc;
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
+}
+
+/* weight_transform (flip 0) + multiply in one call: U_scratch (myolo_wino_u_elems floats) is written only when the filters are not already prepared */
+int myolo_wino_multiply_w(const float* V, const float* w, float* U_scratch, float* M, int N, int H, int W, int Cin, int Cout, void* stream)
+{
+    MYOLO_REQUIRE(V && w && U_scratch && M && N > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "wino_multiply_w: bad arguments");
+    const float* U = w43_filters(w, U_scratch, Cin, Cout, 0, (hipStream_t)stream);
+    return myolo_wino_multiply(V, U, M, N, H, W, Cin, Cout, stream);
 }
 
 int myolo_wino_output_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
@@ -889,10 +906,9 @@ int myolo_conv3x3_wino_fwd(const float* x, const float* w, const float* bias, co
     const size_t ub = u_bytes(Cin, Cout), vb = v_keep ? 0 : plane_bytes(g, Cin), mb = plane_bytes(g, Cout);
     MYOLO_NEED_WS(ub + vb + mb);
     hipStream_t s = (hipStream_t)stream;
-    float* U = (float*)ws;
     float* V = v_keep ? v_keep : (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 0, wino_u_layout(Cin, Cout));
+    const float* U = w43_filters(w, (float*)ws, Cin, Cout, 0, s);
     hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cin / 4))), dim3(256), 0, s, x, V, g, Cin, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = wino_multiply_all(V, U, Mp, g, Cin, Cout, s);
     if (rc != MYOLO_OK) return rc;
@@ -912,10 +928,9 @@ static int wino_bwd_data_impl(const float* dy, const LazyBn* lazy, const float* 
     const size_t ub = u_bytes(Cin, Cout), vb = plane_bytes(g, Cout), mb = plane_bytes(g, Cin);
     MYOLO_NEED_WS(ub + vb + mb);
     hipStream_t s = (hipStream_t)stream;
-    float* U = (float*)ws;
     float* V = (float*)((char*)ws + ub);
     float* Mp = (float*)((char*)ws + ub + vb);
-    hipLaunchKernelGGL(wino_w_kernel, dim3((Cout + 15) / 16, (Cin + 15) / 16), dim3(256), 0, s, w, U, Cin, Cout, 1, wino_u_layout(Cout, Cin));
+    const float* U = w43_filters(w, (float*)ws, Cin, Cout, 1, s);
     if (lazy) hipLaunchKernelGGL(wino_in_kernel<true>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, *lazy);
     else hipLaunchKernelGGL(wino_in_kernel<false>, dim3(ew_grid(g.T * (Cout / 4))), dim3(256), 0, s, dy, V, g, Cout, (const float*)nullptr, (const float*)nullptr, 0, LazyBn{});
     const int rc = wino_multiply_all(V, U, Mp, g, Cout, Cin, s);

@@ -688,6 +688,15 @@ __global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restric
     rec[0] = p1; rec[512] = p2; rec[1024] = p3;
 }
 
+// the three-bf16-piece split of a WEIGHT matrix: into `scratch`, or the copy prepared for this step (prepared-weights registry, csrc/myolo_common.h)
+static const float* x6_split_weights(const float* w, void* scratch, int K, int N, int src_kn, hipStream_t s)
+{
+    const long long total = (long long)K * N;
+    return (const float*)myolo_wprep_resolve(w, WP_X6_SPLIT, K, N, src_kn, (size_t)total * 6, scratch, s, [=](void* d, hipStream_t st) {
+        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (__bf16*)d, K, N, src_kn);
+    });
+}
+
 /* whether the fused deconv + ReLU + 1x1 mask conv GEMM (csrc/gemm_kernels.hip: myolo_deconv2x2s2_mask_fwd) runs on these kernels */
 bool myolo_deconv_mask_mm_ok(int Cin, int Cout) { return !g_myolo_opt.wino_no_bt && (Cin % MM_BK) == 0 && Cin >= MM_BK && (Cout % MM_BN) == 0; }
 size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout) { return align256((size_t)4 * Cin * Cout * 6); }
@@ -708,9 +717,7 @@ int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, cons
     R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
     const long long tiles = (long long)R.mtiles * (N / MM_BN);
     if (g_myolo_opt.wino_x6) {
-        const long long total = (long long)K * N;
-        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 0);
-        a.Bt = (const float*)split;
+        a.Bt = x6_split_weights(w, split, K, N, 0, s);
         hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
     } else {
         a.Bt = w;
@@ -744,6 +751,13 @@ extern "C" size_t myolo_matmul_f32_ws_bytes(int K, int N, int b_is_nk, int produ
 extern "C" int myolo_matmul_f32(const float* A, const float* B, float* C, int64_t M, int K, int N, int b_is_nk, int products,
                                 void* ws, size_t ws_bytes, void* stream)
 {
+    return myolo_matmul_f32_impl(A, B, C, M, K, N, b_is_nk, products, ws, ws_bytes, stream, false);
+}
+
+// b_is_weight: B is a layer's weight tensor (its bf16x6 split may come from the prepared-weights registry); false for arbitrary operands
+int myolo_matmul_f32_impl(const float* A, const float* B, float* C, int64_t M, int K, int N, int b_is_nk, int products,
+                          void* ws, size_t ws_bytes, void* stream, bool b_is_weight)
+{
     MYOLO_REQUIRE(A && B && C && M > 0 && K >= MM_BK && (K % MM_BK) == 0 && N >= MM_BN && (N % MM_BN) == 0,
                   "matmul_f32: needs M > 0, K %% %d == 0, N %% %d == 0", MM_BK, MM_BN);
     MYOLO_REQUIRE(products == MYOLO_PRODUCTS_NATIVE || products == MYOLO_PRODUCTS_BF16X6, "matmul_f32: products must be MYOLO_PRODUCTS_NATIVE or MYOLO_PRODUCTS_BF16X6");
@@ -758,8 +772,11 @@ extern "C" int myolo_matmul_f32(const float* A, const float* B, float* C, int64_
     const long long tiles = (long long)R.mtiles * (N / MM_BN);
     if (products == MYOLO_PRODUCTS_BF16X6) {
         const long long total = (long long)K * N;
-        hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, B, (__bf16*)ws, K, N, b_is_nk ? 0 : 1);
-        a.Bt = (const float*)ws;
+        if (b_is_weight) a.Bt = x6_split_weights(B, ws, K, N, b_is_nk ? 0 : 1, s);
+        else {
+            hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, B, (__bf16*)ws, K, N, b_is_nk ? 0 : 1);
+            a.Bt = (const float*)ws;
+        }
         if (x6_half_tiles(tiles)) hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, false, MM_A_PLAIN, 2>), dim3((unsigned)(2 * tiles)), dim3(256), 0, s, a);
         else hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_PLAIN>, dim3((unsigned)tiles), dim3(256), 0, s, a);
     } else {
@@ -1098,9 +1115,7 @@ int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift
     R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
     R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
     const long long tiles = (long long)R.mtiles * (N / MM_BN);
-    const long long total = (long long)K * N;
-    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 1);
-    a.Bt = (const float*)split;
+    a.Bt = x6_split_weights(w, split, K, N, 1, s);
     if (x6_half_tiles(tiles)) hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true, MM_A_PLAIN, 2>), dim3((unsigned)(2 * tiles)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, true>), dim3((unsigned)tiles), dim3(256), 0, s, a);
     return MYOLO_OK;
@@ -1124,9 +1139,7 @@ int myolo_deconv_x6_fwd(const float* x, const float* w, const float* bias, float
     a.A = x; a.C = y; a.K = K; a.N = N; a.nruns = 1; a.bias = bias; a.H = H; a.W = W; a.Co = Co; a.a_act = act;
     MMRun& R = a.run[0];
     R.rows = M; R.nq = 1; R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
-    const long long total = (long long)K * N;
-    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 0);     // w = [N][K]
-    a.Bt = (const float*)split;
+    a.Bt = x6_split_weights(w, split, K, N, 0, s);     // w = [N][K]
     hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_DECONV, false, MM_A_PLAIN>), dim3((unsigned)((long long)R.mtiles * (N / MM_BN))), dim3(256), 0, s, a);
     return MYOLO_OK;
 }
@@ -1137,9 +1150,7 @@ int myolo_deconv_x6_bwd_data(const float* dy, const float* w, float* dx, long lo
     a.A = dy; a.C = dx; a.K = K; a.N = N; a.nruns = 1; a.H = H; a.W = W; a.Co = Co;
     MMRun& R = a.run[0];
     R.rows = M; R.nq = 1; R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
-    const long long total = (long long)K * N;
-    hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (__bf16*)split, K, N, 1);     // w = [K = (tap, co)][N = ci]
-    a.Bt = (const float*)split;
+    a.Bt = x6_split_weights(w, split, K, N, 1, s);     // w = [K = (tap, co)][N = ci]
     hipLaunchKernelGGL((wino_mm_x6_kernel<MM_EP_PLAIN, false, MM_A_DECONV>), dim3((unsigned)((long long)R.mtiles * (N / MM_BN))), dim3(256), 0, s, a);
     return MYOLO_OK;
 }

@@ -60,6 +60,8 @@ SIGS = {
     "myolo_conv3x3_wino_fwd": [P, P, P, P, P, P, I, I, I, I, I, I, P, P, Z, P],
     "myolo_wino63_weight_transform": [P, P, I, I, P],
     "myolo_wino63_multiply": [P, P, P, I, I, I, P],
+    "myolo_wino63_multiply_w": [P, P, P, P, I, I, I, P],
+    "myolo_wprep_stats": [P, P, P, P],
     "myolo_wino63_input_transform": [P, P, P, I, P, P, P, I, I, P],
     "myolo_wino63_output_input_transform": [P, P, P, P, P, P, P, I, I, I, P],
     "myolo_wino63_output_transform": [P, P, P, P, P, I, I, I, P],
@@ -83,6 +85,7 @@ SIGS = {
     "myolo_wino_weight_transform": [P, P, I, I, I, P],
     "myolo_wino_input_transform": [P, P, I, I, I, I, P],
     "myolo_wino_multiply": [P, P, P, I, I, I, I, I, P],
+    "myolo_wino_multiply_w": [P, P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_transform": [P, P, P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_input_transform": [P, P, P, P, P, P, P, I, I, I, I, I, P],
     "myolo_wino_output_input_transform_keep_pre": [P, P, P, P, P, P, P, I, I, I, I, I, P],
@@ -179,6 +182,15 @@ def load():
     lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
     lib.myolo_wino_output_transform_bn_ws_bytes.argtypes = [I]
     lib.myolo_wino_output_transform_bn_ws_bytes.restype = Z
+    lib.myolo_wprep_create.argtypes = [P, Z, P]
+    lib.myolo_wprep_create.restype = I
+    for fn in (lib.myolo_wprep_destroy, lib.myolo_wprep_activate, lib.myolo_wprep_invalidate):
+        fn.argtypes = [P]
+        fn.restype = I
+    lib.myolo_wprep_count.argtypes = [P]
+    lib.myolo_wprep_count.restype = I
+    lib.myolo_wprep_refresh.argtypes = [P, I, I, I, P]
+    lib.myolo_wprep_refresh.restype = I
     _LIB = lib
     return lib
 
@@ -186,7 +198,8 @@ def load():
 def exported_symbols():
     return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes", "myolo_conv3x3s2_c3_bnstats_ws_bytes", "myolo_dwconv3x3_bnstats_ws_bytes", "myolo_dwconv3x3_bwd_weight_ws_bytes",
                               "myolo_pwconv1x1_bnstats_ws_bytes", "myolo_pwconv1x1_bnstats_ok",
-                              "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes"]
+                              "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes",
+                              "myolo_wprep_create", "myolo_wprep_destroy", "myolo_wprep_activate", "myolo_wprep_invalidate", "myolo_wprep_count", "myolo_wprep_refresh"]
 
 
 def ptr(t):
@@ -206,6 +219,50 @@ def call(name, *args):
     rc = getattr(lib, name)(*args)
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (name, rc, lib.myolo_last_error_string().decode()))
+
+
+class WeightPrep(object):
+    """Prepared-weights registry of the library (include/myolo_hip_internal.h: myolo_wprep_*): the weight-only re-layouts that entry points run in front of
+    their kernels, recorded while the registry is active and re-run by refresh() on the caller's current stream.  Owns its arena (a device tensor)."""
+
+    def __init__(self, device, arena_bytes=768 << 20):
+        self.arena = torch.empty(int(arena_bytes), dtype=torch.uint8, device=device)
+        h = ctypes.c_void_p(0)
+        call("myolo_wprep_create", self.arena.data_ptr(), self.arena.numel(), ctypes.byref(h))
+        self.h = h.value
+
+    def activate(self, on=True):
+        load().myolo_wprep_activate(self.h if on else None)
+
+    def count(self):
+        return int(load().myolo_wprep_count(self.h))
+
+    def invalidate(self):
+        load().myolo_wprep_invalidate(self.h)
+
+    def refresh(self, first=0, last=1 << 30, max_idle=4):
+        n = load().myolo_wprep_refresh(self.h, int(first), int(last), int(max_idle), stream())
+        if n < 0:
+            raise RuntimeError("myolo_wprep_refresh failed: %s" % load().myolo_last_error_string().decode())
+        return n
+
+    def stats(self):
+        a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
+        call("myolo_wprep_stats", self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
+        return dict(hits=a.value, misses=b.value, bytes_used=c.value, entries=self.count())
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib = _LIB
+            if lib is not None:
+                lib.myolo_wprep_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def set_option(name, value):

@@ -262,6 +262,10 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.weight_prep = 1              # training step: weight-only re-layouts (transposes, bf16x6 splits, Winograd filter transforms) re-run on a side stream at the step's start instead of inside the chain (X.WeightPrep); 0 = in place (round 3)
+        self._wprep = None
+        self._wprep_ntrunk = None         # registry entries recorded before the mask head (their consumers are the trunk's first layers)
+        self._wprep_ev = None
         self.seen = 0                     # evaluations of the YOLO loss so far (the reference's `seen`, see _yolo_warm)
         self.keep_deconv_rows = 48        # training forward keeps the ReLU'd deconv output of up to this many positives PER IMAGE (batch total) for the sparse backward; 0 = re-run the deconv there (round 3); beyond the cap the backward re-runs it
         self.fuse_compact_gather = 1      # compacted mask-head backward: gather + BatchNorm apply in one kernel, each pre-BN tensor gathered once (0: round 3's sequence)
@@ -433,18 +437,16 @@ class Net(object):
             # F(6,3)/F(4,3) tiling of a 14x14 map (csrc/wino63_kernels.hip); a kept V stays in the F(4,3) layout its consumer expects
             U = self._new(X.wino63_u_elems(cin, cout))
             V, M = self._new(X.wino63_plane_elems(nimg, cin)), self._new(X.wino63_plane_elems(nimg, cout))
-            X.call("myolo_wino63_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, X.stream())
             X.call("myolo_wino63_input_transform", X.ptr(x), None, None, ACT_NONE, None, None, X.ptr(V), nimg, cin, X.stream())
-            self._call_timed("wino_multiply" if tag == "mask_conv3x3_fwd" else None, "myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(M),
+            self._call_timed("wino_multiply" if tag == "mask_conv3x3_fwd" else None, "myolo_wino63_multiply_w", X.ptr(V), X.ptr(kern), X.ptr(U), X.ptr(M),
                              nimg, cin, cout, X.stream())
             X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(bias), X.ptr(scale), X.ptr(shift), X.ptr(y), nimg, cout, act, X.stream())
         elif self._wino_ok(nimg, h, w, cin, cout):
             T = nimg * ((h + 3) // 4) * ((w + 3) // 4)
             U, V, M = self._new(X.wino_u_elems(cin, cout)), self._new(36, T, cin), self._new(36, T, cout)
-            X.call("myolo_wino_weight_transform", X.ptr(kern), X.ptr(U), cin, cout, 0, X.stream())
             X.call("myolo_wino_input_transform", X.ptr(x), X.ptr(V), nimg, h, w, cin, X.stream())
             # only the dense mask-head launches (tag given) feed bench.py's roofline; feature_map / compacted ones do not
-            self._call_timed("wino_multiply" if tag == "mask_conv3x3_fwd" else None, "myolo_wino_multiply", X.ptr(V), X.ptr(U), X.ptr(M),
+            self._call_timed("wino_multiply" if tag == "mask_conv3x3_fwd" else None, "myolo_wino_multiply_w", X.ptr(V), X.ptr(kern), X.ptr(U), X.ptr(M),
                              nimg, h, w, cin, cout, X.stream())
             X.call("myolo_wino_output_transform", X.ptr(M), X.ptr(bias), X.ptr(scale), X.ptr(shift), X.ptr(y), nimg, h, w, cout, act,
                    X.stream())
@@ -673,6 +675,8 @@ class Net(object):
             a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)
         shape = (N, H // 2, W // 2, C0)
         self.tape["images"] = images
+        if train:
+            self._wprep_wait(0)           # the trunk's prepared weights (a few small kernels on the side stream, under conv1)
         bid = 1
         for f, s in BACKBONE_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
@@ -694,6 +698,9 @@ class Net(object):
         X.call("myolo_pwconv1x1_fwd", X.ptr(a), X.ptr(self.p["conv_23/kernel"]), X.ptr(self.p["conv_23/bias"]), X.ptr(yo),
                n2 * h2 * w2, c2, D, *self._wsargs(), X.stream())
         self.tape["trunk"] = (C4, c4shape, a, shape)
+        if train:
+            self._wprep_mark_trunk()
+            self._wprep_wait(1)           # everything else that was prepared (before any stream forks off this one)
         return Fm, (n, h, w, Cf), yo
 
     def yolo_head_bwd(self, dyolo):
@@ -897,8 +904,9 @@ class Net(object):
                         self._call_timed("wino_in", "myolo_wino_input_transform", X.ptr(x), X.ptr(Vcur), NR, ps, ps, cin, X.stream())
             if use63:
                 U, M = self._new(X.wino63_u_elems(cin, MASK_FILTERS)), self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
-                X.call("myolo_wino63_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, X.stream())
-                self._call_timed("wino_multiply", "myolo_wino63_multiply", X.ptr(Vcur), X.ptr(U), X.ptr(M), NR, cin, MASK_FILTERS, X.stream())
+                # (the transformed filters: prepared at the step's start in training, X.WeightPrep, else formed into U here)
+                self._call_timed("wino_multiply", "myolo_wino63_multiply_w", X.ptr(Vcur), X.ptr(self.p[cn + "/kernel"]), X.ptr(U), X.ptr(M), NR, cin,
+                                 MASK_FILTERS, X.stream())
             else:
                 U, M = self._new(X.wino_u_elems(cin, MASK_FILTERS)), self._new(36, T, MASK_FILTERS)
                 X.call("myolo_wino_weight_transform", X.ptr(self.p[cn + "/kernel"]), X.ptr(U), cin, MASK_FILTERS, 0, X.stream())
@@ -1176,8 +1184,8 @@ class Net(object):
                            self._new(X.wino63_plane_elems(NR, MASK_FILTERS)))
                 self._call_timed("roialign_fwd", "myolo_wino63_input_transform_roialign", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(V),
                                  n, h, w, cf, NR, X.stream())
-                X.call("myolo_wino63_weight_transform", X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), cf, MASK_FILTERS, X.stream())
-                self._call_timed("wino_multiply", "myolo_wino63_multiply", X.ptr(V), X.ptr(U), X.ptr(M), NR, cf, MASK_FILTERS, X.stream())
+                self._call_timed("wino_multiply", "myolo_wino63_multiply_w", X.ptr(V), X.ptr(self.p["myolo_mask_conv1/kernel"]), X.ptr(U), X.ptr(M), NR, cf,
+                                 MASK_FILTERS, X.stream())
                 self.ws.ensure(X.wino63_out_bn_ws_bytes(NR, MASK_FILTERS))
                 X.call("myolo_wino63_output_transform_bn_stats", X.ptr(M), X.ptr(self.p["myolo_mask_conv1/bias"]), X.ptr(y1), NR, MASK_FILTERS,
                        *bn_args, *self._wsargs(), X.stream())
@@ -1531,8 +1539,65 @@ class Net(object):
         self.seen += 1
         return 1 if self.seen < int(self.cfg.WARM_UP_BATCHES) else 0
 
+    # ---- prepared weights (csrc/myolo_common.h): valid inside ONE forward_backward call, for the weights as they are at its start
+    def _wprep_begin(self):
+        if not self.weight_prep:
+            return
+        if self._wprep is None:
+            self._wprep = X.WeightPrep(self.dev)
+        wp = self._wprep
+        self._wprep_ev = None
+        n = wp.count()
+        if n:
+            # every preparation recorded so far, in the order the step first asked for them, on the weight-gradient stream (idle here: the optimizer
+            # joined it), under the first layers of the forward.  Two marks: the trunk's entries, everything.
+            cur = torch.cuda.current_stream()
+            side = self._wgrad_stream
+            side.wait_stream(cur)                 # behind the optimizer's update of the weights
+            nt = min(self._wprep_ntrunk if self._wprep_ntrunk is not None else n, n)
+            ev1, ev2 = torch.cuda.Event(), torch.cuda.Event()
+            with torch.cuda.stream(side):
+                wp.refresh(0, nt)
+                ev1.record(side)
+                wp.refresh(nt, n)
+                ev2.record(side)
+            self._wprep_ev = [ev1, ev2]
+        wp.activate(True)
+
+    def _wprep_wait(self, k):
+        """order the current stream behind mark k (0: the trunk's preparations, 1: all) of this step's refresh; once each."""
+        if self._wprep_ev is not None and self._wprep_ev[k] is not None:
+            for j in range(k + 1):
+                if self._wprep_ev[j] is not None:
+                    torch.cuda.current_stream().wait_event(self._wprep_ev[j])
+                    self._wprep_ev[j] = None
+
+    def _wprep_mark_trunk(self):
+        if self._wprep is not None and self._wprep_ntrunk is None and self.weight_prep:
+            self._wprep_ntrunk = self._wprep.count()
+
+    def _wprep_end(self):
+        if self._wprep is not None:
+            self._wprep.activate(False)
+            self._wprep.invalidate()              # the optimizer (or anyone) may change the weights next
+            self._wprep_ev = None
+
     def forward_backward(self, db):
         """One training forward + backward on a device batch.  Gradients land in self.flat_g."""
+        self._wprep_begin()
+        try:
+            return self._forward_backward(db)
+        finally:
+            self._wprep_end()
+
+    def forward_backward_yolo(self, db):
+        self._wprep_begin()
+        try:
+            return self._forward_backward_yolo(db)
+        finally:
+            self._wprep_end()
+
+    def _forward_backward(self, db):
         self._activate()
         self._await_batch(db)
         cfg = self.cfg
@@ -1668,7 +1733,7 @@ class Net(object):
         return dict(yolo_terms=yterms, mask_terms=mterms, loss_weights=(w1, w2), yolo_output=yo.view(B, G, G, A, 5 + C),
                     output_rois=rois, target_class_ids=tcls, myolo_mask=pred.view(B, R, mh, mw, C), n_pos=npos)
 
-    def forward_backward_yolo(self, db):
+    def _forward_backward_yolo(self, db):
         """'yolo' mode training step (model.py:906-920: outputs [yolo_output, yolo_sum_loss]): backbone + YOLO head
         + yolo_custom_loss, no feature_map / ROIAlign / mask head.  db needs images, true_boxes, y_true."""
         self._activate()

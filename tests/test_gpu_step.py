@@ -142,6 +142,34 @@ def test_train_step_head_config_nbox5(fp32_matmul):
     assert not bad, bad
 
 
+def test_prepared_weights_change_nothing_but_the_launch_order():
+    """Net.weight_prep (X.WeightPrep, csrc/myolo_common.h): from the second step on the weight-only re-layouts come from a side-stream refresh at the
+    step's start instead of launches inside the chain.  The prepared bytes are the same either way, so three optimizer steps end in bit-identical
+    weights and gradients; the registry must have served hits, and an inference call in between (no registry active) must not see stale copies."""
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    res = {}
+    for prep in (0, 1):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        net = model.net
+        net.weight_prep = prep
+        db = net.to_device_batch(batch)
+        outs = []
+        for step in range(3):
+            net.train_step(db, 1e-3)
+            if step == 1:
+                v = net.forward_loss(db)                 # between two training steps: weights just changed, no registry active
+                outs.append(v["yolo_terms"].clone())
+        torch.cuda.synchronize()
+        res[prep] = (net.flat_p.clone(), net.flat_g.clone(), outs[0])
+        if prep:
+            st = net._wprep.stats()
+            assert st["entries"] >= 20 and st["hits"] >= 2 * st["entries"] * 0.8, st
+    assert torch.equal(res[0][2], res[1][2])
+    assert torch.equal(res[0][1], res[1][1]), "gradients differ with prepared weights"
+    assert torch.equal(res[0][0], res[1][0]), "weights differ after three steps with prepared weights"
+
+
 def test_warm_up_batches_follow_the_seen_counter():
     """config.WARM_UP_BATCHES (config.py:38, model.py:193-207): the loss's `seen` counter is incremented by every evaluation and the warm-up
     branch is taken while seen < WARM_UP_BATCHES -- with 3, evaluations 1 and 2 (a training step and a validation forward count alike) are
