@@ -28,6 +28,15 @@ int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const flo
                                  float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act,
                                  void* ws, size_t ws_bytes, void* stream);
 
+/* ---- training-mode BatchNorm (+ activation) backward in ONE launch (same results as myolo_bn_act_bwd(batch_stats = 1) up to the order in which the row
+ * slabs' partial sums are added; bit-reproducible): sums, a grid-wide barrier, dx.  sync: 64 int32 counters, zero before their first use, never reset by
+ * the caller, and used by launches of ONE stream only (two launches in flight on one counter would wait for each other's arrivals); ws:
+ * myolo_bn_act_bwd_fused_ws_bytes (0 = shape not supported: use myolo_bn_act_bwd).  The grid is at most 256 workgroups, all of which must become
+ * resident: do not call from a stream whose progress another stream's running kernel waits for. ---- */
+size_t myolo_bn_act_bwd_fused_ws_bytes(int64_t M, int C);
+int myolo_bn_act_bwd_fused(const float* dy, const float* x, const float* mean, const float* var, const float* scale, const float* shift, float* dx,
+                           float* dgamma, float* dbeta, int64_t M, int C, int act, int32_t* sync, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- prepared-weights registry: the weight-only re-layouts that entry points run in front of their kernels (transposes, bf16x6 piece splits, Winograd
  * filter transforms) recorded once and re-run by the owner on a stream of its choice, off the training step's critical chain (csrc/myolo_common.h).
  * arena: a 256-byte aligned device buffer the slots are carved from (entries that do not fit stay on the in-place path).  activate(h) makes h the

@@ -2430,6 +2430,157 @@ int myolo_bn_act_bwd(const float* dy, const float* x, const float* gamma, const 
     return MYOLO_OK;
 }
 
+// ---------------------------------------------------------------------------------------
+// Training-mode BatchNorm (+ activation) backward in ONE launch: the sums, a grid-wide barrier per channel group, dx.
+// The three-launch form (colreduce_kernel<OpBnBwd>, colreduce_finish<FinBnBwd>, bn_bwd_dx_kernel) is 26 x 3 short dependent kernels on the
+// training step's backward chain.  Here a workgroup owns (row slab s, channel group): it forms its slab's partial sums
+// (the same expressions and the same in-thread order as OpBnBwd), publishes them, waits until the S slabs of ITS channel group have arrived,
+// adds the S partials in slab order (fixed order: bit-reproducible) and writes dx for its slab -- whose dy / x it read a moment ago.
+// Barrier: sync[group] is a counter private to the calling stream, zero before its first use and never reset: a launch adds exactly 256 to it
+// (each of the S = 2^k <= 256 workgroups adds 256 / S), so a workgroup that saw `old` before its own add waits for (old / 256 + 1) * 256.
+// Every workgroup must become resident for the barrier to open: the grid is <= 256 workgroups of 512 threads (a CU holds four), and kernels of
+// other streams only delay that, they cannot depend on this one.
+// ---------------------------------------------------------------------------------------
+struct BnFusedGeom { int cl, pl, cgroups, S; long long rps; };
+static bool bn_fused_geom(long long M, int C, BnFusedGeom* g)
+{
+    const int q = C / 4;
+    if (q < 1 || (C & 3)) return false;
+    int cl = 1;
+    while (cl * 2 <= q && cl * 2 <= 64) cl *= 2;
+    g->cl = cl; g->pl = 512 / cl; g->cgroups = (q + cl - 1) / cl;
+    if (g->cgroups > 64) return false;
+    int S = 1;
+    while (S * 2 * g->cgroups <= 256 && (long long)S * 2 * g->pl * 4 <= M) S *= 2;
+    g->S = S;
+    g->rps = (cdiv64(M, S) + g->pl - 1) / g->pl * g->pl;
+    return true;                                      // (a slab past the last row has no rows: it still arrives, with zero sums)
+}
+
+__global__ __launch_bounds__(512) void bn_bwd_fused_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ var,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                           double* part, unsigned* sync, long long M, int C, int act, float invM, BnFusedGeom g)
+{
+    __shared__ float4 red[512];
+    __shared__ float tots[2][256];
+    const int tid = threadIdx.x;
+    const int cl_i = tid % g.cl, pl_i = tid / g.cl;
+    const int cgid = blockIdx.y, sl = blockIdx.x;
+    const int cq = cgid * g.cl + cl_i;
+    const bool cok = cq < C / 4;
+    const int c = cq * 4;
+    const long long r0 = (long long)sl * g.rps;
+    long long r1 = r0 + g.rps;
+    if (r1 > M) r1 = M;
+    const long long st = g.pl;
+    float4 sc = f4zero(), sh = f4zero(), mu = f4zero(), rs = f4zero();
+    float4 acc0 = f4zero(), acc1 = f4zero();
+    if (cok) {
+        sc = ld4g(scale + c); sh = ld4g(shift + c); mu = ld4g(mean + c);
+        const float4 vr = ld4g(var + c);
+        rs = make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F));
+        auto op = [&](float4 gq, float4 v) {
+            float dz, xh;
+            dz = gq.x * actmask(fmaf(v.x, sc.x, sh.x), act); xh = (v.x - mu.x) * rs.x; acc0.x += dz; acc1.x = fmaf(dz, xh, acc1.x);
+            dz = gq.y * actmask(fmaf(v.y, sc.y, sh.y), act); xh = (v.y - mu.y) * rs.y; acc0.y += dz; acc1.y = fmaf(dz, xh, acc1.y);
+            dz = gq.z * actmask(fmaf(v.z, sc.z, sh.z), act); xh = (v.z - mu.z) * rs.z; acc0.z += dz; acc1.z = fmaf(dz, xh, acc1.z);
+            dz = gq.w * actmask(fmaf(v.w, sc.w, sh.w), act); xh = (v.w - mu.w) * rs.w; acc0.w += dz; acc1.w = fmaf(dz, xh, acc1.w);
+        };
+        long long r = r0 + pl_i;
+        for (; r + 3 * st < r1; r += 4 * st) {
+            const float4 g0 = ld4g(dy + r * C + c), v0 = ld4g(x + r * C + c);
+            const float4 g1 = ld4g(dy + (r + st) * C + c), v1 = ld4g(x + (r + st) * C + c);
+            const float4 g2 = ld4g(dy + (r + 2 * st) * C + c), v2 = ld4g(x + (r + 2 * st) * C + c);
+            const float4 g3 = ld4g(dy + (r + 3 * st) * C + c), v3 = ld4g(x + (r + 3 * st) * C + c);
+            op(g0, v0); op(g1, v1); op(g2, v2); op(g3, v3);
+        }
+        for (; r < r1; r += st) op(ld4g(dy + r * C + c), ld4g(x + r * C + c));
+    }
+    // the slab's partial sums: row lanes combined in lane order, in double
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        __syncthreads();
+        red[tid] = v ? acc1 : acc0;
+        __syncthreads();
+        if (pl_i == 0 && cok) {
+            double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+            for (int j = 0; j < g.pl; ++j) {
+                const float4 t = red[j * g.cl + cl_i];
+                s0 += t.x; s1 += t.y; s2 += t.z; s3 += t.w;
+            }
+            double* o = part + ((long long)sl * 2 + v) * C + c;
+            __builtin_nontemporal_store(s0, o); __builtin_nontemporal_store(s1, o + 1); __builtin_nontemporal_store(s2, o + 2); __builtin_nontemporal_store(s3, o + 3);
+        }
+    }
+    // ---- barrier over the S workgroups of this channel group
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned add = 256u / (unsigned)g.S;
+        const unsigned old = __hip_atomic_fetch_add(sync + cgid, add, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned target = (old / 256u + 1u) * 256u;
+        while ((int)(__hip_atomic_load(sync + cgid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    __threadfence();
+    // ---- totals of this thread's channels: S partials in slab order
+    if (pl_i == 0 && cok) {
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            double t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+            for (int ss = 0; ss < g.S; ++ss) {
+                const double* o = part + ((long long)ss * 2 + v) * C + c;
+                t0 += __hip_atomic_load(o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); t1 += __hip_atomic_load(o + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                t2 += __hip_atomic_load(o + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); t3 += __hip_atomic_load(o + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            tots[v][cl_i * 4 + 0] = (float)t0; tots[v][cl_i * 4 + 1] = (float)t1; tots[v][cl_i * 4 + 2] = (float)t2; tots[v][cl_i * 4 + 3] = (float)t3;
+            if (sl == 0) {
+                float* o = v ? dgamma : dbeta;
+                o[c] = (float)t0; o[c + 1] = (float)t1; o[c + 2] = (float)t2; o[c + 3] = (float)t3;
+            }
+        }
+    }
+    __syncthreads();
+    if (!cok) return;
+    const float4 db = make_float4(tots[0][cl_i * 4], tots[0][cl_i * 4 + 1], tots[0][cl_i * 4 + 2], tots[0][cl_i * 4 + 3]);
+    const float4 dg = make_float4(tots[1][cl_i * 4], tots[1][cl_i * 4 + 1], tots[1][cl_i * 4 + 2], tots[1][cl_i * 4 + 3]);
+    auto one = [&](float4 gq, float4 v) {
+        return make_float4(bn_dx_one(gq.x, v.x, sc.x, sh.x, mu.x, rs.x, db.x, dg.x, invM, act, 1), bn_dx_one(gq.y, v.y, sc.y, sh.y, mu.y, rs.y, db.y, dg.y, invM, act, 1),
+                           bn_dx_one(gq.z, v.z, sc.z, sh.z, mu.z, rs.z, db.z, dg.z, invM, act, 1), bn_dx_one(gq.w, v.w, sc.w, sh.w, mu.w, rs.w, db.w, dg.w, invM, act, 1));
+    };
+    long long r = r0 + pl_i;
+    for (; r + 3 * st < r1; r += 4 * st) {
+        const float4 g0 = ld4g(dy + r * C + c), v0 = ld4g(x + r * C + c);
+        const float4 g1 = ld4g(dy + (r + st) * C + c), v1 = ld4g(x + (r + st) * C + c);
+        const float4 g2 = ld4g(dy + (r + 2 * st) * C + c), v2 = ld4g(x + (r + 2 * st) * C + c);
+        const float4 g3 = ld4g(dy + (r + 3 * st) * C + c), v3 = ld4g(x + (r + 3 * st) * C + c);
+        st4g(dx + r * C + c, one(g0, v0)); st4g(dx + (r + st) * C + c, one(g1, v1));
+        st4g(dx + (r + 2 * st) * C + c, one(g2, v2)); st4g(dx + (r + 3 * st) * C + c, one(g3, v3));
+    }
+    for (; r < r1; r += st) st4g(dx + r * C + c, one(ld4g(dy + r * C + c), ld4g(x + r * C + c)));
+}
+
+size_t myolo_bn_act_bwd_fused_ws_bytes(int64_t M, int C)
+{
+    BnFusedGeom g;
+    if (!bn_fused_geom(M, C, &g)) return 0;
+    return align256((size_t)g.S * 2 * C * sizeof(double));
+}
+
+int myolo_bn_act_bwd_fused(const float* dy, const float* x, const float* mean, const float* var, const float* scale, const float* shift, float* dx,
+                           float* dgamma, float* dbeta, int64_t M, int C, int act, int32_t* sync, void* ws, size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && x && mean && var && scale && shift && dx && dgamma && dbeta && sync && M > 0 && (C & 3) == 0, "bn_act_bwd_fused: bad arguments");
+    BnFusedGeom g;
+    MYOLO_REQUIRE(bn_fused_geom(M, C, &g), "bn_act_bwd_fused: unsupported shape (M = %lld, C = %d)", (long long)M, C);
+    MYOLO_NEED_WS(myolo_bn_act_bwd_fused_ws_bytes(M, C));
+    hipLaunchKernelGGL(bn_bwd_fused_kernel, dim3(g.S, g.cgroups), dim3(512), 0, (hipStream_t)stream, dy, x, scale, shift, mean, var, dx, dgamma, dbeta,
+                       (double*)ws, (unsigned*)sync, (long long)M, C, act, 1.0f / (float)M, g);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
 int myolo_bn_act_bwd_frozen_post(const float* dy, const float* a_post, const float* gamma, const float* beta, const float* scale,
                                  float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act, void* ws, size_t ws_bytes,
                                  void* stream)

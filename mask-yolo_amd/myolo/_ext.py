@@ -62,6 +62,7 @@ SIGS = {
     "myolo_wino63_multiply": [P, P, P, I, I, I, P],
     "myolo_wino63_multiply_w": [P, P, P, P, I, I, I, P],
     "myolo_wprep_stats": [P, P, P, P],
+    "myolo_bn_act_bwd_fused": [P, P, P, P, P, P, P, P, P, L, I, I, P, P, Z, P],
     "myolo_wino63_input_transform": [P, P, P, I, P, P, P, I, I, P],
     "myolo_wino63_output_input_transform": [P, P, P, P, P, P, P, I, I, I, P],
     "myolo_wino63_output_transform": [P, P, P, P, P, I, I, I, P],
@@ -182,6 +183,8 @@ def load():
     lib.myolo_deconv2x2s2_mask_ws_bytes.restype = Z
     lib.myolo_wino_output_transform_bn_ws_bytes.argtypes = [I]
     lib.myolo_wino_output_transform_bn_ws_bytes.restype = Z
+    lib.myolo_bn_act_bwd_fused_ws_bytes.argtypes = [L, I]
+    lib.myolo_bn_act_bwd_fused_ws_bytes.restype = Z
     lib.myolo_wprep_create.argtypes = [P, Z, P]
     lib.myolo_wprep_create.restype = I
     for fn in (lib.myolo_wprep_destroy, lib.myolo_wprep_activate, lib.myolo_wprep_invalidate):
@@ -199,7 +202,7 @@ def exported_symbols():
     return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes", "myolo_conv3x3s2_c3_bnstats_ws_bytes", "myolo_dwconv3x3_bnstats_ws_bytes", "myolo_dwconv3x3_bwd_weight_ws_bytes",
                               "myolo_pwconv1x1_bnstats_ws_bytes", "myolo_pwconv1x1_bnstats_ok",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes",
-                              "myolo_wprep_create", "myolo_wprep_destroy", "myolo_wprep_activate", "myolo_wprep_invalidate", "myolo_wprep_count", "myolo_wprep_refresh"]
+                              "myolo_bn_act_bwd_fused_ws_bytes", "myolo_wprep_create", "myolo_wprep_destroy", "myolo_wprep_activate", "myolo_wprep_invalidate", "myolo_wprep_count", "myolo_wprep_refresh"]
 
 
 def ptr(t):

@@ -262,6 +262,9 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.fused_bn_bwd = 0             # 1 = training-mode BatchNorm backward in one launch (sums, grid-wide barrier, dx: myolo_bn_act_bwd_fused).  Measured: 28.7 against 20.9 ms per step -- the barrier needs all its workgroups resident, and this step runs its chains BESIDE chip-filling kernels of other streams on purpose (profiles/r4_notes.md section 6)
+        self._bn_sync = {}                # stream -> the barrier's counters
+        self._bn_fused_bytes = {}
         self.weight_prep = 1              # training step: weight-only re-layouts (transposes, bf16x6 splits, Winograd filter transforms) re-run on a side stream at the step's start instead of inside the chain (X.WeightPrep); 0 = in place (round 3)
         self._wprep = None
         self._wprep_ntrunk = None         # registry entries recorded before the mask head (their consumers are the trunk's first layers)
@@ -388,6 +391,19 @@ class Net(object):
         else:
             mean, var = self.s[name + "/moving_mean"], self.s[name + "/moving_variance"]
         dx = self._new(M, C)
+        if batch_stats and self.fused_bn_bwd:
+            need = self._bn_fused_bytes.get((M, C))
+            if need is None:
+                need = self._bn_fused_bytes[(M, C)] = int(X.load().myolo_bn_act_bwd_fused_ws_bytes(M, C))
+            if need:
+                # one launch (sums, grid-wide barrier, dx) instead of three; the barrier's counters are private to the stream this runs on
+                sid = torch.cuda.current_stream().cuda_stream
+                sync = self._bn_sync.get(sid)
+                if sync is None:
+                    sync = self._bn_sync[sid] = torch.zeros(64, dtype=torch.int32, device=self.dev)
+                X.call("myolo_bn_act_bwd_fused", X.ptr(da), X.ptr(y), X.ptr(mean), X.ptr(var), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dx),
+                       X.ptr(self.g[name + "/gamma"]), X.ptr(self.g[name + "/beta"]), M, C, act, X.ptr(sync), *self._wsargs(), X.stream())
+                return dx
         X.call("myolo_bn_act_bwd", X.ptr(da), X.ptr(y), X.ptr(self.p[name + "/gamma"]), X.ptr(mean), X.ptr(var),
                X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dx), X.ptr(self.g[name + "/gamma"]), X.ptr(self.g[name + "/beta"]),
                M, C, act, 1 if batch_stats else 0, *self._wsargs(), X.stream())

@@ -323,6 +323,47 @@ def test_deconv_mask_fused(N, H, W, Cin, Cout, C, x6, request):
     assert torch.equal(p, p3), "fused deconv+mask is not bit-reproducible"
 
 
+@pytest.mark.parametrize("M,C,act", [(32 * 112 * 112, 32, 2), (32 * 14 * 14, 512, 2), (32 * 7 * 7, 1024, 2), (4 * 9 * 9, 96, 1), (37, 8, 0), (5000, 256, 2),
+                                     (1, 4, 2), (2051, 1024, 1)])
+def test_batchnorm_backward_in_one_launch(M, C, act):
+    """myolo_bn_act_bwd_fused (sums, grid-wide barrier per channel group, dx in ONE kernel) against the oracle and against the three-launch
+    myolo_bn_act_bwd; the same counters serve many launches in a row (the barrier never resets them), and the result is bit-reproducible."""
+    rng = np.random.default_rng(16)
+    x = rnd(rng, M, C, scale=2.0) + rnd(rng, 1, C)
+    g, b = 1 + rnd(rng, C, scale=0.2), rnd(rng, C, scale=0.3)
+    dy = rnd(rng, M, C)
+    actf = {0: lambda v: v, 1: O.relu, 2: O.relu6}[act]
+    actb = {0: lambda a, d: d, 1: O.relu_bwd, 2: O.relu6_bwd}[act]
+    y_ref, cache = O.bn_train(x, g, b)
+    rdx, rdg, rdb = O.bn_train_bwd(cache, g, actb(actf(y_ref), dy))
+    mean, var, scale, shift = new(C), new(C), new(C), new(C)
+    tmm, tmv = new(C), new(C)
+    xd, dyd = dt(x), dt(dy)
+    X.call("myolo_bn_stats", X.ptr(xd), X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv), M, C,
+           *ws(), X.stream())
+    assert X.load().myolo_bn_act_bwd_fused_ws_bytes(M, C) > 0
+    sync = torch.zeros(64, dtype=torch.int32, device=DEV)
+    outs = []
+    for rep in range(5):
+        dx, dg, db = new(M, C), new(C), new(C)
+        X.call("myolo_bn_act_bwd_fused", X.ptr(dyd), X.ptr(xd), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(dx), X.ptr(dg), X.ptr(db),
+               M, C, act, X.ptr(sync), *ws(), X.stream())
+        outs.append((dx, dg, db))
+    torch.cuda.synchronize()
+    assert int(sync[0].item()) == 5 * 256
+    dx, dg, db = outs[0]
+    check(dx, rdx, what="fused bn dx")
+    check(dg, rdg, what="fused bn dgamma")
+    check(db, rdb, what="fused bn dbeta")
+    for o in outs[1:]:
+        assert all(torch.equal(a, b2) for a, b2 in zip(o, outs[0])), "not bit-reproducible"
+    dx3, dg3, db3 = new(M, C), new(C), new(C)
+    X.call("myolo_bn_act_bwd", X.ptr(dyd), X.ptr(xd), X.ptr(dt(g)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(dx3), X.ptr(dg3), X.ptr(db3),
+           M, C, act, 1, *ws(), X.stream())
+    tol = 1e-5 * max(1.0, float(dx3.abs().max()))
+    assert float((dx - dx3).abs().max()) <= tol and float((dg - dg3).abs().max()) <= 1e-4 * max(1.0, float(dg3.abs().max()))
+
+
 def test_positive_index_on_device():
     """myolo_positive_index == the host construction the engine used through round 3 (an image's positives are its first n_pos ROIs, model.py:593),
     counts clamped to [0, R]."""
