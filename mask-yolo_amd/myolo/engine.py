@@ -698,6 +698,8 @@ class Net(object):
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
         a = self._materialize(a)          # C4 feeds feature_map's 3x3 conv and the YOLO head: written once (28x28x512)
+        if train:
+            self._wprep_phase2()
         C4, c4shape = a, shape
         n, h, w, c = c4shape
         Cf = cfg.TOP_FEATURE_MAP_DEPTH
@@ -1571,14 +1573,32 @@ class Net(object):
             side = self._wgrad_stream
             side.wait_stream(cur)                 # behind the optimizer's update of the weights
             nt = min(self._wprep_ntrunk if self._wprep_ntrunk is not None else n, n)
-            ev1, ev2 = torch.cuda.Event(), torch.cuda.Event()
+            ev1 = torch.cuda.Event()
             with torch.cuda.stream(side):
                 wp.refresh(0, nt)
                 ev1.record(side)
-                wp.refresh(nt, n)
-                ev2.record(side)
-            self._wprep_ev = [ev1, ev2]
+            self._wprep_ev = [ev1, None]
+            self._wprep_rest = (nt, n)            # launched by _wprep_phase2, once the big early layers of the trunk are through
         wp.activate(True)
+
+    def _wprep_phase2(self):
+        """the preparations the mask head and the backward will ask for (Winograd filter transforms, transposes, splits: ~0.25 ms of small kernels):
+        started behind the trunk's 112 / 56 / 28-pixel layers -- beside those they cost the bandwidth-bound first layers 20-30 us each -- and run
+        under its 14 x 14 / 7 x 7 layers, which leave the chip mostly idle."""
+        rest = getattr(self, "_wprep_rest", None)
+        if rest is None or self._wprep_ev is None:
+            return
+        self._wprep_rest = None
+        cur = torch.cuda.current_stream()
+        side = self._wgrad_stream
+        evm = torch.cuda.Event()
+        evm.record(cur)
+        side.wait_event(evm)
+        ev2 = torch.cuda.Event()
+        with torch.cuda.stream(side):
+            self._wprep.refresh(rest[0], rest[1])
+            ev2.record(side)
+        self._wprep_ev[1] = ev2
 
     def _wprep_wait(self, k):
         """order the current stream behind mark k (0: the trunk's preparations, 1: all) of this step's refresh; once each."""
@@ -1597,6 +1617,7 @@ class Net(object):
             self._wprep.activate(False)
             self._wprep.invalidate()              # the optimizer (or anyone) may change the weights next
             self._wprep_ev = None
+            self._wprep_rest = None
 
     def forward_backward(self, db):
         """One training forward + backward on a device batch.  Gradients land in self.flat_g."""
