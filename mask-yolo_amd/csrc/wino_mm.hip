@@ -319,6 +319,8 @@ __device__ __forceinline__ bf16x8 x6_ldb(__amdgpu_buffer_rsrc_t r, unsigned voff
     return __builtin_bit_cast(bf16x8, v);
 }
 
+template <int V> struct IntK { static constexpr int value = V; };
+
 __device__ __forceinline__ float mm_act(float v, int act)
 {
     if (act == MYOLO_ACT_RELU) return fmaxf(v, 0.f);
@@ -463,6 +465,113 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
 #pragma unroll
     for (int pc = 0; pc < 3; ++pc) fa[0][pc] = *reinterpret_cast<const bf16x8*>(As[0] + afr + pc * 32);
 
+    if constexpr (NU == 2 && AG == MM_A_PLAIN && EPI == MM_EP_PLAIN) {
+        // ---- the 128 x 128 tile (14 x 14 / 7 x 7 pointwise layers, under one workgroup per CU): 24 MFMAs per wave and chunk are a third of a global
+        // load's latency, and with the operands of chunk c+2 requested during chunk c the loop ran at one load latency per chunk (1.5 us, whatever
+        // the tile width; profiles/r4_notes.md section 5).  Here chunk k's A values wait in register stage k % 3 (requested THREE chunks ahead) and
+        // its B fragments in stage k % 2 (two ahead).  The loop is unrolled by hand over the period of those queues and of the two LDS buffers
+        // (6), so that a stage is a register NAME: a stage that moved up by a copy made hipcc wait vmcnt(0) at the end of every iteration, and
+        // so did a load inside a conditional block -- the loads past the last chunk are issued anyway, out of range / at k = 0.
+        float4 qa[3][2], qsc[3][2], qsh[3][2];
+        bf16x8 qb[2][NU][3];
+        const float* csc = (PW && p.a_scale) ? p.a_scale : p.A;        // (never dereferenced beyond the first chunk's 16 floats when unused)
+        const float* csh = (PW && p.a_scale) ? p.a_shift : p.A;
+        const bool has_aff = PW && p.a_scale;
+        auto gstage = [&](auto st, bool valid) {
+            constexpr int S = decltype(st)::value;
+            qa[S][0] = mm_bufld4(ra, valid ? aoffg : MM_OOB);
+            qa[S][1] = mm_bufld4(ra, valid ? aoffg + 16u : MM_OOB);
+            aoffg += MM_BK * 4u;
+            if constexpr (PW) {
+                const int kc = (valid && has_aff) ? kch : ah * 8;
+                qsc[S][0] = *reinterpret_cast<const float4*>(csc + kc); qsc[S][1] = *reinterpret_cast<const float4*>(csc + kc + 4);
+                qsh[S][0] = *reinterpret_cast<const float4*>(csh + kc); qsh[S][1] = *reinterpret_cast<const float4*>(csh + kc + 4);
+                kch += MM_BK;
+            }
+        };
+        // the prologue above left chunk 1 in sa / psc / psh and chunk 0's B fragments in bq
+        qa[1][0] = sa[0]; qa[1][1] = sa[1];
+        if constexpr (PW) { qsc[1][0] = psc[0]; qsc[1][1] = psc[1]; qsh[1][0] = psh[0]; qsh[1][1] = psh[1]; }
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                qb[0][u][pc] = bq[u][pc];
+                qb[1][u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, nk > 1 ? bchunk : 0u);
+            }
+        gstage(IntK<2>{}, nk > 2);
+        gstage(IntK<0>{}, nk > 3);
+        auto step = [&](auto ic, int c) {
+            constexpr int I = decltype(ic)::value;
+            constexpr int cur = I & 1, SA = (I + 1) % 3, SB = I & 1;
+            const bool more = c + 1 < nk;
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) fa[1][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + 32 * X6_REC + pc * 32);
+            float x[8] = {qa[SA][0].x, qa[SA][0].y, qa[SA][0].z, qa[SA][0].w, qa[SA][1].x, qa[SA][1].y, qa[SA][1].z, qa[SA][1].w};
+            if constexpr (PW) {
+                if (has_aff) {
+                    const float sc8[8] = {qsc[SA][0].x, qsc[SA][0].y, qsc[SA][0].z, qsc[SA][0].w, qsc[SA][1].x, qsc[SA][1].y, qsc[SA][1].z, qsc[SA][1].w};
+                    const float sh8[8] = {qsh[SA][0].x, qsh[SA][0].y, qsh[SA][0].z, qsh[SA][0].w, qsh[SA][1].x, qsh[SA][1].y, qsh[SA][1].z, qsh[SA][1].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] = mm_act(fmaf(x[e], sc8[e], sh8[e]), p.a_act);
+                }
+            }
+            gstage(IntK<SA>{}, c + 4 < nk);                              // chunk c+4 takes the stage chunk c+1 just left
+            const unsigned b2 = c + 2 < nk ? bso + 2u * bchunk : bso;
+            u32x4 p1, p2, p3;
+            bf16x8 fn0, fn1, fn2;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+#define X6_TILE(t)                                                                                                     \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][2], acc[t][u], 0, 0, 0);       \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][2], qb[SB][u][0], acc[t][u], 0, 0, 0);       \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], qb[SB][u][1], acc[t][u], 0, 0, 0);       \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][1], acc[t][u], 0, 0, 0);       \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], qb[SB][u][0], acc[t][u], 0, 0, 0);       \
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][0], acc[t][u], 0, 0, 0);
+                X6_TILE(0)
+                X6_TILE(1)
+#undef X6_TILE
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc) qb[SB][u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, b2);      // chunk c+2 into the stage chunk c leaves
+                if (u == 0) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float a0 = x[2 * e], a1 = x[2 * e + 1];
+                        const float b0 = x6_rest(a0), b1 = x6_rest(a1);
+                        p1[e] = x6_top(a0, a1);
+                        p2[e] = x6_top(b0, b1);
+                        p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
+                    }
+                    if (more) {
+                        *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto) = p1;
+                        *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 32) = p2;
+                        *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 64) = p3;
+                    }
+                } else {
+                    __syncthreads();
+                    if (more) {
+                        fn0 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr);
+                        fn1 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 32);
+                        fn2 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 64);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) { fa[0][0] = fn0; fa[0][1] = fn1; fa[0][2] = fn2; }
+            bso = more ? bso + bchunk : bso;
+        };
+        int c0 = 0;
+        for (; c0 + 6 <= nk; c0 += 6) {
+            step(IntK<0>{}, c0); step(IntK<1>{}, c0 + 1); step(IntK<2>{}, c0 + 2);
+            step(IntK<3>{}, c0 + 3); step(IntK<4>{}, c0 + 4); step(IntK<5>{}, c0 + 5);
+        }
+        if (c0 < nk) step(IntK<0>{}, c0);
+        if (c0 + 1 < nk) step(IntK<1>{}, c0 + 1);
+        if (c0 + 2 < nk) step(IntK<2>{}, c0 + 2);
+        if (c0 + 3 < nk) step(IntK<3>{}, c0 + 3);
+        if (c0 + 4 < nk) step(IntK<4>{}, c0 + 4);
+    } else
     // One barrier per chunk, and no LDS read is waited for right behind its issue:
     //   u = 0, 1: row tile 1's fragments of THIS chunk are read first thing (used six MFMAs later: each column tile runs row tile 0's
     //             six terms, then row tile 1's); chunk c+1, in registers since the previous chunk, is split into the other buffer
