@@ -431,10 +431,17 @@ class MaskYOLO(object):
         self.compile(cfg.LEARNING_RATE if learning_rate is None else learning_rate, cfg.LEARNING_MOMENTUM)
         rank, world = self._data_parallel()          # rank r takes images [r*B, (r+1)*B) of each global batch of world*B
         results = []
+        import torch
+        side = self.net._copy_stream                 # batch i+1 is produced there while step i runs (its kernels are a few hundred microseconds)
+
+        def produce(i):
+            lo = start_index + (i * world + rank) * cfg.BATCH_SIZE
+            return prod.batch(list(range(lo, lo + cfg.BATCH_SIZE)), stream=side, consumer=torch.cuda.current_stream())
         with _gc_parked():
+            nxt = produce(0) if steps else None
             for i in range(steps):
-                lo = start_index + (i * world + rank) * cfg.BATCH_SIZE
-                results.append(self.train_on_batch(prod.batch(list(range(lo, lo + cfg.BATCH_SIZE)))))
+                cur, nxt = nxt, (produce(i + 1) if i + 1 < steps else None)
+                results.append(self.train_on_batch(cur))
                 if verbose and i:
                     print("step %d loss %.4f" % (i, results[i - 1]["loss"]))      # one step behind: no wait on the step in flight
                 if i >= 2:

@@ -178,6 +178,7 @@ class ShapesProducer(object):
         self.lut = torch.tensor((np.arange(256) / 255.).astype(np.float32), device=self.dev)
         self.anchors = torch.tensor(np.asarray(cfg.ANCHORS, np.float64), device=self.dev)
         self.ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.dev)
+        self._pin, self._pin_i = None, 0
 
     def specs(self, indices):
         H, W = self.cfg.IMAGE_SHAPE[0], self.cfg.IMAGE_SHAPE[1]
@@ -194,15 +195,37 @@ class ShapesProducer(object):
                     out[k, o + 7:o + 13] = np.array([x, y - s_, x - kk, y + s_, x + kk, y + s_]).astype(np.int32)
         return out
 
-    def batch(self, indices):
-        """-> dict(images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks) of device tensors."""
+    def batch(self, indices, stream=None, consumer=None):
+        """-> dict(images, true_boxes, y_true, gt_ids, gt_boxes, gt_masks) of device tensors.
+        stream (a torch.cuda.Stream): produce there instead of on the current stream -- the specifications go up from a pinned ring buffer without
+        blocking the host (a pageable `.to(device)` waits for everything queued on the current stream: the whole previous step), the batch carries
+        the event `_ready` that Net.forward_backward waits for, and its tensors are registered with `consumer` (the stream that will read them)."""
         import torch
         from . import _ext as X
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                d = self.batch(indices)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            if consumer is not None:
+                for t in d.values():
+                    t.record_stream(consumer)
+            d["_ready"] = ev
+            return d
         cfg = self.cfg
         B = len(indices)
         H, W = cfg.IMAGE_SHAPE[0], cfg.IMAGE_SHAPE[1]
         G, A, C, T = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES, cfg.TRUE_BOX_BUFFER
-        spec = torch.from_numpy(self.specs(indices)).to(self.dev)
+        sp = self.specs(indices)
+        if self._pin is None or self._pin[0][0].shape != sp.shape:
+            self._pin = [(torch.empty(sp.shape, dtype=torch.int32, pin_memory=True), torch.cuda.Event()) for _ in range(4)]
+            self._pin_i = 0
+        host, used = self._pin[self._pin_i]
+        self._pin_i = (self._pin_i + 1) % len(self._pin)
+        used.synchronize()                       # the copy that last read this slot (four batches ago) is done
+        host.numpy()[...] = sp
+        spec = host.to(self.dev, non_blocking=True)
+        used.record(torch.cuda.current_stream())
         d = dict(images=torch.empty(B, H, W, 3, device=self.dev),
                  gt_masks=torch.empty(B, H, W, T, dtype=torch.uint8, device=self.dev),
                  gt_boxes=torch.empty(B, T, 4, dtype=torch.int32, device=self.dev),
