@@ -145,6 +145,14 @@ int myolo_wino63_multiply_w(const float* V, const float* w, float* U_scratch, fl
  * (flags NULL: everywhere) */
 int myolo_wino63_input_transform(const float* x, const float* scale, const float* shift, int act, float* y, const int32_t* flags, float* V,
                                  int N, int C, void* stream);
+/* the flagged outputs of the three keeping calls (input_transform's y, *_keep_pre's ypre) written in COMPACT order for the sparse mask-head backward:
+ * slots [N] = compact slot of an image or -1 (myolo_positive_index); image n's rows go to block slots[n] when 0 <= slots[n] < cap -- no gather later */
+int myolo_wino63_input_transform_slots(const float* x, const float* scale, const float* shift, int act, float* y_compact, const int32_t* slots, int cap,
+                                       float* V, int N, int C, void* stream);
+int myolo_wino63_output_input_transform_keep_pre_slots(const float* M, const float* bias, const float* scale, const float* shift, float* ypre_compact,
+                                                       const int32_t* slots, int cap, float* Vn, int N, int C, int act, void* stream);
+int myolo_wino63_output_transform_keep_pre_slots(const float* M, const float* bias, const float* scale, const float* shift, float* y, float* ypre_compact,
+                                                 const int32_t* slots, int cap, int N, int C, int act, void* stream);
 /* layer boundary in one kernel: M_i -> act((A^T m A + bias)*scale + shift) -> V_{i+1}; y / flags as above */
 int myolo_wino63_output_input_transform(const float* M, const float* bias, const float* scale, const float* shift, float* y,
                                         const int32_t* flags, float* Vn, int N, int C, int act, void* stream);

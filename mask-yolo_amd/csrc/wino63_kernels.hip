@@ -174,7 +174,19 @@ struct W63Args {
     // everywhere); with ypre set, `flags` governs ypre and y (if any) is written everywhere.  The exact-sparsity backward reads the frozen BatchNorms'
     // backward off THIS tensor for the positive ROIs: no (a - beta) / gamma reconstruction from the post-activation value
     float* ypre;
+    // keep_cap > 0: `flags` holds SLOTS (myolo_positive_index: slot >= 0 or -1) and the flagged tensor (ypre, or y when there is no ypre) is written in
+    // COMPACT order -- image img at row block flags[img] if 0 <= flags[img] < keep_cap -- so that the sparse backward needs no gather
+    int keep_cap;
 };
+
+// where the flagged output of image img goes: its own row block, the compact one of its slot, or -1 (not kept)
+__device__ __forceinline__ long long w63_keep_dst(const W63Args& a, long long img)
+{
+    if (!a.flags) return img;
+    const int f = a.flags[img];
+    if (a.keep_cap > 0) return (f >= 0 && f < a.keep_cap) ? (long long)f : -1;
+    return f != 0 ? img : -1;
+}
 
 __device__ __forceinline__ float w63_act(float v, int act)
 {
@@ -202,9 +214,11 @@ __device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& p
     }
     const float b = a.bias ? a.bias[c] : 0.f;
     const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
-    float* ybase = wr ? a.y + (img * W63_HW * W63_HW) * a.C + c : nullptr;
-    const bool wrp = a.ypre && (!a.flags || a.flags[img] != 0);
-    float* pbase = wrp ? a.ypre + (img * W63_HW * W63_HW) * a.C + c : nullptr;
+    const long long yd = a.ypre ? img : w63_keep_dst(a, img);          // (wr: yd >= 0)
+    float* ybase = wr ? a.y + (yd * W63_HW * W63_HW) * a.C + c : nullptr;
+    const long long pd = a.ypre ? w63_keep_dst(a, img) : -1;
+    const bool wrp = pd >= 0;
+    float* pbase = wrp ? a.ypre + (pd * W63_HW * W63_HW) * a.C + c : nullptr;
 #pragma unroll
     for (int i = 0; i < MY; ++i) {
         float r[6];
@@ -317,7 +331,8 @@ __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, 
     const int c = slice * W63_CS + lane;
     const int ty = wave / 3, tx = wave - ty * 3;
     const W63Planes pl = w63_planes(a.NR, img, ty, tx, a.C, c);
-    const bool wr = a.y && (a.ypre || !a.flags || a.flags[img] != 0);
+    const long long ydst = a.ypre ? img : w63_keep_dst(a, img);
+    const bool wr = a.y && ydst >= 0;
     if (FRONT == W63_FROM_M) {
         const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;           // output origin: 0, 6, 10
         float s1 = 0.f, s2 = 0.f;
@@ -376,7 +391,7 @@ __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, 
     } else {
         const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
         const float* xb = a.src + (img * W63_HW * W63_HW) * a.C + c;
-        float* yb = wr ? a.y + (img * W63_HW * W63_HW) * a.C + c : nullptr;
+        float* yb = wr ? a.y + (ydst * W63_HW * W63_HW) * a.C + c : nullptr;
         float ka = 0.f, kb = 0.f;
         const float* gb = nullptr;
         if (FRONT == W63_FROM_LAZY) {
@@ -620,6 +635,42 @@ int myolo_wino63_output_transform_keep_pre(const float* M, const float* bias, co
     MYOLO_REQUIRE(M && ypre && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_output_transform_keep_pre: bad arguments (C %% 64 == 0)");
     W63Args a{M, nullptr, y, flags, bias, scale, shift, N, C, act};
     a.ypre = ypre;
+    w63_launch<W63_FROM_M, W63_TO_NONE>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+/* ---- the three calls above with the kept tensor written in COMPACT order: slots [N] = compact slot of an image or -1 (myolo_positive_index), rows of
+ * image n at block slots[n] when 0 <= slots[n] < cap.  input_transform_slots: y_compact = the activation act(x * scale + shift) of the kept images;
+ * the *_keep_pre_slots pair: ypre_compact = the conv's pre-BatchNorm output of the kept images (y of output_transform stays dense). ---- */
+int myolo_wino63_input_transform_slots(const float* x, const float* scale, const float* shift, int act, float* y_compact, const int32_t* slots, int cap,
+                                       float* V, int N, int C, void* stream)
+{
+    MYOLO_REQUIRE(x && V && y_compact && slots && cap > 0 && N > 0 && (C % W63_CS) == 0 && !scale == !shift, "wino63_input_transform_slots: bad arguments (C %% 64 == 0)");
+    W63Args a{x, V, y_compact, slots, nullptr, scale, shift, N, C, act};
+    a.keep_cap = cap;
+    w63_launch<W63_FROM_ACT, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+int myolo_wino63_output_input_transform_keep_pre_slots(const float* M, const float* bias, const float* scale, const float* shift, float* ypre_compact,
+                                                       const int32_t* slots, int cap, float* Vn, int N, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && Vn && ypre_compact && slots && cap > 0 && N > 0 && (C % W63_CS) == 0 && !scale == !shift,
+                  "wino63_output_input_transform_keep_pre_slots: bad arguments (C %% 64 == 0)");
+    W63Args a{M, Vn, nullptr, slots, bias, scale, shift, N, C, act};
+    a.ypre = ypre_compact; a.keep_cap = cap;
+    w63_launch<W63_FROM_M, W63_TO_V>(a, (hipStream_t)stream);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+int myolo_wino63_output_transform_keep_pre_slots(const float* M, const float* bias, const float* scale, const float* shift, float* y, float* ypre_compact,
+                                                 const int32_t* slots, int cap, int N, int C, int act, void* stream)
+{
+    MYOLO_REQUIRE(M && ypre_compact && slots && cap > 0 && N > 0 && (C % W63_CS) == 0 && !scale == !shift,
+                  "wino63_output_transform_keep_pre_slots: bad arguments (C %% 64 == 0)");
+    W63Args a{M, nullptr, y, slots, bias, scale, shift, N, C, act};
+    a.ypre = ypre_compact; a.keep_cap = cap;
     w63_launch<W63_FROM_M, W63_TO_NONE>(a, (hipStream_t)stream);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

@@ -61,6 +61,9 @@ SIGS = {
     "myolo_wino63_weight_transform": [P, P, I, I, P],
     "myolo_wino63_multiply": [P, P, P, I, I, I, P],
     "myolo_wino63_multiply_w": [P, P, P, P, I, I, I, P],
+    "myolo_wino63_input_transform_slots": [P, P, P, I, P, P, I, P, I, I, P],
+    "myolo_wino63_output_input_transform_keep_pre_slots": [P, P, P, P, P, P, I, P, I, I, I, P],
+    "myolo_wino63_output_transform_keep_pre_slots": [P, P, P, P, P, P, P, I, I, I, I, P],
     "myolo_wprep_stats": [P, P, P, P],
     "myolo_bn_act_bwd_fused": [P, P, P, P, P, P, P, P, P, L, I, I, P, P, Z, P],
     "myolo_wino63_input_transform": [P, P, P, I, P, P, P, I, I, P],

@@ -270,6 +270,7 @@ class Net(object):
         self._wprep_ntrunk = None         # registry entries recorded before the mask head (their consumers are the trunk's first layers)
         self._wprep_ev = None
         self.seen = 0                     # evaluations of the YOLO loss so far (the reference's `seen`, see _yolo_warm)
+        self.keep_rows_compact = 1        # the rows the training forward keeps for the sparse backward (pre-BatchNorm outputs of conv2-4, bn1's activation) are written in compact order by the layer boundaries: no gathers in the backward chain; 0 = dense positions + gathers (round 3)
         self.keep_deconv_rows = 48        # training forward keeps the ReLU'd deconv output of up to this many positives PER IMAGE (batch total) for the sparse backward; 0 = re-run the deconv there (round 3); beyond the cap the backward re-runs it
         self.fuse_compact_gather = 1      # compacted mask-head backward: gather + BatchNorm apply in one kernel, each pre-BN tensor gathered once (0: round 3's sequence)
         self.bucket1_on_wgrad_stream = 1  # data-parallel: bucket 1 released on the weight-gradient stream (0: round 3's join of that stream into the compute stream)
@@ -848,7 +849,8 @@ class Net(object):
                  and (not train or pos_flags is not None))
         if chain:
             # ROIAlign is fused into conv1's input transform: the [NR,14,14,256] crops are never written
-            x = self._mask_convs_winograd_chain(None, convs, NR, ps, cf, train, pos_flags, roi=(Fm, boxes, bind, n, h, w))
+            x = self._mask_convs_winograd_chain(None, convs, NR, ps, cf, train, pos_flags, roi=(Fm, boxes, bind, n, h, w),
+                                                slots=keep[0] if (keep is not None and self.keep_rows_compact) else None)
         else:
             x = self._new(NR * ps * ps, cf)
             self._call_timed("roialign_fwd", "myolo_crop_and_resize_fwd", X.ptr(Fm), X.ptr(boxes), X.ptr(bind), X.ptr(x),
@@ -881,7 +883,7 @@ class Net(object):
         self.tape["mask"] = (convs, x, d)
         return p
 
-    def _mask_convs_winograd_chain(self, x, convs, NR, ps, cin, train, pos_flags, roi=None):
+    def _mask_convs_winograd_chain(self, x, convs, NR, ps, cin, train, pos_flags, roi=None, slots=None):
         """myolo_mask_conv1-4 (+bn, ReLU) as a chain of Winograd stages; appends each conv's input to `convs` (an input the
         forward never materialised is recorded as ("lazy_bn", pre-BN tensor, bn layer)).  Returns conv4's activation.
         cfg.WINOGRAD_TILES = "f63": conv2-4 (whose inputs and outputs are MASK_FILTERS wide 14x14 maps) use the F(6,3)/F(4,3)
@@ -946,7 +948,12 @@ class Net(object):
                 keep_pre = bool(train and self.mask_keep_pre)     # what is kept for the positive ROIs is the conv's PRE-BatchNorm output (exact backward, any gamma)
                 if use63:
                     Vn = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
-                    if keep_pre:
+                    if keep_pre and slots is not None:
+                        # the kept rows in COMPACT order (slot of each positive ROI, myolo_positive_index): the sparse backward reads them without a gather
+                        self._call_timed("wino_out_in", "myolo_wino63_output_input_transform_keep_pre_slots", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
+                                         X.ptr(buf[3]), X.ptr(ykeep), X.ptr(slots), NR, X.ptr(Vn), NR, MASK_FILTERS, ACT_RELU, X.stream())
+                        self.tape.setdefault("compact_rows", set()).add(id(ykeep))
+                    elif keep_pre:
                         self._call_timed("wino_out_in", "myolo_wino63_output_input_transform_keep_pre", X.ptr(M), X.ptr(bias), X.ptr(buf[2]),
                                          X.ptr(buf[3]), X.ptr(ykeep), X.ptr(pos_flags), X.ptr(Vn), NR, MASK_FILTERS, ACT_RELU, X.stream())
                     else:
@@ -969,8 +976,13 @@ class Net(object):
                 if fold:
                     if use63 and train and pos_flags is not None and self.mask_keep_pre:
                         ypre = self._new(NR * q, MASK_FILTERS)
-                        X.call("myolo_wino63_output_transform_keep_pre", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), X.ptr(ypre),
-                               X.ptr(pos_flags), NR, MASK_FILTERS, ACT_RELU, X.stream())
+                        if slots is not None:
+                            X.call("myolo_wino63_output_transform_keep_pre_slots", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), X.ptr(ypre),
+                                   X.ptr(slots), NR, NR, MASK_FILTERS, ACT_RELU, X.stream())
+                            self.tape.setdefault("compact_rows", set()).add(id(ypre))
+                        else:
+                            X.call("myolo_wino63_output_transform_keep_pre", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), X.ptr(ypre),
+                                   X.ptr(pos_flags), NR, MASK_FILTERS, ACT_RELU, X.stream())
                         self.tape[bn] = (ypre, ACT_RELU, False)
                     elif use63:
                         X.call("myolo_wino63_output_transform", X.ptr(M), X.ptr(bias), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(y), NR, MASK_FILTERS,
@@ -1005,8 +1017,15 @@ class Net(object):
                     self.tape[bn] = (y, ACT_RELU, True)
                     if next63:
                         Vcur = self._new(X.wino63_plane_elems(NR, MASK_FILTERS))
-                        X.call("myolo_wino63_input_transform", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, None, None, X.ptr(Vcur),
-                               NR, MASK_FILTERS, X.stream())
+                        if slots is not None and train:
+                            # ... and conv2's input (bn1's activation) of the positive ROIs in compact order: conv2's weight gradient reads it as it is
+                            a1k = self._new(NR * q, MASK_FILTERS)
+                            X.call("myolo_wino63_input_transform_slots", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, X.ptr(a1k), X.ptr(slots), NR,
+                                   X.ptr(Vcur), NR, MASK_FILTERS, X.stream())
+                            self.tape["conv2_in_rows"] = a1k
+                        else:
+                            X.call("myolo_wino63_input_transform", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, None, None, X.ptr(Vcur),
+                                   NR, MASK_FILTERS, X.stream())
                     else:
                         Vcur = self._new(36, T, MASK_FILTERS)
                         X.call("myolo_wino_input_transform_affine", X.ptr(y), X.ptr(buf[2]), X.ptr(buf[3]), ACT_RELU, X.ptr(Vcur),
@@ -1283,9 +1302,20 @@ class Net(object):
                 self.on_bucket_ready(2)
             return dF
         q = ps * ps
-        gather = (lambda t, rows: t) if compact else (lambda t, rows: self._gather(t, idx_d, NP, rows))
+        kept = self.tape.get("compact_rows", ())          # tensors the forward wrote in compact order (rows of positive k at block k)
+
+        def gather(t, rows):
+            if compact:
+                return t
+            if id(t) in kept:
+                return t[:NP * rows]
+            return self._gather(t, idx_d, NP, rows)
         dz_p = gather(dz, 4 * q)
-        a4_p = gather(a4, q)
+        # conv4's activation on the positives: re-formed from its kept pre-BatchNorm rows where those are compact (only the deconv's weight gradient reads it
+        # then, off the chain), else gathered
+        pre4 = self.tape["myolo_mask_bn4"][0]
+        a4_lazy = (not compact and torch.is_tensor(pre4) and id(pre4) in kept and isinstance(d, tuple) and NP <= d[2])
+        a4_p = None if a4_lazy else gather(a4, q)
         if isinstance(d, tuple):          # ("kept", rows, cap): the fused forward wrote the positives' deconv output in compact order
             d_p = d[1] if NP <= d[2] else None
             d = None
@@ -1327,11 +1357,16 @@ class Net(object):
                 t.record_stream(self._wgrad_stream)
             self._wgrad_pending = True
 
+        a4_w = self._new(NP * q, MASK_FILTERS) if a4_lazy else a4_p
+
         def deconv_wgrad():
-            X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_p), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
+            if a4_lazy:
+                b4 = self.bnbuf["myolo_mask_bn4"]
+                X.call("myolo_bn_apply_act", X.ptr(pre4), X.ptr(b4[2]), X.ptr(b4[3]), X.ptr(a4_w), NP * q, MASK_FILTERS, ACT_RELU, X.stream())
+            X.call("myolo_deconv2x2s2_bwd_weight", X.ptr(a4_w), X.ptr(dd), X.ptr(self.g["myolo_mask_deconv/kernel"]), NP, ps, ps,
                    MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
             self.colsum(dd, self.g["myolo_mask_deconv/bias"])
-        off_chain(deconv_wgrad, (a4_p, dd))
+        off_chain(deconv_wgrad, (a4_w, dd) + ((pre4,) if a4_lazy else ()))
         da = self._new(NP * q, MASK_FILTERS)
         X.call("myolo_deconv2x2s2_bwd_data", X.ptr(dd), X.ptr(self.p["myolo_mask_deconv/kernel"]), X.ptr(da), NP, ps, ps,
                MASK_FILTERS, MASK_FILTERS, *self._wsargs(), X.stream())
@@ -1339,7 +1374,20 @@ class Net(object):
         for i in range(4, 1, -1):
             cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
             src = convs[i - 1]
-            if isinstance(src, tuple):        # ("lazy_bn", pre-BN tensor, bn layer): the forward normalised on load
+            lazy_xin = None
+            if isinstance(src, tuple) and not compact and id(src[1]) in kept:
+                # the forward kept this conv's input rows compact, as pre-BatchNorm values: the BatchNorm backward below reads them as they are, and the
+                # normalised form -- only this conv's WEIGHT gradient needs it -- is formed where that runs
+                _, ypre, bsrc = src
+                yp = ypre[:NP * q]
+                xin = self._new(NP * q, MASK_FILTERS)
+                def lazy_xin(xin=xin, yp=yp, bsrc=bsrc):
+                    X.call("myolo_bn_apply_act", X.ptr(yp), X.ptr(self.bnbuf[bsrc][2]), X.ptr(self.bnbuf[bsrc][3]), X.ptr(xin), NP * q, MASK_FILTERS,
+                           ACT_RELU, X.stream())
+                pre_rows[id(ypre)] = yp
+            elif isinstance(src, tuple) and not compact and src[2] == "myolo_mask_bn1" and "conv2_in_rows" in self.tape:
+                xin = self.tape["conv2_in_rows"][:NP * q]          # bn1's activation of the positives, written compact by conv2's input transform
+            elif isinstance(src, tuple):      # ("lazy_bn", pre-BN tensor, bn layer): the forward normalised on load
                 _, ypre, bsrc = src
                 xin = self._new(NP * q, MASK_FILTERS)
                 if compact or not self.fuse_compact_gather:
@@ -1366,13 +1414,15 @@ class Net(object):
             else:
                 c_p = pre_rows.get(id(self.tape[bn][0])) if self.fuse_compact_gather else None
                 if c_p is None:
-                    c_p = gather(self.tape[bn][0], q)
+                    c_p = gather(self.tape[bn][0], q)          # (a view when the forward kept these rows compact)
                 dy = self.bn_act_bwd(bn, da, y_override=c_p)
             a_next = xin                  # conv_i's input = post-activation of layer i-1
-            def conv_wgrad(xin=xin, dy=dy, cn=cn):
+            def conv_wgrad(xin=xin, dy=dy, cn=cn, lazy_xin=lazy_xin):
+                if lazy_xin is not None:
+                    lazy_xin()
                 self.conv3x3_bwd_weight(xin, None, dy, cn, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
                 self.colsum(dy, self.g[cn + "/bias"])
-            off_chain(conv_wgrad, (xin, dy))
+            off_chain(conv_wgrad, (xin, dy) + ((src[1],) if lazy_xin is not None else ()))
             da = self._new(NP * q, MASK_FILTERS)
             self.conv3x3_bwd_data(dy, cn, da, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
         # bn1: batch statistics -> dense dx from the row-sparse upstream gradient
