@@ -1086,6 +1086,14 @@ def test_winograd_f63_conv_operators(N, Cin, Cout, x6, request):
         torch.cuda.synchronize()
         assert float((dw - dw3).abs().max()) <= 2e-5 * float(dw3.abs().max())
         assert torch.equal(dw, dw4)
+        if Cin % 256 == 0:          # option tn_wgs: a fixed number of workgroups walking the work units (the kernel's other instantiation; the split differs)
+            dw5, dw6 = new(3, 3, Cin, Cout), new(3, 3, Cin, Cout)
+            with X.option("tn_wgs", 24):
+                X.call("myolo_conv3x3_wino63_bwd_weight", None, X.ptr(vk), X.ptr(dy_t), X.ptr(dw5), N, Cin, Cout, *wsa, st)
+                X.call("myolo_conv3x3_wino63_bwd_weight", None, X.ptr(vk), X.ptr(dy_t), X.ptr(dw6), N, Cin, Cout, *wsa, st)
+            torch.cuda.synchronize()
+            check(dw5, rdw, what="wino63 dw, walking workgroups")
+            assert torch.equal(dw5, dw6)
     if X.wino63_ok(14, 14, Cout, Cin):
         dx = new(N, H, W, Cin)
         X.call("myolo_conv3x3_wino63_bwd_data", X.ptr(dy_t), X.ptr(w_t), X.ptr(dx), N, Cin, Cout, *wsa, st)

@@ -170,6 +170,29 @@ def test_prepared_weights_change_nothing_but_the_launch_order():
     assert torch.equal(res[0][0], res[1][0]), "weights differ after three steps with prepared weights"
 
 
+def test_prepared_weights_with_an_arena_that_is_too_small():
+    """Entries that do not fit the registry's arena stay on the in-place path: same gradients as without a registry, some hits, some misses."""
+    from myolo import _ext as X
+    cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
+    res = {}
+    for prep in (0, 1):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        net = model.net
+        net.weight_prep = prep
+        if prep:
+            net._wprep = X.WeightPrep(net.dev, arena_bytes=3 << 20)          # a few of the small entries only
+        db = net.to_device_batch(batch)
+        for step in range(3):
+            net.train_step(db, 1e-3)
+        torch.cuda.synchronize()
+        res[prep] = (net.flat_p.clone(), net.flat_g.clone())
+        if prep:
+            st = net._wprep.stats()
+            assert st["hits"] > 0 and st["misses"] > st["entries"] and st["bytes_used"] <= 3 << 20, st
+    assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
+
+
 def test_warm_up_batches_follow_the_seen_counter():
     """config.WARM_UP_BATCHES (config.py:38, model.py:193-207): the loss's `seen` counter is incremented by every evaluation and the warm-up
     branch is taken while seen < WARM_UP_BATCHES -- with 3, evaluations 1 and 2 (a training step and a validation forward count alike) are
