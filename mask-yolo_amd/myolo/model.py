@@ -482,6 +482,40 @@ class MaskYOLO(object):
         else:
             predict = self.net.predict_graphed if getattr(cfg, "INFERENCE_HIP_GRAPH", True) else self.net.predict
             yolo_output, det_d, mask_d = predict(x)                        # device tensors
+        return [self._select_and_unmold(det_d[0], None if mask_d is None else mask_d[0], image.shape, cs_threshold,
+                                        feature=feature if selected_only else None)]
+
+    def detect_many(self, images, weights_dir=None, cs_threshold=0.35, in_flight=3):
+        """detect() for a sequence of images at the throughput of Net.predict_stream: the images go through the inference graph in batches of
+        config.BATCH_SIZE with `in_flight` batches running at once (one stream / hipGraph / scratch per lane: the launch-bound trunk of one
+        batch under the matrix-pipe-bound mask head of another), and every image gets detect()'s own selection and unmolding
+        (model.py:1238-1328).  Returns one result dict per image, equal to detect(image)[0]."""
+        cfg = self.config
+        assert self.mode == 'inference'
+        if weights_dir is not None:
+            self.load_weights(weights_dir)
+        images = list(images)
+        for im in images:
+            assert list(im.shape) == list(cfg.IMAGE_SHAPE) and im.dtype == 'uint8'
+        B = int(cfg.BATCH_SIZE)
+        dev = self.net.dev
+
+        def batches():
+            for lo in range(0, len(images), B):
+                grp = images[lo:lo + B]
+                grp = grp + [grp[-1]] * (B - len(grp))                       # a short last batch is padded (the captured graph has one shape)
+                yield torch.as_tensor(np.ascontiguousarray(mutils._U8_OVER_255[np.stack(grp)]), device=dev)      # == (image / 255.).astype(float32)
+        out = []
+        for bi, (_, det_d, mask_d) in enumerate(self.net.predict_stream(batches(), in_flight=in_flight)):
+            for k in range(min(B, len(images) - bi * B)):
+                out.append(self._select_and_unmold(det_d[k], mask_d[k], images[bi * B + k].shape, cs_threshold))
+        return out
+
+    def _select_and_unmold(self, det_img, mask_img, image_shape, cs_threshold, feature=None):
+        """detect()'s post-processing of ONE image: det_img [R,6], mask_img [R,mh,mw,C] (None: the mask head runs here, on the survivors) device tensors."""
+        cfg = self.config
+        det_d, mask_d = det_img.unsqueeze(0), None if mask_img is None else mask_img.unsqueeze(0)
+        selected_only = mask_img is None
         # decode_masks (model.py:1330-1391) unmolds every box and the caller then keeps <= 10 of them (model.py:1290-1304);
         # the selection needs only boxes / scores / classes, so it runs first and only the survivors are unmolded
         # (same output: full_masks[:, :, nmb] of the all-box result).
@@ -500,16 +534,16 @@ class MaskYOLO(object):
                 mask_s = self.net.predict_masks(feature, det_s[:, :4].unsqueeze(0))[0]
             else:
                 mask_s = mask_d[0].index_select(0, sel).contiguous()
-            _, _, _, full_masks = self._decode_masks_device(det_s, mask_s, image.shape)
+            _, _, _, full_masks = self._decode_masks_device(det_s, mask_s, image_shape)
         else:
-            full_masks = np.empty((int(image.shape[0]), int(image.shape[1]), 0), dtype=bool)
-        H_img, W_img = float(image.shape[0]), float(image.shape[1])
-        return [{
+            full_masks = np.empty((int(image_shape[0]), int(image_shape[1]), 0), dtype=bool)
+        H_img, W_img = float(image_shape[0]), float(image_shape[1])
+        return {
             "bboxes": boxes[nmb] * np.array([W_img, H_img, W_img, H_img], dtype=boxes.dtype),     # pixels (model.py:1307)
             "class_ids": class_ids[nmb],
             "confidence_scores": scores[nmb],
             "full_masks": full_masks,
-        }]
+        }
 
     def _decode_masks_device(self, det, masks, image_shape):
         """decode_masks (model.py:1330-1391) with the unmold/paste of every detection on the GPU

@@ -802,6 +802,32 @@ def test_detect_masks_for_selected_only_matches_full_detect():
     assert (a["full_masks"] != b["full_masks"]).mean() < 1e-4
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_detect_many_equals_detect_per_image(dtype):
+    """MaskYOLO.detect_many: batches of config.BATCH_SIZE through Net.predict_stream (three in flight, a padded last batch) give, image by image, the
+    result of detect() on a model that sees the same batch shape -- boxes / classes / scores identical, pasted masks identical."""
+    rng = np.random.default_rng(3)
+    imgs = [(rng.random((416, 416, 3)) * 255).astype(np.uint8) for _ in range(6)]
+    cfg = make_config(RiceConfig, BATCH_SIZE=4, INFERENCE_DTYPE=dtype)
+    m = MaskYOLO(mode="inference", config=cfg, seed=4)
+    many = m.detect_many(imgs, cs_threshold=0.0)
+    assert len(many) == 6 and sum(r["full_masks"].shape[2] for r in many) >= 6
+    # the reference path image by image: the same graph shape (batch 4, the image first, padded with itself) through predict_graphed
+    for k in (0, 3, 5):
+        x = torch.as_tensor(np.ascontiguousarray((np.stack([imgs[k]] * 4) / 255.).astype(np.float32)), device=m.net.dev)
+        _, det_d, mask_d = m.net.predict_graphed(x)
+        one = m._select_and_unmold(det_d[0], mask_d[0], imgs[k].shape, 0.0)
+        for key in ("bboxes", "class_ids", "confidence_scores", "full_masks"):
+            assert np.array_equal(one[key], many[k][key]), (k, key)
+    # ... and detect() itself (batch 1: other launch shapes, so fp32 summation orders may differ in the last bits)
+    cfg1 = make_config(RiceConfig, BATCH_SIZE=1, INFERENCE_DTYPE=dtype)
+    m1 = MaskYOLO(mode="inference", config=cfg1, seed=4)
+    m1.load_state_dict(m.state_dict())
+    d0 = m1.detect(imgs[0], cs_threshold=0.0)[0]
+    assert d0["class_ids"].shape == many[0]["class_ids"].shape and np.array_equal(d0["class_ids"], many[0]["class_ids"])
+    assert np.allclose(d0["bboxes"], many[0]["bboxes"], atol=2e-2) and np.allclose(d0["confidence_scores"], many[0]["confidence_scores"], atol=1e-2 if dtype == "bf16" else 1e-4)
+
+
 def test_two_runs_bit_identical_forward():
     """determinism: everything except the ROIAlign scatter-add (fp32 atomics) is order-fixed."""
     cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4)
