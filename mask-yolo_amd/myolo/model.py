@@ -507,11 +507,12 @@ class MaskYOLO(object):
                 yield torch.as_tensor(np.ascontiguousarray(mutils._U8_OVER_255[np.stack(grp)]), device=dev)      # == (image / 255.).astype(float32)
         out = []
         for bi, (_, det_d, mask_d) in enumerate(self.net.predict_stream(batches(), in_flight=in_flight)):
+            det_all = det_d.cpu().numpy()
             for k in range(min(B, len(images) - bi * B)):
-                out.append(self._select_and_unmold(det_d[k], mask_d[k], images[bi * B + k].shape, cs_threshold))
+                out.append(self._select_and_unmold(det_d[k], mask_d[k], images[bi * B + k].shape, cs_threshold, det_host=det_all[k]))
         return out
 
-    def _select_and_unmold(self, det_img, mask_img, image_shape, cs_threshold, feature=None):
+    def _select_and_unmold(self, det_img, mask_img, image_shape, cs_threshold, feature=None, det_host=None):
         """detect()'s post-processing of ONE image: det_img [R,6], mask_img [R,mh,mw,C] (None: the mask head runs here, on the survivors) device tensors."""
         cfg = self.config
         det_d, mask_d = det_img.unsqueeze(0), None if mask_img is None else mask_img.unsqueeze(0)
@@ -519,7 +520,7 @@ class MaskYOLO(object):
         # decode_masks (model.py:1330-1391) unmolds every box and the caller then keeps <= 10 of them (model.py:1290-1304);
         # the selection needs only boxes / scores / classes, so it runs first and only the survivors are unmolded
         # (same output: full_masks[:, :, nmb] of the all-box result).
-        det_h = det_d[0].cpu().numpy()
+        det_h = det_d[0].cpu().numpy() if det_host is None else det_host          # (detect_many: one download per batch)
         boxes, scores, class_ids = det_h[:, :4], det_h[:, 4], det_h[:, 5].astype(np.int32)
         keep = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0)[0]     # model.py:1373-1380
         boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
@@ -534,7 +535,7 @@ class MaskYOLO(object):
                 mask_s = self.net.predict_masks(feature, det_s[:, :4].unsqueeze(0))[0]
             else:
                 mask_s = mask_d[0].index_select(0, sel).contiguous()
-            _, _, _, full_masks = self._decode_masks_device(det_s, mask_s, image_shape)
+            _, _, _, full_masks = self._decode_masks_device(det_s, mask_s, image_shape, det_host=det_h[keep[nmb]])
         else:
             full_masks = np.empty((int(image_shape[0]), int(image_shape[1]), 0), dtype=bool)
         H_img, W_img = float(image_shape[0]), float(image_shape[1])
@@ -545,11 +546,11 @@ class MaskYOLO(object):
             "full_masks": full_masks,
         }
 
-    def _decode_masks_device(self, det, masks, image_shape):
+    def _decode_masks_device(self, det, masks, image_shape, det_host=None):
         """decode_masks (model.py:1330-1391) with the unmold/paste of every detection on the GPU
-        (myolo_unmold_masks).  det [N,6], masks [N,mh,mw,C] device tensors of one image."""
+        (myolo_unmold_masks).  det [N,6], masks [N,mh,mw,C] device tensors of one image (det_host: det's host copy, if the caller has it)."""
         from . import _ext as X
-        det_h = det.cpu().numpy()
+        det_h = det.cpu().numpy() if det_host is None else det_host
         boxes, scores = det_h[:, :4], det_h[:, 4]
         class_ids = det_h[:, 5].astype(np.int32)
         keep = np.where((boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1]) > 0)[0]     # model.py:1373-1380
