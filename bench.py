@@ -959,7 +959,7 @@ def main():
                 ai = copy.copy(args)
                 ai.batch, ai.batch_given, ai.cpu_images, ai.steps, ai.warmup = 4, True, 0, max(20, args.steps), 3
                 ri = bench_infer(ai)
-                res["inference_rice416_bf16"] = {k: ri[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "one_in_flight", "roofline")}
+                res["inference_rice416_bf16"] = {k: ri[k] for k in ("metric", "value", "unit", "ms_per_step", "dtype", "one_in_flight", "detect_many", "roofline")}
                 res["inference_rice416_bf16"]["workload"] = ri["config"]["workload"]
             except Exception as e:
                 res["inference_rice416_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -37,6 +37,7 @@ new = '''## 7. Results (round 4, measured on 1x MI355X by ONE `python bench.py -
 | `secondary_nbox5` | %(n5v).1f | %(n5ms).2f | repository-HEAD head, N_BOX=5, R=245 |
 | `inference_rice416_bf16` | %(iv).1f | %(ims).2f | BASELINE configs[3]: Rice 416x416, batch 4, bf16 mask head, hipGraph replays, `config.in_flight` batches in flight (`Net.predict_stream`; three by default) |
 | `inference_rice416_bf16.one_in_flight` | %(i1v).1f | %(i1ms).2f | the same forwards strictly one after the other (what rounds 1-2 reported) |
+| `inference_rice416_bf16.detect_many` | %(dmv).1f | | the public call: `MaskYOLO.detect_many` on uint8 images -- upload, the same graphs, detect()'s selection and unmolding per image |
 | `cpu_baseline` | %(cpu).2f | | torch-CPU fp32 restatement, %(cores)d threads, 32-image training step |
 
 Dominant kernel (`roofline`): %(kname)s: **%(kms).3f ms per launch = %(ach).0f TFLOP/s of bf16 piece products = %(frac).3f of 2.5 PFLOP/s** (`frac_composite` %(fcomp).3f against max(flop / peak, bytes / measured copy rate))
@@ -64,6 +65,7 @@ Per-layer trunk table (`roofline.trunk_layers`; ms = HIP events around the layer
            s5v=sw["n_pos_5"]["images_per_sec"], s10v=sw["n_pos_10"]["images_per_sec"], s20v=sw["n_pos_20"]["images_per_sec"],
            s5=sw["n_pos_5"]["ms_per_step"], s10=sw["n_pos_10"]["ms_per_step"], s20=sw["n_pos_20"]["ms_per_step"],
            n5v=nb5.get("value", 0.0), n5ms=nb5.get("ms_per_step", 0.0), iv=inf.get("value", 0.0), ims=inf.get("ms_per_step", 0.0),
+           dmv=(inf.get("detect_many") or {}).get("images_per_sec", 0.0),
            i1v=inf.get("one_in_flight", {}).get("value", 0.0), i1ms=inf.get("one_in_flight", {}).get("ms_per_step", 0.0),
            mfb=d.get("mfma_measured_tflops", {}).get("bf16_32x32x16", 0.0), mff32=d.get("mfma_measured_tflops", {}).get("f32_32x32x2", 0.0),
            cpu=d["cpu_baseline"]["value"], cores=d["cpu_baseline"]["cores"],
