@@ -934,23 +934,24 @@ struct TNArgs {
     int nruns;
     int tiles_k, tiles_n;      // Ka / 256, N / 256
     long long nunits;          // (plane, split) pairs x tiles
+    long long unit_base;       // first unit of this launch (option "tn_wgs": the units go out in launches of at most that many workgroups)
     TNRun run[4];
 };
 
-template <bool AG = false, bool WALK = false>
+template <bool AG = false>
 __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 {
     __shared__ __attribute__((aligned(16))) unsigned char Ls[2][2][TN_T * X6_REC];      // [buffer][A | B][column record]: 112 KB
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3, half = lane >> 5, l31 = lane & 31;
-    // unit = ((plane, split) pair, tile): tiles of one pair are consecutive units.  One workgroup per unit, or (option "tn_wgs") a fixed number of
-    // workgroups walking the units: with 112 KB of LDS a CU holds ONE of these workgroups, so a grid of 224 leaves four CUs of every XCD to
-    // whatever runs beside this kernel (the trunk's backward chain: dozens of short dependent kernels that otherwise starve behind its
-    // half-millisecond workgroups)
+    // unit = ((plane, split) pair, tile): tiles of one pair are consecutive units.  One workgroup per unit; with option "tn_wgs" the units go out in
+    // several launches of at most that many workgroups (unit_base): with 112 KB of LDS a CU holds ONE of these workgroups, so launches of 224 leave
+    // four CUs of every XCD to whatever runs beside this kernel (the trunk's backward chain: dozens of short dependent kernels that otherwise
+    // starve behind its half-millisecond workgroups)
     const int ntile = p.tiles_k * p.tiles_n;
-  long long bid = blockIdx.x;
-  do {                                        // WALK = false (the default launch): once, the code of the one-unit-per-workgroup kernel
+  const long long bid = p.unit_base + blockIdx.x;
+  {
     const long long pair = bid / ntile;
     const int tile = (int)(bid - pair * ntile);
     const int kat = tile / p.tiles_n, nt = tile - kat * p.tiles_n;
@@ -1100,8 +1101,7 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 #pragma unroll
             for (int u = 0; u < 2; ++u) Pp[(long long)row * p.N + u * 32] = acc[t][u][r];
         }
-    if constexpr (WALK) bid += gridDim.x;
-  } while (WALK && bid < p.nunits);
+  }
 }
 
 // C[plane] = sum over the plane's splits of part[(plane, split)], fixed order; grid (element quads / 256, planes)
@@ -1204,8 +1204,10 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
     }
     if (pairs <= 0) return MYOLO_OK;
     a.nunits = pairs * a.tiles_k * a.tiles_n;
-    if (tn_x6_grid(a.nunits) < a.nunits) hipLaunchKernelGGL((wino_tn_x6_kernel<false, true>), dim3((unsigned)tn_x6_grid(a.nunits)), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((wino_tn_x6_kernel<false, false>), dim3((unsigned)a.nunits), dim3(512), 0, s, a);
+    for (long long base = 0, g = tn_x6_grid(a.nunits); base < a.nunits; base += g) {
+        a.unit_base = base;
+        hipLaunchKernelGGL(wino_tn_x6_kernel<false>, dim3((unsigned)(a.nunits - base < g ? a.nunits - base : g)), dim3(512), 0, s, a);
+    }
     const long long n4 = (long long)Ka * N / 4;
     hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), planes), dim3(256), 0, s, a);
     return MYOLO_OK;
@@ -1292,8 +1294,10 @@ int myolo_deconv_x6_bwd_weight(const float* x, const float* dy, float* dw, long 
     }
     a.run[0].a_off = 0; a.run[0].b_off = 0;
     a.nunits = pairs * a.tiles_k * a.tiles_n;
-    if (tn_x6_grid(a.nunits) < a.nunits) hipLaunchKernelGGL((wino_tn_x6_kernel<true, true>), dim3((unsigned)tn_x6_grid(a.nunits)), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((wino_tn_x6_kernel<true, false>), dim3((unsigned)a.nunits), dim3(512), 0, s, a);
+    for (long long base = 0, g = tn_x6_grid(a.nunits); base < a.nunits; base += g) {
+        a.unit_base = base;
+        hipLaunchKernelGGL(wino_tn_x6_kernel<true>, dim3((unsigned)(a.nunits - base < g ? a.nunits - base : g)), dim3(512), 0, s, a);
+    }
     const long long n4 = (long long)Ka * N / 4;
     hipLaunchKernelGGL(tn_x6_reduce_kernel, dim3((unsigned)((n4 + 255) / 256), 1), dim3(256), 0, s, a);
     return MYOLO_OK;
