@@ -31,7 +31,7 @@ extern "C" int myolo_version(void) { return 211; }
 // ---------------------------------------------------------------------------------------
 // tuning switches (myolo_set_option): plain process-wide ints, no environment reads anywhere
 // ---------------------------------------------------------------------------------------
-static MyoloOptions default_options() { MyoloOptions o = {}; o.bn_fused_tf_variance = 1; return o; }
+static MyoloOptions default_options() { MyoloOptions o = {}; o.bn_fused_tf_variance = 1; o.tn_wgs = 224; return o; }
 MyoloOptions g_myolo_opt = default_options();
 static int* option_slot(const char* name)
 {

@@ -8,7 +8,7 @@
 extern "C" void myolo_set_error(const char* fmt, ...);
 
 // Process-wide tuning switches, changed ONLY through myolo_set_option() (include/myolo_hip.h): the launch path reads
-// plain ints, never the environment.  Tuning switches default to 0 = the shipped behaviour.
+// plain ints, never the environment.  Tuning switches default to 0 = the shipped behaviour (tn_wgs: 224, see below).
 struct MyoloOptions {
     int no_nt;            // gemm: never use streaming (non-temporal) stores for large outputs
     int gemm_generic;     // gemm: force the generic (guarded) kernels
@@ -37,7 +37,7 @@ struct MyoloOptions {
     int dw_wgrad_generic; // depthwise weight gradient: the generic 9-accumulator column reduction instead of the tiled kernel (ablation)
     int pw_no_x6;         // pointwise convs with >= 256 channels: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)
-    int tn_wgs;           // wino_tn_x6_kernel: at most this many workgroups walking the work units (0 = one workgroup per unit); one fits a CU, so 224 leaves 32 CUs free
+    int tn_wgs;           // wino_tn_x6_kernel: its work units go out in launches of at most this many workgroups (default 224; 0 = one launch).  112 KB of LDS = one workgroup per CU, so 224 leave four CUs of every XCD to the chains of small kernels that run beside a weight gradient (profiles/r4_notes.md section 8)
     int no_trunk_fusion;  // *_bnstats_fwd: the conv, then a separate statistics pass (ablation of the producer-fused BatchNorm statistics)
     // NOT a tuning switch -- which Keras/TF pair the BatchNorm moving-variance update restates (default 1):
     // 1 = Keras 2.2.x on TF-1.x through tf.nn.fused_batch_norm (Bessel-corrected batch variance, then Keras' n/(n-(1+eps)));

@@ -220,6 +220,9 @@ class Net(object):
         self.single_wgrad_stream = 1
         self.overlap_trunk_wgrad = True
         self._twg_pending = False
+        self._twg_used = set()
+        self._twg_override = None              # (stream, scratch) the trunk's weight gradients go to instead, see backbone_wgrad_on_yolo_stream
+        self.backbone_wgrad_on_yolo_stream = 1 # 1 = the backbone's weight gradients (the last part of the step) run on the YOLO-head stream, idle by then, instead of queueing behind conv1's weight gradient on the weight-gradient stream
         # ... and started only when conv1's data gradient (the other matrix-pipe-bound kernel of that window) has been issued: two MFMA-bound
         # kernels sharing the chip each run at half speed, an MFMA-bound one beside the small HBM- / latency-bound kernels of the trunk
         # backward costs neither much (0 = start it together with the data gradient, as in round 2)
@@ -606,6 +609,8 @@ class Net(object):
 
     @property
     def _twg_stream(self):
+        if self._twg_override is not None:
+            return self._twg_override[0]
         if self.single_wgrad_stream:
             return self._wgrad_stream
         if self._twg_stream_own_ is None:
@@ -614,6 +619,8 @@ class Net(object):
 
     @property
     def _ws_twg(self):
+        if self._twg_override is not None:
+            return self._twg_override[1]
         return self._ws_wgrad if self.single_wgrad_stream else self._ws_twg_own
 
     def _on_wgrad_stream(self, fn, tensors):
@@ -633,11 +640,14 @@ class Net(object):
             if torch.is_tensor(t):
                 t.record_stream(self._twg_stream)
         self._twg_pending = True
+        self._twg_used.add(self._twg_stream)
 
     def join_trunk_wgrad(self):
         """make the current stream wait for the trunk's weight-gradient stream"""
         if self._twg_pending:
-            torch.cuda.current_stream().wait_stream(self._twg_stream)
+            for st in self._twg_used:
+                torch.cuda.current_stream().wait_stream(st)
+            self._twg_used.clear()
             self._twg_pending = False
 
     def dw_block_bwd(self, bid, da):
@@ -802,9 +812,14 @@ class Net(object):
                 self.join_trunk_wgrad()
                 self.on_bucket_ready(1)
         da = dC4
-        for _ in BACKBONE_BLOCKS:
-            da = self.dw_block_bwd(bid, da)
-            bid -= 1
+        if self.backbone_wgrad_on_yolo_stream and self.overlap_trunk_wgrad and self.overlap_yolo_bwd:
+            self._twg_override = (self._yolo_stream, self._ws_side)
+        try:
+            for _ in BACKBONE_BLOCKS:
+                da = self.dw_block_bwd(bid, da)
+                bid -= 1
+        finally:
+            self._twg_override = None
         dy = self.bn_act_bwd("conv1_bn", da)
         images = self.tape["images"]
         N, H, W, _ = images.shape
