@@ -2766,8 +2766,127 @@ int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, con
     return myolo_bn_stats_launch(y, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, M, Cout, ws, ws_bytes, s);
 }
 
+static int conv3x3s2_c3_bwd_weight_colreduce(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* ws,
+                                             size_t ws_bytes, void* stream);
+
+// conv1's weight gradient (3x3 / s2, 3 input channels, model.py:42-52), LDS-staged.  The column-reduction form (OpConv1Dw) fetched the 27 patch
+// values of an output pixel with 27 scalar loads in EACH of the Co/4 lanes that share the pixel: 190 us for 70 MB, the last kernel of the step's
+// backward chain.  Here a workgroup owns a chunk of output rows of one image: the three input rows of an output row are put in LDS once (left
+// zero column included), a thread = (pixel lane, channel quad) walks the row's pixels with one 16-byte load of dy and 27 LDS reads each; the
+// 27 x 4 sums per thread are combined over the pixel lanes in LDS and leave as one row of partials per workgroup, summed by
+// colreduce_finish<FinD2F> in workgroup order (deterministic).
+#define C1W_ROWS 8
+__global__ __launch_bounds__(256) void conv1_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, double* __restrict__ part,
+                                                          int H, int W, int Co, int chunks)
+{
+    extern __shared__ __attribute__((aligned(16))) float c1w_lds[];        // [3][(W + 1) * 3] input rows | reduction scratch [4 waves][27][Co]
+    const int Ho = H / 2, Wo = W / 2;
+    const int cq = Co / 4, pl = 256 / cq;                  // cq a power of two <= 64 (checked by the launcher)
+    const int tid = threadIdx.x, cl_i = tid % cq, pl_i = tid / cq;
+    const int n = blockIdx.x / chunks, ch = blockIdx.x - n * chunks;
+    const int oy0 = ch * C1W_ROWS, oy1 = min(oy0 + C1W_ROWS, Ho);
+    const int rowf = (W + 1) * 3, nst = 3 * rowf;
+    // staging: element e = k * rowf + q, q = (ix + 1) * 3 + ci; a thread's elements are the same for every output row (only iy moves):
+    // their offsets are formed once, the next row's values are fetched into registers while this row is accumulated
+    constexpr int SMAX = 12;                               // 3 * (W + 1) * 3 / 256 <= 12 for W <= 340
+    int soff[SMAX], sk[SMAX];
+    float sv[SMAX];
+#pragma unroll
+    for (int t = 0; t < SMAX; ++t) {
+        const int e = tid + t * 256;
+        const int k = e / rowf, q = e - k * rowf, ix = q / 3 - 1;
+        sk[t] = e < nst ? k : -100000;                     // (never a valid input row)
+        soff[t] = (e < nst && ix >= 0) ? ix * 3 + (q - (ix + 1) * 3) : -1;
+    }
+    auto fetch = [&](int oy) {
+#pragma unroll
+        for (int t = 0; t < SMAX; ++t) {
+            const int iy = 2 * oy + sk[t] - 1;
+            sv[t] = (soff[t] >= 0 && iy >= 0 && iy < H) ? x[((long long)n * H + iy) * W * 3 + soff[t]] : 0.f;
+        }
+    };
+    float4 acc[27];
+#pragma unroll
+    for (int v = 0; v < 27; ++v) acc[v] = f4zero();
+    fetch(oy0);
+    for (int oy = oy0; oy < oy1; ++oy) {
+        __syncthreads();                                   // the previous row's readers are done
+#pragma unroll
+        for (int t = 0; t < SMAX; ++t)
+            if (tid + t * 256 < nst) c1w_lds[tid + t * 256] = sv[t];
+        __syncthreads();
+        if (oy + 1 < oy1) fetch(oy + 1);
+        const float* grow = dy + (((long long)n * Ho + oy) * Wo) * Co + cl_i * 4;
+        for (int ox = pl_i; ox < Wo; ox += pl) {
+            const float4 g = ld4g(grow + (long long)ox * Co);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float* r = c1w_lds + ky * rowf + 2 * ox * 3;      // (ix + 1) * 3 with ix = 2 ox + kx - 1
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {                           // j = kx * 3 + ci
+                    const float a = r[j];
+                    float4& A = acc[ky * 9 + j];
+                    A.x = fmaf(a, g.x, A.x); A.y = fmaf(a, g.y, A.y); A.z = fmaf(a, g.z, A.z); A.w = fmaf(a, g.w, A.w);
+                }
+            }
+        }
+    }
+    // combine the pixel lanes: inside a wave by shuffles (the lanes of one channel quad are cq apart), the four waves through LDS, fixed order
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll                                  // (a runtime index into acc[] would move the 27 accumulators to scratch)
+    for (int v = 0; v < 27; ++v) {
+        for (int m = cq; m < 64; m <<= 1) {
+            acc[v].x += __shfl_xor(acc[v].x, m, 64); acc[v].y += __shfl_xor(acc[v].y, m, 64);
+            acc[v].z += __shfl_xor(acc[v].z, m, 64); acc[v].w += __shfl_xor(acc[v].w, m, 64);
+        }
+    }
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(c1w_lds);       // [wave][27][cq]
+    if (cq >= 64 || lane < cq) {
+#pragma unroll
+        for (int v = 0; v < 27; ++v) red[(wave * 27 + v) * cq + (lane % cq)] = acc[v];
+    }
+    __syncthreads();
+    for (int e = tid; e < 27 * cq; e += 256) {
+        const float4 a = red[e], b = red[27 * cq + e], c = red[2 * 27 * cq + e], d = red[3 * 27 * cq + e];
+        const int v = e / cq, q4 = e - v * cq;
+        double* o = part + ((long long)blockIdx.x * 27 + v) * Co + q4 * 4;
+        o[0] = ((double)a.x + (double)b.x) + ((double)c.x + (double)d.x); o[1] = ((double)a.y + (double)b.y) + ((double)c.y + (double)d.y);
+        o[2] = ((double)a.z + (double)b.z) + ((double)c.z + (double)d.z); o[3] = ((double)a.w + (double)b.w) + ((double)c.w + (double)d.w);
+    }
+}
+
+static bool conv1_wgrad_lds_ok(int H, int W, int Cout)
+{
+    const int cq = Cout / 4;
+    return cq >= 1 && cq <= 64 && (cq & (cq - 1)) == 0 && (H & 1) == 0 && (W & 1) == 0 && W <= 340 && !(g_myolo_opt.tune0 & 1024);
+}
+
 int myolo_conv3x3s2_c3_bwd_weight(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* ws,
                                   size_t ws_bytes, void* stream)
+{
+    if (x && dy && dw && N > 0 && (Cout & 3) == 0 && conv1_wgrad_lds_ok(H, W, Cout)) {
+        const int chunks = (H / 2 + C1W_ROWS - 1) / C1W_ROWS;
+        const long long wgs = (long long)N * chunks;
+        const size_t pb = align256((size_t)wgs * 27 * Cout * sizeof(double));
+        if (wgs < (1ll << 30) && ws && pb + 27 * Cout * sizeof(double) <= ws_bytes) {
+            double* part = (double*)ws;
+            double* tot = (double*)((char*)ws + pb);
+            hipStream_t s = (hipStream_t)stream;
+            size_t lds = (size_t)3 * (W + 1) * 3 * sizeof(float);
+            if (lds < (size_t)4 * 27 * Cout * sizeof(float)) lds = (size_t)4 * 27 * Cout * sizeof(float);
+            hipLaunchKernelGGL(conv1_wgrad_kernel, dim3((unsigned)wgs), dim3(256), lds, s, x, dy, part, H, W, Cout, chunks);
+            const int nvc = 27 * Cout;
+            hipLaunchKernelGGL((colreduce_finish<FinD2F>), dim3((nvc + 7) / 8), dim3(256), 0, s, part, tot, (int)wgs, nvc, Cout, FinD2F{dw});
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+    }
+    return conv3x3s2_c3_bwd_weight_colreduce(x, dy, dw, N, H, W, Cout, ws, ws_bytes, stream);
+}
+
+static int conv3x3s2_c3_bwd_weight_colreduce(const float* x, const float* dy, float* dw, int N, int H, int W, int Cout, void* ws,
+                                             size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(x && dy && dw && N > 0 && (Cout & 3) == 0, "conv3x3s2_c3_bwd_weight: bad arguments");
     const long long M = (long long)N * (H / 2) * (W / 2);
