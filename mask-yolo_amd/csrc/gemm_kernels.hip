@@ -1383,6 +1383,63 @@ __global__ __launch_bounds__(256) void pw_skinny_fwd_kernel(const float* __restr
     }
 }
 
+// Data gradient of the THIN pointwise layers (conv_pw_1..4: 32-128 input channels, up to 256 output channels, 25 088 - 401 408 rows):
+//     dx [M][N = Cin] = dy [M][K = Cout] * w^T,  w [N][K] -- already the [n][k] operand.
+// These launches move 40-150 MB and a handful of MFLOP per row tile; through gemm_nn_fast (128-row LDS tiles built for big K) they ran at
+// 1.0-1.5 TB/s at the very end of the step's backward chain.  Here a wave owns 32 rows and ALL N columns and feeds v_mfma_f32_32x32x2f32
+// straight from registers: lane (row l31, half h) loads 16 bytes of its row per step, k = 8 j + 4 h .. + 3, and the matching 16 bytes of w's row
+// n = l31 (+ 32 u) -- the reduction index may be walked in any order as long as both operands agree, so no transposition and no LDS.  Fixed
+// order, one accumulator per output: deterministic.  fp32 operands on the fp32 matrix pipe (the same arithmetic as gemm_nn_fast).
+template <int NU>
+__global__ __launch_bounds__(256) void pw_bwd_data_thin_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                                                               long long M, int K, int N)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
+    const long long nblk = (M + 31) / 32;
+    const long long wave0 = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long long)gridDim.x * 4;
+    const int nj = K / 8;
+    const float* wb = w + (long long)l31 * K + 4 * half;
+    for (long long blk = wave0; blk < nblk; blk += nwave) {
+        const long long row = blk * 32 + l31;
+        const float* ap = dy + (row < M ? row : M - 1) * K + 4 * half;       // (rows past the end repeat the last one; never stored)
+        f32x16 acc[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+#pragma unroll 2
+        for (int j = 0; j < nj; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(ap + 8 * j);
+            float4 b[NU];
+#pragma unroll
+            for (int u = 0; u < NU; ++u) b[u] = *reinterpret_cast<const float4*>(wb + (long long)u * 32 * K + 8 * j);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b[u].x, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b[u].y, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b[u].z, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b[u].w, acc[u], 0, 0, 0);
+            }
+        }
+        // acc[u][r]: row (r & 3) + 8 (r >> 2) + 4 half of the block, column 32 u + l31: 128-byte row segments per store
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long orow = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (orow < M) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) dx[orow * N + 32 * u + l31] = acc[u][r];
+            }
+        }
+    }
+}
+
+static bool pw_bwd_data_thin_ok(long long M, int Cin, int Cout)
+{
+    // (Cin = 128, i.e. conv_pw_4 with 25 088 rows: 784 waves of 32 steps x 16 MFMAs each do not fill the chip -- gemm_nn_fast keeps that layer)
+    return (Cin == 32 || Cin == 64) && Cout <= 256 && (Cout % 8) == 0 && M >= 8192 && !(g_myolo_opt.tune0 & 2048);
+}
+
+
 extern "C" {
 
 int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float* y,
@@ -1425,6 +1482,15 @@ int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
                              int64_t M, int Cin, int Cout, void* ws, size_t ws_bytes, void* stream)
 {
     MYOLO_REQUIRE(dy && w && dx && M > 0, "pwconv1x1_bwd_data: bad arguments");
+    if (pw_bwd_data_thin_ok(M, Cin, Cout) && (((uintptr_t)dy | (uintptr_t)w | (uintptr_t)dx) & 15) == 0) {
+        long long wgs = ((M + 31) / 32 + 3) / 4;
+        if (wgs > 4096) wgs = 4096;                       // (16 workgroups per CU: the waves walk the row blocks)
+        hipStream_t st = (hipStream_t)stream;
+        if (Cin == 32) hipLaunchKernelGGL(pw_bwd_data_thin_kernel<1>, dim3((unsigned)wgs), dim3(256), 0, st, dy, w, dx, (long long)M, Cout, Cin);
+        else hipLaunchKernelGGL(pw_bwd_data_thin_kernel<2>, dim3((unsigned)wgs), dim3(256), 0, st, dy, w, dx, (long long)M, Cout, Cin);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     MYOLO_NEED_WS((size_t)Cin * Cout * sizeof(float));
     hipStream_t s = (hipStream_t)stream;
     if (g_myolo_opt.wino_x6 && !g_myolo_opt.pw_no_x6 && (Cin % 256) == 0 && (Cout % 16) == 0 && M >= pw_x6_min_rows() &&

@@ -67,7 +67,8 @@ def rnd(rng, *shape, scale=1.0):
                                              (676, 1024, 35, True), (1571, 1024, 35, False), (10, 16, 63, True),    # pw_skinny_fwd_kernel (conv_23)
 
                                              (4096, 64, 128, False), (257, 512, 1024, False),
-                                             (20003, 32, 64, False), (16391, 64, 128, False), (25088, 64, 64, False)])   # thin-layer weight gradient
+                                             (20003, 32, 64, False), (16391, 64, 128, False), (25088, 64, 64, False),    # thin-layer weight gradient
+                                             (25088, 128, 256, False), (100352, 32, 64, False), (8193, 64, 24, False)])   # + pw_bwd_data_thin_kernel
 def test_pwconv1x1(M, Cin, Cout, bias):
     rng = np.random.default_rng(1)
     x, w = rnd(rng, M, Cin), rnd(rng, Cin, Cout, scale=0.1)
