@@ -1433,6 +1433,127 @@ __global__ __launch_bounds__(256) void pw_bwd_data_thin_kernel(const float* __re
     }
 }
 
+// Forward of the THIN pointwise layers in training (conv_pw_1..3: 32 / 64 input, 64 / 128 output channels, 100 352 - 401 408 rows), the mirror of the
+// kernel above:  y [M][N] = act(x * in_scale + in_shift) [M][K] * w [K][N], column sums of y and y^2 for the BatchNorm that follows.
+// A wave owns 32 rows and all N columns; lane (row l31, half h) loads 16 bytes of its row per step (k = 8 j + 4 h .. + 3), normalises them in
+// registers, and reads the matching 16 bytes of w^T's row n from LDS (w, 8-32 KB, transposed into LDS once per workgroup, rows padded to K + 4
+// floats: conflict-free 16-byte reads).  The statistics: 16 rows per lane in fp32, then doubles -- over the wave's row blocks, the two half-waves,
+// the four waves (LDS); one row of partials per workgroup, summed in a fixed order by the finish kernel: bit-reproducible.
+template <int NU, int NJ>
+__global__ __launch_bounds__(256) void pw_fwd_thin_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                          double* __restrict__ stat, long long M, const float* __restrict__ a_scale,
+                                                          const float* __restrict__ a_shift, int a_act)
+{
+    constexpr int K = 8 * NJ, N = 32 * NU, LDW = K + 4;
+    extern __shared__ __align__(16) float pwt_lds[];             // [N][K + 4] floats, afterwards [4][2][N] doubles
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    for (int e = tid; e < K * N; e += 256) {
+        const int k = e / N, n = e - k * N;
+        pwt_lds[n * LDW + k] = w[e];
+    }
+    float4 sc[NJ], sh[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        sc[j] = a_scale ? *reinterpret_cast<const float4*>(a_scale + 8 * j + 4 * half) : make_float4(1.f, 1.f, 1.f, 1.f);
+        sh[j] = a_scale ? *reinterpret_cast<const float4*>(a_shift + 8 * j + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int act = a_scale ? a_act : MYOLO_ACT_NONE;
+    __syncthreads();
+    const long long nblk = (M + 31) / 32;
+    const long long wave0 = (long long)blockIdx.x * 4 + wave, nwave = (long long)gridDim.x * 4;
+    const float* wb = pwt_lds + l31 * LDW + 4 * half;
+    double d1[NU], d2[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { d1[u] = 0.0; d2[u] = 0.0; }
+    for (long long blk = wave0; blk < nblk; blk += nwave) {
+        const long long row = blk * 32 + l31;
+        const float* ap = x + (row < M ? row : M - 1) * K + 4 * half;        // (rows past the end repeat the last one; never stored, never summed)
+        float4 a[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) a[j] = *reinterpret_cast<const float4*>(ap + 8 * j);
+        f32x16 acc[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[u][r] = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float4 v = a[j];
+            v.x = gemm_act(fmaf(v.x, sc[j].x, sh[j].x), act); v.y = gemm_act(fmaf(v.y, sc[j].y, sh[j].y), act);
+            v.z = gemm_act(fmaf(v.z, sc[j].z, sh[j].z), act); v.w = gemm_act(fmaf(v.w, sc[j].w, sh[j].w), act);
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const float4 b = *reinterpret_cast<const float4*>(wb + u * 32 * LDW + 8 * j);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.x, b.x, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.y, b.y, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.z, b.z, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(v.w, b.w, acc[u], 0, 0, 0);
+            }
+        }
+        // acc[u][r]: row (r & 3) + 8 (r >> 2) + 4 half of the block, column 32 u + l31
+        float s1[NU], s2[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { s1[u] = 0.f; s2[u] = 0.f; }
+        const bool full = blk * 32 + 32 <= M;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long orow = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (full || orow < M) {
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const float t = acc[u][r];
+                    y[orow * N + 32 * u + l31] = t;
+                    s1[u] += t; s2[u] = fmaf(t, t, s2[u]);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) { d1[u] += (double)s1[u]; d2[u] += (double)s2[u]; }
+    }
+    if (!stat) return;
+    __syncthreads();                                         // every wave is done with w^T in LDS
+    double* red = reinterpret_cast<double*>(pwt_lds);          // [4 waves][2][N]
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        d1[u] += __shfl_xor(d1[u], 32, 64);
+        d2[u] += __shfl_xor(d2[u], 32, 64);
+        if (half == 0) { red[(wave * 2 + 0) * N + 32 * u + l31] = d1[u]; red[(wave * 2 + 1) * N + 32 * u + l31] = d2[u]; }
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * N; e += 256)
+        stat[(long long)blockIdx.x * 2 * N + e] = (red[0 * 2 * N + e] + red[1 * 2 * N + e]) + (red[2 * 2 * N + e] + red[3 * 2 * N + e]);
+}
+
+static bool pw_fwd_thin_ok(long long M, int Cin, int Cout)
+{
+    // 128 output channels (conv_pw_3, 100 352 rows = one row block per wave): 43 us here against 36 us on gemm_nn_fast -- the 32 KB of w^T every
+    // workgroup stages are not amortised; tune0 & 8192 lets the test reach that instantiation
+    return (Cin == 32 || Cin == 64) && (Cout == 64 || (Cout == 128 && (g_myolo_opt.tune0 & 8192))) && M >= 8192 && !(g_myolo_opt.tune0 & 4096) &&
+           !g_myolo_opt.no_trunk_fusion;
+}
+
+// workgroups of pw_fwd_thin_kernel = rows of statistics partials it writes (never more than the 128-row tiles the scratch is sized for)
+static int pw_fwd_thin_wgs(long long M)
+{
+    long long wgs = ((M + 31) / 32 + 3) / 4;
+    if (wgs > 2048) wgs = 2048;
+    return (int)wgs;
+}
+
+static void pw_fwd_thin_launch(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y, double* stat,
+                               long long M, int Cin, int Cout, hipStream_t s)
+{
+    const unsigned wgs = (unsigned)pw_fwd_thin_wgs(M);
+    size_t lds = (size_t)Cout * (Cin + 4) * sizeof(float);
+    if (lds < (size_t)8 * Cout * sizeof(double)) lds = (size_t)8 * Cout * sizeof(double);
+#define PWT(NU_, NJ_) hipLaunchKernelGGL((pw_fwd_thin_kernel<NU_, NJ_>), dim3(wgs), dim3(256), lds, s, x, w, y, stat, M, in_scale, in_shift, in_act)
+    if (Cin == 32 && Cout == 64) PWT(2, 4);
+    else if (Cin == 32) PWT(4, 4);
+    else if (Cout == 64) PWT(2, 8);
+    else PWT(4, 8);
+#undef PWT
+}
+
 static bool pw_bwd_data_thin_ok(long long M, int Cin, int Cout)
 {
     // (Cin = 128, i.e. conv_pw_4 with 25 088 rows: 784 waves of 32 steps x 16 MFMAs each do not fill the chip -- gemm_nn_fast keeps that layer)
@@ -1633,6 +1754,15 @@ int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const flo
         if (phases & 1) myolo_pw_x6_fwd(x, in_scale, in_shift, in_act, w, y, part, M, Cin, Cout, split, s);
         MYOLO_CHECK_LAUNCH();
         if (phases & 2) myolo_bn_stats_from_partials(part, tot, tiles, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
+    if (pw_fwd_thin_ok(M, Cin, Cout)) {
+        // conv_pw_1..3: the register-fed kernel (pw_fwd_thin_kernel); its partial rows are one per workgroup
+        const int wgs = pw_fwd_thin_wgs(M);
+        if (phases & 1) pw_fwd_thin_launch(x, in_scale, in_shift, in_act, w, y, part, M, Cin, Cout, s);
+        MYOLO_CHECK_LAUNCH();
+        if (phases & 2) myolo_bn_stats_from_partials(part, tot, wgs, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }

@@ -1231,7 +1231,9 @@ def test_dwconv3x3_bnstats_fwd_and_affine_in_weight_gradient(N, H, W, C, stride,
 @pytest.mark.parametrize("nofuse", [0, 1])
 @pytest.mark.parametrize("M,Cin,Cout,lazy", [(300, 32, 64, True), (4096, 64, 128, True), (25088, 64, 64, True), (6272, 512, 512, True), (1568, 512, 1024, True),
                                              (1568, 1024, 1024, False), (130, 16, 16, True), (20003, 32, 64, True), (257, 256, 512, True), (100352, 64, 128, True),
-                                             (25088, 256, 256, True), (3000, 256, 512, False)])
+                                             (25088, 256, 256, True), (3000, 256, 512, False),
+                                             # round 4: the register-fed thin-layer forward (32 / 64 -> 64 / 128 channels from 8192 rows): the fourth instantiation, no prologue, a 1-row tail
+                                             (9001, 32, 128, False), (8192, 64, 64, False)])
 def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy, nofuse, x6, request):
     """pointwise conv whose A operand is relu6(x * in_scale + in_shift) formed on load, with the batch statistics of its output from
     the GEMM epilogue (one pass) or, for the split-K shapes (M = 1568), from a statistics pass; and its weight gradient
@@ -1250,7 +1252,7 @@ def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy,
     mean, var, scale, shift = new(Cout), new(Cout), new(Cout), new(Cout)
     tmm, tmv = dt(mm), dt(mv)
     wsb = torch.empty(X.pw_bnstats_ws_bytes(M, Cin, Cout), dtype=torch.uint8, device=DEV)
-    with X.option("no_trunk_fusion", nofuse):
+    with X.option("no_trunk_fusion", nofuse), X.option("tune0", 8192):        # (8192: the thin-layer forward also for 128 output channels)
         X.call("myolo_pwconv1x1_bnstats_fwd", X.ptr(dt(x)), X.ptr(dt(isc)) if lazy else None, X.ptr(dt(ish)) if lazy else None, 2, X.ptr(dt(w)), X.ptr(y),
                X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv),
                M, Cin, Cout, 3, wsb.data_ptr(), wsb.numel(), X.stream())

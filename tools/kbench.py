@@ -279,6 +279,29 @@ def main():
             tot_b += nb
             print("dw_fused %3dx%3dx%4d s%d: %.4f ms %6.0f GB/s   (finish launch %.4f ms)" % (H, H, Cc, s, ms, nb / ms / 1e6, ms_fin))
         print("dw_fused total: %.3f ms, %.0f GB/s (%.1f%% of 8000)" % (tot_ms, tot_b / tot_ms / 1e6, tot_b / tot_ms / 1e6 / 80))
+    elif a.which == "bn_bwd":
+        # training-mode BatchNorm + ReLU6 backward of the trunk's layers (three launches: sums, finish, dx), inputs rotated through > 600 MB:
+        # 5 tensor passes (dy, x read twice; dx written once)
+        shapes = [("conv1/dw1", 401408, 32), ("pw1", 401408, 64), ("dw2-3/pw2", 100352, 64), ("pw3", 100352, 128), ("dw4", 25088, 128), ("pw4-5/dw5-6", 25088, 256),
+                  ("pw6", 25088, 512), ("dw7", 6272, 512)]
+        tot = [0.0, 0.0]
+        for name, Mr, Cc in shapes:
+            nbuf = max(2, int(640e6 // (2 * Mr * Cc * 4)) + 1)
+            xs, dys = [rn(Mr, Cc) for _ in range(nbuf)], [rn(Mr, Cc) for _ in range(nbuf)]
+            gam, mean, var = torch.rand(Cc, device=dev) + 0.5, rn(Cc) * 0.1, torch.rand(Cc, device=dev) + 0.5
+            scale = gam / torch.sqrt(var + 1e-3); shift = -mean * scale
+            dx, dg, db = torch.empty(Mr, Cc, device=dev), torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+            it = [0]
+
+            def f():
+                i = it[0]; it[0] += 1
+                X.call("myolo_bn_act_bwd", X.ptr(dys[i % nbuf]), X.ptr(xs[i % nbuf]), X.ptr(gam), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift),
+                       X.ptr(dx), X.ptr(dg), X.ptr(db), Mr, Cc, 2, 1, ws.data_ptr(), ws.numel(), st)
+            ms = timeit(f, a.iters)
+            nb = 5.0 * Mr * Cc * 4
+            tot[0] += ms; tot[1] += nb
+            print("bn_bwd %-12s M=%6d C=%4d: %.4f ms %6.0f GB/s" % (name, Mr, Cc, ms, nb / ms / 1e6))
+        print("bn_bwd total (one of each): %.3f ms, %.0f GB/s" % (tot[0], tot[1] / tot[0] / 1e6))
     elif a.which in ("dw_bwd", "pw_fused"):
         # the trunk's other launches as the training step runs them, inputs rotated through > 600 MB of buffers (no Infinity-Cache hits):
         #   dw_bwd:   depthwise data gradient and weight gradient (input re-normalised on load) of the 14 layers
