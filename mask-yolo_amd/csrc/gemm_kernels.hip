@@ -1659,7 +1659,7 @@ static int pw_bwd_weight_impl(const float* x, const float* in_scale, const float
     MYOLO_REQUIRE(x && dy && dw && M > 0, "pwconv1x1_bwd_weight: bad arguments");
     if ((Cin == 32 || Cin == 64) && (Cout == 64 || Cout == 128) && M >= 16384 && !g_myolo_opt.gemm_generic) {
         // thin layer: one wave holds the whole result (pw_wgrad_thin)
-        const int nblk = g_myolo_opt.tune0 > 0 ? g_myolo_opt.tune0 : (M >= 300000 ? 512 : 256);     // measured: tools/pw_layers.py
+        const int nblk = M >= 300000 ? 512 : 256;     // measured: tools/pw_layers.py (tune0 is a bit mask of A/B switches: it must not size anything here)
         const size_t need = (size_t)nblk * Cin * Cout * sizeof(float);
         if (ws && need <= ws_bytes) {
             hipStream_t s = (hipStream_t)stream;

@@ -923,6 +923,113 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     }
 }
 
+// The same conv with its input through LDS (training forward at 224^2: 19 MB in, 51 MB out; conv1_fwd_kernel above took 72-80 us for it: 27
+// scalar global loads per thread and three 64-bit divisions per output).  A workgroup owns C1F_STEPS pairs of output rows of one image; the five
+// input rows of a pair (one contiguous span of the image) arrive as 16-byte loads, the next pair's while this one is computed; a row in LDS is
+// [4 floats of left padding][3 W floats], so the nine values of one kernel row of a pixel are nine consecutive floats.  A thread keeps the 27
+// filter values of its four channels in registers (its channel quad never changes: 256 % (Co / 4) == 0) and walks the 2 Wo pixels of the pair.
+// Same order of the 27 products per output as conv1_fwd_kernel (the padded taps add 0 * w): bit-identical y.
+#define C1F_STEPS 2
+#define C1F_SMAX 6
+__global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
+                                                             int H, int W, int Co, int cq_shift, int chunks, double* __restrict__ stat)
+{
+    extern __shared__ __attribute__((aligned(16))) float c1f_lds[];     // [5][4 + 3 W]
+    __shared__ float4 red[256];
+    const int tid = threadIdx.x, Ho = H / 2, Wo = W / 2, cq = Co / 4;
+    const int n = blockIdx.x / chunks, ch = blockIdx.x - n * chunks;
+    const int row3 = 3 * W, rowf = 4 + row3, nf4 = 5 * row3 / 4;
+    const int c4 = (tid & (cq - 1)) * 4;
+    float4 wr[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) wr[k] = ld4g(w + k * Co + c4);
+    if (tid < 20) c1f_lds[(tid >> 2) * rowf + (tid & 3)] = 0.f;
+    const int nsteps = (Ho + 1) / 2;
+    const int st0 = ch * C1F_STEPS, st1 = st0 + C1F_STEPS < nsteps ? st0 + C1F_STEPS : nsteps;
+    const float* xi = x + (long long)n * H * row3;
+    float4 sv[C1F_SMAX];
+    int soff[C1F_SMAX], srow[C1F_SMAX];
+#pragma unroll
+    for (int t = 0; t < C1F_SMAX; ++t) {
+        const int f = 4 * (tid + t * 256);
+        srow[t] = f < 5 * row3 ? f / row3 : -100000;
+        soff[t] = f;
+    }
+    auto fetch = [&](int step) {
+        const int iy0 = 4 * step - 1;
+#pragma unroll
+        for (int t = 0; t < C1F_SMAX; ++t) {
+            const int iy = iy0 + srow[t];
+            sv[t] = (iy >= 0 && iy < H) ? ld4g(xi + (long long)iy0 * row3 + soff[t]) : f4zero();
+        }
+    };
+    float4 s1 = f4zero(), s2 = f4zero();
+    if (st0 < st1) fetch(st0);
+    for (int step = st0; step < st1; ++step) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < C1F_SMAX; ++t)
+            if (srow[t] >= 0) *reinterpret_cast<float4*>(c1f_lds + srow[t] * rowf + 4 + (soff[t] - srow[t] * row3)) = sv[t];
+        __syncthreads();
+        if (step + 1 < st1) fetch(step + 1);
+        const int oy0 = 2 * step;
+        for (int it = tid; it < 2 * Wo * cq; it += 256) {
+            const int p = it >> cq_shift;
+            const int rr = p >= Wo ? 1 : 0, ox = p - rr * Wo, oy = oy0 + rr;
+            if (oy >= Ho) break;
+            const float* b = c1f_lds + 2 * rr * rowf + 1 + 6 * ox;
+            float4 acc = f4zero();
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int j = 0; j < 9; ++j) {
+                    const float a = b[ky * rowf + j];
+                    const float4 wv = wr[ky * 9 + j];
+                    acc.x = fmaf(a, wv.x, acc.x); acc.y = fmaf(a, wv.y, acc.y);
+                    acc.z = fmaf(a, wv.z, acc.z); acc.w = fmaf(a, wv.w, acc.w);
+                }
+            st4g(y + (((long long)n * Ho + oy) * Wo + ox) * Co + c4, acc);
+            s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
+            s2 = f4fma(acc, acc, s2);
+        }
+    }
+    if (stat) {          // per-workgroup partial sums of the output, as conv1_fwd_kernel leaves them
+        const int pl = 256 / cq, cl_i = tid & (cq - 1);
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            __syncthreads();
+            red[tid] = v == 0 ? s1 : s2;
+            __syncthreads();
+            if (tid < cq) {
+                double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+                for (int j = 0; j < pl; ++j) {
+                    const float4 t = red[j * cq + cl_i];
+                    a0 += t.x; a1 += t.y; a2 += t.z; a3 += t.w;
+                }
+                double* o = stat + ((long long)blockIdx.x * 2 + v) * Co + cl_i * 4;
+                o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3;
+            }
+        }
+    }
+}
+
+// the LDS-staged forward takes: rows that are whole 16-byte groups (W % 4 == 0), at most C1F_SMAX * 256 groups per five rows, a power-of-two number of
+// channel quads <= 64
+static bool conv1_fwd_rows_ok(int H, int W, int Cout)
+{
+    const int cq = Cout / 4;
+    return (H & 1) == 0 && (W & 3) == 0 && 5 * 3 * W / 4 <= C1F_SMAX * 256 && cq >= 1 && cq <= 64 && (cq & (cq - 1)) == 0 && !(g_myolo_opt.tune0 & 16384);
+}
+static int conv1_fwd_rows_chunks(int H) { return ((H / 2 + 1) / 2 + C1F_STEPS - 1) / C1F_STEPS; }
+static void conv1_fwd_rows_launch(const float* x, const float* w, float* y, int N, int H, int W, int Cout, double* stat, hipStream_t s)
+{
+    const int chunks = conv1_fwd_rows_chunks(H);
+    int sh = 0;
+    while ((1 << sh) < Cout / 4) ++sh;
+    hipLaunchKernelGGL(conv1_fwd_rows_kernel, dim3((unsigned)(N * chunks)), dim3(256), (size_t)5 * (4 + 3 * W) * sizeof(float), s, x, w, y, H, W, Cout, sh, chunks,
+                       stat);
+}
+
 // dw[k][co] = sum_pixels patch[k] * dy[co]; rows = output pixels, "channels" = Co, 27 accumulators
 struct OpConv1Dw {
     static constexpr int NV = 27;
@@ -2750,8 +2857,11 @@ int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y, int N, int 
 {
     MYOLO_REQUIRE(x && w && y && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0, "conv3x3s2_c3_fwd: bad arguments");
     const long long total = (long long)N * (H / 2) * (W / 2) * (Cout / 4);
-    hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), (hipStream_t)stream,
-                       x, w, y, N, H, W, Cout, (double*)nullptr);
+    if (conv1_fwd_rows_ok(H, W, Cout) && (long long)N * conv1_fwd_rows_chunks(H) < (1ll << 31))
+        conv1_fwd_rows_launch(x, w, y, N, H, W, Cout, nullptr, (hipStream_t)stream);
+    else
+        hipLaunchKernelGGL(conv1_fwd_kernel, dim3(ew_blocks(total)), dim3(256), 27 * Cout * sizeof(float), (hipStream_t)stream,
+                           x, w, y, N, H, W, Cout, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
@@ -2759,10 +2869,17 @@ int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y, int N, int 
 /* conv_block of the backbone in training mode (model.py:42-52): the conv and the batch statistics of its output (what myolo_bn_stats
  * gives) in two launches -- the conv leaves per-workgroup partial sums, the finish turns them into mean / var / scale / shift / moving
  * averages.  ws: myolo_conv3x3s2_c3_bnstats_ws_bytes. */
+// rows of statistics partials the fused conv1 forward may write: one per workgroup (1024 for the grid-stride kernel)
+static size_t conv1_stat_rows(int N, int H, int W, int Cout)
+{
+    const size_t rows = conv1_fwd_rows_ok(H, W, Cout) ? (size_t)N * conv1_fwd_rows_chunks(H) : 0;
+    return rows > 1024 ? rows : 1024;
+}
+
 size_t myolo_conv3x3s2_c3_bnstats_ws_bytes(int N, int H, int W, int Cout)
 {
     const long long M = (long long)N * (H / 2) * (W / 2);
-    const size_t fused = align256((size_t)1024 * 2 * Cout * sizeof(double)) + 2 * Cout * sizeof(double);
+    const size_t fused = align256(conv1_stat_rows(N, H, W, Cout) * 2 * Cout * sizeof(double)) + 2 * Cout * sizeof(double);
     const size_t plain = align256(col_ws_bytes(M, Cout, 2)) + 2 * Cout * sizeof(double);
     return fused > plain ? fused : plain;
 }
@@ -2782,8 +2899,11 @@ int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, con
         int blocks = ew_blocks(total);
         if (blocks > 1024) blocks = 1024;
         double* part = (double*)ws;
-        double* tot = (double*)((char*)ws + align256((size_t)1024 * 2 * Cout * sizeof(double)));
-        if (phases & 1) hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, part);
+        double* tot = (double*)((char*)ws + align256(conv1_stat_rows(N, H, W, Cout) * 2 * Cout * sizeof(double)));
+        const bool rows = conv1_fwd_rows_ok(H, W, Cout) && (long long)N * conv1_fwd_rows_chunks(H) < (1ll << 31);
+        if (rows) blocks = N * conv1_fwd_rows_chunks(H);
+        if ((phases & 1) && rows) conv1_fwd_rows_launch(x, w, y, N, H, W, Cout, part, s);
+        else if (phases & 1) hipLaunchKernelGGL(conv1_fwd_kernel, dim3(blocks), dim3(256), 27 * Cout * sizeof(float), s, x, w, y, N, H, W, Cout, part);
         if (phases & 2)
             hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((Cout + 3) / 4), dim3(256), 0, s, part, tot, blocks, 2 * Cout, Cout,
                                FinBnStats{gamma, beta, mean, var, scale, shift, moving_mean, moving_var, (double)M, g_myolo_opt.bn_fused_tf_variance});

@@ -270,6 +270,7 @@ class Net(object):
         self._bn_fused_bytes = {}
         self.weight_prep = 1              # training step: weight-only re-layouts (transposes, bf16x6 splits, Winograd filter transforms) re-run on a side stream at the step's start instead of inside the chain (X.WeightPrep); 0 = in place (round 3)
         self._wprep = None
+        self.wprep_wait_late = 1          # 0: wait for the trunk's prepared weights right behind conv1 (A/B)
         self._wprep_ntrunk = None         # registry entries recorded before the mask head (their consumers are the trunk's first layers)
         self._wprep_ev = None
         self.seen = 0                     # evaluations of the YOLO loss so far (the reference's `seen`, see _yolo_warm)
@@ -702,12 +703,19 @@ class Net(object):
             a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)
         shape = (N, H // 2, W // 2, C0)
         self.tape["images"] = images
-        if train:
-            self._wprep_wait(0)           # the trunk's prepared weights (a few small kernels on the side stream, under conv1)
+        # the trunk's prepared weights (a few small kernels on the side stream, ~0.1 ms from the start of the step): their first consumers are the
+        # pointwise layers with >= 256 input channels (bf16x6 splits) and feature_map's filter transform; the thin first layers read w as it is, so
+        # the wait sits in front of the first block with >= 128 channels and not behind conv1, where it stalled the stream for ~50 us
+        waited = not train
         bid = 1
         for f, s in BACKBONE_BLOCKS:
+            if not waited and (shape[3] >= 128 or not self.wprep_wait_late):
+                self._wprep_wait(0)
+                waited = True
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
+        if not waited:
+            self._wprep_wait(0)
         a = self._materialize(a)          # C4 feeds feature_map's 3x3 conv and the YOLO head: written once (28x28x512)
         if train:
             self._wprep_phase2()

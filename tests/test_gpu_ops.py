@@ -459,7 +459,7 @@ def test_dw_s2_impulse_pins_pad_side():
     assert np.array_equal(got[0, 1, 1], w[1, 1]) and got[0, 0, 0].sum() == 0
 
 
-@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (4, 128, 128, 32), (2, 224, 224, 32), (3, 36, 20, 64), (1, 2, 2, 4)])
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (4, 128, 128, 32), (2, 224, 224, 32), (3, 36, 20, 64), (1, 2, 2, 4), (2, 14, 16, 8), (1, 6, 400, 256)])
 def test_conv1(N, H, W, Co):
     rng = np.random.default_rng(5)
     x, w = rng.random((N, H, W, 3), dtype=np.float32), rnd(rng, 3, 3, 3, Co)
@@ -1266,7 +1266,7 @@ def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy,
 
 
 @pytest.mark.parametrize("nofuse", [0, 1])
-@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (8, 64, 64, 32)])
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (8, 64, 64, 32), (2, 14, 16, 8), (5, 224, 224, 32), (2, 30, 18, 32)])
 def test_conv1_bnstats_fwd(N, H, W, Co, nofuse):
     rng = np.random.default_rng(23)
     x, w = rng.random((N, H, W, 3), dtype=np.float32), rnd(rng, 3, 3, 3, Co, scale=0.3)

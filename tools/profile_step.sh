@@ -30,11 +30,11 @@ python - "$OUT/bench/bench_kernel_trace.csv" > "$OUT/${TAG}_timeline.txt" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows]
-starts = [i for i, e in enumerate(ev) if e[2].startswith("conv1_fwd_kernel")]
+starts = [i for i, e in enumerate(ev) if e[2].startswith("conv1_fwd_")]
 if len(starts) >= 3:
     a, b = starts[-2], starts[-1]                       # the last complete step
     step = ev[a:b]
-    marks = [("trunk forward (conv1 .. yolo_loss)", "conv1_fwd_kernel", "yolo_loss_kernel"),
+    marks = [("trunk forward (conv1 .. yolo_loss)", "conv1_fwd_", "yolo_loss_kernel"),
              ("mask head forward (.. bce)", "yolo_loss_kernel", "bce_"),
              ("mask head backward (.. ROIAlign bwd)", "bce_", "crop_bwd"),
              ("backbone backward + Adam (.. end of step)", "crop_bwd", None)]
@@ -71,7 +71,7 @@ python - "$OUT/bench/bench_kernel_trace.csv" > "$OUT/${TAG}_step_sequence.txt" <
 # kernel on the timeline (negative = overlapped with it: another stream), stream / queue id, grid, name
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("conv1_fwd_kernel")]
+starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("conv1_fwd_")]
 if len(starts) >= 3:
     a, b = starts[-2], starts[-1]
     t0 = int(rows[a]["Start_Timestamp"])
