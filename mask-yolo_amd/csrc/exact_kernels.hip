@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(const float* __restri
     __shared__ short dest[MT_MAXR];
     __shared__ short src_of_dest[MT_MAXR];
     __shared__ int npos_s;
+    __shared__ int wcnt[2][4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const float* prop = proposals + (long long)b * R * 4;
 
@@ -114,24 +115,42 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(const float* __restri
         arg[r] = (short)bi;
     }
     __syncthreads();
-    if (tid == 0) {   // stable partition: positives first, then negatives, index order kept
-        int np = 0, nn = 0;
-        for (int r = 0; r < R; ++r) np += posf[r] == 1;
-        int ip = 0;
-        for (int r = 0; r < R; ++r) {
-            if (posf[r] == 1) dest[r] = (short)(ip++);
-            else if (posf[r] == 0) dest[r] = (short)(np + nn++);
-            else dest[r] = -1;
+    // stable partition: positives first, then negatives, index order kept -- ranks by ballots over chunks of 256 proposals (a single thread walking
+    // the R proposals four times through LDS took ~15 us of the step's critical path)
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        int base_p = 0, base_n = 0;
+        for (int r0 = 0; r0 < R; r0 += 256) {
+            const int r = r0 + tid;
+            const int f = r < R ? posf[r] : 2;
+            const unsigned long long bp = __ballot(f == 1), bn = __ballot(f == 0);
+            if (lane == 0) { wcnt[0][wave] = __popcll(bp); wcnt[1][wave] = __popcll(bn); }
+            __syncthreads();
+            int offp = base_p, offn = base_n;
+            for (int w2 = 0; w2 < wave; ++w2) { offp += wcnt[0][w2]; offn += wcnt[1][w2]; }
+            if (f == 1) dest[r] = (short)(offp + __popcll(bp & lower));
+            else if (f == 0) dest[r] = (short)(-2 - (offn + __popcll(bn & lower)));         // negatives: rank among negatives, shifted below
+            else if (r < R) dest[r] = -1;
+            base_p += wcnt[0][0] + wcnt[0][1] + wcnt[0][2] + wcnt[0][3];
+            base_n += wcnt[1][0] + wcnt[1][1] + wcnt[1][2] + wcnt[1][3];
+            __syncthreads();
         }
-        npos_s = np;
-        npos_out[b] = np;
-        for (int d = 0; d < R; ++d) src_of_dest[d] = -1;
-        for (int r = 0; r < R; ++r)
-            if (dest[r] >= 0) src_of_dest[dest[r]] = (short)r;
+        if (tid == 0) { npos_s = base_p; if (blockIdx.y == 0) npos_out[b] = base_p; }
+        for (int d = tid; d < R; d += blockDim.x) src_of_dest[d] = -1;
+        __syncthreads();
+        for (int r = tid; r < R; r += blockDim.x) {
+            int d = dest[r];
+            if (d <= -2) { d = base_p + (-2 - d); dest[r] = (short)d; }
+            if (d >= 0) src_of_dest[d] = (short)r;
+        }
     }
     __syncthreads();
     const int npos = npos_s;
     // rois + class ids
+    // (every workgroup of an image repeats the matching above -- a few microseconds -- and fills its share of the image's target masks, 115 000
+    // values at 28 x 28 and R = 147; the first one also writes the ROIs and class ids)
+    if (blockIdx.y == 0)
     for (int d = tid; d < R; d += blockDim.x) {
         const int r = src_of_dest[d];
         float* o = rois + ((long long)b * R + d) * 4;
@@ -147,7 +166,9 @@ __global__ __launch_bounds__(256) void mask_targets_kernel(const float* __restri
     // mask targets: crop_and_resize(gt_mask[g], [y1,x1,y2,x2], mh x mw) then tf.round (model.py:558-589)
     const int msz = mh * mw;
     float* tm = tmasks + (long long)b * R * msz;
-    for (int i = tid; i < R * msz; i += blockDim.x) {
+    const int per = (R * msz + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int i_lo = (int)blockIdx.y * per, i_hi = i_lo + per < R * msz ? i_lo + per : R * msz;
+    for (int i = i_lo + tid; i < i_hi; i += blockDim.x) {
         const int d = i / msz;
         float v = 0.0f;
         if (d < npos) {
@@ -603,7 +624,7 @@ int myolo_mask_targets(const float* proposals, const int32_t* gt_class_ids, cons
                   "mask_targets: null pointer");
     MYOLO_REQUIRE(B > 0 && R > 0 && R <= MT_MAXR && T > 0 && T <= MT_MAXT && mh > 1 && mw > 1,
                   "mask_targets: need R<=%d, T<=%d, mask shape > 1", MT_MAXR, MT_MAXT);
-    hipLaunchKernelGGL(mask_targets_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, proposals, gt_class_ids, gt_boxes_px,
+    hipLaunchKernelGGL(mask_targets_kernel, dim3(B, B >= 128 ? 2 : 8), dim3(256), 0, (hipStream_t)stream, proposals, gt_class_ids, gt_boxes_px,
                        gt_masks, rois, target_class_ids, target_masks, n_pos, R, T, H, W, mh, mw);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
