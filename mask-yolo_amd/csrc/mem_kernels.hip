@@ -2269,14 +2269,22 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* __restrict__ tm, 
     if (threadIdx.x == 0) part[blockIdx.x] = red[0];
 }
 
-__global__ void bce_finish_kernel(const double* __restrict__ part, int nblk, const int* __restrict__ npos_p, int hw,
-                                  float* __restrict__ out)
+__global__ __launch_bounds__(256) void bce_finish_kernel(const double* __restrict__ part, int nblk, const int* __restrict__ npos_p, int hw,
+                                                         float* __restrict__ out)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // (one thread adding the 1024 partials one dependent load after the other held the step's main stream for 50 us)
+    __shared__ double red[256];
     double s = 0;
-    for (int b = 0; b < nblk; ++b) s += part[b];
+    for (int b = threadIdx.x; b < nblk; b += 256) s += part[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     const int npos = *npos_p;
-    out[0] = npos > 0 ? (float)(s / ((double)npos * hw)) : 0.f;
+    out[0] = npos > 0 ? (float)(red[0] / ((double)npos * hw)) : 0.f;
     out[1] = (float)npos;
 }
 
@@ -3406,7 +3414,7 @@ int myolo_mask_bce(const float* target_masks, const int32_t* target_class_ids, c
     hipLaunchKernelGGL(bce_count_kernel, dim3(1), dim3(256), 0, s, target_class_ids, NR, npos);
     hipLaunchKernelGGL(bce_kernel, dim3(nblk), dim3(256), 0, s, target_masks, target_class_ids, pred, npos, loss_weight, part, dz,
                        NR, h * w, C);
-    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, s, part, nblk, npos, h * w, loss_out);
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(256), 0, s, part, nblk, npos, h * w, loss_out);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }
