@@ -500,17 +500,30 @@ class MaskYOLO(object):
         B = int(cfg.BATCH_SIZE)
         dev = self.net.dev
 
+        # the bytes go up as they are (a quarter of the float32 image) from a ring of pinned buffers, and (image / 255.).astype(float32) is formed on the
+        # device: a float64 division rounded to float32, which is what numpy does on the host -- bit-identical to detect()'s input (the host
+        # normalisation + pageable upload of 8 MB per batch of four 416 x 416 images cost 2.3 ms per batch, more than half the forward)
+        key = (B, tuple(cfg.IMAGE_SHAPE), 2 * in_flight + 2)
+        if getattr(self, "_stage_ring_key", None) != key:            # (pinning costs ~5 ms per buffer: once per model, not once per call)
+            self._stage_ring = [torch.empty((B,) + tuple(cfg.IMAGE_SHAPE), dtype=torch.uint8).pin_memory() for _ in range(key[2])]
+            self._stage_ring_key = key
+        ring = self._stage_ring
+
         def batches():
-            for lo in range(0, len(images), B):
+            for bi, lo in enumerate(range(0, len(images), B)):
                 grp = images[lo:lo + B]
                 grp = grp + [grp[-1]] * (B - len(grp))                       # a short last batch is padded (the captured graph has one shape)
-                yield torch.as_tensor(np.ascontiguousarray(mutils._U8_OVER_255[np.stack(grp)]), device=dev)      # == (image / 255.).astype(float32)
+                stage = ring[bi % len(ring)]             # (predict_stream runs at most 2 * in_flight batches ahead of the results handed out)
+                np.stack(grp, out=stage.numpy())
+                yield (stage.to(dev, non_blocking=True).to(torch.float64) / 255.).to(torch.float32)
         out = []
         for bi, (_, det_d, mask_d) in enumerate(self.net.predict_stream(batches(), in_flight=in_flight)):
             det_all = det_d.cpu().numpy()
             for k in range(min(B, len(images) - bi * B)):
                 out.append(self._select_and_unmold(det_d[k], mask_d[k], images[bi * B + k].shape, cs_threshold, det_host=det_all[k]))
         return out
+        # (one unmold launch and one download per BATCH instead of per image was measured: 514 img/s against 865 -- a pageable 6.9 MB download runs at
+        # 2 GB/s where four of 1.7 MB do not, and cutting the H x W x 40 block into per-image H x W x n arrays costs the host another 0.5 ms per image)
 
     def _select_and_unmold(self, det_img, mask_img, image_shape, cs_threshold, feature=None, det_host=None):
         """detect()'s post-processing of ONE image: det_img [R,6], mask_img [R,mh,mw,C] (None: the mask head runs here, on the survivors) device tensors."""
@@ -529,7 +542,13 @@ class MaskYOLO(object):
         nmb = mutils.NMB(boxes[kept], class_ids[kept], kept, cfg.IMAGE_SHAPE, nms_threshold=0.7) if len(kept) else kept
         nmb = np.asarray(nmb, dtype=np.int64)
         if len(nmb):
-            sel = torch.as_tensor(keep[nmb], device=det_d.device)
+            # (the few indices go up from a pinned buffer without blocking; the download of the pasted masks below ends every image with a
+            # synchronisation, so the buffer is free again by the next one)
+            pin = getattr(self, "_sel_pin", None)
+            if pin is None or pin.numel() < len(nmb):
+                pin = self._sel_pin = torch.empty(max(64, len(nmb)), dtype=torch.int64).pin_memory()
+            pin[:len(nmb)].copy_(torch.from_numpy(np.ascontiguousarray(keep[nmb], dtype=np.int64)))
+            sel = pin[:len(nmb)].to(det_d.device, non_blocking=True)
             det_s = det_d[0].index_select(0, sel).contiguous()
             if selected_only:
                 mask_s = self.net.predict_masks(feature, det_s[:, :4].unsqueeze(0))[0]
@@ -567,7 +586,8 @@ class MaskYOLO(object):
         ws = torch.empty(N, dtype=torch.int32, device=det.device)
         X.call("myolo_unmold_masks", X.ptr(masks.contiguous()), X.ptr(det.contiguous()), X.ptr(full), N, mh, mw, C, H, W,
                ws.data_ptr(), ws.numel() * 4, X.stream())
-        return boxes, class_ids, scores, full.cpu().numpy().astype(bool)
+        # (a pinned staging buffer for this download was measured slower: the host's astype() then reads uncached memory)
+        return boxes, class_ids, scores, full.view(torch.bool).cpu().numpy()        # (the kernel writes 0 / 1 bytes: the bool view saves the host's astype pass)
 
     def decode_masks(self, detections, myolo_mask, image_shape):
         """model.py:1330-1391 (numpy in / numpy out; the unmolding runs on the GPU)."""
