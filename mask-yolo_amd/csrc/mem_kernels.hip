@@ -284,11 +284,13 @@ struct FinD2F {                      // out[i] = (float)tot[i]
     __device__ void operator()(int i, double t) const { out[i] = (float)t; }
 };
 
-template <class FIN>
-__global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc, int C,
+// BL = block lanes (rows of partials walked side by side): 32 (256 threads) everywhere except the mask head's bn1, whose 4704 per-ROI rows made
+// every lane walk 147 rows in 18 dependent trips (34 us on the step's main stream): 128 lanes (1024 threads) there.
+template <class FIN, int BL = 32>
+__global__ __launch_bounds__(8 * BL) void colreduce_finish(const double* __restrict__ part, double* __restrict__ tot, int nblk, int nvc, int C,
                                                         FIN fin)
 {
-    __shared__ double red[32][9];
+    __shared__ double red[BL][9];
     __shared__ double fin_tot[8];
     const int ol = threadIdx.x & 7, bl = threadIdx.x >> 3;
     // PAIR (NV == 2): a workgroup owns 4 channels x both sums, so FIN sees (sum0, sum1) of a channel together
@@ -299,13 +301,13 @@ __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict
         // 8 independent loads in flight per thread: the loop is pure load latency (a few hundred partial rows per thread-lane)
         double s2 = 0, s3 = 0, s4 = 0, s5 = 0, s6 = 0, s7 = 0;
         int b = bl;
-        for (; b + 224 < nblk; b += 256) {
+        for (; b + 7 * BL < nblk; b += 8 * BL) {
             const double* q = part + (long long)b * nvc + i;
-            const long long st = 32ll * nvc;
+            const long long st = (long long)BL * nvc;
             const double v0 = q[0], v1 = q[st], v2 = q[2 * st], v3 = q[3 * st], v4 = q[4 * st], v5 = q[5 * st], v6 = q[6 * st], v7 = q[7 * st];
             s0 += v0; s1 += v1; s2 += v2; s3 += v3; s4 += v4; s5 += v5; s6 += v6; s7 += v7;
         }
-        for (; b < nblk; b += 32) s0 += part[(long long)b * nvc + i];
+        for (; b < nblk; b += BL) s0 += part[(long long)b * nvc + i];
         s0 = ((s0 + s1) + (s2 + s3)) + ((s4 + s5) + (s6 + s7));
         s1 = 0;
     }
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(256) void colreduce_finish(const double* __restrict
     if (bl == 0) {
         double t = 0;
 #pragma unroll
-        for (int k = 0; k < 32; ++k) t += red[k][ol];
+        for (int k = 0; k < BL; ++k) t += red[k][ol];
         if (ok) tot[i] = t;
         if constexpr (FIN::PAIR != 0) fin_tot[ol] = t;
         else if (ok) fin(i, t);
@@ -2449,8 +2451,9 @@ static int mask_out_bwd_impl(const float* x, const float* w, const float* dz, fl
 void myolo_bn_stats_from_partials(const double* part, double* tot, int nblk, int C, double M, const float* gamma, const float* beta,
                                   float* mean, float* var, float* scale, float* shift, float* mmean, float* mvar, hipStream_t s)
 {
-    hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C,
-                       FinBnStats{gamma, beta, mean, var, scale, shift, mmean, mvar, M, g_myolo_opt.bn_fused_tf_variance});
+    const FinBnStats fin{gamma, beta, mean, var, scale, shift, mmean, mvar, M, g_myolo_opt.bn_fused_tf_variance};
+    if (nblk >= 2048) hipLaunchKernelGGL((colreduce_finish<FinBnStats, 128>), dim3((C + 3) / 4), dim3(1024), 0, s, part, tot, nblk, 2 * C, C, fin);
+    else hipLaunchKernelGGL((colreduce_finish<FinBnStats>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C, fin);
 }
 
 // statistics pass over x [M][C] + finish, for other translation units (gemm_kernels.hip: the split-K pointwise layers)
