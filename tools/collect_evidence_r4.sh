@@ -17,6 +17,8 @@ cp gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_stats.csv gpurun_out/p
   echo "--- depthwise data / weight gradients (cold inputs); then with the round-3 kernels (dw_bwd_legacy=1)"
   python tools/kbench.py dw_bwd --iters 20 2>&1 | grep -v amdgpu
   KBENCH_OPTIONS=dw_bwd_legacy=1 python tools/kbench.py dw_bwd --iters 20 2>&1 | grep -v amdgpu | grep total
+  echo "--- BatchNorm + ReLU6 backward of the trunk layers (three launches: sums, finish, dx; cold inputs)"
+  python tools/kbench.py bn_bwd --iters 20 2>&1 | grep -v amdgpu
   echo "--- pointwise layers (fp32 MFMA kernels; then wino_x6=1 = the product's FP32_MATMUL=bf16x6)"
   python tools/kbench.py pw_fused --iters 20 2>&1 | grep -v amdgpu
   KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py pw_fused --iters 20 2>&1 | grep -v amdgpu
