@@ -729,6 +729,13 @@ static size_t wino_tn_ws_bytes(const TileGeom& g, int Cin, int Cout)
         const size_t b = myolo_gemm_tn_batched_ws_bytes(runs[k].rows, Cin, Cout, runs[k].nq);
         if (b > m) m = b;
     }
+    if (myolo_gemm_tn_x6_ok(Cin, Cout)) {
+        long long rows[4];
+        int nq[4];
+        for (int k = 0; k < n; ++k) { rows[k] = runs[k].rows; nq[k] = runs[k].nq; }
+        const size_t b = myolo_gemm_tn_x6_ws_bytes(n, rows, nq, Cin, Cout);
+        if (b > m) m = b;
+    }
     return m;
 }
 // dU[q] = V[q]^T Q[q]
@@ -737,6 +744,19 @@ static int wino_tn_all(const float* V, const float* Q, float* dU, const TileGeom
 {
     GroupRun runs[4];
     const int n = group_runs(g, runs);
+    if (myolo_gemm_tn_x6_ok(Cin, Cout) && !(g_myolo_opt.tune0 & 32768)) {
+        // FP32_MATMUL = "bf16x6": all 36 planes in one launch of wino_tn_x6_kernel, as the F(6,3) chain does (feature_map's weight gradient, 512 -> 256
+        // channels on 28 x 28: 166-185 us in the step on the fp32 matrix pipe, one gemm_tn_fast launch per run of planes)
+        long long rows[4], ao[4], bo[4];
+        int nq[4];
+        bool all = true;
+        for (int k = 0; k < n; ++k) {
+            rows[k] = runs[k].rows; nq[k] = runs[k].nq; ao[k] = runs[k].row0 * Cin; bo[k] = runs[k].row0 * Cout;
+            if (runs[k].rows <= 0) all = false;                // (an empty run would shift the plane numbering of myolo_gemm_tn_x6_runs)
+        }
+        if (all && part && myolo_gemm_tn_x6_ws_bytes(n, rows, nq, Cin, Cout) <= part_bytes)
+            return myolo_gemm_tn_x6_runs(V, Q, dU, n, rows, ao, bo, nq, Cin, Cout, part, part_bytes, s);
+    }
     for (int k = 0; k < n; ++k) {
         const int rc = myolo_gemm_tn_batched(V + runs[k].row0 * Cin, Q + runs[k].row0 * Cout, dU + (long long)runs[k].q0 * Cin * Cout,
                                              runs[k].rows, Cin, Cout, runs[k].nq, part, part_bytes, s);
