@@ -1716,7 +1716,7 @@ size_t myolo_pwconv1x1_bnstats_ws_bytes(int64_t M, int Cin, int Cout)
 {
     const size_t tiles = (size_t)cdiv64(M, BM);
     const size_t fused = align256(tiles * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double)) +
-                         ((Cin >= 256 && (Cout % 256) == 0) ? myolo_pw_x6_split_bytes(Cin, Cout) : 0);
+                         ((Cin >= 128 && (Cout % 256) == 0) ? myolo_pw_x6_split_bytes(Cin, Cout) : 0);
     // split-K path / ablation: the partial outputs, then a statistics pass over y (<= 1024 slabs of 2*Cout doubles)
     const size_t split = pw_split_bytes(M, Cout) + align256((size_t)1024 * 2 * Cout * sizeof(double)) + align256(2 * Cout * sizeof(double));
     return fused > split ? fused : split;

@@ -1217,7 +1217,9 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
 /* pointwise conv of the trunk on the bf16 matrix pipe with six exact piece products (FP32_MATMUL = "bf16x6", layers with Cout % 256 == 0):
  * y [M][N] = act_in(x * in_scale + in_shift) [M][K] * w [K][N], optional per-row-tile partial sums of y's columns (stat).
  * ws: the split filters (K*N*6 bytes).  Two launches (split, GEMM). */
-bool myolo_pw_x6_ok(int K, int N) { return g_myolo_opt.wino_x6 && !g_myolo_opt.pw_no_x6 && K >= 256 && (K % MM_BK) == 0 && (N % MM_BN) == 0; }
+// (tune0 & 65536: from 128 input channels -- conv_pw_4, 25 088 x 128 -> 256, is 34.4 -> 28.2 us stand-alone that way and the step 0.05 ms SLOWER, four runs each:
+//  one more weight split on the side stream and one more bf16-MFMA kernel in the trunk; not the default)
+bool myolo_pw_x6_ok(int K, int N) { return g_myolo_opt.wino_x6 && !g_myolo_opt.pw_no_x6 && K >= ((g_myolo_opt.tune0 & 65536) ? 128 : 256) && (K % MM_BK) == 0 && (N % MM_BN) == 0; }
 size_t myolo_pw_x6_split_bytes(int K, int N) { return align256((size_t)K * N * 6); }
 int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y, double* stat,
                     long long M, int K, int N, void* split, hipStream_t s)

@@ -1233,7 +1233,7 @@ def test_dwconv3x3_bnstats_fwd_and_affine_in_weight_gradient(N, H, W, C, stride,
                                              (1568, 1024, 1024, False), (130, 16, 16, True), (20003, 32, 64, True), (257, 256, 512, True), (100352, 64, 128, True),
                                              (25088, 256, 256, True), (3000, 256, 512, False),
                                              # round 4: the register-fed thin-layer forward (32 / 64 -> 64 / 128 channels from 8192 rows): the fourth instantiation, no prologue, a 1-row tail
-                                             (9001, 32, 128, False), (8192, 64, 64, False)])
+                                             (9001, 32, 128, False), (8192, 64, 64, False), (4100, 128, 256, True)])
 def test_pwconv1x1_bnstats_fwd_and_affine_in_weight_gradient(M, Cin, Cout, lazy, nofuse, x6, request):
     """pointwise conv whose A operand is relu6(x * in_scale + in_shift) formed on load, with the batch statistics of its output from
     the GEMM epilogue (one pass) or, for the split-K shapes (M = 1568), from a statistics pass; and its weight gradient
