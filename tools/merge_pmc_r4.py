@@ -29,6 +29,10 @@ notes = {
     "r4_pmc_crop_fwd": "ROIAlign forward, stand-alone crop_fwd_kernel (the step fuses it into conv1's Winograd input transform); algorithmic 0.970 GB",
     "r4_pmc_crop_bwd": "ROIAlign backward, 2 x 2 pixel quads in XCD-contiguous order (round 4); algorithmic 0.944 GB read + 0.026 GB written",
     "r4_pmc_crop_bwd_round3_order": "option tune0=1: round 3's workgroup = four consecutive pixels, plain order",
+    "r4_pmc_dw_bwd_data_s2": "depthwise data gradient, stride 2: dw_bwd_data_s2_kernel (late round 4: a dy pixel's thread writes its 2 x 2 block of dx); algorithmic = dy + dx of dw2 / dw4 / dw7 / dw13",
+    "r4_pmc_pw_thin_fwd": "conv_pw_1 / conv_pw_2 forward on pw_fwd_thin_kernel (late round 4: register-fed fp32 MFMA, BatchNorm of the input in registers, statistics epilogue); algorithmic = x + y: 154 / 51 MB",
+    "r4_pmc_bn_bwd_sums": "BatchNorm + ReLU6 backward, pass 1 (colreduce_kernel<OpBnBwd>: reads dy and x) at the trunk shapes of tools/kbench.py bn_bwd; algorithmic = 2 x M x C x 4 bytes",
+    "r4_pmc_bn_bwd_dx": "BatchNorm + ReLU6 backward, pass 2 (bn_bwd_dx_kernel: reads dy and x, writes dx); algorithmic = 3 x M x C x 4 bytes",
 }
 for f in sorted(glob.glob(os.path.join(src, "*.json"))):
     key = os.path.basename(f)[:-5]
