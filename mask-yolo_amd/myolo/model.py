@@ -473,9 +473,12 @@ class MaskYOLO(object):
         assert self.mode == 'inference'
         if weights_dir is not None:
             self.load_weights(weights_dir)
-        # (image / 255.).astype(float32) formed on the device from the uploaded bytes: a float64 division rounded to float32, as numpy does it on the
-        # host -- bit-identical, a quarter of the bytes over PCIe and no 4 MB float64 temporary on the host (see detect_many)
-        x = (torch.from_numpy(np.ascontiguousarray(image)).to(self.net.dev).to(torch.float64) / 255.).to(torch.float32).unsqueeze(0)
+        # (image / 255.).astype(float32) formed on the device from the uploaded bytes (myolo_u8_to_unit_f32: the float32 of the float64 quotient, as numpy
+        # forms it on the host) -- bit-identical, a quarter of the bytes over PCIe and no 4 MB float64 temporary on the host (see detect_many)
+        from . import _ext as X
+        raw = torch.from_numpy(np.ascontiguousarray(image)).to(self.net.dev)
+        x = torch.empty((1,) + tuple(raw.shape), dtype=torch.float32, device=self.net.dev)
+        X.call("myolo_u8_to_unit_f32", X.ptr(raw), X.ptr(x), raw.numel(), X.stream())
         selected_only = bool(getattr(cfg, "DETECT_MASKS_FOR_SELECTED_ONLY", False))
         if selected_only:
             yolo_output, det_d, feature = self.net.predict_detections(x)   # the mask head runs below, on the survivors only
@@ -501,8 +504,9 @@ class MaskYOLO(object):
         B = int(cfg.BATCH_SIZE)
         dev = self.net.dev
 
+        from . import _ext as X
         # the bytes go up as they are (a quarter of the float32 image) from a ring of pinned buffers, and (image / 255.).astype(float32) is formed on the
-        # device: a float64 division rounded to float32, which is what numpy does on the host -- bit-identical to detect()'s input (the host
+        # device (myolo_u8_to_unit_f32: the float32 of the float64 quotient, which is what numpy does on the host) -- bit-identical to detect()'s input (the host
         # normalisation + pageable upload of 8 MB per batch of four 416 x 416 images cost 2.3 ms per batch, more than half the forward)
         key = (B, tuple(cfg.IMAGE_SHAPE), 2 * in_flight + 2)
         if getattr(self, "_stage_ring_key", None) != key:            # (pinning costs ~5 ms per buffer: once per model, not once per call)
@@ -516,7 +520,10 @@ class MaskYOLO(object):
                 grp = grp + [grp[-1]] * (B - len(grp))                       # a short last batch is padded (the captured graph has one shape)
                 stage = ring[bi % len(ring)]             # (predict_stream runs at most 2 * in_flight batches ahead of the results handed out)
                 np.stack(grp, out=stage.numpy())
-                yield (stage.to(dev, non_blocking=True).to(torch.float64) / 255.).to(torch.float32)
+                raw = stage.to(dev, non_blocking=True)
+                x = torch.empty(raw.shape, dtype=torch.float32, device=dev)
+                X.call("myolo_u8_to_unit_f32", X.ptr(raw), X.ptr(x), raw.numel(), X.stream())       # one launch (three float64 torch kernels took 0.37 ms per batch)
+                yield x
         out = []
         for bi, (_, det_d, mask_d) in enumerate(self.net.predict_stream(batches(), in_flight=in_flight)):
             det_all = det_d.cpu().numpy()
