@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // filter values of its four channels in registers (its channel quad never changes: 256 % (Co / 4) == 0) and walks the 2 Wo pixels of the pair.
 // Same order of the 27 products per output as conv1_fwd_kernel (the padded taps add 0 * w): bit-identical y.
 #define C1F_STEPS 2
-#define C1F_SMAX 6
+#define C1F_SMAX 8
 __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                              int H, int W, int Co, int cq_shift, int chunks, double* __restrict__ stat)
 {

@@ -459,7 +459,7 @@ def test_dw_s2_impulse_pins_pad_side():
     assert np.array_equal(got[0, 1, 1], w[1, 1]) and got[0, 0, 0].sum() == 0
 
 
-@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (4, 128, 128, 32), (2, 224, 224, 32), (3, 36, 20, 64), (1, 2, 2, 4), (2, 14, 16, 8), (1, 6, 400, 256)])
+@pytest.mark.parametrize("N,H,W,Co", [(2, 32, 32, 16), (3, 16, 24, 32), (4, 128, 128, 32), (2, 224, 224, 32), (3, 36, 20, 64), (1, 2, 2, 4), (2, 14, 16, 8), (1, 6, 400, 256), (1, 8, 544, 16), (1, 4, 548, 8)])
 def test_conv1(N, H, W, Co):
     rng = np.random.default_rng(5)
     x, w = rng.random((N, H, W, 3), dtype=np.float32), rnd(rng, 3, 3, 3, Co)
