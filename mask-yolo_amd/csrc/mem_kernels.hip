@@ -2098,6 +2098,141 @@ __global__ __launch_bounds__(64 * TP * TP) void crop_bwd_grouped_lds_kernel(cons
     st4g(dimg + (pix * cq + (threadIdx.x & 63)) * 4, acc);
 }
 
+// The same gather with a 2 x 2 pixel quad per WAVE (a workgroup = a 4 x 4 pixel tile): a crop sample touches up to 2 x 2 feature pixels, and with one
+// pixel per wave its four readers were four waves (or workgroups) whose progress through the boxes drifts apart -- 1.72x the algorithmic bytes fetched
+// into L2 (profiles/r4_pmc_trunk.json).  Here a sample that touches the quad is loaded ONCE and added to each of its pixels in turn.  Per pixel the samples
+// still arrive in ascending (box, py, px) order with the same weights (wy * wx, one rounding, as above), and a pixel the sample does not touch is skipped,
+// so the sums are bit-identical to crop_bwd_grouped_lds_kernel's.
+__global__ __launch_bounds__(256) void crop_bwd_quadwave_kernel(const float* __restrict__ dout, const float* __restrict__ boxes,
+                                                                float* __restrict__ dimg, int H, int W, int R, int ch, int cw, unsigned xcd_tiles)
+{
+    extern __shared__ __attribute__((aligned(16))) float sp[];      // [R][8]: y1 x1 y2 x2 | y0 1/sy x0 1/sx  (1/s = 0: degenerate)
+    constexpr int C = 256, cq = 64;
+    unsigned bid = blockIdx.x;
+    if (xcd_tiles) bid = (bid & 7u) * xcd_tiles + (bid >> 3);
+    const unsigned tw = (unsigned)W / 4, tpi = ((unsigned)H / 4) * tw;
+    const int b = (int)(bid / tpi);
+    const unsigned tr = bid - (unsigned)b * tpi;
+    const unsigned ty4 = tr / tw, tx4 = tr - ty4 * tw;
+    const int wv = threadIdx.x >> 6;
+    const int y0 = 4 * (int)ty4 + 2 * (wv >> 1), x0 = 4 * (int)tx4 + 2 * (wv & 1);       // the wave's quad: rows y0, y0 + 1, columns x0, x0 + 1
+    const int c = (threadIdx.x & 63) * 4;
+    for (int r = threadIdx.x; r < R; r += 256) {
+        const float4 bx = ld4g(boxes + ((long long)b * R + r) * 4);
+        const float sy = (ch > 1) ? (bx.z - bx.x) * (float)(H - 1) / (float)(ch - 1) : 0.f;
+        const float sx = (cw > 1) ? (bx.w - bx.y) * (float)(W - 1) / (float)(cw - 1) : 0.f;
+        const float yo = (ch > 1) ? bx.x * (float)(H - 1) : 0.5f * (bx.x + bx.z) * (float)(H - 1);
+        const float xo = (cw > 1) ? bx.y * (float)(W - 1) : 0.5f * (bx.y + bx.w) * (float)(W - 1);
+        *reinterpret_cast<float4*>(&sp[r * 8]) = bx;
+        *reinterpret_cast<float4*>(&sp[r * 8 + 4]) =
+            make_float4(yo, fabsf(sy) > 1e-6f ? 1.f / sy : 0.f, xo, fabsf(sx) > 1e-6f ? 1.f / sx : 0.f);
+    }
+    __syncthreads();
+    float4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f4zero();
+    const float fya = (float)y0 - 1.f, fyb = (float)y0 + 2.f, fxa = (float)x0 - 1.f, fxb = (float)x0 + 2.f;     // what can touch rows y0 .. y0 + 1
+    const int lane = threadIdx.x & 63;
+    for (int r0 = 0; r0 < R; r0 += 64) {
+        const int rt = r0 + lane;
+        bool hit = false;
+        if (rt < R) {
+            const float4 q = *reinterpret_cast<const float4*>(&sp[rt * 8 + 4]);      // y0, 1/sy, x0, 1/sx
+            int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
+            hit = true;
+            if (q.y != 0.f) {
+                const float a = (fya - q.x) * q.y, cc = (fyb - q.x) * q.y;
+                pya = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pyb = min(ch - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            } else if (q.x < fya - 0.5f || q.x > fyb + 0.5f) hit = false;
+            if (q.w != 0.f) {
+                const float a = (fxa - q.z) * q.w, cc = (fxb - q.z) * q.w;
+                pxa = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pxb = min(cw - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            } else if (q.z < fxa - 0.5f || q.z > fxb + 0.5f) hit = false;
+            if (pya > pyb || pxa > pxb) hit = false;
+        }
+        unsigned long long todo = __ballot(hit);
+        while (todo) {
+            const int r = r0 + __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const float4 bx = *reinterpret_cast<const float4*>(&sp[r * 8]);
+            const float4 q = *reinterpret_cast<const float4*>(&sp[r * 8 + 4]);
+            int pya = 0, pyb = ch - 1, pxa = 0, pxb = cw - 1;
+            if (q.y != 0.f) {
+                const float a = (fya - q.x) * q.y, cc = (fyb - q.x) * q.y;
+                pya = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pyb = min(ch - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            }
+            if (q.w != 0.f) {
+                const float a = (fxa - q.z) * q.w, cc = (fxb - q.z) * q.w;
+                pxa = max(0, (int)floorf(fminf(a, cc)) - 2);
+                pxb = min(cw - 1, (int)ceilf(fmaxf(a, cc)) + 2);
+            }
+            const long long bi = (long long)b * R + r;
+            const int wxn = pxb - pxa + 1;
+            const int ncand = (pyb - pya + 1) * wxn;
+            for (int k0 = 0; k0 < ncand; k0 += 64) {
+                const int k = k0 + lane;
+                float wy0 = 0.f, wy1 = 0.f, wx0 = 0.f, wx1 = 0.f;         // weights of this sample on rows y0 / y0 + 1 and on columns x0 / x0 + 1
+                int off = 0;
+                bool use = false;
+                if (k < ncand) {
+                    const int py = pya + k / wxn, px = pxa + k % wxn;
+                    float iny, inx;
+                    if (crop_coord(bx.x, bx.z, H, ch, py, iny) && crop_coord(bx.y, bx.w, W, cw, px, inx)) {
+                        const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+                        const int lx = (int)floorf(inx), rx = (int)ceilf(inx);
+                        const float ly = iny - (float)ty, lxw = inx - (float)lx;
+                        const bool ry0 = ty == y0 || by == y0, ry1 = ty == y0 + 1 || by == y0 + 1;
+                        const bool cx0 = lx == x0 || rx == x0, cx1 = lx == x0 + 1 || rx == x0 + 1;
+                        if ((ry0 || ry1) && (cx0 || cx1)) {
+                            wy0 = (ty == y0 ? (1.f - ly) : 0.f) + (by == y0 ? ly : 0.f);
+                            wy1 = (ty == y0 + 1 ? (1.f - ly) : 0.f) + (by == y0 + 1 ? ly : 0.f);
+                            wx0 = (lx == x0 ? (1.f - lxw) : 0.f) + (rx == x0 ? lxw : 0.f);
+                            wx1 = (lx == x0 + 1 ? (1.f - lxw) : 0.f) + (rx == x0 + 1 ? lxw : 0.f);
+                            // which of the four pixels the sample touches (the test of the one-pixel kernel, per pixel): bits 0..3 = (row, column)
+                            off = ((py * cw + px) << 4) | (ry0 && cx0 ? 1 : 0) | (ry0 && cx1 ? 2 : 0) | (ry1 && cx0 ? 4 : 0) | (ry1 && cx1 ? 8 : 0);
+                            use = true;
+                        }
+                    }
+                }
+                unsigned long long cm = __ballot(use);
+                while (cm) {                 // four samples per trip: their loads are in flight together, the sums stay in order
+                    float a0[4], a1[4], b0[4], b1[4];
+                    int tm[4];
+                    float4 g[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const bool any = cm != 0;
+                        const int src = any ? __builtin_ctzll(cm) : 0;
+                        cm &= cm - 1;                                   // 0 stays 0
+                        const int o = __shfl(off, src, 64);
+                        tm[u] = any ? (o & 15) : 0;
+                        a0[u] = __shfl(wy0, src, 64); a1[u] = __shfl(wy1, src, 64);
+                        b0[u] = __shfl(wx0, src, 64); b1[u] = __shfl(wx1, src, 64);
+                        g[u] = any ? ld4g(dout + (bi * ch * cw + (o >> 4)) * C + c) : f4zero();
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (tm[u] & 1) { const float w = a0[u] * b0[u]; acc[0][0].x = fmaf(g[u].x, w, acc[0][0].x); acc[0][0].y = fmaf(g[u].y, w, acc[0][0].y); acc[0][0].z = fmaf(g[u].z, w, acc[0][0].z); acc[0][0].w = fmaf(g[u].w, w, acc[0][0].w); }
+                        if (tm[u] & 2) { const float w = a0[u] * b1[u]; acc[0][1].x = fmaf(g[u].x, w, acc[0][1].x); acc[0][1].y = fmaf(g[u].y, w, acc[0][1].y); acc[0][1].z = fmaf(g[u].z, w, acc[0][1].z); acc[0][1].w = fmaf(g[u].w, w, acc[0][1].w); }
+                        if (tm[u] & 4) { const float w = a1[u] * b0[u]; acc[1][0].x = fmaf(g[u].x, w, acc[1][0].x); acc[1][0].y = fmaf(g[u].y, w, acc[1][0].y); acc[1][0].z = fmaf(g[u].z, w, acc[1][0].z); acc[1][0].w = fmaf(g[u].w, w, acc[1][0].w); }
+                        if (tm[u] & 8) { const float w = a1[u] * b1[u]; acc[1][1].x = fmaf(g[u].x, w, acc[1][1].x); acc[1][1].y = fmaf(g[u].y, w, acc[1][1].y); acc[1][1].z = fmaf(g[u].z, w, acc[1][1].z); acc[1][1].w = fmaf(g[u].w, w, acc[1][1].w); }
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            st4g(dimg + ((((long long)b * H + y0 + i) * W + x0 + j) * cq + (threadIdx.x & 63)) * 4, acc[i][j]);
+}
+
 // ---------------------------------------------------------------------------------------
 // final mask conv 1x1 (Cin -> C<=8) + bias + sigmoid.  One wave per row: each lane owns
 // channel quads {lane, lane+64, ...}, partial dots are combined with a wave butterfly.
@@ -3356,7 +3491,16 @@ int myolo_roialign_bwd_grouped(const float* dout, const float* boxes, float* dim
     MYOLO_REQUIRE(dout && boxes && dimage && B > 0 && R > 0 && (C & 3) == 0, "roialign_bwd_grouped: bad arguments");
     const long long total = (long long)B * H * W * (C / 4);
     if (C == 256 && ((long long)H * W) % 4 == 0 && R <= 1536 && !g_myolo_opt.crop_bwd_nolds) {
-        const int mode = g_myolo_opt.tune0;            // ablation (kbench): 1 = round-3 pixel order, 3 = tiles without the XCD-contiguous order, 4 = 4 x 4 tiles
+        if ((H & 3) == 0 && (W & 3) == 0 && (g_myolo_opt.tune0 & 131072)) {
+            // a 2 x 2 pixel quad per wave, a 4 x 4 tile per workgroup (crop_bwd_quadwave_kernel)
+            const unsigned wgs = (unsigned)((long long)B * (H / 4) * (W / 4));
+            const unsigned xcd = (wgs % 8 == 0 && wgs >= 64) ? wgs / 8 : 0u;
+            hipLaunchKernelGGL(crop_bwd_quadwave_kernel, dim3(wgs), dim3(256), (size_t)R * 8 * sizeof(float), (hipStream_t)stream, dout, boxes, dimage, H, W, R,
+                               crop_h, crop_w, xcd);
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+        const int mode = g_myolo_opt.tune0 & 7;        // ablation (kbench): 1 = round-3 pixel order, 3 = tiles without the XCD-contiguous order, 4 = 4 x 4 tiles
         const bool t4 = (H % 4) == 0 && (W % 4) == 0 && mode == 4;      // (4 x 4 tiles, 1024 threads: measured slower than 2 x 2 -- 0.368 against 0.346 ms)
         const int quad = ((H | W) & 1) == 0 && mode != 1;
         const unsigned wgs = (unsigned)(total / (t4 ? 1024 : 256));

@@ -542,7 +542,7 @@ def test_crop_and_resize(B, H, W, C, nb, crop):
     check(dimg, O.crop_and_resize_bwd_image(dout, boxes, bind, img.shape), 1e-4, "crop bwd")
 
 
-@pytest.mark.parametrize("B,H,W,C,R,crop", [(2, 28, 28, 256, 20, 14), (3, 7, 9, 16, 5, 5), (2, 12, 12, 64, 7, 14)])
+@pytest.mark.parametrize("B,H,W,C,R,crop", [(2, 28, 28, 256, 20, 14), (3, 7, 9, 16, 5, 5), (2, 12, 12, 64, 7, 14), (8, 28, 28, 256, 147, 14), (3, 8, 12, 256, 70, 7)])
 def test_roialign_bwd_grouped(B, H, W, C, R, crop):
     """gather formulation == scatter formulation (oracle), incl. degenerate all-zero boxes and boxes
     outside the image; and it is bit-reproducible."""
@@ -557,6 +557,12 @@ def test_roialign_bwd_grouped(B, H, W, C, R, crop):
     X.call("myolo_roialign_bwd_grouped", X.ptr(dt(dout)), X.ptr(dt(boxes)), X.ptr(d2), B, H, W, C, R, crop, crop, X.stream())
     check(d1, ref, 1e-4, "roialign bwd grouped")
     assert torch.equal(d1, d2)
+    if C == 256 and H % 4 == 0 and W % 4 == 0:
+        # the quad-per-wave form (a crop sample that touches a 2 x 2 pixel quad is loaded once; option tune0 & 131072): the same sums bit for bit
+        d3 = new(B, H, W, C)
+        with X.option("tune0", 131072):
+            X.call("myolo_roialign_bwd_grouped", X.ptr(dt(dout)), X.ptr(dt(boxes)), X.ptr(d3), B, H, W, C, R, crop, crop, X.stream())
+        assert torch.equal(d1, d3), float((d1 - d3).abs().max())
 
 
 @pytest.mark.parametrize("B,G,A,C", [(4, 7, 3, 4), (2, 13, 5, 2), (3, 4, 3, 4)])
