@@ -14,6 +14,10 @@ from myolo.model import MaskYOLO
 from myolo.shapes import make_shapes_samples
 from myolo.myolo_utils import BatchGenerator
 B = 8
+for kv in os.environ.get("MYOLO_LIB_OPTIONS", "").split(","):          # kernel selections for A/B runs, e.g. MYOLO_LIB_OPTIONS=tune0=23552
+    if "=" in kv:
+        from myolo import _ext as _X
+        _X.load(); _X.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 over = dict(a.split("=", 1) for a in sys.argv[1:])
 SEED = int(over.pop("SEED", 1))                # weight-init seed
 cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], BATCH_SIZE=B, **over)
