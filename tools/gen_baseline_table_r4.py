@@ -22,7 +22,7 @@ rows = "\n".join("| %s | %s | %.1f | %.0f | %.1f | %s | %.2f | %.1f | %.2f |" % 
                  for l in r.get("trunk_layers", []))
 new = '''## 7. Results (round 4, measured on 1x MI355X by ONE `python bench.py --steps 20 --warmup 5`; evidence `profiles/%(tag)s_*`, notes `profiles/r4_notes.md`)
 
-(generated from `profiles/%(tag)s_bench.json` by `tools/gen_baseline_table_r4.py`; box-to-box spread of the headline over the round's boxes: 20.3-21.1 ms (evidence runs of the last hours of the round: 20.27, 20.33, 20.59, 20.55, 20.16 with the three-queue tail, 20.06 with the LDS-staged conv1 weight gradient and the register-fed thin data gradients, 19.65-20.35 in same-box A/Bs; three evidence runs of the final code on three boxes: 20.00, 20.16, 20.05 -- the last one is the committed set))
+(generated from `profiles/%(tag)s_bench.json` by `tools/gen_baseline_table_r4.py`; box-to-box spread of the headline over the round's boxes: 19.65-21.1 ms (evidence runs of the last hours of the round: 20.27, 20.33, 20.59, 20.55, 20.16 with the three-queue tail, 20.06 with the LDS-staged conv1 weight gradient and the register-fed thin data gradients, 19.65-20.35 in same-box A/Bs; three evidence runs of the final code on three boxes: 20.00, 20.16, 20.05 -- the last one is the committed set))
 
 | Object of the line | img/s | ms | what it is |
 |---|---|---|---|
