@@ -36,6 +36,25 @@ for fixed in (True, False, True, False):
     run(8, fixed)
     a, b = run(16, fixed), run(48, fixed)
     print("%s: %.3f ms per step (marginal, 48 - 16 steps)" % ("fixed batch through train_on_batch" if fixed else "produced on the copy stream", 1e3 * (b - a) / 32))
+from myolo.model import _gc_parked
+def run2(n, read_loss, parked):
+    side = m.net._copy_stream
+    produce = lambda i: prod.batch(list(range(32 * i, 32 * i + 32)), stream=side, consumer=torch.cuda.current_stream())
+    torch.cuda.synchronize(); t = time.perf_counter()
+    import contextlib
+    with (_gc_parked() if parked else contextlib.nullcontext()):
+        nxt = produce(0)
+        res = []
+        for i in range(n):
+            cur, nxt = nxt, produce(i + 1)
+            res.append(m.train_on_batch(cur))
+            if i >= 2: res[i - 2] = res[i - 2]["loss"] if read_loss else None
+    torch.cuda.synchronize()
+    return time.perf_counter() - t
+for rl, pk in ((False, False), (True, False), (False, True), (True, True), (False, False), (True, True)):
+    run2(8, rl, pk)
+    a_, b_ = run2(16, rl, pk), run2(64, rl, pk)
+    print("loop: read_loss=%d gc_parked=%d: %.3f ms per step" % (rl, pk, 1e3 * (b_ - a_) / 48))
 def api(n):
     torch.cuda.synchronize(); t = time.perf_counter(); m.train_shapes_stream(n); torch.cuda.synchronize(); return time.perf_counter() - t
 api(8)
