@@ -61,3 +61,25 @@ api(8)
 for rep in range(3):
     a, b = api(16), api(64)
     print("train_shapes_stream(): %.3f ms per step (marginal, 64 - 16 steps); 64-step call %.1f ms" % (1e3 * (b - a) / 48, 1e3 * b))
+# the public call's body with single pieces switched off
+def body(n, new_prod=True, recompile=True):
+    torch.cuda.synchronize(); t = time.perf_counter()
+    p2 = ShapesProducer(cfg, seed=1234, device=m._device) if new_prod else prod
+    if recompile:
+        m.set_trainable(".*"); m.compile(cfg.LEARNING_RATE, cfg.LEARNING_MOMENTUM)
+    side = m.net._copy_stream
+    produce = lambda i: p2.batch(list(range(32 * i, 32 * i + 32)), stream=side, consumer=torch.cuda.current_stream())
+    results = []
+    with _gc_parked():
+        nxt = produce(0)
+        for i in range(n):
+            cur, nxt = nxt, (produce(i + 1) if i + 1 < n else None)
+            results.append(m.train_on_batch(cur))
+            if i >= 2: results[i - 2] = results[i - 2]["loss"]
+    losses = [r if isinstance(r, float) else r["loss"] for r in results]
+    torch.cuda.synchronize()
+    return time.perf_counter() - t
+for np_, rc in ((True, True), (False, True), (True, False), (False, False), (True, True)):
+    body(8, np_, rc)
+    a_, b_ = body(16, np_, rc), body(64, np_, rc)
+    print("body: new producer=%d recompile=%d: %.3f ms per step (16-step call %.1f ms)" % (np_, rc, 1e3 * (b_ - a_) / 48, 1e3 * a_))
