@@ -22,13 +22,14 @@ rows = "\n".join("| %s | %s | %.1f | %.0f | %.1f | %s | %.2f | %.1f | %.2f |" % 
                  for l in r.get("trunk_layers", []))
 new = '''## 7. Results (round 4, measured on 1x MI355X by ONE `python bench.py --steps 20 --warmup 5`; evidence `profiles/%(tag)s_*`, notes `profiles/r4_notes.md`)
 
-(generated from `profiles/%(tag)s_bench.json` by `tools/gen_baseline_table_r4.py`; box-to-box spread of the headline over the round's boxes: 19.65-21.1 ms (evidence runs of the last hours of the round: 20.27, 20.33, 20.59, 20.55, 20.16 with the three-queue tail, 20.06 with the LDS-staged conv1 weight gradient and the register-fed thin data gradients, 19.65-20.35 in same-box A/Bs; three evidence runs of the final code on three boxes: 20.00, 20.16, 20.05 -- the last one is the committed set))
+(generated from `profiles/%(tag)s_bench.json` by `tools/gen_baseline_table_r4.py`; box-to-box spread of the headline over the round's boxes: 19.65-21.1 ms (evidence runs of the last hours of the round: 20.27, 20.33, 20.59, 20.55, 20.16 with the three-queue tail, 20.06 with the LDS-staged conv1 weight gradient and the register-fed thin data gradients, 19.65-20.35 in same-box A/Bs; four evidence runs of the final code on four boxes: 20.00, 20.16, 20.05, 19.63 -- the last one is the committed set))
 
 | Object of the line | img/s | ms | what it is |
 |---|---|---|---|
 | **headline** `value` (`config.fp32_products = "%(fp)s"`, `dtype f32`) | **%(val).1f** | **%(ms).2f** (p10 %(p10).2f / p50 %(p50).2f / p90 %(p90).2f) | Shapes 224x224, batch 32, N_BOX=3 (R=147), forward + backward + Adam; round 3: 1487.8 / 21.51, round 2: 1139.2 / 28.09, round 1: 863.4 / 37.06 |
 | `train_api.train` = `MaskYOLO.train()` on a 512-image ShapesDataset | %(tav).1f | %(tams).2f | the drop-in call (model.py:943-1060): host BatchGenerator on a prefetch thread, pinned byte staging, lazy losses |
 | `train_api.train_shapes_stream` | %(tsv).1f | %(tsms).2f | inputs produced on the device |
+| `train_api.reference_same_state` | %(rsv).1f | %(rsms).2f | `Net.train_step` on resident batches right after those calls, same weights (%(rsn).2f positives per image; the headline's random-init net: %(hn)s): the like-for-like reference of the public calls |
 | `comm_overlap_probe_ms.ms_per_step_with_probe` | | %(cpms).2f | the same step with the three gradient buckets all-reduced on the copy stream (1-rank RCCL communicator through the C-ABI) |
 | `variants.fp32_products_native` | %(nat_v).1f | %(nat_ms).2f | the same step with every product on `v_mfma_f32_32x32x2_f32` |
 | `variants.dense_mask_backward` | %(dn_v).1f | %(dn_ms).2f | structural zeros of the mask-head backward not exploited |
@@ -57,6 +58,8 @@ Per-layer trunk table (`roofline.trunk_layers`; ms = HIP events around the layer
 |---|---|---|---|---|---|---|---|---|
 %(rows)s
 ''' % dict(tag=tag, tav=d.get('train_api', {}).get('train', {}).get('images_per_sec', 0.0), tams=d.get('train_api', {}).get('train', {}).get('ms_per_step', 0.0),
+           rsv=(d.get('train_api', {}).get('reference_same_state') or {}).get('images_per_sec', 0.0), rsms=(d.get('train_api', {}).get('reference_same_state') or {}).get('ms_per_step', 0.0),
+           rsn=(d.get('train_api', {}).get('reference_same_state') or {}).get('n_pos_mean', 0.0), hn='%.2f' % d['config'].get('n_pos_mean', 0.0),
            tsv=d.get('train_api', {}).get('train_shapes_stream', {}).get('images_per_sec', 0.0), tsms=d.get('train_api', {}).get('train_shapes_stream', {}).get('ms_per_step', 0.0),
            cpms=d.get('comm_overlap_probe_ms', {}).get('ms_per_step_with_probe', 0.0), fcomp=r.get('frac_composite', 0.0), fp=d["config"].get("fp32_products"), val=d["value"], ms=d["ms_per_step"], p10=d["step_ms"]["p10"], p50=d["step_ms"]["p50"], p90=d["step_ms"]["p90"],
            nat_v=v["fp32_products_native"]["value"], nat_ms=v["fp32_products_native"]["ms_per_step"],
