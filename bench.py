@@ -42,6 +42,103 @@ FP32_MFMA_PEAK = 157.3       # TFLOP/s
 BF16_MFMA_PEAK = 2500.0      # TFLOP/s dense
 
 
+MAX_LINE_BYTES = 6000        # the driver keeps a bounded tail of stdout: the ONE line it parses stays far below it (round 4's 22 KB line was lost)
+
+
+def _r(x, nd=4):
+    """round floats (recursively) so the line stays short; everything else unchanged."""
+    if isinstance(x, float):
+        return round(x, nd) if abs(x) < 1e6 else float("%.6g" % x)
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(res):
+    """The ONE stdout line (contract keys + roofline of the dominant kernel + cpu_baseline + a few scalars), < MAX_LINE_BYTES.  The full
+    result (per-layer trunk table, probes, variants, the Rice-416 kernels' own roofline ...) goes to bench_detail.json and to stderr."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    if "step_ms" in res:
+        out["step_ms"] = _pick(res["step_ms"], ("p10", "p50", "p90", "min", "max", "n"))
+    cfg = res.get("config", {})
+    c = _pick(cfg, ("workload", "winograd_tiles", "fp32_products", "global_batch", "parallelism", "rois_per_image", "n_pos_mean", "n_pos_sweep_ms",
+                    "train_api_images_per_sec", "final_loss", "in_flight", "forced_positives", "share_gpu", "lib_options", "net_attrs"))
+    if "workload" in c:
+        c["workload"] = c["workload"][:360]
+    for k in ("lib_options", "net_attrs", "forced_positives", "share_gpu"):
+        if k in c and not c[k]:
+            del c[k]
+    out["config"] = c
+    rf = res.get("roofline") or {}
+    r = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_composite", "traffic", "algorithmic_bytes", "algorithmic_flop",
+                   "avg_launch_ms", "launches_timed"))
+    if "kernel" in r:
+        r["kernel"] = r["kernel"][:200]
+    if rf.get("traffic") and rf.get("algorithmic_bytes"):
+        r["traffic_over_algorithmic"] = rf["traffic"] / rf["algorithmic_bytes"]
+        r["traffic_measured_in_this_run"] = "traffic_from_profiles" in rf
+    if "depthwise" in rf:
+        r["depthwise"] = _pick(rf["depthwise"], ("frac", "frac_net", "avg_ms"))
+    if "roialign" in rf and "frac" in rf["roialign"]:
+        r["roialign"] = _pick(rf["roialign"], ("frac", "avg_ms"))
+    if "pointwise" in rf and "frac_of_fp32_mfma_peak" in rf["pointwise"]:
+        pw = rf["pointwise"]
+        r["pointwise"] = {"frac": pw["frac_of_fp32_mfma_peak"], "frac_net": pw.get("frac_of_fp32_mfma_peak_net"), "avg_ms": pw["avg_ms"],
+                          "frac_mfma_bound_layers": (pw.get("mfma_bound_layers") or {}).get("frac_of_fp32_mfma_peak")}
+    if "deconv_mask" in rf:         # --config rice416-bf16
+        r["deconv_mask_frac"] = rf["deconv_mask"]["achieved"] / rf["deconv_mask"]["peak"]
+        r["roialign_frac"] = rf["roialign"]["achieved"] / rf["roialign"]["peak"]
+    out["roofline"] = r
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        cb = dict(cb)
+        if "sample" in cb:
+            cb["sample"] = cb["sample"][:300]
+    out["cpu_baseline"] = cb
+    if "comm" in res:
+        out["comm"] = _pick(res["comm"], ("backend", "rccl_ranks_seen", "bucket_allreduce_ms", "bucket_bytes", "weights_identical_across_ranks"))
+        out["comm"]["backend"] = str(out["comm"].get("backend"))[:80]
+    sec = res.get("secondary_nbox5")
+    if isinstance(sec, dict):
+        out["nbox5_images_per_sec"] = sec.get("value", sec.get("error"))
+    inf = res.get("inference_rice416_bf16")
+    if isinstance(inf, dict):
+        out["rice416_bf16_images_per_sec"] = inf.get("value", inf.get("error"))
+        out["rice416_bf16_one_in_flight_images_per_sec"] = (inf.get("one_in_flight") or {}).get("value")
+        out["rice416_bf16_detect_many_images_per_sec"] = (inf.get("detect_many") or {}).get("images_per_sec")
+    if isinstance(res.get("one_in_flight"), dict):
+        out["one_in_flight_images_per_sec"] = res["one_in_flight"].get("value")
+    if isinstance(res.get("detect_many"), dict):
+        out["detect_many_images_per_sec"] = res["detect_many"].get("images_per_sec")
+    hw = res.get("host_wait_on_n_pos_ms_per_step")
+    if isinstance(hw, dict):
+        out["host_wait_on_n_pos_ms_per_step"] = hw.get("value")
+    if isinstance(res.get("variants"), dict) and "dense_mask_backward" in res["variants"]:
+        out["dense_mask_backward_ms_per_step"] = res["variants"]["dense_mask_backward"]["ms_per_step"]
+    out["detail"] = "bench_detail.json"
+    return _r(out)
+
+
+def write_detail(res, args):
+    """the full result object: bench_detail.json at the repo root (and in gpurun_out/ when that exists, so it travels back), and on stderr."""
+    txt = json.dumps(res, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, args.detail_name), "w") as f:
+                    f.write(txt + "\n")
+            except OSError:
+                pass
+    sys.stderr.write("bench.py detail:\n" + txt + "\n")
+    sys.stderr.flush()
+
+
 def make_batches(cfg, rank, world, per_gpu, nbatches):
     """nbatches distinct host batches for this rank; image g of the global stream is seeded by g."""
     from myolo.shapes import make_shapes_samples
@@ -652,7 +749,10 @@ def bench_train(args, rank, world, local):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "step_ms": percentiles(step_ms),
-        "config": {"winograd_tiles": net.wino_tiles, "fp32_products": net.fp32_matmul, "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
+        "config": {"winograd_tiles": net.wino_tiles, "fp32_products": net.fp32_matmul,
+                   "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step (fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
+                       args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R, "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS),
+                   "workload_detail": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step "
                                "(fwd+bwd+Adam%s); mask head FORWARD on %s ROIs; mask-head BACKWARD behind bn1 (conv2-4, deconv, myolo_mask) on "
                                "the positive ROIs only -- exact: bn2-4 are frozen and the loss reads positives only, so the other ROIs' "
                                "gradients are structural zeros (dense-backward time in variants.dense_mask_backward); " % (
@@ -933,6 +1033,7 @@ def main():
                     help="engine (myolo.engine.Net) scheduling switches for this run, e.g. overlap_conv1_wgrad=0; recorded in config.net_attrs")
     ap.add_argument("--lib-option", action="append", default=[], metavar="NAME=VALUE",
                     help="myolo_set_option switches for this run (kernel A/B comparisons, e.g. wino_x6=1); recorded in config.lib_options")
+    ap.add_argument("--detail-name", default="bench_detail.json", help="file name of the full result object (written at the repo root and in gpurun_out/)")
     args = ap.parse_args()
     args.batch_given = args.batch is not None
     if args.batch is None:
@@ -991,7 +1092,10 @@ def main():
                 res["inference_rice416_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         sys.stdout.flush()
-        os.write(json_fd, (json.dumps(res) + "\n").encode())
+        line = json.dumps(compact_line(res))
+        assert len(line) < MAX_LINE_BYTES, "bench line grew to %d bytes: move detail to bench_detail.json" % len(line)
+        write_detail(res, args)
+        os.write(json_fd, (line + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

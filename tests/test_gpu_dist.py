@@ -232,7 +232,10 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["config"]["share_gpu"] is True
     assert d["comm"]["rccl_ranks_seen"] == 2 and len(d["comm"]["bucket_allreduce_ms"]) == 3 and all(v > 0 for v in d["comm"]["bucket_allreduce_ms"])
     assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
-    assert "variants" in d and "dense_mask_backward" in d["variants"]            # the variants ran in lockstep on both ranks
+    assert d["dense_mask_backward_ms_per_step"] > 0                               # the variants ran in lockstep on both ranks
+    assert len(lines[0]) < 6000 and d["detail"] == "bench_detail.json"            # the compact line; the full object is beside it
+    full = json.load(open(os.path.join(root, "bench_detail.json")))
+    assert "variants" in full and "dense_mask_backward" in full["variants"] and "trunk_layers" in full["roofline"]
 
 
 def test_bench_eight_ranks_at_full_config2_size_on_one_gpu():
@@ -250,7 +253,7 @@ def test_bench_eight_ranks_at_full_config2_size_on_one_gpu():
                         "--no-variant", "--no-extras"], env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
+    assert len(lines) == 1 and len(lines[0]) < 6000, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp8" and d["config"]["share_gpu"] is True
     assert d["comm"]["rccl_ranks_seen"] == 8 and len(d["comm"]["bucket_allreduce_ms"]) == 3

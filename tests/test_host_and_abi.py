@@ -298,6 +298,47 @@ def test_bench_self_launches_under_torchrun(monkeypatch):
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
+def test_bench_line_is_compact():
+    """the ONE stdout line of bench.py stays far below what the driver's capture keeps (round 4's 22 KB line was lost: BENCH_r04 parsed = null).
+    compact_line() is fed round 4's full result object (profiles/r4_bench.json, 22 KB) and the Rice-416 one: < 6000 bytes, every contract key,
+    roofline and cpu_baseline present, main() asserts the same bound before it prints."""
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert bench.MAX_LINE_BYTES <= 6000
+    full = json.load(open(os.path.join(root, "profiles", "r4_bench.json")))
+    assert len(json.dumps(full)) > 20000
+    line = json.dumps(bench.compact_line(full))
+    assert len(line) < bench.MAX_LINE_BYTES, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "step_ms", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["value"] == round(full["value"], 4) and d["ms_per_step"] == round(full["ms_per_step"], 4)
+    for k in ("workload", "fp32_products", "n_pos_mean", "n_pos_sweep_ms", "train_api_images_per_sec", "global_batch", "parallelism"):
+        assert k in d["config"], k
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_composite", "traffic", "algorithmic_bytes", "algorithmic_flop", "avg_launch_ms"):
+        assert k in d["roofline"], k
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-3
+    for fam in ("depthwise", "roialign", "pointwise"):
+        assert 0 < d["roofline"][fam]["frac"] < 1
+    assert "trunk_layers" not in d["roofline"] and "variants" not in d and "train_api" not in d
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    for k in ("nbox5_images_per_sec", "rice416_bf16_images_per_sec", "rice416_bf16_detect_many_images_per_sec"):
+        assert d[k] > 0
+    # a line with a comm object (N > 1) and long strings everywhere still fits
+    full["comm"] = {"backend": "RCCL via torch.distributed (nccl)" * 4, "rccl_ranks_seen": 8, "bucket_allreduce_ms": [0.123456789] * 3,
+                    "weights_identical_across_ranks": True, "bucket_bytes": [1 << 20] * 3, "note": "x" * 4000}
+    full["config"]["workload"] = "w" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    full["cpu_baseline"]["sample"] = "s" * 5000
+    assert len(json.dumps(bench.compact_line(full))) < bench.MAX_LINE_BYTES
+    ri = json.load(open(os.path.join(root, "profiles", "r3c_bench_rice416_bf16.json")))
+    di = bench.compact_line(ri)
+    assert len(json.dumps(di)) < bench.MAX_LINE_BYTES and di["dtype"] == "bf16" and di["roofline"]["deconv_mask_frac"] > 0
+
+
 def test_bench_algorithmic_work_matches_survey():
     import importlib
     bench = importlib.import_module("bench")
