@@ -44,9 +44,17 @@ class Config(object):
     # ---- backbone (config.py:61-92) ---------------------------------------
     BACKBONE = "mobilenet"
     ALPHA = 1.0                  # new: MobileNet width multiplier
+    COMPUTE_BACKBONE_SHAPE = None
     BACKBONE_STRIDES = [8]
+    FPN_CLASSIF_FC_LAYERS_SIZE = 1024
     TOP_FEATURE_MAP_DEPTH = 256
     SECOND_PHASE_YOLO_DEPTH = 512
+    # Mask R-CNN leftovers of the reference's table (config.py:94-110): read by nothing on the path, kept so that a user's subclass and
+    # display() see the same attribute set (tests/golden/ref_config.json is the imported reference class, attribute by attribute)
+    RPN_ANCHOR_SCALES = (32, 64, 128, 256, 512)
+    RPN_ANCHOR_RATIOS = [0.5, 1, 2]
+    RPN_ANCHOR_STRIDE = 1
+    RPN_NMS_THRESHOLD = 0.7
 
     # ---- masks / ROIs (config.py:120-180) ---------------------------------
     USE_MINI_MASK = False

@@ -80,16 +80,79 @@ def extract_bboxes(mask):
     return boxes
 
 
+def resize(image, output_shape, order=1, mode='constant', cval=0, clip=True, preserve_range=False, anti_aliasing=False,
+           anti_aliasing_sigma=None):
+    """The reference's scikit-image wrapper (myolo_utils.py:433-455) restated for the one way the path calls it: order 1, mode 'constant', cval 0,
+    clip, no anti-aliasing -- skimage.transform.resize as a per-channel bilinear warp with pixel centres aligned (src = (dst + .5) * in / out - .5),
+    samples outside the image reading cval, computed in float64, clipped to the input's range.  Pinned by tests/golden/ref_load_image_gt.npz
+    (the reference's wrapper executed with scikit-image 0.18.3): float results to 1e-10, the uint8 image of resize_image to 1 count on < 0.1 % of
+    the pixels (skimage estimates its affine matrix by least squares, so a value that is an integer up to rounding may truncate either way)."""
+    if order != 1 or mode != 'constant' or anti_aliasing:
+        raise NotImplementedError("resize: only order=1, mode='constant', anti_aliasing=False (what myolo_utils.py:388,903 use)")
+    img = np.asarray(image)
+    a = img.astype(np.float64)
+    if not preserve_range:
+        if img.dtype == np.uint8:
+            a = a / 255.
+        elif img.dtype == bool:
+            a = img.astype(np.float64)
+    h, w = a.shape[:2]
+    oh, ow = int(output_shape[0]), int(output_shape[1])
+    flat = a.ndim == 2
+    if flat:
+        a = a[:, :, None]
+    ys = (np.arange(oh, dtype=np.float64) + 0.5) * (h / float(oh)) - 0.5
+    xs = (np.arange(ow, dtype=np.float64) + 0.5) * (w / float(ow)) - 0.5
+    y0, x0 = np.floor(ys).astype(int), np.floor(xs).astype(int)
+    y1, x1 = np.ceil(ys).astype(int), np.ceil(xs).astype(int)
+    dy, dx = (ys - y0)[:, None, None], (xs - x0)[None, :, None]
+    P = np.full((h + 2, w + 2, a.shape[2]), float(cval))
+    P[1:-1, 1:-1] = a
+
+    def px(yi, xi):
+        return P[np.clip(yi + 1, 0, h + 1)][:, np.clip(xi + 1, 0, w + 1)]
+    top = (1 - dx) * px(y0, x0) + dx * px(y0, x1)
+    bot = (1 - dx) * px(y1, x0) + dx * px(y1, x1)
+    out = (1 - dy) * top + dy * bot
+    if clip:
+        out = np.clip(out, a.min(), a.max())
+    return out[:, :, 0] if flat else out
+
+
+def resize_image(image, net_image_shape):
+    """-> (image resized to net_image_shape[:2] in its own dtype, [scale_y, scale_x]) (myolo_utils.py:369-392)."""
+    image_dtype = image.dtype
+    h, w = image.shape[:2]
+    scale = [net_image_shape[0] / h, net_image_shape[1] / w]
+    if scale != [1, 1]:
+        image = resize(image, (round(h * scale[0]), round(w * scale[1])), preserve_range=True)
+    return image.astype(image_dtype), scale
+
+
+def resize_mask(mask, scale):
+    """scipy.ndimage.zoom(mask, [scale_y, scale_x, 1], order=0) restated (myolo_utils.py:395-411): output extent round(n * scale), output
+    index o reads input index floor(o * (n - 1) / (out - 1) + .5) (corner-aligned nearest neighbour)."""
+    h, w = mask.shape[:2]
+    oh, ow = int(round(h * scale[0])), int(round(w * scale[1]))
+
+    def idx(n, o):
+        if o <= 1:
+            return np.zeros(max(o, 0), int)
+        return np.floor(np.arange(o) * ((n - 1) / float(o - 1)) + 0.5).astype(int)
+    return mask[idx(h, oh)][:, idx(w, ow)]
+
+
 def load_image_gt(dataset, config, image_id, augment=False, augmentation=None, use_mini_mask=False):
-    """-> image, class_ids, bbox [n,(x1,y1,x2,y2)], mask [H,W,n] (myolo_utils.py:274-366).
-    Resizing / augmentation are image-file I/O paths outside the hot path: images must already
-    have config.IMAGE_SHAPE."""
-    image = dataset.load_image(image_id)
-    mask, class_ids = dataset.load_mask(image_id)
-    if list(image.shape) != list(config.IMAGE_SHAPE):
-        raise NotImplementedError("image resize is outside the hot path; supply %s images" % (config.IMAGE_SHAPE,))
+    """-> image, class_ids, bbox [n,(x1,y1,x2,y2)], mask [H,W,n] (myolo_utils.py:274-366): load, resize image and masks to
+    config.IMAGE_SHAPE, drop the instances whose mask came out empty, tight boxes.  Augmentation (imgaug) and mini-masks are image-file
+    I/O options outside the hot path and are refused.  Pinned by tests/golden/ref_load_image_gt.npz (the reference's function executed)."""
     if augment or augmentation is not None or use_mini_mask:
         raise NotImplementedError("augmentation / mini-masks are outside the hot path")
+    image = dataset.load_image(image_id)
+    mask, class_ids = dataset.load_mask(image_id)
+    if list(image.shape[:2]) != list(config.IMAGE_SHAPE[:2]):
+        image, scale = resize_image(image, config.IMAGE_SHAPE)
+        mask = resize_mask(mask, scale)
     keep = np.sum(mask, axis=(0, 1)) > 0
     mask = mask[:, :, keep]
     class_ids = class_ids[keep]
