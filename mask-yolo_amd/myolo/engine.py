@@ -1579,36 +1579,56 @@ class Net(object):
                 ("y_true", (n, cfg.GRID_H, G, A, 5 + C), torch.float32)]
         if not yolo:
             spec += [("gt_ids", (n, T), torch.int32), ("gt_boxes", (n, T, 4), torch.int32), ("gt_masks", (n, H, W, cfg.MAX_GT_INSTANCES), torch.uint8)]
-        if self._stage is None:
-            self._stage = [dict(bufs={}, ev=None) for _ in range(self._STAGE_SETS)]
-            self._stage_i = 0
-            self._upload_stream = _shared_stream(dev, "batch_upload") if self.upload_own_stream else self._copy_stream
         with self._stage_lock:
-            st = self._stage[self._stage_i]
-            self._stage_i = (self._stage_i + 1) % self._STAGE_SETS
-        if st["ev"] is not None:
-            st["ev"].synchronize()                    # the staging set's previous H2D (a few batches ago): long finished
-        arrays = []
-        for key, shape, dt in spec:
-            pin = st["bufs"].get(key)
-            if pin is None or tuple(pin.shape) != shape or pin.dtype != dt:
-                pin = st["bufs"][key] = torch.empty(shape, dtype=dt, pin_memory=True)
-            arrays.append(pin.numpy())
-        fill(arrays)
-        out = {}
-        with torch.cuda.stream(self._upload_stream):
+            if self._stage is None:
+                self._stage = [dict(bufs={}, ev=None, busy=threading.Lock()) for _ in range(self._STAGE_SETS)]
+                self._stage_i = 0
+                self._upload_stream = _shared_stream(dev, "batch_upload") if self.upload_own_stream else self._copy_stream
+            # a staging set belongs to ONE caller from here until its upload has been queued and its event recorded (`busy`): MaskYOLO.train()'s
+            # prefetch thread and the main thread's validation batches go through this ring at the same time.  First set in ring order
+            # that nobody is filling; if every set is taken, queue for the next one in order.
+            st = None
+            for k in range(self._STAGE_SETS):
+                cand = self._stage[(self._stage_i + k) % self._STAGE_SETS]
+                if cand["busy"].acquire(False):
+                    st = cand
+                    self._stage_i = (self._stage_i + k + 1) % self._STAGE_SETS
+                    break
+            if st is None:
+                wait_for = self._stage[self._stage_i]
+                self._stage_i = (self._stage_i + 1) % self._STAGE_SETS
+        if st is None:
+            wait_for["busy"].acquire()
+            st = wait_for
+        try:
+            if st["ev"] is not None:
+                st["ev"].synchronize()                    # the staging set's previous H2D (a few batches ago): long finished
+            arrays = []
             for key, shape, dt in spec:
-                t = torch.empty(shape, dtype=dt, device=dev)
-                t.copy_(st["bufs"][key], non_blocking=True)
-                out[key] = t
-            if u8_images:
-                raw = out["images"]
-                out["images"] = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
-                X.call("myolo_u8_to_unit_f32", X.ptr(raw), X.ptr(out["images"]), raw.numel(), X.stream())
-                out["_raw_images"] = raw              # (kept until the conversion has run)
-            st["ev"] = torch.cuda.Event()
-            st["ev"].record(self._upload_stream)
-        out["_ready"] = st["ev"]
+                # keyed by (name, dtype, shape): train() stages byte images, validation / to_device_batch float ones through the same ring --
+                # each keeps its own pinned buffer instead of re-pinning on every switch
+                pin = st["bufs"].get((key, shape, dt))
+                if pin is None:
+                    pin = st["bufs"][(key, shape, dt)] = torch.empty(shape, dtype=dt, pin_memory=True)
+                arrays.append(pin.numpy())
+            fill(arrays)
+            out = {}
+            with torch.cuda.stream(self._upload_stream):
+                for key, shape, dt in spec:
+                    t = torch.empty(shape, dtype=dt, device=dev)
+                    t.copy_(st["bufs"][(key, shape, dt)], non_blocking=True)
+                    out[key] = t
+                if u8_images:
+                    raw = out["images"]
+                    out["images"] = torch.empty((n, H, W, 3), dtype=torch.float32, device=dev)
+                    X.call("myolo_u8_to_unit_f32", X.ptr(raw), X.ptr(out["images"]), raw.numel(), X.stream())
+                    out["_raw_images"] = raw              # (kept until the conversion has run)
+                ev = torch.cuda.Event()
+                ev.record(self._upload_stream)
+                st["ev"] = ev
+            out["_ready"] = ev
+        finally:
+            st["busy"].release()
         return out
 
     _STAGE_SETS = 3

@@ -150,23 +150,36 @@ def _gc_parked():
 
 class _Prefetcher(object):
     """Runs `make(i)` for the items of `schedule` one step ahead on a thread (Keras' fit_generator does the same with its
-    generator queue, model.py:1055-1058: max_queue_size 3, one worker).  make = BatchGenerator.__getitem__ + the pinned
-    staging + the asynchronous upload (Net.to_device_batch): numpy's copies and the event waits release the GIL, so this
-    overlaps the main thread's kernel launches."""
+    generator queue, model.py:1055-1058: max_queue_size 3, one worker).  make = BatchGenerator.fill into the engine's pinned
+    staging arrays + the asynchronous upload (Net.stage_batch): numpy's copies and the event waits release the GIL, so this
+    overlaps the main thread's kernel launches.  close() (train() calls it on every way out: normal end, exception in a step or
+    a callback, KeyboardInterrupt) stops the thread and drops what it had staged."""
 
     def __init__(self, schedule, make, device, depth=2):
         self._q = queue.Queue(maxsize=depth)
         self._err = None
+        self._stop = threading.Event()
+
+        def put(item):
+            while not self._stop.is_set():
+                try:
+                    self._q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def run():
             try:
-                torch.cuda.set_device(device)
+                if device is not None:
+                    torch.cuda.set_device(device)
                 for i in schedule:
-                    self._q.put((i, make(i)))
+                    if self._stop.is_set() or not put((i, make(i))):
+                        return
             except BaseException as e:                # surfaced in the consumer
                 self._err = e
             finally:
-                self._q.put(None)
+                put(None)
         self._th = threading.Thread(target=run, name="myolo-batch-prefetch", daemon=True)
         self._th.start()
 
@@ -178,6 +191,22 @@ class _Prefetcher(object):
                     raise self._err
                 return
             yield item
+
+    def close(self, timeout=10.0):
+        """stop the thread (it leaves at its next queue operation), drain the queue so that the staged device batches are released, join."""
+        self._stop.set()
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        self._th.join(timeout)
+        try:
+            while True:
+                self._q.get_nowait()
+        except queue.Empty:
+            pass
+        return not self._th.is_alive()
 
 
 class MaskYOLO(object):
@@ -379,44 +408,49 @@ class MaskYOLO(object):
 
         # ONE prefetcher for the whole run (Keras' generator queue also keeps running across epoch ends): the first batches of epoch e+1
         # are encoded and uploaded while epoch e finishes
-        stream = iter(_Prefetcher([(e, i) for e in range(epochs) for i in schedule], lambda it: make(it[1]), self.net.dev))
-        with _gc_parked():                          # for the whole run: a full collection at every epoch end cost ~50 ms per epoch
-            for ep in range(epochs):
-                losses = []
-                pending = None
-                for _ in schedule:
-                    t0 = time.perf_counter()
-                    (_, i), db = next(stream)
-                    t1 = time.perf_counter()
-                    out = self.train_on_batch(db)
-                    self.host_times["wait_for_batch_s"] += t1 - t0      # the launch thread blocked on the prefetch queue
-                    self.host_times["launch_step_s"] += time.perf_counter() - t1
-                    self.host_times["steps"] += 1
-                    if pending is not None:            # step i-1's numbers are read once step i is queued behind it: the
-                        report(ep, *pending)           # host never waits for the step it has just launched
-                    pending = (i, out)
-                if pending is not None:
-                    report(ep, *pending)
-                gc.collect(0)                          # the young generation only (cheap): what this epoch's steps left behind
-                history.append(float(np.mean(losses)))
-                logs = {"loss": history[-1]}
-                if val_gen is not None and len(val_info) >= cfg.BATCH_SIZE:
-                    # validation_data=val_generator, validation_steps=len(val_generator) (model.py:1053-1054): forward only, BN on
-                    # moving statistics, batch-mean of the total loss.  Every rank evaluates the same (small) set.
-                    vl = [self.evaluate_on_batch(val_gen[j][0])["loss"] for j in range(len(val_gen))]
-                    logs["val_loss"] = float(np.mean(vl))
-                    if verbose:
-                        print("epoch %d val_loss %.4f" % (ep + 1, logs["val_loss"]))
-                self.history["loss"].append(logs["loss"])
-                self.history["val_loss"].append(logs.get("val_loss", float("nan")))
-                if self.model_dir and rank == 0:
-                    os.makedirs(self.model_dir, exist_ok=True)
-                    stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
-                    self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
-                for cb in (custom_callbacks or []):
-                    (cb.on_epoch_end if hasattr(cb, "on_epoch_end") else cb)(ep, dict(logs))
-        for _ in stream:                               # (drains the prefetch thread: nothing is left when every epoch ran)
-            pass
+        prefetch = _Prefetcher([(e, i) for e in range(epochs) for i in schedule], lambda it: make(it[1]), self.net.dev)
+        stream = iter(prefetch)
+        try:
+            with _gc_parked():                          # for the whole run: a full collection at every epoch end cost ~50 ms per epoch
+                for ep in range(epochs):
+                    losses = []
+                    pending = None
+                    for _ in schedule:
+                        t0 = time.perf_counter()
+                        (_, i), db = next(stream)
+                        t1 = time.perf_counter()
+                        out = self.train_on_batch(db)
+                        self.host_times["wait_for_batch_s"] += t1 - t0      # the launch thread blocked on the prefetch queue
+                        self.host_times["launch_step_s"] += time.perf_counter() - t1
+                        self.host_times["steps"] += 1
+                        if pending is not None:            # step i-1's numbers are read once step i is queued behind it: the
+                            report(ep, *pending)           # host never waits for the step it has just launched
+                        pending = (i, out)
+                    if pending is not None:
+                        report(ep, *pending)
+                    gc.collect(0)                          # the young generation only (cheap): what this epoch's steps left behind
+                    history.append(float(np.mean(losses)))
+                    logs = {"loss": history[-1]}
+                    if val_gen is not None and len(val_info) >= cfg.BATCH_SIZE:
+                        # validation_data=val_generator, validation_steps=len(val_generator) (model.py:1053-1054): forward only, BN on
+                        # moving statistics, batch-mean of the total loss.  Every rank evaluates the same (small) set.
+                        vl = [self.evaluate_on_batch(val_gen[j][0])["loss"] for j in range(len(val_gen))]
+                        logs["val_loss"] = float(np.mean(vl))
+                        if verbose:
+                            print("epoch %d val_loss %.4f" % (ep + 1, logs["val_loss"]))
+                    self.history["loss"].append(logs["loss"])
+                    self.history["val_loss"].append(logs.get("val_loss", float("nan")))
+                    if self.model_dir and rank == 0:
+                        os.makedirs(self.model_dir, exist_ok=True)
+                        stamp = datetime.datetime.now().strftime('%b%d-%H-%M')
+                        self.save_weights(os.path.join(self.model_dir, 'saved_model_' + stamp + '.npz'))   # model.py:1026
+                    for cb in (custom_callbacks or []):
+                        (cb.on_epoch_end if hasattr(cb, "on_epoch_end") else cb)(ep, dict(logs))
+            for _ in stream:                               # (drains the prefetch thread: nothing is left when every epoch ran)
+                pass
+        finally:
+            prefetch.close()       # every way out (a failing step or callback, Ctrl-C): no thread is left staging into the engine's ring
+
         self.epoch = max(self.epoch, epochs)
         return history
 

@@ -1173,6 +1173,58 @@ def test_stage_batch_fill_equals_to_device_batch_of_getitem():
         assert torch.equal(a[k], b[k])
 
 
+def test_stage_batch_from_two_threads_never_shares_a_staging_set():
+    """train()'s prefetch thread and the main thread's validation batches go through Net.stage_batch at the same time.  Two threads
+    stage distinct batches in a loop, with slow fills (a sleep between the array writes: the window in which the ring used to hand the same
+    pinned set to the other thread): every device batch must hold exactly its own thread's data -- images and ids from one fill, never mixed --
+    and byte / float image buffers keep separate pinned allocations (no re-pinning when callers alternate)."""
+    import threading
+    import time
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=4)
+    net = MaskYOLO(mode="training", config=cfg, seed=0).net
+    errs, outs = [], {0: [], 1: []}
+
+    def worker(tid, n_iter):
+        try:
+            torch.cuda.set_device(0)
+            for it in range(n_iter):
+                tag = 10 * it + tid + 1                            # < 256: fits the byte images
+
+                def fill(arrays, tag=tag):
+                    arrays[0][...] = tag
+                    time.sleep(0.004)                              # another thread runs meanwhile
+                    for a in arrays[1:]:
+                        a[...] = tag % 2
+                    time.sleep(0.002)
+                    arrays[3][...] = tag
+                outs[tid].append((tag, net.stage_batch(fill, 4, u8_images=(tid == 0))))
+        except BaseException as e:
+            errs.append(e)
+    ths = [threading.Thread(target=worker, args=(t, 12)) for t in (0, 1)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    torch.cuda.synchronize()
+    for tid in (0, 1):
+        assert len(outs[tid]) == 12
+        for tag, d in outs[tid]:
+            want = np.float32(tag) / np.float32(255.0) if tid == 0 else np.float32(tag)
+            img = d["images"]
+            assert img.dtype == torch.float32 and bool((img == float(want)).all()), (tid, tag, img.unique())
+            assert bool((d["gt_ids"] == tag).all()) and bool((d["gt_masks"] == tag % 2).all())
+    kinds = set()
+    for st in net._stage:
+        assert not st["busy"].locked()
+        kinds |= {(k[0], str(k[2])) for k in st["bufs"]}
+    assert ("images", "torch.uint8") in kinds and ("images", "torch.float32") in kinds
+    pins = {id(b) for st in net._stage for b in st["bufs"].values()}
+    for tid in (0, 1):                                              # another round: no new pinned allocations
+        worker(tid, 3)
+    assert pins == {id(b) for st in net._stage for b in st["bufs"].values()}
+
+
 def test_step_result_is_lazy_and_train_equals_a_hand_loop():
     """train_on_batch returns a Mapping whose scalars come from one small async copy and whose tensors are fetched on demand;
     MaskYOLO.train (prefetch thread, pinned byte staging, results read one step late) produces the same weights and losses as

@@ -379,3 +379,37 @@ def test_batch_generator_fill_equals_getitem_and_byte_images():
     out = [np.zeros(ref[0].shape, np.float32), np.ones((4, T, 4), np.float32), np.ones(ref[2].shape, np.float32)]
     ygen.fill(0, out)
     assert np.array_equal(out[0], ref[0]) and np.array_equal(out[2], ref[2].astype(np.float32))
+
+
+def test_prefetcher_close_stops_a_blocked_thread_and_surfaces_errors():
+    """MaskYOLO.train()'s prefetch thread must not outlive a training loop that ends early (exception in a step or callback,
+    KeyboardInterrupt): close() unblocks a thread stuck in q.put(), drains what it had staged and joins it; errors of make() still reach
+    the consumer; a full run still delivers every item in order."""
+    import threading
+    import time
+    from myolo.model import _Prefetcher
+    made = []
+
+    def make(i):
+        made.append(i)
+        return i * i
+    p = _Prefetcher(range(100), make, None, depth=2)
+    it = iter(p)
+    assert next(it) == (0, 0) and next(it) == (1, 1)
+    time.sleep(0.2)                                  # the thread is now blocked on a full queue, far from the schedule's end
+    assert p._th.is_alive() and len(made) < 10
+    assert p.close() is True and not p._th.is_alive()
+    assert p._q.empty() and len(made) < 10
+    assert [x for x in _Prefetcher(range(7), make, None)] == [(i, i * i) for i in range(7)]
+
+    def bad(i):
+        if i == 3:
+            raise ValueError("boom")
+        return i
+    q = _Prefetcher(range(10), bad, None)
+    got = []
+    with pytest.raises(ValueError):
+        for item in q:
+            got.append(item)
+    assert got == [(0, 0), (1, 1), (2, 2)] and q.close()
+    assert not [t for t in threading.enumerate() if t.name == "myolo-batch-prefetch" and t.is_alive()]
