@@ -286,6 +286,16 @@ class Net(object):
         self.timed_tags = set()           # bench.py: kernel tags to bracket with HIP events
         self.timings = {}                 # tag -> [(start_event, end_event), ...]
         self.host_wait_s = 0.0            # wall time the host spent blocked on the n_pos copy (bench.py reports it per step)
+        # inference forwards: the weight-only preparations (bf16 packing + BatchNorm folding of the mask head, bf16x6 splits of the pointwise layers,
+        # Winograd filter transforms) are made ONCE per weight version and kept -- round 4 re-ran them in every forward (5 packs, ~17 splits, a filter
+        # transform: ~0.14 ms of a 3.7 ms Rice-416 batch) although the weights of an inference net are frozen.  `_wver` is bumped by load_state_dict,
+        # every optimizer step and every training forward (moving statistics); code that writes flat_p / flat_s directly calls mark_weights_changed().
+        self.infer_weight_cache = 1       # 0 = prepare inside every forward (round 4)
+        self._wver = 0
+        self._iprep = None                # X.WeightPrep of the inference path (arena owned by it)
+        self._iprep_state = (-1, -1)      # (weight version, registry entries) the arena + packs were last refreshed for
+        self._iprep_ev = None
+        self._bf16_packs = {}             # layer -> (packed bf16 weights, folded bias) of mask_head_fwd_bf16, refreshed with the arena
         self.load_state_dict(init_state_dict(cfg, seed))
 
     def _activate(self):
@@ -312,10 +322,16 @@ class Net(object):
                 continue
             v = np.asarray(v, np.float32).reshape(dst.shape)
             dst.copy_(torch.from_numpy(np.ascontiguousarray(v)))
+        self.mark_weights_changed()
         if strict:
             missing = [k for k in list(self.p) + list(self.s) if k not in sd]
             if missing:
                 raise KeyError("missing tensors: %s" % missing[:5])
+
+    def mark_weights_changed(self):
+        """tell the engine that parameters or moving statistics were written (load_state_dict, the optimizer and the training forward call this
+        themselves): the next inference forward re-makes its cached weight preparations (_infer_prep_sync) before it runs or replays a graph."""
+        self._wver += 1
 
     def grads_dict(self):
         self.join_conv1_wgrad()           # conv1's weight gradient may still be running on its side stream
@@ -1094,7 +1110,7 @@ class Net(object):
     def mask_head_fwd_bf16(self, Fm, fshape, rois):
         """Inference-only mask head with bf16 activations / fp32 accumulation (cfg.INFERENCE_DTYPE == "bf16").
         Same graph as mask_head_fwd(train=False) (model.py:680-714); the frozen BN of each conv is folded
-        into bf16 weights packed here from the live fp32 parameters (so training and load_weights need no hook)."""
+        into bf16 weights -- packed once per weight version into persistent buffers (_bf16_operand / _infer_prep_sync)."""
         cfg = self.cfg
         B, R = rois.shape[:2]
         n, h, w, cf = fshape
@@ -1111,19 +1127,12 @@ class Net(object):
                          n, h, w, cf, NR, ps, ps, X.stream())
         cin = cf
         for i in range(1, 5):
-            cn, bn = "myolo_mask_conv%d" % i, "myolo_mask_bn%d" % i
-            wt = self._new(MASK_FILTERS, 9 * cin, dtype=bf)
-            bfold = self._new(MASK_FILTERS)
-            X.call("myolo_pack_weights_bf16", X.ptr(self.p[cn + "/kernel"]), 9 * cin, MASK_FILTERS, 0, X.ptr(self.p[cn + "/bias"]),
-                   X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(self.s[bn + "/moving_mean"]),
-                   X.ptr(self.s[bn + "/moving_variance"]), X.ptr(wt), X.ptr(bfold), X.stream())
+            wt, bfold = self._bf16_operand(i, cin)
             y = self._new(NR * ps * ps, MASK_FILTERS, dtype=bf)
             self._call_timed("mask_conv3x3_fwd", "myolo_conv3x3_bf16_fwd", X.ptr(x), X.ptr(wt), X.ptr(bfold), X.ptr(y),
                              NR, ps, ps, cin, MASK_FILTERS, ACT_RELU, X.stream())
             x, cin = y, MASK_FILTERS
-        wt = self._new(4 * MASK_FILTERS, MASK_FILTERS, dtype=bf)
-        X.call("myolo_pack_weights_bf16", X.ptr(self.p["myolo_mask_deconv/kernel"]), MASK_FILTERS, 4 * MASK_FILTERS, 1, None,
-               None, None, None, None, X.ptr(wt), None, X.stream())
+        wt, _ = self._bf16_operand("deconv", MASK_FILTERS)
         C = cfg.NUM_CLASSES
         p = self._new(NR * 4 * ps * ps, C)
         if C <= 4 and MASK_FILTERS % 128 == 0:       # deconv + ReLU + 1x1 + sigmoid fused: the 28x28x256 tensor is never written
@@ -1729,6 +1738,7 @@ class Net(object):
 
     def _forward_backward(self, db):
         self._activate()
+        self.mark_weights_changed()           # (the BatchNorm moving statistics move in every training forward)
         self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
@@ -1867,6 +1877,7 @@ class Net(object):
         """'yolo' mode training step (model.py:906-920: outputs [yolo_output, yolo_sum_loss]): backbone + YOLO head
         + yolo_custom_loss, no feature_map / ROIAlign / mask head.  db needs images, true_boxes, y_true."""
         self._activate()
+        self.mark_weights_changed()
         self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
@@ -1899,59 +1910,135 @@ class Net(object):
         lr_t = float(lr * np.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t))
         X.call("myolo_adam_step", X.ptr(self.flat_p), X.ptr(self.flat_g), X.ptr(self.flat_m), X.ptr(self.flat_v),
                self.nparam, lr_t, b1, b2, eps, float(self.grad_scale), X.stream())
+        self.mark_weights_changed()
 
     def train_step(self, db, lr):
         out = self.forward_backward(db)
         self.adam_step(lr)
         return out
 
+    def _pack_bf16(self, key):
+        """(re)make one cached bf16 operand of mask_head_fwd_bf16 in its persistent buffers: conv i = kernel with the frozen BatchNorm folded + bias;
+        'deconv' = the transposed-conv kernel in its GEMM layout."""
+        wt, bfold = self._bf16_packs[key]
+        if key == "deconv":
+            X.call("myolo_pack_weights_bf16", X.ptr(self.p["myolo_mask_deconv/kernel"]), MASK_FILTERS, 4 * MASK_FILTERS, 1, None,
+                   None, None, None, None, X.ptr(wt), None, X.stream())
+            return
+        cn, bn = "myolo_mask_conv%d" % key, "myolo_mask_bn%d" % key
+        X.call("myolo_pack_weights_bf16", X.ptr(self.p[cn + "/kernel"]), wt.shape[1], MASK_FILTERS, 0, X.ptr(self.p[cn + "/bias"]),
+               X.ptr(self.p[bn + "/gamma"]), X.ptr(self.p[bn + "/beta"]), X.ptr(self.s[bn + "/moving_mean"]),
+               X.ptr(self.s[bn + "/moving_variance"]), X.ptr(wt), X.ptr(bfold), X.stream())
+
+    def _bf16_operand(self, key, cin):
+        """-> (packed bf16 weights, folded bias or None) for conv `key` (1..4) / 'deconv': from the cache (made once per weight version), or packed
+        here into fresh tensors when the cache is off."""
+        bf = torch.bfloat16
+        shape = (4 * MASK_FILTERS, MASK_FILTERS) if key == "deconv" else (MASK_FILTERS, 9 * cin)
+        if not self.infer_weight_cache:
+            self._bf16_packs[key] = (self._new(*shape, dtype=bf), None if key == "deconv" else self._new(MASK_FILTERS))
+            self._pack_bf16(key)
+            return self._bf16_packs.pop(key)
+        ent = self._bf16_packs.get(key)
+        if ent is None or tuple(ent[0].shape) != shape:
+            # first use (never while a graph is being captured: _capture_predict's warm-up forwards come first)
+            self._bf16_packs[key] = (self._new(*shape, dtype=bf), None if key == "deconv" else self._new(MASK_FILTERS))
+            self._pack_bf16(key)
+        return self._bf16_packs[key]
+
+    def _infer_prep_sync(self):
+        """Bring the inference path's cached weight preparations up to the current weight version on the current stream (no-op when they are),
+        and order the current stream behind the last refresh.  Called by every eager inference forward and before every graph replay; never
+        launches anything while a graph is being captured (the capture's warm-up forwards have refreshed everything)."""
+        if not self.infer_weight_cache:
+            return
+        if self._iprep is None:
+            self._iprep = X.WeightPrep(self.dev, arena_bytes=256 << 20)
+        ip = self._iprep
+        state = (self._wver, ip.count())
+        cur = torch.cuda.current_stream()
+        if state != self._iprep_state and not torch.cuda.is_current_stream_capturing():
+            if state[0] != self._iprep_state[0]:
+                # the weights changed: forwards of other lanes may still be reading the arena / the packs
+                torch.cuda.synchronize(self.dev)
+                ip.invalidate()
+            ip.refresh(0, 1 << 30, max_idle=0)
+            for key in list(self._bf16_packs):
+                self._pack_bf16(key)
+            self._iprep_state = state
+            self._iprep_ev = torch.cuda.Event()
+            self._iprep_ev.record(cur)
+        elif self._iprep_ev is not None and not torch.cuda.is_current_stream_capturing():
+            cur.wait_event(self._iprep_ev)
+
+    class _InferPrep(object):
+        """with net._infer_prep(): the inference registry is the library's active one (sites resolve their prepared weights from its arena)."""
+
+        def __init__(self, net):
+            self.net = net
+
+        def __enter__(self):
+            self.net._infer_prep_sync()
+            if self.net._iprep is not None and self.net.infer_weight_cache:
+                self.net._iprep.activate(True)
+
+        def __exit__(self, *exc):
+            if self.net._iprep is not None:
+                self.net._iprep.activate(False)
+
+    def _infer_prep(self):
+        return Net._InferPrep(self)
+
     def predict(self, images):
         """inference graph (model.py:922-936): -> yolo_output, detections [B,R,6], myolo_mask."""
-        self._activate()
-        cfg = self.cfg
-        self.tape = {}
-        B = images.shape[0]
-        G, A, C = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES
-        R = G * G * A
-        mh, mw = cfg.MASK_SHAPE
-        Fm, fshape, yo = self.trunk_fwd(images, False)
-        det = self._new(B, R, 6)
-        X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
-        rois = det[..., :4].contiguous()
-        if cfg.INFERENCE_DTYPE == "bf16":
-            pred = self.mask_head_fwd_bf16(Fm, fshape, rois)
-        elif cfg.INFERENCE_DTYPE == "fp32":
-            pred = self.mask_head_fwd(Fm, fshape, rois, False)
-        else:
-            raise ValueError("INFERENCE_DTYPE must be 'fp32' or 'bf16' (got %r)" % (cfg.INFERENCE_DTYPE,))
-        self.tape = {}
-        return yo.view(B, G, G, A, 5 + C), det, pred.view(B, R, mh, mw, C)
+        with self._infer_prep():
+            self._activate()
+            cfg = self.cfg
+            self.tape = {}
+            B = images.shape[0]
+            G, A, C = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES
+            R = G * G * A
+            mh, mw = cfg.MASK_SHAPE
+            Fm, fshape, yo = self.trunk_fwd(images, False)
+            det = self._new(B, R, 6)
+            X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
+            rois = det[..., :4].contiguous()
+            if cfg.INFERENCE_DTYPE == "bf16":
+                pred = self.mask_head_fwd_bf16(Fm, fshape, rois)
+            elif cfg.INFERENCE_DTYPE == "fp32":
+                pred = self.mask_head_fwd(Fm, fshape, rois, False)
+            else:
+                raise ValueError("INFERENCE_DTYPE must be 'fp32' or 'bf16' (got %r)" % (cfg.INFERENCE_DTYPE,))
+            self.tape = {}
+            return yo.view(B, G, G, A, 5 + C), det, pred.view(B, R, mh, mw, C)
 
     def predict_detections(self, images):
         """first half of the inference graph: -> yolo_output, detections [B,R,6], and the feature map the mask head reads."""
-        self._activate()
-        cfg = self.cfg
-        self.tape = {}
-        B = images.shape[0]
-        G, A, C = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES
-        Fm, fshape, yo = self.trunk_fwd(images, False)
-        det = self._new(B, G * G * A, 6)
-        X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
-        self.tape = {}
-        return yo.view(B, G, G, A, 5 + C), det, (Fm, fshape)
+        with self._infer_prep():
+            self._activate()
+            cfg = self.cfg
+            self.tape = {}
+            B = images.shape[0]
+            G, A, C = cfg.GRID_W, cfg.N_BOX, cfg.NUM_CLASSES
+            Fm, fshape, yo = self.trunk_fwd(images, False)
+            det = self._new(B, G * G * A, 6)
+            X.call("myolo_yolo_detections", X.ptr(yo), X.ptr(self.anchors), X.ptr(det), B, G, A, C, X.stream())
+            self.tape = {}
+            return yo.view(B, G, G, A, 5 + C), det, (Fm, fshape)
 
     def predict_masks(self, feature, rois):
         """second half for a chosen subset of boxes: rois [B, n, 4] (the first four detection columns) -> [B, n, mh, mw, C]."""
-        self._activate()
-        cfg = self.cfg
-        Fm, fshape = feature
-        self.tape = {}
-        B, n = rois.shape[:2]
-        mh, mw = cfg.MASK_SHAPE
-        rois = rois.contiguous()
-        pred = self.mask_head_fwd_bf16(Fm, fshape, rois) if cfg.INFERENCE_DTYPE == "bf16" else self.mask_head_fwd(Fm, fshape, rois, False)
-        self.tape = {}
-        return pred.view(B, n, mh, mw, cfg.NUM_CLASSES)
+        with self._infer_prep():
+            self._activate()
+            cfg = self.cfg
+            Fm, fshape = feature
+            self.tape = {}
+            B, n = rois.shape[:2]
+            mh, mw = cfg.MASK_SHAPE
+            rois = rois.contiguous()
+            pred = self.mask_head_fwd_bf16(Fm, fshape, rois) if cfg.INFERENCE_DTYPE == "bf16" else self.mask_head_fwd(Fm, fshape, rois, False)
+            self.tape = {}
+            return pred.view(B, n, mh, mw, cfg.NUM_CLASSES)
 
     def _lane_state(self, lane):
         """Everything a forward WRITES outside the allocator (scratch buffer, frozen-BatchNorm coefficient buffers), once per lane of
@@ -1999,6 +2086,7 @@ class Net(object):
                 if saved is not None:
                     self._ws_main, self._ws_active, self.bnbuf, self._fz_coeffs = saved
         graph, static_in, outs = ent
+        self._infer_prep_sync()                  # the graph reads the cached weight preparations: re-made here (eagerly) when the weights changed
         static_in.copy_(images)
         graph.replay()
         return outs
@@ -2071,9 +2159,10 @@ class Net(object):
 
     def predict_yolo(self, images):
         """'yolo' mode forward (model.py:906-920)."""
-        self._activate()
-        self.tape = {}
-        cfg = self.cfg
-        _, _, yo = self.trunk_fwd(images, False)
-        self.tape = {}
-        return yo.view(images.shape[0], cfg.GRID_H, cfg.GRID_W, cfg.N_BOX, 5 + cfg.NUM_CLASSES)
+        with self._infer_prep():
+            self._activate()
+            self.tape = {}
+            cfg = self.cfg
+            _, _, yo = self.trunk_fwd(images, False)
+            self.tape = {}
+            return yo.view(images.shape[0], cfg.GRID_H, cfg.GRID_W, cfg.N_BOX, 5 + cfg.NUM_CLASSES)

@@ -717,10 +717,67 @@ def test_inference_hip_graph_replay_equals_eager_and_sees_weight_updates():
     for it in range(3):
         x = torch.as_tensor(rng.random((2, 128, 128, 3), dtype=np.float32), device=net.dev)
         if it == 2:
-            net.flat_p.mul_(1.01)                   # weights change between replays
+            net.flat_p.mul_(1.01)                   # weights change between replays: written directly, so the engine is told
+            net.mark_weights_changed()
         g = [t.clone() for t in net.predict_graphed(x)]
         e = net.predict(x)
         assert all(torch.equal(a, b) for a, b in zip(g, e)), "graph replay differs from eager at iteration %d" % it
+    assert len(net._graphs) == 1
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_inference_weight_preparations_are_cached_per_weight_version(dtype):
+    """the inference forward re-packed / BatchNorm-folded the bf16 mask-head weights, re-split the pointwise weights and
+    re-transformed the Winograd filters in EVERY call.  Now once per weight version: the registry's hit counter moves and its miss counter
+    does not on the second forward; results are bit-identical with the cache off; load_state_dict, an optimizer step and
+    mark_weights_changed() each invalidate (the next forward equals a fresh uncached one); a captured graph holds no preparation launch
+    and still sees new weights."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=1.0, BATCH_SIZE=2, INFERENCE_DTYPE=dtype)
+    P = np_model.init_params(cfg, seed=4, bias_scale=0.05)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+    rng = np.random.default_rng(2)
+    x = torch.as_tensor(rng.random((2, 128, 128, 3), dtype=np.float32), device=net.dev)
+
+    def uncached():
+        net.infer_weight_cache = 0
+        try:
+            return [t.clone() for t in net.predict(x)]
+        finally:
+            net.infer_weight_cache = 1
+    ref = uncached()
+    a = [t.clone() for t in net.predict(x)]            # records the sites (misses), packs the bf16 operands
+    s1 = net._iprep.stats()
+    b = [t.clone() for t in net.predict(x)]            # refreshed: every site hits
+    s2 = net._iprep.stats()
+    # (bf16 at this size: the trunk's layers are below the sizes that use prepared operands -- the cache is then the five packed bf16 operands)
+    assert (s1["entries"] > 0 or dtype == "bf16") and s2["entries"] == s1["entries"]
+    assert s2["misses"] == s1["misses"] and s2["hits"] >= s1["hits"] + s1["entries"]
+    assert all(torch.equal(u, v) and torch.equal(u, w) for u, v, w in zip(ref, a, b))
+    if dtype == "bf16":
+        assert set(net._bf16_packs) == {1, 2, 3, 4, "deconv"}
+        ptrs = {k: v[0].data_ptr() for k, v in net._bf16_packs.items()}
+    g0 = [t.clone() for t in net.predict_graphed(x)]
+    assert all(torch.equal(u, v) for u, v in zip(ref, g0))
+    # three ways the weights change
+    P2 = {k: (v * 1.02).astype(np.float32) for k, v in P.items()}
+    for how in ("load_state_dict", "mark", "adam"):
+        if how == "load_state_dict":
+            model.load_state_dict(P2)
+        elif how == "mark":
+            net.flat_p.mul_(0.99)
+            net.mark_weights_changed()
+        else:
+            net.flat_g.fill_(1e-3)
+            net.adam_step(1e-3)
+        got_g = [t.clone() for t in net.predict_graphed(x)]
+        got_e = [t.clone() for t in net.predict(x)]
+        want = uncached()
+        assert all(torch.equal(u, v) and torch.equal(u, w) for u, v, w in zip(want, got_g, got_e)), how
+        assert not all(torch.equal(u, v) for u, v in zip(want, ref)), how
+    if dtype == "bf16":
+        assert ptrs == {k: v[0].data_ptr() for k, v in net._bf16_packs.items()}       # persistent buffers: the graph reads them
     assert len(net._graphs) == 1
 
 
@@ -739,6 +796,7 @@ def test_predict_stream_matches_predict(in_flight, dtype):
     for rnd in range(2):
         if rnd == 1:
             net.flat_p.mul_(1.01)
+            net.mark_weights_changed()
         want = [[t.clone() for t in net.predict(x)] for x in xs]
         got = []
         for outs in net.predict_stream(iter(xs), in_flight=in_flight):
