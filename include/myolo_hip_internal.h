@@ -132,6 +132,22 @@ int myolo_wino_output_input_transform(const float* M, const float* bias, const f
 int myolo_wino_output_input_transform_keep_pre(const float* M, const float* bias, const float* scale, const float* shift, float* ypre,
                                                const int32_t* flags, float* V_next, int N, int H, int W, int C, int act, void* stream);
 
+/* ---- trunk backward: BatchNorm-backward sums from the producer of the BatchNorm's output gradient (csrc/mem_kernels.hip) ---- */
+/* The same data gradient when dx is the gradient reaching a TRAINING-mode BatchNorm + activation (the conv_pw_{b-1}_bn / conv1_bn in front of this
+ * depthwise conv, model.py:51,68-77): xbn = that BatchNorm's pre-BN tensor [N,H,W,C], scale / shift / mean / var = its forward coefficients.  The
+ * kernel also leaves the BatchNorm backward's sums (sum dz, sum dz * xhat) as `rows` rows of [2][C] double partials in `part`;
+ * myolo_bn_act_bwd_from_partials finishes them (fixed order) and forms the BatchNorm's dx -- the pass over (dx, xbn) myolo_bn_act_bwd starts with
+ * is gone.  rows = myolo_dwconv3x3_bwd_data_bnsums_rows(...); 0 = not available for these sizes (use the two plain calls). */
+int myolo_dwconv3x3_bwd_data_bnsums_rows(int N, int H, int W, int C, int stride);
+int myolo_dwconv3x3_bwd_data_bnsums(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, const float* xbn,
+                                    const float* scale, const float* shift, const float* mean, const float* var, int act, double* part, int rows,
+                                    void* stream);
+/* myolo_bn_act_bwd(batch_stats = 1) from sums a producer already left as nblk rows of [2][C] double partials (myolo_dwconv3x3_bwd_data_bnsums):
+ * finish in row order -> dgamma, dbeta; then dx.  ws: 2 * C doubles. */
+int myolo_bn_act_bwd_from_partials(const float* dy, const float* x, const float* mean, const float* var, const float* scale, const float* shift,
+                                   float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act, const double* part, int nblk,
+                                   void* ws, size_t ws_bytes, void* stream);
+
 /* ---- F(6,3)/F(4,3) tiling of 14x14 maps: buffer sizes and stages (csrc/wino63_kernels.hip) ---- */
 size_t myolo_wino63_plane_elems(int N, int C);
 size_t myolo_wino63_u_elems(int Cin, int Cout);

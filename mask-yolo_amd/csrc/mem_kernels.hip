@@ -1076,7 +1076,11 @@ struct DwAffine { const float* scale; const float* shift; int act; };   // scale
 // activation, done on the load of its pre-BN output (zero padding stays zero) -- the normalised tensor is never written;
 // `stat` != nullptr: per-workgroup partial sums (sum, sum of squares) of THIS conv's output per channel, [workgroup][2][C] doubles,
 // finished by colreduce_finish<FinBnStats> -- the statistics pass over the output disappears.  Needs 256 % (C/4) == 0.
-struct DwFuse { DwAffine in; double* stat; };
+// `bw.x` != nullptr (data-gradient use, MODE 3): the conv's OUTPUT is the gradient reaching a training-mode BatchNorm + activation whose pre-BN tensor is
+// bw.x (same shape as the output): the partial sums of that BatchNorm's backward -- sum dz, sum dz * xhat, dz = out * actmask(x * scale + shift) --
+// leave in bw.part [workgroup][2][C] doubles, finished by colreduce_finish<FinBnBwd>: colreduce_kernel<OpBnBwd>'s pass over (dy, x) disappears.
+struct DwBnBwd { const float* x; const float* scale; const float* shift; const float* mean; const float* var; int act; double* part; };
+struct DwFuse { DwAffine in; double* stat; DwBnBwd bw; };
 
 template <int S, int TW, int TH>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -1279,7 +1283,8 @@ __device__ __forceinline__ dw_f4p dw_affine_pk(dw_f4p v, dw_f4p sc, dw_f4p sh, f
 // so there is no branch around a load (a load inside an exec-masked branch makes hipcc wait vmcnt(0) at every use: an earlier form drained
 // its prefetch queue once per row).
 // MODE 0: plain; 1: the producing layer's BatchNorm + activation on load, statistics of the output when fu.stat; 2: folded frozen
-// BatchNorm + activation on the way out (inference).
+// BatchNorm + activation on the way out (inference); 3 (stride 1, the data gradient): plain + the BatchNorm-backward sums of the output against
+// fu.bw.x (see DwBnBwd) -- the pre-BN row of an output row is requested PF rows ahead, like the input rows.
 template <int S, int CQB, int MODE, bool R6>
 __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                          int H, int W, int C, int Ho, int Wo, int strips, int chunks, int rc, int ncb,
@@ -1355,6 +1360,20 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
     const unsigned off0 = (colin && !(flags & 2)) ? (unsigned)(col * C + c) * 4u : DW_OOB;
     const unsigned off1 = col2in ? off0 + (unsigned)C * 4u : DW_OOB;
     const int rstride = W * C * 4;                 // bytes; a row index outside [0, H) drives the offset out of the descriptor's range
+    // MODE 3: per-channel terms of the BatchNorm whose backward sums are formed, and the queue of its pre-BN rows (step r emits output row y0 + r - 2)
+    dw_f4p bsc = dw_zero(), bsh = dw_zero(), bmu = dw_zero(), brs = dw_zero();
+    float blo = -INFINITY, bhi = INFINITY;
+    float4 yq[PF];
+    __amdgpu_buffer_rsrc_t rq = ry;
+    if (MODE == 3) {
+        static_assert(MODE != 3 || S == 1, "the fused BatchNorm-backward sums exist for the stride-1 row kernel");
+        bsc = dw_pk(ld4g(fu.bw.scale + c)); bsh = dw_pk(ld4g(fu.bw.shift + c)); bmu = dw_pk(ld4g(fu.bw.mean + c));
+        const float4 vr = ld4g(fu.bw.var + c);
+        brs = dw_pk(make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F)));
+        blo = fu.bw.act == MYOLO_ACT_NONE ? -INFINITY : 0.f;
+        bhi = fu.bw.act == MYOLO_ACT_RELU6 ? 6.f : INFINITY;
+        rq = __builtin_amdgcn_make_buffer_rsrc((void*)(fu.bw.x + (long long)n * Ho * Wo * C), 0, Ho * Wo * C * 4, 0x00020000);
+    }
     float4 pf[PF][NL];
     auto fetch = [&](int r, float4* dst) {
         const int iy = row0 + r;
@@ -1368,21 +1387,47 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
     dw_f4p a1 = dw_zero(), a2 = dw_zero();          // S=1: outputs iy / iy-1 in the making; S=2: a1 = current output row
     dw_f4p s1 = dw_zero(), s2 = dw_zero();
     const unsigned yoff = (live && !(flags & 4)) ? (unsigned)(ox * C + c) * 4u : DW_OOB;
+    const unsigned qoff = live ? (unsigned)(ox * C + c) * 4u : DW_OOB;
     const int ystride = Wo * C * 4;
+    auto fetchq = [&](int r, float4& dst) {         // pre-BN row of the output row that step r emits (rows outside this chunk: out of range, zeros)
+        const int oy = y0 + r - 2;
+        const bool ok = r >= 2 && oy < y1;          // uniform
+        dst = dw_bufld(rq, qoff + (ok ? (unsigned)(oy * ystride) : DW_OOB));
+    };
+    if (MODE == 3) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) fetchq(2 + j, yq[j]);
+    }
+    dw_f4p qv = dw_zero();                          // MODE 3: the pre-BN values of the row being emitted
     auto emit = [&](dw_f4p o, int oy) {             // (only called for rows that exist: y0 <= oy < y1; dead lanes are zeroed out of the sums at the end)
         if (MODE == 1) {
             s1.lo += o.lo; s1.hi += o.hi;
             s2 = dw_fma(o, o, s2);
+        }
+        if (MODE == 3) {
+            // dz = out * actmask(x * scale + shift); xhat = (x - mean) * rstd  (OpBnBwd's expressions)
+            const dw_f4p z = dw_fma(qv, bsc, bsh);
+            dw_f4p dz;
+            dz.lo.x = (z.lo.x > blo && z.lo.x < bhi) ? o.lo.x : 0.f; dz.lo.y = (z.lo.y > blo && z.lo.y < bhi) ? o.lo.y : 0.f;
+            dz.hi.x = (z.hi.x > blo && z.hi.x < bhi) ? o.hi.x : 0.f; dz.hi.y = (z.hi.y > blo && z.hi.y < bhi) ? o.hi.y : 0.f;
+            dw_f4p xh;
+            xh.lo = (qv.lo - bmu.lo) * brs.lo; xh.hi = (qv.hi - bmu.hi) * brs.hi;
+            s1.lo += dz.lo; s1.hi += dz.hi;
+            s2 = dw_fma(dz, xh, s2);
         }
         if (MODE == 2) o = dw_affine_pk<R6>(o, sc0, sh0, lo, hi);
         dw_bufst(ry, yoff + (unsigned)(oy * ystride), dw_unpk(o));
     };
     // one input row: value(s) -> (input map) -> LDS -> barrier -> neighbours; PEEL = 0: an ordinary row; 1 / 2: the first / second row of the
     // chunk, which only open accumulators (S=2: only 1 exists)
-    auto row = [&](int r, float4* cur, auto peel) {
+    auto row = [&](int r, float4* cur, auto peel, float4* qcur = nullptr) {
         constexpr int PEEL = decltype(peel)::value;
         dw_f4p v0 = dw_pk(cur[0]), v1 = dw_pk(cur[NL - 1]);
         fetch(r + PF, cur);
+        if (MODE == 3 && PEEL == 0) {
+            qv = dw_pk(*qcur);
+            fetchq(r + PF, *qcur);
+        }
         const int iy = row0 + r;
         if (MODE == 1) {
             if (iy >= 0 && iy < H) {                // uniform; a row outside the image stays zero (the load returned zeros)
@@ -1426,10 +1471,10 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < UN; ++j) {
             const int r = it + j;
-            if (r < nrows) row(r, pf[(NPEEL + j) % PF], std::integral_constant<int, 0>{});       // uniform
+            if (r < nrows) row(r, pf[(NPEEL + j) % PF], std::integral_constant<int, 0>{}, &yq[j % PF]);       // uniform
         }
     }
-    if (MODE == 1 && fu.stat) {
+    if ((MODE == 1 && fu.stat) || MODE == 3) {
         // reduction over the PX threads that share a channel quad, in double; this workgroup's slice of partial row (n, strip, chunk)
         const long long blk = ((long long)n * strips + sx) * chunks + ch;
         if (!live) { s1 = dw_zero(); s2 = dw_zero(); }
@@ -1444,7 +1489,7 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
                     const float4 tt = red[j * CQB + tid];
                     d0 += tt.x; d1 += tt.y; d2 += tt.z; d3 += tt.w;
                 }
-                double* o = fu.stat + (blk * 2 + v) * C + (cb * CQB + tid) * 4;
+                double* o = (MODE == 3 ? fu.bw.part : fu.stat) + (blk * 2 + v) * C + (cb * CQB + tid) * 4;
                 o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
             }
         }
@@ -1607,7 +1652,8 @@ static void dw_rows_launch(const DwRowsGeom& g, const float* x, const float* w, 
     const unsigned xcd = (g.tiles % 8 == 0 && g.tiles >= 64 && !(g_myolo_opt.tune0 & 8)) ? (unsigned)(g.tiles / 8) : 0u;
     const int flags = ((g_myolo_opt.tune0 & 16) ? 2 : 0) | ((g_myolo_opt.tune0 & 32) ? 4 : 0) | (flip ? 8 : 0);      // 2 / 4: timing-only ablations (no loads / no stores)
 #define DW_ROWS_GO(MODE, R6) hipLaunchKernelGGL((dw_rows_kernel<S, CQB, MODE, R6>), dim3((unsigned)g.tiles), dim3(256), 0, s, x, w, y, H, W, C, H / S, W / S, g.strips, g.chunks, g.rc, g.ncb, xcd, flags, af, fu)
-    if (fu.in.scale || fu.stat) { if (fu.in.scale && fu.in.act == MYOLO_ACT_RELU6) DW_ROWS_GO(1, true); else DW_ROWS_GO(1, false); }
+    if (fu.bw.x) { if constexpr (S == 1) DW_ROWS_GO(3, false); }
+    else if (fu.in.scale || fu.stat) { if (fu.in.scale && fu.in.act == MYOLO_ACT_RELU6) DW_ROWS_GO(1, true); else DW_ROWS_GO(1, false); }
     else if (af.scale) { if (af.act == MYOLO_ACT_RELU6) DW_ROWS_GO(2, true); else DW_ROWS_GO(2, false); }
     else DW_ROWS_GO(0, false);
 #undef DW_ROWS_GO
@@ -1646,12 +1692,17 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 
 // stride 2, even H and W (padding 0 before / 1 after, as TF SAME gives): the thread of output-gradient pixel (r, q) writes the 2 x 2 block of dx at
 // (2r.., 2q..) from dy[r-1..r][q-1..q] -- one 16-byte load per store instead of 2.25 with a branch ladder (dw_bwd_data_kernel<2>: 2.0 TB/s).
+template <bool BW>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
-                                                             int Ho, int Wo, int C, long long total)
+                                                             int Ho, int Wo, int C, long long total, DwBnBwd bw)
 {
+    __shared__ float4 red[256];
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= total) return;
+    const bool in = e < total;
+    if (!BW && !in) return;
     const int cq = C >> 2;
+    float4 s1 = f4zero(), s2 = f4zero();
+    if (in) {
     const unsigned eu = (unsigned)(e % ((long long)Wo * cq));
     const long long row = e / ((long long)Wo * cq);            // n * Ho + r
     const int q = eu / (unsigned)cq, c = (eu - q * cq) * 4;
@@ -1666,12 +1717,52 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 9; ++k) wk[k] = ld4g(w + k * C + c);
     const int W = 2 * Wo;
-    float* o = dx + ((row * 2) * W + 2 * q) * (long long)C + c;
+    const long long o0 = ((row * 2) * W + 2 * q) * (long long)C + c;
+    float* o = dx + o0;
     // same order of accumulation as dw_bwd_data_kernel<2> (ky = 0, 1, 2; kx = 0, 1, 2): bit-identical results
-    st4g(o, f4fma(g00, wk[8], f4fma(g01, wk[6], f4fma(g10, wk[2], f4fma(g11, wk[0], z)))));
-    st4g(o + C, f4fma(g01, wk[7], f4fma(g11, wk[1], z)));
-    st4g(o + (long long)W * C, f4fma(g10, wk[5], f4fma(g11, wk[3], z)));
-    st4g(o + (long long)W * C + C, f4fma(g11, wk[4], z));
+    const float4 d00 = f4fma(g00, wk[8], f4fma(g01, wk[6], f4fma(g10, wk[2], f4fma(g11, wk[0], z))));
+    const float4 d01 = f4fma(g01, wk[7], f4fma(g11, wk[1], z));
+    const float4 d10 = f4fma(g10, wk[5], f4fma(g11, wk[3], z));
+    const float4 d11 = f4fma(g11, wk[4], z);
+    st4g(o, d00);
+    st4g(o + C, d01);
+    st4g(o + (long long)W * C, d10);
+    st4g(o + (long long)W * C + C, d11);
+    if (BW) {
+        // the 2 x 2 block of dx is the gradient reaching a training-mode BatchNorm whose pre-BN tensor is bw.x (DwBnBwd): its backward sums
+        const float4 sc = ld4g(bw.scale + c), sh = ld4g(bw.shift + c), mu = ld4g(bw.mean + c), vr = ld4g(bw.var + c);
+        const float4 rs = make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F));
+        const float* xq = bw.x + o0;
+        const float4 x00 = ld4g(xq), x01 = ld4g(xq + C), x10 = ld4g(xq + (long long)W * C), x11 = ld4g(xq + (long long)W * C + C);
+        auto add = [&](float4 g, float4 v) {
+            float dz, xh;
+            dz = g.x * actmask(fmaf(v.x, sc.x, sh.x), bw.act); xh = (v.x - mu.x) * rs.x; s1.x += dz; s2.x = fmaf(dz, xh, s2.x);
+            dz = g.y * actmask(fmaf(v.y, sc.y, sh.y), bw.act); xh = (v.y - mu.y) * rs.y; s1.y += dz; s2.y = fmaf(dz, xh, s2.y);
+            dz = g.z * actmask(fmaf(v.z, sc.z, sh.z), bw.act); xh = (v.z - mu.z) * rs.z; s1.z += dz; s2.z = fmaf(dz, xh, s2.z);
+            dz = g.w * actmask(fmaf(v.w, sc.w, sh.w), bw.act); xh = (v.w - mu.w) * rs.w; s1.w += dz; s2.w = fmaf(dz, xh, s2.w);
+        };
+        add(d00, x00); add(d01, x01); add(d10, x10); add(d11, x11);
+    }
+    }
+    if (BW) {
+        // 256 consecutive elements = 256 / cq pixels x cq channel quads (256 % cq == 0, checked by the launcher): thread t's quad is t % cq
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            __syncthreads();
+            red[tid] = v == 0 ? s1 : s2;
+            __syncthreads();
+            if (tid < cq) {
+                double d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+                for (int j = tid; j < 256; j += cq) {
+                    const float4 tt = red[j];
+                    d0 += tt.x; d1 += tt.y; d2 += tt.z; d3 += tt.w;
+                }
+                double* o = bw.part + ((long long)blockIdx.x * 2 + v) * C + tid * 4;
+                o[0] = d0; o[1] = d1; o[2] = d2; o[3] = d3;
+            }
+        }
+    }
 }
 
 // dw[k][c] = sum over output pixels of x[shifted] * dy
@@ -3333,7 +3424,62 @@ int myolo_dwconv3x3_bnstats_fwd(const float* x, const float* in_scale, const flo
     return MYOLO_OK;
 }
 
+/* rows of [2][C] double partial sums myolo_dwconv3x3_bwd_data_bnsums leaves for these sizes; 0 = that entry point does not apply (the caller
+ * then uses myolo_dwconv3x3_bwd_data + myolo_bn_act_bwd) */
+int myolo_dwconv3x3_bwd_data_bnsums_rows(int N, int H, int W, int C, int stride)
+{
+    if (N <= 0 || (C & 3) || g_myolo_opt.dw_bwd_legacy || (g_myolo_opt.tune0 & 262144)) return 0;
+    if (stride == 1) return dw_rows_ok(H, W, C) ? dw_rows_geom(N, H, W, C, 1).nblk : 0;
+    if (stride != 2 || (H & 1) || (W & 1)) return 0;
+    const int cq = C / 4;
+    const long long total = (long long)N * (H / 2) * (W / 2) * cq;
+    if (cq > 256 || (256 % cq) != 0 || total >= (1ll << 31) * 256) return 0;
+    // 256-thread workgroups over the dy elements; with cq > 64 a workgroup covers 256 / cq < 4 pixels: that many rows of partials would outweigh
+    // the pass they replace -- only the thin layers (conv_dw_2, conv_dw_4) qualify
+    if (cq > 64) return 0;
+    return (int)((total + 255) / 256);
+}
+
+static int dw_bwd_data_impl(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, DwBnBwd bw, void* stream);
+
 int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, void* stream)
+{
+    return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, DwBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr}, stream);
+}
+
+/* myolo_dwconv3x3_bwd_data whose output dx is the gradient reaching a training-mode BatchNorm (+ activation) with pre-BN tensor xbn [N,H,W,C] and the
+ * coefficients of its forward: the data-gradient kernel also leaves that BatchNorm's backward sums as `rows` x [2][C] double partials in part
+ * (rows = myolo_dwconv3x3_bwd_data_bnsums_rows(...) > 0), to be finished by myolo_bn_act_bwd_from_partials -- the separate pass over (dx, xbn) that
+ * myolo_bn_act_bwd starts with disappears (model.py:51 / 68-77 backward). */
+int myolo_dwconv3x3_bwd_data_bnsums(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, const float* xbn,
+                                    const float* scale, const float* shift, const float* mean, const float* var, int act, double* part, int rows,
+                                    void* stream)
+{
+    MYOLO_REQUIRE(xbn && scale && shift && mean && var && part, "dwconv3x3_bwd_data_bnsums: bad arguments");
+    MYOLO_REQUIRE(rows > 0 && rows == myolo_dwconv3x3_bwd_data_bnsums_rows(N, H, W, C, stride), "dwconv3x3_bwd_data_bnsums: rows does not match these sizes");
+    return dw_bwd_data_impl(dy, w, dx, N, H, W, C, stride, DwBnBwd{xbn, scale, shift, mean, var, act, part}, stream);
+}
+
+/* the rest of myolo_bn_act_bwd(batch_stats = 1) when the sums already exist as nblk rows of [2][C] double partials: fixed-order finish (dgamma, dbeta),
+ * then dx.  ws: 2 * C doubles. */
+int myolo_bn_act_bwd_from_partials(const float* dy, const float* x, const float* mean, const float* var, const float* scale, const float* shift,
+                                   float* dx, float* dgamma, float* dbeta, int64_t M, int C, int act, const double* part, int nblk, void* ws,
+                                   size_t ws_bytes, void* stream)
+{
+    MYOLO_REQUIRE(dy && x && mean && var && scale && shift && dx && dgamma && dbeta && part && nblk > 0 && M > 0 && (C & 3) == 0,
+                  "bn_act_bwd_from_partials: bad arguments");
+    MYOLO_NEED_WS(2 * (size_t)C * sizeof(double));
+    double* tot = (double*)ws;
+    hipStream_t s = (hipStream_t)stream;
+    if (nblk >= 2048) hipLaunchKernelGGL((colreduce_finish<FinBnBwd, 128>), dim3((C + 3) / 4), dim3(1024), 0, s, part, tot, nblk, 2 * C, C, FinBnBwd{dgamma, dbeta});
+    else hipLaunchKernelGGL((colreduce_finish<FinBnBwd>), dim3((C + 3) / 4), dim3(256), 0, s, part, tot, nblk, 2 * C, C, FinBnBwd{dgamma, dbeta});
+    const long long nq = (long long)M * C / 4;
+    hipLaunchKernelGGL(bn_bwd_dx_kernel, dim3(ew_blocks4(nq)), dim3(256), 0, s, dy, x, scale, shift, mean, var, tot, dx, nq, C, act, 1, 1.0f / (float)M);
+    MYOLO_CHECK_LAUNCH();
+    return MYOLO_OK;
+}
+
+static int dw_bwd_data_impl(const float* dy, const float* w, float* dx, int N, int H, int W, int C, int stride, DwBnBwd bw, void* stream)
 {
     MYOLO_REQUIRE(dy && w && dx && N > 0 && (C & 3) == 0 && (stride == 1 || stride == 2), "dwconv3x3_bwd_data: bad arguments");
     hipStream_t s = (hipStream_t)stream;
@@ -3344,7 +3490,7 @@ int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, 
         // 1.5-2.2x the algorithmic bytes, profiles/r4_pmc_trunk.json)
         const DwRowsGeom g = dw_rows_geom(N, H, W, C, 1);
         const DwAffine none{nullptr, nullptr, MYOLO_ACT_NONE};
-        const DwFuse nof{none, nullptr};
+        const DwFuse nof{none, nullptr, bw};
         if (g.cqb == 32) dw_rows_launch<1, 32>(g, dy, w, dx, H, W, C, none, nof, s, true);
         else if (g.cqb == 16) dw_rows_launch<1, 16>(g, dy, w, dx, H, W, C, none, nof, s, true);
         else dw_rows_launch<1, 8>(g, dy, w, dx, H, W, C, none, nof, s, true);
@@ -3352,7 +3498,8 @@ int myolo_dwconv3x3_bwd_data(const float* dy, const float* w, float* dx, int N, 
         hipLaunchKernelGGL((dw_bwd_data_kernel<1>), dim3((per_row + 255) / 256, H, N), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
     else if (!(H & 1) && !(W & 1) && !g_myolo_opt.dw_bwd_legacy && (long long)N * Ho * Wo * (C / 4) < (1ll << 40)) {
         const long long total = (long long)N * Ho * Wo * (C / 4);
-        hipLaunchKernelGGL(dw_bwd_data_s2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, w, dx, Ho, Wo, C, total);
+        if (bw.x) hipLaunchKernelGGL((dw_bwd_data_s2_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, w, dx, Ho, Wo, C, total, bw);
+        else hipLaunchKernelGGL((dw_bwd_data_s2_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, w, dx, Ho, Wo, C, total, bw);
     } else
         hipLaunchKernelGGL((dw_bwd_data_kernel<2>), dim3((per_row + 255) / 256, H, N), dim3(256), 0, s, dy, w, dx, N, H, W, C, Ho, Wo);
     MYOLO_CHECK_LAUNCH();

@@ -24,6 +24,8 @@ SIGS = {
     "myolo_dwconv3x3_fwd": [P, P, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_affine_act_fwd": [P, P, P, P, I, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_bwd_data": [P, P, P, I, I, I, I, I, P],
+    "myolo_dwconv3x3_bwd_data_bnsums": [P, P, P, I, I, I, I, I, P, P, P, P, P, I, P, I, P],
+    "myolo_bn_act_bwd_from_partials": [P, P, P, P, P, P, P, P, P, L, I, I, P, I, P, Z, P],
     "myolo_dwconv3x3_bwd_weight": [P, P, P, I, I, I, I, I, P, Z, P],
     "myolo_pwconv1x1_fwd": [P, P, P, P, L, I, I, P, Z, P],
     "myolo_pwconv1x1_affine_act_fwd": [P, P, P, P, I, P, L, I, I, P, Z, P],
@@ -195,6 +197,8 @@ def load():
         fn.restype = I
     lib.myolo_wprep_count.argtypes = [P]
     lib.myolo_wprep_count.restype = I
+    lib.myolo_dwconv3x3_bwd_data_bnsums_rows.argtypes = [I, I, I, I, I]
+    lib.myolo_dwconv3x3_bwd_data_bnsums_rows.restype = I
     lib.myolo_wprep_refresh.argtypes = [P, I, I, I, P]
     lib.myolo_wprep_refresh.restype = I
     _LIB = lib
@@ -205,7 +209,7 @@ def exported_symbols():
     return list(SIGS) + ["myolo_version", "myolo_last_error_string", "myolo_workspace_bytes", "myolo_conv3x3_wino_ws_bytes", "myolo_wino_plane_elems", "myolo_wino_u_elems", "myolo_wino63_u_elems", "myolo_wino63_plane_elems", "myolo_wino63_ok", "myolo_wino63_bwd_data_ws_bytes", "myolo_wino63_bwd_weight_ws_bytes", "myolo_wino63_bwd_data_from_v_ws_bytes", "myolo_wino63_bwd_weight_from_q_ws_bytes", "myolo_wino63_output_transform_bn_ws_bytes", "myolo_conv3x3_wino63_ws_bytes", "myolo_matmul_f32_ws_bytes", "myolo_conv3x3s2_c3_bnstats_ws_bytes", "myolo_dwconv3x3_bnstats_ws_bytes", "myolo_dwconv3x3_bwd_weight_ws_bytes",
                               "myolo_pwconv1x1_bnstats_ws_bytes", "myolo_pwconv1x1_bnstats_ok",
                               "myolo_deconv2x2s2_mask_ws_bytes", "myolo_wino_output_transform_bn_ws_bytes",
-                              "myolo_bn_act_bwd_fused_ws_bytes", "myolo_wprep_create", "myolo_wprep_destroy", "myolo_wprep_activate", "myolo_wprep_invalidate", "myolo_wprep_count", "myolo_wprep_refresh"]
+                              "myolo_bn_act_bwd_fused_ws_bytes", "myolo_dwconv3x3_bwd_data_bnsums_rows", "myolo_wprep_create", "myolo_wprep_destroy", "myolo_wprep_activate", "myolo_wprep_invalidate", "myolo_wprep_count", "myolo_wprep_refresh"]
 
 
 def ptr(t):
@@ -379,6 +383,11 @@ def matmul_ws_bytes(k, n, b_is_nk, products):
 def wino_u_elems(cin, cout):
     """floats to allocate for the transformed filters U of myolo_wino_weight_transform"""
     return int(load().myolo_wino_u_elems(int(cin), int(cout)))
+
+
+def dw_bwd_data_bnsums_rows(n, h, w, c, stride):
+    """rows of partial sums myolo_dwconv3x3_bwd_data_bnsums leaves (0: not available for these sizes)."""
+    return int(load().myolo_dwconv3x3_bwd_data_bnsums_rows(int(n), int(h), int(w), int(c), int(stride)))
 
 
 def wino63_ok(h, w, cin, cout):

@@ -265,6 +265,8 @@ class Net(object):
         self._copy_stream = _shared_stream(self.dev, "n_pos_copy")
         self._npos_ready = torch.cuda.Event()
         self._npos_pinned = None
+        self.fuse_bn_bwd_sums = 1         # trunk backward: the depthwise data gradient leaves the sums of the BatchNorm its output reaches (conv_pw_{b-1}_bn / conv1_bn) in its epilogue -- that BatchNorm's backward is finish + dx, its pass over (dy, x) is gone (round 5); 0 = three launches per BatchNorm
+        self._bn_sums = {}                # BatchNorm name -> (partials, rows) left by the producer of its output gradient
         self.fused_bn_bwd = 0             # 1 = training-mode BatchNorm backward in one launch (sums, grid-wide barrier, dx: myolo_bn_act_bwd_fused).  Measured: 28.7 against 20.9 ms per step -- the barrier needs all its workgroups resident, and this step runs its chains BESIDE chip-filling kernels of other streams on purpose (profiles/r4_notes.md section 6)
         self._bn_sync = {}                # stream -> the barrier's counters
         self._bn_fused_bytes = {}
@@ -412,6 +414,13 @@ class Net(object):
         else:
             mean, var = self.s[name + "/moving_mean"], self.s[name + "/moving_variance"]
         dx = self._new(M, C)
+        pre = self._bn_sums.pop(name, None) if batch_stats else None
+        if pre is not None:
+            # the producer of `da` (the depthwise data gradient behind this BatchNorm) left the sums: finish + dx
+            part, rows = pre
+            X.call("myolo_bn_act_bwd_from_partials", X.ptr(da), X.ptr(y), X.ptr(mean), X.ptr(var), X.ptr(buf[2]), X.ptr(buf[3]), X.ptr(dx),
+                   X.ptr(self.g[name + "/gamma"]), X.ptr(self.g[name + "/beta"]), M, C, act, X.ptr(part), rows, *self._wsargs(), X.stream())
+            return dx
         if batch_stats and self.fused_bn_bwd:
             need = self._bn_fused_bytes.get((M, C))
             if need is None:
@@ -667,7 +676,9 @@ class Net(object):
             self._twg_used.clear()
             self._twg_pending = False
 
-    def dw_block_bwd(self, bid, da):
+    def dw_block_bwd(self, bid, da, next_bn=None):
+        """next_bn: the training-mode BatchNorm this block's input gradient reaches next (conv_pw_{bid-1}_bn / conv1_bn); with
+        fuse_bn_bwd_sums the depthwise data gradient leaves that BatchNorm's backward sums in its epilogue (bn_act_bwd then finishes them)."""
         a, shape, stride, ad = self.tape["blk%d" % bid]
         N, H, W, C = shape
         Ho, Wo = H // stride, W // stride
@@ -695,7 +706,18 @@ class Net(object):
                 X.call("myolo_dwconv3x3_bwd_weight", X.ptr(a), X.ptr(dy), X.ptr(self.g[dwn + "/depthwise_kernel"]), N, H, W, C, stride, wsp, wsz, X.stream())
         self._on_wgrad_stream(dw_wgrad, (dy, a))
         dx = self._new(N * H * W, C)
-        X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(dx), N, H, W, C, stride, X.stream())
+        rows = 0
+        if next_bn is not None and self.fuse_bn_bwd_sums and next_bn in self.tape and self.tape[next_bn][2] and not self.fused_bn_bwd:
+            rows = X.dw_bwd_data_bnsums_rows(N, H, W, C, stride)
+        if rows:
+            yb, actb, _ = self.tape[next_bn]
+            bb = self.bnbuf[next_bn]
+            part = self._new(rows * 2 * C, dtype=torch.float64)
+            X.call("myolo_dwconv3x3_bwd_data_bnsums", X.ptr(dy), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(dx), N, H, W, C, stride, X.ptr(yb),
+                   X.ptr(bb[2]), X.ptr(bb[3]), X.ptr(bb[0]), X.ptr(bb[1]), actb, X.ptr(part), rows, X.stream())
+            self._bn_sums[next_bn] = (part, rows)
+        else:
+            X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(self.p[dwn + "/depthwise_kernel"]), X.ptr(dx), N, H, W, C, stride, X.stream())
         return dx
 
     # ---- trunk: backbone, feature_map, YOLO head -----------------------------------
@@ -767,8 +789,10 @@ class Net(object):
         da = self._new(M7, c2)
         X.call("myolo_pwconv1x1_bwd_data", X.ptr(dyolo), X.ptr(self.p["conv_23/kernel"]), X.ptr(da), M7, c2, D, *self._wsargs(), X.stream())
         bid = len(BACKBONE_BLOCKS) + len(YOLO_BLOCKS)
+        first = len(BACKBONE_BLOCKS) + 1
         for _ in YOLO_BLOCKS:
-            da = self.dw_block_bwd(bid, da)
+            # (the first YOLO block's input gradient is added to feature_map's before it reaches conv_pw_6_bn: no fused sums there)
+            da = self.dw_block_bwd(bid, da, next_bn=("conv_pw_%d_bn" % (bid - 1)) if bid > first else None)
             bid -= 1
         return da
 
@@ -840,7 +864,7 @@ class Net(object):
             self._twg_override = (self._yolo_stream, self._ws_side)
         try:
             for _ in BACKBONE_BLOCKS:
-                da = self.dw_block_bwd(bid, da)
+                da = self.dw_block_bwd(bid, da, next_bn=("conv_pw_%d_bn" % (bid - 1)) if bid > 1 else "conv1_bn")
                 bid -= 1
         finally:
             self._twg_override = None
@@ -1917,10 +1941,10 @@ class Net(object):
         self.adam_step(lr)
         return out
 
-    def _pack_bf16(self, key):
-        """(re)make one cached bf16 operand of mask_head_fwd_bf16 in its persistent buffers: conv i = kernel with the frozen BatchNorm folded + bias;
-        'deconv' = the transposed-conv kernel in its GEMM layout."""
-        wt, bfold = self._bf16_packs[key]
+    def _pack_bf16(self, key, bufs=None):
+        """(re)make one bf16 operand of mask_head_fwd_bf16 -- conv i = kernel with the frozen BatchNorm folded + bias; 'deconv' = the transposed-conv
+        kernel in its GEMM layout -- in its persistent cache buffers, or in `bufs`."""
+        wt, bfold = bufs if bufs is not None else self._bf16_packs[key]
         if key == "deconv":
             X.call("myolo_pack_weights_bf16", X.ptr(self.p["myolo_mask_deconv/kernel"]), MASK_FILTERS, 4 * MASK_FILTERS, 1, None,
                    None, None, None, None, X.ptr(wt), None, X.stream())
@@ -1936,9 +1960,9 @@ class Net(object):
         bf = torch.bfloat16
         shape = (4 * MASK_FILTERS, MASK_FILTERS) if key == "deconv" else (MASK_FILTERS, 9 * cin)
         if not self.infer_weight_cache:
-            self._bf16_packs[key] = (self._new(*shape, dtype=bf), None if key == "deconv" else self._new(MASK_FILTERS))
-            self._pack_bf16(key)
-            return self._bf16_packs.pop(key)
+            bufs = (self._new(*shape, dtype=bf), None if key == "deconv" else self._new(MASK_FILTERS))
+            self._pack_bf16(key, bufs)
+            return bufs
         ent = self._bf16_packs.get(key)
         if ent is None or tuple(ent[0].shape) != shape:
             # first use (never while a graph is being captured: _capture_predict's warm-up forwards come first)

@@ -1197,6 +1197,58 @@ def _check_bn_outputs(y_ref2d, g, b, mm, mv, mean, var, scale, shift, tmm, tmv):
     check(tmv, rmv, 1e-5, "fused moving var")
 
 
+@pytest.mark.parametrize("act", [2, 0])
+@pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (3, 14, 14, 512, 1), (2, 8, 8, 1024, 1), (32, 28, 28, 256, 1), (2, 46, 40, 96, 1), (4, 9, 7, 1024, 1),
+                                            (2, 112, 112, 32, 1), (2, 16, 16, 32, 2), (2, 46, 40, 64, 2), (1, 30, 58, 160, 2), (3, 112, 112, 64, 2), (2, 56, 56, 128, 2),
+                                            (2, 28, 28, 512, 2), (2, 12, 12, 24, 1)])
+def test_dw_bwd_data_with_batchnorm_backward_sums(N, H, W, C, stride, act):
+    """round 5: the depthwise data gradient whose output dx reaches a training-mode BatchNorm leaves that BatchNorm's backward
+    sums in its epilogue (myolo_dwconv3x3_bwd_data_bnsums), finished by myolo_bn_act_bwd_from_partials.  Against the two plain calls
+    (myolo_dwconv3x3_bwd_data + myolo_bn_act_bwd, themselves checked against the oracle above): dx of the conv bit-identical; dgamma / dbeta / the
+    BatchNorm's dx equal up to the order of the fp32 partial sums; sizes the fused kernels do not take report rows == 0.  Repeated calls are
+    bit-identical (fixed-order finish)."""
+    rng = np.random.default_rng(33)
+    Ho, Wo = H // stride, W // stride
+    dy, w = dt(rnd(rng, N, Ho, Wo, C)), dt(rnd(rng, 3, 3, C))
+    xbn = dt(rnd(rng, N, H, W, C, scale=2.0))                      # the pre-BN tensor of the BatchNorm in front of this conv
+    g, b = 1 + rnd(rng, C, scale=0.2), rnd(rng, C, scale=0.3) + (1.0 if act else 0.0)
+    M = N * H * W
+    mean, var, scale, shift = new(C), new(C), new(C), new(C)
+    mm, mv = dt(np.zeros(C, np.float32)), dt(np.ones(C, np.float32))
+    st = X.stream()
+    X.call("myolo_bn_stats", X.ptr(xbn), X.ptr(dt(g)), X.ptr(dt(b)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(mm), X.ptr(mv),
+           M, C, *ws(), st)
+    dx0, dbn0, dg0, db0 = new(N, H, W, C), new(M, C), new(C), new(C)
+    X.call("myolo_dwconv3x3_bwd_data", X.ptr(dy), X.ptr(w), X.ptr(dx0), N, H, W, C, stride, st)
+    X.call("myolo_bn_act_bwd", X.ptr(dx0), X.ptr(xbn), X.ptr(dt(g)), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(dbn0), X.ptr(dg0),
+           X.ptr(db0), M, C, act, 1, *ws(), st)
+    rows = X.dw_bwd_data_bnsums_rows(N, H, W, C, stride)
+    if C % 32 or (stride == 2 and (C > 256 or 256 % (C // 4))):
+        assert rows == 0                   # sizes the fused kernels do not take: the caller falls back to the two plain calls
+        return
+    assert rows > 0
+    outs = []
+    for rep in range(2):
+        part = torch.full((rows * 2 * C,), float("nan"), dtype=torch.float64, device="cuda")
+        dx1, dbn1, dg1, db1 = new(N, H, W, C), new(M, C), new(C), new(C)
+        X.call("myolo_dwconv3x3_bwd_data_bnsums", X.ptr(dy), X.ptr(w), X.ptr(dx1), N, H, W, C, stride, X.ptr(xbn), X.ptr(scale), X.ptr(shift),
+               X.ptr(mean), X.ptr(var), act, X.ptr(part), rows, st)
+        X.call("myolo_bn_act_bwd_from_partials", X.ptr(dx1), X.ptr(xbn), X.ptr(mean), X.ptr(var), X.ptr(scale), X.ptr(shift), X.ptr(dbn1),
+               X.ptr(dg1), X.ptr(db1), M, C, act, X.ptr(part), rows, *ws(), st)
+        torch.cuda.synchronize()
+        assert not torch.isnan(part).any()
+        outs.append((dx1, dbn1, dg1, db1))
+    dx1, dbn1, dg1, db1 = outs[0]
+    assert torch.equal(dx0, dx1), "the conv's data gradient must not change"
+    check(dg1, dg0.cpu().numpy(), 2e-5, "fused sums dgamma")
+    check(db1, db0.cpu().numpy(), 2e-5, "fused sums dbeta")
+    check(dbn1, dbn0.cpu().numpy(), 2e-5, "BatchNorm dx from fused sums")
+    assert all(torch.equal(u, v) for u, v in zip(outs[0], outs[1])), "not bit-reproducible"
+    lib = X.load()
+    assert lib.myolo_dwconv3x3_bwd_data_bnsums(X.ptr(dy), X.ptr(w), X.ptr(dx1), N, H, W, C, stride, X.ptr(xbn), X.ptr(scale), X.ptr(shift),
+                                               X.ptr(mean), X.ptr(var), act, X.ptr(part), rows + 1, st) != 0          # wrong row count: refused
+
+
 @pytest.mark.parametrize("nofuse", [0, 1])
 @pytest.mark.parametrize("N,H,W,C,stride,lazy", [(2, 16, 16, 32, 1, True), (2, 16, 16, 32, 2, True), (3, 14, 14, 512, 1, True), (3, 14, 14, 512, 2, False),
                                                  (2, 8, 8, 1024, 1, True), (1, 14, 10, 64, 2, True), (2, 12, 12, 16, 1, True), (2, 6, 6, 24, 1, True),
