@@ -670,7 +670,7 @@ def bench_train(args, rank, world, local):
             if args.batch * R == 32 * 147 and c1_63:            # the default path: every dense launch on the F(6,3)/F(4,3) tiling
                 pj = json.load(open(os.path.join(ROOT, "profiles", "r3_pmc_x6.json")))["multiply_x6"]
                 traffic = pj["traffic_bytes_per_launch_corrected"]
-                traffic_src = ("profiles/r3_pmc_x6.json (tools/collect_pmc_r3.sh: separate rocprofv3 --pmc passes on tools/kbench.py wino63_mm, FETCH_SIZE x2 + "
+                traffic_src = ("profiles/r3_pmc_x6.json (tools/collect_pmc.sh x6: separate rocprofv3 --pmc passes on tools/kbench.py wino63_mm, FETCH_SIZE x2 + "
                                "WRITE_SIZE = %.2fx the algorithmic bytes; not re-measured in this run)" % pj["traffic_over_algorithmic"])
             elif args.batch * R == 32 * 147 and not t63:
                 pj = json.load(open(os.path.join(ROOT, "profiles", pmc)))

@@ -1,47 +1,40 @@
 #!/bin/bash
-# Everything profiles/<tag>_* is made of, in one gpurun call:   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r2g'
-#   bench lines (default config -- FP32_MATMUL=bf16x6 since round 3 -- with variants, extras and the CPU baseline; FP32_MATMUL=native; rice416-bf16), rocprofv3 kernel stats / by-grid /
-#   step timeline for both matmul modes, the per-kernel micro-benchmarks, the MFMA/VALU overlap microbenchmark.
-TAG=${1:-r3}
+# The evidence set of a round in one gpurun call:   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r5'   (-> gpurun_out/evidence_<tag>/, copy into profiles/)
+#   the full default bench line, the step profile (default and 20 forced positives), the kernel micro-benchmarks on cold inputs.
+TAG=${1:-r5}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
-python bench.py --steps 20 --warmup 5 2> $OUT/bench.err | tail -1 > $OUT/${TAG}_bench.json
-python bench.py --steps 20 --warmup 5 --fp32-matmul native --cpu-images 0 --no-extras 2> $OUT/bench_native.err | tail -1 > $OUT/${TAG}_bench_native.json
-python bench.py --config rice416-bf16 --steps 20 2> $OUT/bench_rice.err | tail -1 > $OUT/${TAG}_bench_rice416_bf16.json
-bash tools/profile_step.sh $TAG > /dev/null 2>&1
+python bench.py --steps 20 --warmup 5 --detail-name ${TAG}_bench_detail.json 2> $OUT/bench.err | tail -1 > $OUT/${TAG}_bench.json      # the ONE compact line the driver parses
+cp gpurun_out/${TAG}_bench_detail.json $OUT/${TAG}_bench_detail.json          # the full object (per-layer table, probes, variants)
+rm -f ${TAG}_bench_detail.json
+bash tools/profile_step.sh $TAG --steps 10 > /dev/null 2>&1
 cp gpurun_out/prof_$TAG/${TAG}_bench_kernel_stats.csv gpurun_out/prof_$TAG/${TAG}_bench_kernel_by_grid.csv gpurun_out/prof_$TAG/${TAG}_timeline.txt gpurun_out/prof_$TAG/${TAG}_step_sequence.txt $OUT/
-bash tools/profile_step.sh ${TAG}native --fp32-matmul native > /dev/null 2>&1
-cp gpurun_out/prof_${TAG}native/${TAG}native_bench_kernel_stats.csv gpurun_out/prof_${TAG}native/${TAG}native_bench_kernel_by_grid.csv gpurun_out/prof_${TAG}native/${TAG}native_timeline.txt $OUT/
+bash tools/profile_step.sh ${TAG}_pos20 --steps 10 --force-pos 20 > /dev/null 2>&1
+cp gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_stats.csv gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_by_grid.csv gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_timeline.txt gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_step_sequence.txt $OUT/
 {
-  for k in wino_fwd wino63_fwd wino63_mm wino63_wgrad wino63_boundary wino_bwd_data wino_bwd_weight conv3x3_fwd deconv_mask_fwd roialign_fwd roialign_bwd dw; do
-    python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -16      # steady state: 30 untimed launches first (clock transient after idle, r3_notes.md)
-  done
-  echo "--- KBENCH_OPTIONS=wino_x6=1"
-  for k in wino_fwd wino63_fwd wino63_mm wino63_wgrad wino_bwd_data deconv_mask_fwd; do
-    KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -1
-  done
-  echo "--- bf16 inference kernels (default; bf16_no_c3=1 = the nine-fetch implicit GEMM; bf16_no256=1 = the 128^2 kernels; bf16_no_loopn=1)"
-  python tools/kbench.py conv3x3_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no_c3=1 python tools/kbench.py conv3x3_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py conv3x3_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
-  python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no_loopn=1 python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
-  KBENCH_OPTIONS=bf16_no256=1 python tools/kbench.py deconv_mask_bf16_fwd --warm 30 --iters 20 2>&1 | tail -1
-  echo "--- tools/overlap_mm_boundary.py"
-  python tools/overlap_mm_boundary.py 2>&1 | tail -1
-  KBENCH_OPTIONS=wino_x6=1 python tools/overlap_mm_boundary.py 2>&1 | tail -1
-  echo "--- HBM stream copy (hand-written float4 kernel, grid sweep) beside torch copy_"
-  python tools/kbench.py copy --iters 5 2>&1 | grep -v amdgpu
-  echo "--- matrix-pipe ceiling (myolo_mfma_probe: register operands, no memory traffic)"
-  python tools/kbench.py mfma --warm 5 2>&1 | grep -v amdgpu
-  echo "--- wino_mm_x6_kernel as a plain GEMM at constant FLOPs over K (tools/experiments/x6_k_sweep.py)"
-  python tools/experiments/x6_k_sweep.py 2>&1 | grep -v amdgpu
-  echo "--- tools/pw_layers.py"
-  python tools/pw_layers.py 2>&1 | grep -E "total"
+  echo "--- depthwise forward as the step runs it (cold inputs); then with the round-3 kernel (dw_legacy=1)"
+  python tools/kbench.py dw_fused --iters 20 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=dw_legacy=1 python tools/kbench.py dw_fused --iters 20 2>&1 | grep -v amdgpu | tail -1
+  echo "--- depthwise data / weight gradients (cold inputs); then with the round-3 kernels (dw_bwd_legacy=1)"
+  python tools/kbench.py dw_bwd --iters 20 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=dw_bwd_legacy=1 python tools/kbench.py dw_bwd --iters 20 2>&1 | grep -v amdgpu | grep total
+  echo "--- BatchNorm + ReLU6 backward of the trunk layers (three launches: sums, finish, dx; cold inputs; in the step the sums of 14 of the 29 come from the depthwise data gradient's epilogue, round 5)"
+  python tools/kbench.py bn_bwd --iters 20 2>&1 | grep -v amdgpu
+  echo "--- pointwise layers (fp32 MFMA kernels; then wino_x6=1 = the product's FP32_MATMUL=bf16x6)"
+  python tools/kbench.py pw_fused --iters 20 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py pw_fused --iters 20 2>&1 | grep -v amdgpu
+  echo "--- ROIAlign forward / backward (backward: default, tune0=1 = round-3 pixel order, tune0=4 = 4x4 tiles)"
+  python tools/kbench.py roialign_fwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=tune0=1 python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  KBENCH_OPTIONS=tune0=4 python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
+  echo "--- Winograd kernels (unchanged this round), steady state"
+  for k in wino63_mm wino63_wgrad wino63_boundary; do KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
+  echo "--- HBM stream copy"
+  python tools/kbench.py copy --iters 5 2>&1 | grep -v amdgpu | head -8
+  echo "--- stream / process-group experiment (tools/experiments/pg_stream_cost.py): default = high-priority side streams; MYOLO_STREAM_PRIORITY=0 = rounds 1-3"
+  for m in none pg_first pg; do HSA_ENABLE_IPC_MODE_LEGACY=0 python tools/experiments/pg_stream_cost.py $m 2>&1 | grep "ms per step"; done
+  for m in none pg_first pg; do MYOLO_STREAM_PRIORITY=0 HSA_ENABLE_IPC_MODE_LEGACY=0 python tools/experiments/pg_stream_cost.py $m 2>&1 | grep "ms per step"; done
 } > $OUT/${TAG}_kbench.txt
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/ovl tools/mfma_valu_overlap.hip 2>/dev/null && /tmp/ovl > $OUT/${TAG}_mfma_valu_overlap.txt 2>&1
-head -c 400 $OUT/${TAG}_bench.json; echo; head -c 300 $OUT/${TAG}_bench_native.json; echo; head -c 300 $OUT/${TAG}_bench_rice416_bf16.json; echo
-bash tools/profile_infer.sh $TAG > $OUT/infer_top.txt 2>&1
-cp gpurun_out/prof_infer_$TAG/${TAG}_infer_kernel_stats.csv $OUT/
-cat $OUT/${TAG}_timeline.txt | grep -E "wall" ; cat $OUT/${TAG}native_timeline.txt | grep -E "wall"; head -8 $OUT/infer_top.txt
+head -c 600 $OUT/${TAG}_bench.json; echo; grep wall $OUT/${TAG}_timeline.txt; grep wall $OUT/${TAG}_pos20_timeline.txt; tail -8 $OUT/${TAG}_kbench.txt

@@ -1,46 +1,92 @@
 #!/usr/bin/env python
-"""Rewrites BASELINE.md section 5 (round-2 results) from the committed evidence in profiles/r2g_*.json, so that every number in the
-table is one bench.py printed.   python tools/gen_baseline_table.py"""
+"""Appends / rewrites the results section of a round in BASELINE.md from the committed evidence profiles/<tag>_bench_detail.json (the full object
+bench.py writes beside its compact line), so that every number in the table is one bench.py printed.
+    python tools/gen_baseline_table.py r5 [section number, default 8] [free text appended to the provenance line]
+(sections 5-7 = rounds 2-4, written by earlier forms of this script from profiles/r2g_*, r3c_*, r4_bench.json)"""
 import json
 import os
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r5"
+sec = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+spread = sys.argv[3] if len(sys.argv) > 3 else ""
+rnd = tag[1:2]
 p = os.path.join(ROOT, "BASELINE.md")
 s = open(p).read()
-i = s.index('## 5. Results (round 2')
-L = lambda n: json.load(open(os.path.join(ROOT, "profiles", n)))
-d, x, rc = L("r2g_bench.json"), L("r2g_bench_bf16x6.json"), L("r2g_bench_rice416_bf16.json")
-v, xv, rr, r = d['variants'], x['variants'], rc['roofline'], d['roofline']
-new = '''## 5. Results (round 2, measured on 1× MI355X by `bench.py`; evidence under `profiles/r2*`, notes in `profiles/r2_notes.md`)
+d = json.load(open(os.path.join(ROOT, "profiles", "%s_bench_detail.json" % tag)))
+r, v = d["roofline"], d["variants"]
+sw = v["n_pos_sweep"]
+hb = d.get("hbm_copy_measured_gbs", {})
+inf = d.get("inference_rice416_bf16", {})
+nb5 = d.get("secondary_nbox5", {})
+mf = r["pointwise"].get("mfma_bound_layers", {})
+rows = "\n".join("| %s | %s | %.1f | %.0f | %.1f | %s | %.2f | %.1f | %.2f |" % (l["layer"], l["shape"], l["ms"] * 1e3, l["gbs"], l["tflops"], l["roof"], l["frac"],
+                                                                           l.get("ms_net", 0.0) * 1e3, l.get("frac_net", 0.0))
+                 for l in r.get("trunk_layers", []))
+new = '''## %(sec)d. Results (round %(rnd)s, measured on 1x MI355X by ONE `python bench.py --steps 20 --warmup 5`; evidence `profiles/%(tag)s_*`, notes `profiles/r%(rnd)s_notes.md`)
 
-(this table is generated from `profiles/r2g_*.json` by `tools/gen_baseline_table.py`)
+(generated from `profiles/%(tag)s_bench_detail.json` by `tools/gen_baseline_table.py`; %(spread)s)
 
-| Config | img/s | step ms | dominant kernel (`roofline`) | whole 3×3 conv op | other `roofline` objects | CPU restatement |
-|---|---|---|---|---|---|---|
-| Shapes 224², B=32, fp32, N_BOX=3 (R=147), all-ROI forward (**headline**; `profiles/r2g_bench.json`) | **%.1f** (round 1: 857–865) | **%.2f** | `wino_mm_kernel`: ONE launch of the 64 per-point GEMMs of the Winograd multiply on the F(6,3)/F(4,3) tiling (14 = 6+4+4: 400 point-tiles per ROI, 0.247 TFLOP): **%.2f ms = %.0f TFLOP/s = %.1f %%** of the 157.3 TFLOP/s fp32 MFMA peak; HBM traffic 3.90 GB vs 3.87 GB algorithmic (`r2_pmc_wino63_multiply.json`); `SQ_VALU_MFMA_BUSY_CYCLES` = the minimum for that work; MFMA pipe busy 82 %% at an effective 2.02 GHz. (Same kernel on the F(4,3)/F(2,3) tiling, 484 point-tiles: 2.51 ms = 119 TFLOP/s = 75.7 %%; rocBLAS `bmm` on those shapes: 112–114 TFLOP/s) | %.2f ms (round 1: 4.33) = %.0f direct-equivalent TFLOP/s | depthwise (14 layers, in-step events) %.2f ms; stand-alone 0.148 ms = 4.5 TB/s = 57 %% of 8 TB/s (round 1: 43 %%); ROIAlign fwd fused into conv1's input transform %.2f ms (= %.0f %% of 8 TB/s on SURVEY §8(d) bytes; the kernel writes the 2.0× larger Winograd image at 4.2 TB/s), stand-alone 0.17–0.21 ms = 57–70 %%; ROIAlign bwd 0.41 ms = 2.4 TB/s (round 1: 0.73 ms); pointwise (14 layers) %.2f ms = %.0f TFLOP/s = %.0f %% of the fp32 MFMA peak; Winograd layer boundary %.2f ms = %.2f TB/s (a plain device copy: 4.9 TB/s) | **%.2f img/s**: 32-image training step of the torch-CPU fp32 restatement, 16 threads (all usable cores of an EPYC 9575F), median of 2 after 1 warm-up |
-| same, `FP32_MATMUL="bf16x6"` (opt-in, DESIGN §3 / §8: six exact bf16 piece products per fp32 product; `profiles/r2g_bench_bf16x6.json`, also `variants.winograd_multiply_bf16x6` of the headline run: %.1f ms) | **%.1f** | **%.2f** | `wino_mm_x6_kernel`: %.2f ms = %.0f TFLOP/s of bf16 piece products = %.0f %% of 2.5 PFLOP/s (%.0f fp32-equivalent TFLOP/s); bf16 pipe busy 65 %% at an effective 1.67 GHz (PMC on the 484-point-tile launch) | %.2f ms; fused deconv+mask GEMM 2.43 ms (native 3.99) | | |
-| headline config, dense mask-head backward (`variants.dense_mask_backward`) | %.1f | %.1f | | | | |
-| headline config, positives-only forward (`variants.mask_head_forward_on_positives_only`, opt-in, DESIGN §4b) | %.1f | %.1f (bf16x6: %.1f) | | | | |
-| headline config, first k proposals of every image forced onto a ground-truth box (`variants.n_pos_sweep`) | %s at k = 5 / 10 / 20 | %s | the compacted mask-head backward costs ≈0.3 ms per positive per image; the headline batch (random-init net) has %.2f positives per image | | | |
-| Rice 416², 5 anchors, inference, batch 4, bf16 mask head (`python bench.py --config rice416-bf16`; `profiles/r2g_bench_rice416_bf16.json`) | %.0f | %.2f | %s: %.3f ms = %.0f TFLOP/s = %.1f %% of 2.5 PFLOP/s dense bf16 | | | |
+| Object of the line | img/s | ms | what it is |
+|---|---|---|---|
+| **headline** `value` (`config.fp32_products = "%(fp)s"`, `dtype f32`) | **%(val).1f** | **%(ms).2f** (p10 %(p10).2f / p50 %(p50).2f / p90 %(p90).2f) | Shapes 224x224, batch 32, N_BOX=3 (R=147), forward + backward + Adam; round 4: 1596 / 20.05 (best box 1630 / 19.63), round 3: 1487.8 / 21.51, round 2: 1139.2 / 28.09, round 1: 863.4 / 37.06 |
+| `train_api.train` = `MaskYOLO.train()` on a 512-image ShapesDataset | %(tav).1f | %(tams).2f | the drop-in call (model.py:943-1060): host BatchGenerator on a prefetch thread, pinned byte staging, lazy losses |
+| `train_api.train_shapes_stream` | %(tsv).1f | %(tsms).2f | inputs produced on the device |
+| `train_api.reference_same_state` | %(rsv).1f | %(rsms).2f | `Net.train_step` on resident batches right after those calls, same weights (%(rsn).2f positives per image; the headline's random-init net: %(hn)s): the like-for-like reference of the public calls |
+| `comm_overlap_probe_ms.ms_per_step_with_probe` | | %(cpms).2f | the same step with the three gradient buckets all-reduced on the copy stream (1-rank RCCL communicator through the C-ABI) |
+| `variants.fp32_products_native` | %(nat_v).1f | %(nat_ms).2f | the same step with every product on `v_mfma_f32_32x32x2_f32` |
+| `variants.dense_mask_backward` | %(dn_v).1f | %(dn_ms).2f | structural zeros of the mask-head backward not exploited |
+| `variants.mask_head_forward_on_positives_only` | %(po_v).1f | %(po_ms).2f | opt-in, DESIGN 4b; never the headline |
+| `variants.n_pos_sweep` k = 5 / 10 / 20 | %(s5v).0f / %(s10v).0f / %(s20v).0f | %(s5).2f / %(s10).2f / %(s20).2f | first k proposals of every image forced onto a ground-truth box: the band of a trained net |
+| `secondary_nbox5` | %(n5v).1f | %(n5ms).2f | repository-HEAD head, N_BOX=5, R=245 |
+| `inference_rice416_bf16` | %(iv).1f | %(ims).2f | BASELINE configs[3]: Rice 416x416, batch 4, bf16 mask head, hipGraph replays, `config.in_flight` batches in flight (`Net.predict_stream`; three by default) |
+| `inference_rice416_bf16.one_in_flight` | %(i1v).1f | %(i1ms).2f | the same forwards strictly one after the other (what rounds 1-2 reported) |
+| `inference_rice416_bf16.detect_many` | %(dmv).1f | | the public call: `MaskYOLO.detect_many` on uint8 images -- upload, the same graphs, detect()'s selection and unmolding per image |
+| `cpu_baseline` | %(cpu).2f | | torch-CPU fp32 restatement, %(cores)d threads, 32-image training step |
 
-History of the single-GPU headline this round (same workload; all parity suites green at every step): 859.7 img/s (round-1 kernels) →
-954.9 (mixed F(4,3)/F(2,3) Winograd tiling) → 969.5 (reduction-finish kernels with 8 loads in flight, ROIAlign backward with
-lane-parallel box / sample tests, depthwise vertical strips) → 995–1004 (`wino_mm_kernel`: k-contiguous operands, `ds_read_b128`
-fragments, one launch for all point groups; split-K for the 7×7 pointwise layers) → 1049–1067 (conv2-4 on the F(6,3)/F(4,3) tiling:
-17 %% fewer products and plane bytes) → **1103–1118** (conv1 forward, data and weight gradient on it as well) — and 1372–1385 with the
-opt-in bf16x6 product formation on top.
-''' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['achieved'], 100 * r['frac'],
-       r['conv_op']['avg_ms'], r['conv_op']['direct_equivalent_tflops'],
-       r['depthwise']['avg_ms'], r['roialign']['avg_ms'], 100 * r['roialign']['frac'], r['pointwise']['avg_ms'], r['pointwise']['achieved_tflops'],
-       100 * r['pointwise']['frac_of_fp32_mfma_peak'], r['hbm_stages'][-1]['avg_ms'], r['hbm_stages'][-1]['achieved'] / 1000, d['cpu_baseline']['value'],
-       v['winograd_multiply_bf16x6']['ms_per_step'], x['value'], x['ms_per_step'], x['roofline']['avg_launch_ms'], x['roofline']['achieved'],
-       100 * x['roofline']['frac'], x['roofline']['fp32_equivalent_tflops'], x['roofline']['conv_op']['avg_ms'],
-       v['dense_mask_backward']['value'], v['dense_mask_backward']['ms_per_step'],
-       v['mask_head_forward_on_positives_only']['value'], v['mask_head_forward_on_positives_only']['ms_per_step'],
-       xv['mask_head_forward_on_positives_only']['ms_per_step'],
-       " / ".join("%.0f" % v['n_pos_sweep']['n_pos_%d' % k]['images_per_sec'] for k in (5, 10, 20)),
-       " / ".join("%.1f" % v['n_pos_sweep']['n_pos_%d' % k]['ms_per_step'] for k in (5, 10, 20)), d['config']['n_pos_mean'],
-       rc['value'], rc['ms_per_step'], rr['kernel'].split(' ')[0], rr['avg_launch_ms'], rr['achieved'], 100 * rr['frac'])
-open(p, 'w').write(s[:i] + new)
-print("BASELINE.md section 5 rewritten: %.1f img/s, %.2f ms" % (d['value'], d['ms_per_step']))
+Dominant kernel (`roofline`): %(kname)s: **%(kms).3f ms per launch = %(ach).0f TFLOP/s of bf16 piece products = %(frac).3f of 2.5 PFLOP/s** (`frac_composite` %(fcomp).3f against max(flop / peak, bytes / measured copy rate))
+(%(eq).0f fp32-equivalent TFLOP/s; the fp32 MFMA peak is 157.3); whole conv op %(cop).2f ms; HBM traffic %(traf)s.
+Measured HBM copy bandwidth (`hbm_copy_measured_gbs`, GB/s): float4 copy %(c1).0f at 8 workgroups per CU, **%(c2).0f at one workgroup per CU**;
+read-only %(c3).0f / %(c4).0f; write-only %(c5).0f / %(c6).0f. Measured matrix-pipe rate with register operands (`mfma_measured_tflops`): bf16 %(mfb).0f, fp32 %(mff32).0f TFLOP/s. Winograd layer boundary (`hbm_stages`): %(bms).3f ms = %(bgb).0f GB/s.
+Depthwise (14 layers, in-step, HIP-event brackets around each fused launch): %(dwms).3f ms = %(dwf).2f of 8 TB/s on SURVEY 8(d) bytes; minus the event
+brackets' own cost %(dwn).3f ms = %(dwfn).2f (rocprofv3 kernel time of the same launches: `profiles/%(tag)s_bench_kernel_by_grid.csv`). ROIAlign forward (fused into
+conv1's input transform): %(roims).3f ms = %(roif).2f on 8(d) bytes, %(roiw).0f GB/s on the bytes it writes. Pointwise (14 layers): %(pwms).3f ms;
+MFMA-bound layers %(mff).2f of 157.3 TF/s in fp32-equivalent flops.
+
+Per-layer trunk table (`roofline.trunk_layers`; ms = HIP events around the layer's forward call in the step: conv + its BatchNorm statistics):
+
+(`us net` / `frac net`: the same bracket minus `roofline.event_bracket_ms` = %(brus).1f us, what a pair of timing events around a 4-byte fill kernel reads)
+
+| layer | shape | us | GB/s | TFLOP/s | roof | frac | us net | frac net |
+|---|---|---|---|---|---|---|---|---|
+%(rows)s
+''' % dict(tag=tag, sec=sec, rnd=rnd, spread=spread, tav=d.get('train_api', {}).get('train', {}).get('images_per_sec', 0.0), tams=d.get('train_api', {}).get('train', {}).get('ms_per_step', 0.0),
+           rsv=(d.get('train_api', {}).get('reference_same_state') or {}).get('images_per_sec', 0.0), rsms=(d.get('train_api', {}).get('reference_same_state') or {}).get('ms_per_step', 0.0),
+           rsn=(d.get('train_api', {}).get('reference_same_state') or {}).get('n_pos_mean', 0.0), hn='%.2f' % d['config'].get('n_pos_mean', 0.0),
+           tsv=d.get('train_api', {}).get('train_shapes_stream', {}).get('images_per_sec', 0.0), tsms=d.get('train_api', {}).get('train_shapes_stream', {}).get('ms_per_step', 0.0),
+           cpms=d.get('comm_overlap_probe_ms', {}).get('ms_per_step_with_probe', 0.0), fcomp=r.get('frac_composite', 0.0), fp=d["config"].get("fp32_products"), val=d["value"], ms=d["ms_per_step"], p10=d["step_ms"]["p10"], p50=d["step_ms"]["p50"], p90=d["step_ms"]["p90"],
+           nat_v=v["fp32_products_native"]["value"], nat_ms=v["fp32_products_native"]["ms_per_step"],
+           dn_v=v["dense_mask_backward"]["value"], dn_ms=v["dense_mask_backward"]["ms_per_step"],
+           po_v=v["mask_head_forward_on_positives_only"]["value"], po_ms=v["mask_head_forward_on_positives_only"]["ms_per_step"],
+           s5v=sw["n_pos_5"]["images_per_sec"], s10v=sw["n_pos_10"]["images_per_sec"], s20v=sw["n_pos_20"]["images_per_sec"],
+           s5=sw["n_pos_5"]["ms_per_step"], s10=sw["n_pos_10"]["ms_per_step"], s20=sw["n_pos_20"]["ms_per_step"],
+           n5v=nb5.get("value", 0.0), n5ms=nb5.get("ms_per_step", 0.0), iv=inf.get("value", 0.0), ims=inf.get("ms_per_step", 0.0),
+           dmv=(inf.get("detect_many") or {}).get("images_per_sec", 0.0),
+           i1v=inf.get("one_in_flight", {}).get("value", 0.0), i1ms=inf.get("one_in_flight", {}).get("ms_per_step", 0.0),
+           mfb=d.get("mfma_measured_tflops", {}).get("bf16_32x32x16", 0.0), mff32=d.get("mfma_measured_tflops", {}).get("f32_32x32x2", 0.0),
+           cpu=d["cpu_baseline"]["value"], cores=d["cpu_baseline"]["cores"],
+           kname=r["kernel"].split(":")[0], kms=r["avg_launch_ms"], ach=r["achieved"], frac=r["frac"], eq=r.get("fp32_equivalent_tflops") or 0.0,
+           cop=r["conv_op"]["avg_ms"], traf=("%.2f GB per launch (PMC, %s)" % (r["traffic"] / 1e9, r.get("traffic_source", "profiles/r3_pmc_x6.json")[:60])) if r.get("traffic") else "n/a",
+           c1=hb.get("float4", 0), c2=hb.get("float4_1wg_per_cu", 0), c3=hb.get("read_only", 0), c4=hb.get("read_only_1wg_per_cu", 0),
+           c5=hb.get("write_only", 0), c6=hb.get("write_only_1wg_per_cu", 0),
+           bms=r["hbm_stages"][-1]["avg_ms"], bgb=r["hbm_stages"][-1]["achieved"],
+           dwms=r["depthwise"]["avg_ms"], dwf=r["depthwise"]["frac"], dwn=r["depthwise"].get("avg_ms_net", 0.0), dwfn=r["depthwise"].get("frac_net", 0.0),
+           brus=1e3 * r.get("event_bracket_ms", 0.0), roims=r["roialign"]["avg_ms"], roif=r["roialign"]["frac"],
+           roiw=r["roialign"].get("achieved_on_written_bytes") or 0.0, pwms=r["pointwise"]["avg_ms"], mff=mf.get("frac_of_fp32_mfma_peak", 0.0), rows=rows)
+head = "## %d. Results (round %s" % (sec, rnd)
+if head in s:
+    s = s[:s.index(head)]
+s = s.rstrip() + "\n\n" + new
+open(p, "w").write(s)
+print("BASELINE.md section %d written from" % sec, tag)

@@ -3,7 +3,7 @@
 (FETCH_SIZE, WRITE_SIZE; --kernel-trace only) on a tools/kbench.py target, steady-state launches only (the last five of 36), corrected for gfx950
 (FETCH_SIZE counts half of a wide streaming read): traffic = (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 per launch.  Prints ONE JSON line.
     python tools/pmc_traffic.py wino63_mm wino_mm_x6_kernel [KBENCH_OPTIONS]
-bench.py runs this as a subprocess after its timed region (`roofline.traffic_live`); tools/collect_pmc_r3.sh is the fuller offline version."""
+bench.py runs this as a subprocess after its timed region (`roofline.traffic_live`); tools/collect_pmc.sh x6 is the fuller offline version."""
 import collections
 import csv
 import json
