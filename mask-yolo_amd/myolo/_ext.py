@@ -236,6 +236,8 @@ class WeightPrep(object):
     their kernels, recorded while the registry is active and re-run by refresh() on the caller's current stream.  Owns its arena (a device tensor)."""
 
     def __init__(self, device, arena_bytes=768 << 20):
+        # a recorded preparation that does not fit the arena is simply made in place by its site, as without a registry (myolo_wprep_resolve):
+        # the size is a capacity, not a requirement.  Net sizes it from its layer table (engine.Net._wprep_arena_bytes).
         self.arena = torch.empty(int(arena_bytes), dtype=torch.uint8, device=device)
         h = ctypes.c_void_p(0)
         call("myolo_wprep_create", self.arena.data_ptr(), self.arena.numel(), ctypes.byref(h))

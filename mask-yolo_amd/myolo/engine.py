@@ -267,6 +267,7 @@ class Net(object):
         self._npos_pinned = None
         self.fuse_bn_bwd_sums = 1         # trunk backward: the depthwise data gradient leaves the sums of the BatchNorm its output reaches (conv_pw_{b-1}_bn / conv1_bn) in its epilogue -- that BatchNorm's backward is finish + dx, its pass over (dy, x) is gone (round 5); 0 = three launches per BatchNorm
         self._bn_sums = {}                # BatchNorm name -> (partials, rows) left by the producer of its output gradient
+        self._np_seen = None              # positives of the last step whose counts the host has read (sizes the next step's kept-rows buffer)
         self.fused_bn_bwd = 0             # 1 = training-mode BatchNorm backward in one launch (sums, grid-wide barrier, dx: myolo_bn_act_bwd_fused).  Measured: 28.7 against 20.9 ms per step -- the barrier needs all its workgroups resident, and this step runs its chains BESIDE chip-filling kernels of other streams on purpose (profiles/r4_notes.md section 6)
         self._bn_sync = {}                # stream -> the barrier's counters
         self._bn_fused_bytes = {}
@@ -1233,6 +1234,7 @@ class Net(object):
         npos_h = self._npos_pinned.numpy()
         if "pos_index" in self.tape:            # built on the device in front of the forward (myolo_positive_index): only the total is needed here
             NP = int(np.clip(npos_h[:B], 0, R).sum())
+            self._np_seen = NP
             return (NP,) + (self.tape["pos_index"] if NP else (None, None))
         pos = np.concatenate([np.arange(b * R, b * R + int(npos_h[b]), dtype=np.int32) for b in range(B)]) if B else np.zeros(0, np.int32)
         NP = int(pos.shape[0])
@@ -1688,7 +1690,7 @@ class Net(object):
         if not self.weight_prep:
             return
         if self._wprep is None:
-            self._wprep = X.WeightPrep(self.dev)
+            self._wprep = X.WeightPrep(self.dev, arena_bytes=self._wprep_arena_bytes())
         wp = self._wprep
         self._wprep_ev = None
         n = wp.count()
@@ -1706,6 +1708,19 @@ class Net(object):
             self._wprep_ev = [ev1, None]
             self._wprep_rest = (nt, n)            # launched by _wprep_phase2, once the big early layers of the trunk are through
         wp.activate(True)
+
+    def _wprep_arena_bytes(self):
+        """capacity of a prepared-weights arena for this net (was a fixed 768 MiB): every weight matrix may be kept once as a transpose
+        (4 bytes per value), once as a bf16x6 split (6) and every 3x3 kernel once as 64 transformed planes of six bytes (64 / 9 * 6 per value),
+        + 256-byte alignment per entry.  ~330 MiB at the alpha-1 Shapes net; an entry beyond the capacity is made in place by its site."""
+        n = 0
+        for k, v in self.p.items():
+            if v.dim() == 4 and v.shape[0] == 3 and v.shape[2] > 3:            # 3x3 convs with many input channels: Winograd filter planes
+                n += int(v.numel()) * (64 * 6 // 9 + 10)
+            elif v.dim() >= 2:
+                n += int(v.numel()) * 10
+            n += 512
+        return int(min(max(n, 64 << 20), 768 << 20))
 
     def _wprep_phase2(self):
         """the preparations the mask head and the backward will ask for (Winograd filter transforms, transposes, splits: ~0.25 ms of small kernels):
@@ -1825,7 +1840,13 @@ class Net(object):
                 X.call("myolo_positive_index", X.ptr(npos), B, R, X.ptr(flags), X.ptr(idx_d), X.ptr(inv_d), None, X.stream())
                 self.tape["pos_index"] = (idx_d, inv_d)
                 if self.keep_deconv_rows:
-                    keep = (inv_d, max(1, min(B * R, int(self.keep_deconv_rows * B))))
+                    # capacity of the kept-rows buffer (803 KB per ROI): keep_deconv_rows per image at most, and no more than twice (+ 64) what the last
+                    # step that read its counts really had (the full cap -- 1.2 GB at B = 32 -- was allocated every step whatever the positives;
+                    # beyond the capacity the backward re-runs the deconv for the positives, same results)
+                    cap = min(B * R, int(self.keep_deconv_rows * B))
+                    if self._np_seen is not None:
+                        cap = min(cap, 2 * self._np_seen + 64)
+                    keep = (inv_d, max(1, cap))
             pred = self.mask_head_fwd(Fm, fshape, rois, True, pos_flags=flags, keep=keep)
             tmask_l, tcls_l = tmask, tcls
         if pred is None:                  # positives-only forward without a positive ROI (model.py:750-752)
@@ -1977,7 +1998,7 @@ class Net(object):
         if not self.infer_weight_cache:
             return
         if self._iprep is None:
-            self._iprep = X.WeightPrep(self.dev, arena_bytes=256 << 20)
+            self._iprep = X.WeightPrep(self.dev, arena_bytes=min(self._wprep_arena_bytes(), 256 << 20))
         ip = self._iprep
         state = (self._wver, ip.count())
         cur = torch.cuda.current_stream()

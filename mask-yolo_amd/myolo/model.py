@@ -69,7 +69,12 @@ class StepResult(collections.abc.Mapping):
     ('loss', 'yolo_sum_loss', 'mask_loss', 'loss_xy', 'loss_wh', 'loss_conf', 'loss_class', 'recall') wait for that event
     when first read, and the tensor keys ('yolo_output', 'yolo_proposals', 'output_rois', 'myolo_mask', 'target_class_ids',
     'target_mask', 'n_pos', 'feature_map') are downloaded only when indexed (the device tensors stay referenced here, so
-    reading them later still gives this step's values).  A read-only Mapping: out['loss'], out.get(...), dict(out) all work."""
+    reading them later still gives this step's values).  A read-only Mapping: out['loss'], out.get(...), dict(out) all work.
+
+    Lifetime: while a StepResult is alive it keeps its step's output tensors on the DEVICE (~100 MB at config 2).  Code that collects results
+    over many steps should keep numbers, not StepResults: `out["loss"]`, or `out.release()` once the scalars have been read (drops every device
+    reference; tensor keys already fetched stay readable, the others then raise), or `out.as_dict()` for a plain, picklable / json-able dict
+    of what has been read plus the scalars.  MaskYOLO.train() and train_shapes_stream() do this themselves (they keep the loss of step i-2)."""
 
     SCALARS = ("loss", "yolo_sum_loss", "mask_loss", "loss_xy", "loss_wh", "loss_conf", "loss_class", "recall")
 
@@ -117,6 +122,21 @@ class StepResult(collections.abc.Mapping):
     def device(self, k):
         """the device tensor behind a tensor key (no copy)."""
         return self._t[k]
+
+    def release(self):
+        """read the scalars (waits for the step's small copy), then drop every device tensor this result holds; returns self.  Tensor keys that
+        were downloaded before stay available, the others raise KeyError afterwards."""
+        self._scalars()
+        self._t = {k: None for k in self._t if k in self._host}
+        return self
+
+    def as_dict(self, tensors=()):
+        """a plain dict: the eight scalars, every tensor key already downloaded, and the keys named in `tensors` (downloaded now)."""
+        d = dict(self._scalars())
+        for k in tensors:
+            self[k]
+        d.update({k: v for k, v in self._host.items()})
+        return d
 
     def __iter__(self):
         return iter(list(self._t.keys()) + list(self.SCALARS))
@@ -305,8 +325,10 @@ class MaskYOLO(object):
         self.net.adam_t = 0
 
     def train_on_batch(self, batch, learning_rate=None):
-        """One optimisation step on a host batch (the six arrays of model.py:896-897).
-        Returns the reference's training outputs (model.py:899) + loss scalars as numpy."""
+        """One optimisation step on a host batch (the six arrays of model.py:896-897) or an already staged device batch.
+        Returns a StepResult -- a read-only Mapping of the reference's training outputs (model.py:899) and the loss scalars: scalars from one
+        small asynchronous copy (first read waits for the step), tensors downloaded when indexed.  It keeps the step's output tensors on the
+        device until dropped: see StepResult (release / as_dict) before collecting results over many steps."""
         lr = self._lr if learning_rate is None else learning_rate
         if lr is None:
             lr = self.config.LEARNING_RATE
