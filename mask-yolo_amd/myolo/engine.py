@@ -268,6 +268,7 @@ class Net(object):
         self.fuse_bn_bwd_sums = 1         # trunk backward: the depthwise data gradient leaves the sums of the BatchNorm its output reaches (conv_pw_{b-1}_bn / conv1_bn) in its epilogue -- that BatchNorm's backward is finish + dx, its pass over (dy, x) is gone (round 5); 0 = three launches per BatchNorm
         self._bn_sums = {}                # BatchNorm name -> (partials, rows) left by the producer of its output gradient
         self._np_seen = None              # positives of the last step whose counts the host has read (sizes the next step's kept-rows buffer)
+        self._keep_cap_hw = 0
         self.fused_bn_bwd = 0             # 1 = training-mode BatchNorm backward in one launch (sums, grid-wide barrier, dx: myolo_bn_act_bwd_fused).  Measured: 28.7 against 20.9 ms per step -- the barrier needs all its workgroups resident, and this step runs its chains BESIDE chip-filling kernels of other streams on purpose (profiles/r4_notes.md section 6)
         self._bn_sync = {}                # stream -> the barrier's counters
         self._bn_fused_bytes = {}
@@ -1840,12 +1841,18 @@ class Net(object):
                 X.call("myolo_positive_index", X.ptr(npos), B, R, X.ptr(flags), X.ptr(idx_d), X.ptr(inv_d), None, X.stream())
                 self.tape["pos_index"] = (idx_d, inv_d)
                 if self.keep_deconv_rows:
-                    # capacity of the kept-rows buffer (803 KB per ROI): keep_deconv_rows per image at most, and no more than twice (+ 64) what the last
-                    # step that read its counts really had (the full cap -- 1.2 GB at B = 32 -- was allocated every step whatever the positives;
-                    # beyond the capacity the backward re-runs the deconv for the positives, same results)
+                    # capacity of the kept-rows buffer (803 KB per ROI): keep_deconv_rows per image at most, and no more than the high-water mark of
+                    # what the steps whose counts the host has read really needed -- twice the positives + 64, rounded up to a power of two, never
+                    # shrinking: the size changes a handful of times in a run, so the allocator does not see a new request every step (a fresh
+                    # hipMalloc inside a step is a ~35 ms stall).  ADVICE r4: the full cap, 1.2 GB at B = 32, was allocated every step whatever the
+                    # positives.  Beyond the capacity the backward re-runs the deconv for the positives: same results.
                     cap = min(B * R, int(self.keep_deconv_rows * B))
                     if self._np_seen is not None:
-                        cap = min(cap, 2 * self._np_seen + 64)
+                        want = 64
+                        while want < 2 * self._np_seen + 64:
+                            want *= 2
+                        self._keep_cap_hw = max(self._keep_cap_hw, want)
+                        cap = min(cap, self._keep_cap_hw)
                     keep = (inv_d, max(1, cap))
             pred = self.mask_head_fwd(Fm, fshape, rois, True, pos_flags=flags, keep=keep)
             tmask_l, tcls_l = tmask, tcls

@@ -386,6 +386,48 @@ def test_sparse_mask_backward_equals_dense():
     raise AssertionError("no seeded case without a ReLU flip between the two forwards: %r" % (seen,))
 
 
+def test_kept_deconv_rows_capacity_follows_the_positive_count():
+    """the buffer of kept deconv rows (803 KB per ROI) was allocated at its full cap every step.  Now its capacity is the high-water mark of
+    2 x positives + 64 (power of two) over the steps whose counts the host has read -- never above keep_deconv_rows per image, never shrinking.  A step
+    whose positives exceed the capacity re-runs the deconv for them in the backward: gradients equal those of a net that keeps every row, whatever the
+    capacity was (cap 0 rows = always re-run, the round-3 behaviour, is the reference here)."""
+    cfg, P, batch, _ = make_case(ShapesConfig, 128, 0.5, 4, seed=1)
+    R = cfg.TRAIN_ROIS_PER_IMAGE
+
+    def run(keep_rows, forced):
+        model = MaskYOLO(mode="training", config=cfg)
+        model.load_state_dict(P)
+        net = model.net
+        net.keep_deconv_rows = keep_rows
+        caps, grads = [], []
+        orig = net.mask_head_fwd
+
+        def spy(*a, **k):
+            if k.get("keep") is not None:
+                caps.append(k["keep"][1])
+            return orig(*a, **k)
+        net.mask_head_fwd = spy
+        for k in forced:
+            if k:
+                _force_first_proposals_onto_gt(net, cfg, k)
+            else:
+                net.proposals_hook = None
+            model.train_on_batch(batch, learning_rate=0.0)
+            grads.append(net.grads_dict())
+        return caps, grads
+    forced = (0, 12, 1)                      # few positives, then 48 in the batch (> the first capacity), then few again
+    caps, g_keep = run(48, forced)
+    _, g_ref = run(0, forced)
+    assert caps[0] == min(4 * R, 48 * 4)     # nothing read yet: the full cap
+    assert caps[1] in (64, 128)              # the first step had a handful of positives: 2 * n + 64 rounded up to a power of two
+    assert caps[2] >= 128 and caps[2] >= caps[1]          # grown after the step with 48, and never shrinking
+    for a, b in zip(g_keep, g_ref):
+        for k in a:
+            if np.abs(b[k]).max() < 1e-12:
+                continue
+            assert rel(a[k], b[k]) < 1e-4, k
+
+
 @pytest.mark.parametrize("tiles", ["f63", "f43"])
 def test_sparse_mask_backward_with_zero_and_tiny_frozen_bn_gammas(tiles):
     """bn2-4 of the mask head are frozen affine maps; the exact-sparsity backward reads their backward off the conv's PRE-BatchNorm output, kept
