@@ -222,6 +222,45 @@ def test_full_size_step_sparse_equals_dense_and_is_reproducible():
     assert float(d) < 1e-4, float(d)                                               # sparse == dense gradients
 
 
+def test_host_jitter_below_the_launch_slack_does_not_reach_the_gpu():
+    """VERDICT r4 weak 9 / item 7, the claim measured: the host reads the per-image positive counts once per step and is blocked on that read for
+    most of a step -- host IDLE time: when the read returns, the rest of the mask head's forward (~11 ms of GPU work) is still queued behind it.
+    So a host that loses up to that slack in every step (a slow data loader, a collector pause, a slow rank's Python) does not slow the GPU: with
+    8 ms of sleep before every step the step time stays within 4 % (and the blocked time shrinks by about what was slept); with 30 ms -- more than
+    a whole step -- the GPU does run dry, which is what a pipeline of depth one must do.  Full config-2 size, batches resident."""
+    import time
+    from myolo.config import make_config, ShapesConfig
+    from myolo.model import MaskYOLO
+    from myolo.shapes import make_shapes_samples
+    from myolo.myolo_utils import BatchGenerator
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[224, 224, 3], ALPHA=1.0, BATCH_SIZE=32)
+    net = MaskYOLO(mode="training", config=cfg, seed=0).net
+    dbs = []
+    for k in range(2):
+        batch, _ = BatchGenerator(make_shapes_samples(32, cfg, start_index=32 * k), cfg, 'training', shuffle=False, norm=True)[0]
+        dbs.append(net.to_device_batch(batch))
+    for i in range(6):
+        net.train_step(dbs[i % 2], 1e-3)
+
+    def run(sleep_s, steps=12):
+        torch.cuda.synchronize()
+        net.host_wait_s = 0.0
+        t0 = time.perf_counter()
+        for i in range(steps):
+            if sleep_s:
+                time.sleep(sleep_s)
+            net.train_step(dbs[i % 2], 1e-3)
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / steps, 1e3 * net.host_wait_s / steps
+    base, wait0 = run(0.0)
+    jit, wait1 = run(0.008)
+    slow, _ = run(0.030)
+    assert wait0 > 9.0, (base, wait0)                       # the host really is idle for more than the 8 ms it is about to lose
+    assert jit < 1.04 * base + 0.3, (base, jit)             # ... and losing them does not reach the GPU
+    assert wait1 < wait0 - 4.0, (wait0, wait1)
+    assert slow > base + 8.0, (base, slow)                  # beyond the slack the GPU starves: the pipeline is one step deep
+
+
 SAFE_BATCH_START = 1224      # tools/find_safe_config2_batch.py: every proposal's best IoU is >= 4.9e-3 away from the 0.5 threshold
 _CFG2 = {}
 
