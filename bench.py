@@ -83,6 +83,10 @@ def compact_line(res):
     if rf.get("traffic") and rf.get("algorithmic_bytes"):
         r["traffic_over_algorithmic"] = rf["traffic"] / rf["algorithmic_bytes"]
         r["traffic_measured_in_this_run"] = "traffic_from_profiles" in rf
+    pl = res.get("power_limit_probe")
+    if isinstance(pl, dict) and "ms_random" in pl:
+        # the dominant kernel alone, back to back: ms on random / constant operands, package power and shader clock while it runs (cap, nominal 2400 MHz)
+        r["power_limit_probe"] = _pick(pl, ("ms_random", "ms_constant", "power_w", "cap_w", "sclk_mhz"))
     if "depthwise" in rf:
         r["depthwise"] = _pick(rf["depthwise"], ("frac", "frac_net", "avg_ms"))
     if "roialign" in rf and "frac" in rf["roialign"]:
@@ -583,6 +587,14 @@ def bench_train(args, rank, world, local):
             extras["mfma_measured_tflops"] = dict(Xe.measure_mfma_tflops(device=dev), nominal_bf16=BF16_MFMA_PEAK, nominal_f32=FP32_MFMA_PEAK)
         except Exception as e:
             extras["mfma_measured_tflops"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        # (a3) is the dominant kernel power-limited?  The same multiply on random and on constant operands, socket power and shader clock meanwhile
+        try:
+            pl = Xe.measure_power_limit(n_rois=args.batch * cfg.TRAIN_ROIS_PER_IMAGE, device=dev)
+            pl["note"] = ("wino_mm_x6_kernel at the launch shape of the mask-head convs, 500 launches back to back: same instructions and traffic on normally "
+                          "distributed and on constant operands; power / clock sampled with rocm-smi while the random-data launches run (nominal 2400 MHz)")
+            extras["power_limit_probe"] = pl
+        except Exception as e:
+            extras["power_limit_probe"] = {"error": "%s: %s" % (type(e).__name__, e)}
         # (b) what the three real gradient buckets cost as RCCL collectives on the comm stream while backward runs: a 1-rank
         #     communicator through the C-ABI (launch + stream + kernel cost of the exchange, not the wire), and the step with it
         try:

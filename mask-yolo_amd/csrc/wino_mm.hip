@@ -935,6 +935,7 @@ struct TNArgs {
     int tiles_k, tiles_n;      // Ka / 256, N / 256
     long long nunits;          // (plane, split) pairs x tiles
     long long unit_base;       // first unit of this launch (option "tn_wgs": the units go out in launches of at most that many workgroups)
+    int tune;                  // MM_X6_TUNE builds only (tools/experiments/tn_x6_tune.sh): timing-only ablations of wino_tn_x6_kernel, results are wrong
     TNRun run[4];
 };
 
@@ -1005,6 +1006,18 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
             g_x = xk;
             return;
         }
+#ifdef MM_X6_TUNE
+        if (p.tune & 1) {                                   // no operand traffic: every load out of range
+#pragma unroll
+            for (int k = 0; k < 16; ++k) st[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)MM_OOB, 0, 0));
+            return;
+        }
+        if (p.tune & 16) {                                  // the chunk's first 16 rows every time: L2 hits instead of HBM traffic
+#pragma unroll
+            for (int k = 0; k < 16; ++k) st[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)k * rowb), 0));
+            return;
+        }
+#endif
 #pragma unroll
         for (int k = 0; k < 16; ++k) st[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)(soff + (unsigned)k * rowb), 0));
         soff += 16u * rowb;
@@ -1025,11 +1038,17 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float a0 = st[8 * h + 2 * e], a1 = st[8 * h + 2 * e + 1];
+#ifdef MM_X6_TUNE
+            if (p.tune & 2) { p1[e] = x6_top(a0, a1); p2[e] = p1[e]; p3[e] = p1[e]; continue; }      // no exact split
+#endif
             const float b0 = x6_rest(a0), b1 = x6_rest(a1);
             p1[e] = x6_top(a0, a1);
             p2[e] = x6_top(b0, b1);
             p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
         }
+#ifdef MM_X6_TUNE
+        if (p.tune & 8) return;                              // no LDS writes
+#endif
         unsigned char* w = wbase + buf * (2 * TN_T * X6_REC) + h * 16;
         *reinterpret_cast<u32x4*>(w) = p1;
         *reinterpret_cast<u32x4*>(w + 32) = p2;
@@ -1073,6 +1092,9 @@ __global__ __launch_bounds__(512, 1) void wino_tn_x6_kernel(TNArgs p)
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) fn[pc] = *reinterpret_cast<const bf16x8*>(la + afr + (t + 1) * 32 * X6_REC + pc * 32);
             }
+#ifdef MM_X6_TUNE
+            if (!(p.tune & 4))                        // (4: no MFMAs -- what the rest of the loop costs by itself)
+#endif
 #pragma unroll
             for (int u = 0; u < 2; ++u) {             // smallest terms first
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0], fb[u][2], acc[t][u], 0, 0, 0);
@@ -1204,6 +1226,9 @@ int myolo_gemm_tn_x6_runs(const float* A, const float* B, float* C, int nruns, c
     }
     if (pairs <= 0) return MYOLO_OK;
     a.nunits = pairs * a.tiles_k * a.tiles_n;
+#ifdef MM_X6_TUNE
+    a.tune = g_myolo_opt.tune0;
+#endif
     for (long long base = 0, g = tn_x6_grid(a.nunits); base < a.nunits; base += g) {
         a.unit_base = base;
         hipLaunchKernelGGL(wino_tn_x6_kernel<false>, dim3((unsigned)(a.nunits - base < g ? a.nunits - base : g)), dim3(512), 0, s, a);

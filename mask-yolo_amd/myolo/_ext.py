@@ -326,6 +326,68 @@ def measure_hbm_copy_gbs(nbytes=2 << 30, iters=5, device="cuda:0"):
     return out
 
 
+def _smi_power_clock():
+    """(socket power W, shader clock MHz) from rocm-smi, or (None, None)."""
+    import subprocess
+    try:
+        t = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+        pw = [float(l.split(":")[-1]) for l in t.splitlines() if "Socket Graphics Package Power" in l]
+        sc = [float(l.split("(")[-1].split("Mhz")[0]) for l in t.splitlines() if "sclk" in l]
+        return (pw[0] if pw else None), (sc[0] if sc else None)
+    except Exception:
+        return None, None
+
+
+def measure_power_limit(n_rois=32 * 147, launches=500, device="cuda:0"):
+    """Is the dominant kernel power-limited?  The F(6,3) Winograd multiply (bf16x6 products, the launch shape of the step's mask-head convs) run
+    back to back on (a) normally distributed operands and (b) constant operands -- the same instruction stream, the same memory traffic, fewer
+    bits toggling -- with the socket power and shader clock rocm-smi reports while (a) runs.  On MI355X (1400 W package cap, 2400 MHz) the kernel
+    reaches the cap and is clocked down on real data (profiles/r5_notes.md section 8): its distance from the nominal matrix-pipe peak is then
+    an energy budget, not a schedule.  -> dict(ms_random, ms_constant, power_w, sclk_mhz, cap_w)"""
+    import subprocess
+    old = set_option("wino_x6", 1)
+    try:
+        C = 256
+        pe = wino63_plane_elems(n_rois, C)
+        g = torch.Generator(device=device).manual_seed(0)
+        V = torch.randn(pe, device=device, generator=g)
+        w = torch.randn(3, 3, C, C, device=device, generator=g) * 0.02
+        M = torch.empty(pe, device=device)
+        U = torch.empty(wino63_u_elems(C, C), device=device)
+        out = {}
+        for name in ("random", "constant"):
+            if name == "constant":
+                V.fill_(1.0)
+                w.fill_(1.0)
+            call("myolo_wino63_weight_transform", ptr(w), ptr(U), C, C, stream())
+            for _ in range(40):                                   # through the clock transient after idle
+                call("myolo_wino63_multiply", ptr(V), ptr(U), ptr(M), n_rois, C, C, stream())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(launches):
+                call("myolo_wino63_multiply", ptr(V), ptr(U), ptr(M), n_rois, C, C, stream())
+            e1.record()
+            if name == "random":                                  # the queue holds ~0.65 s of launches: two samples while they run (the power
+                import time                                       # figure is a moving average: the later sample is the settled one)
+                time.sleep(0.2)
+                p1, c1 = _smi_power_clock()
+                p2, c2 = _smi_power_clock()
+                ps_, cs_ = [v for v in (p1, p2) if v is not None], [v for v in (c1, c2) if v is not None]
+                out["power_w"], out["sclk_mhz"] = (max(ps_) if ps_ else None), (min(cs_) if cs_ else None)
+            torch.cuda.synchronize()
+            out["ms_" + name] = e0.elapsed_time(e1) / launches
+        try:
+            t = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showmaxpower"], capture_output=True, text=True, timeout=10).stdout
+            cap = [float(l.split(":")[-1]) for l in t.splitlines() if "Max Graphics Package Power" in l]
+            out["cap_w"] = cap[0] if cap else None
+        except Exception:
+            out["cap_w"] = None
+        return out
+    finally:
+        set_option("wino_x6", old)
+
+
 def measure_mfma_tflops(iters=20000, reps=3, device="cuda:0"):
     """{"bf16_32x32x16": TFLOP/s, "f32_32x32x2": TFLOP/s} the matrix pipes sustain with nothing else going on (myolo_mfma_probe: two
     workgroups of four waves per CU, eight independent accumulator blocks per wave, register operands), timed with HIP events."""

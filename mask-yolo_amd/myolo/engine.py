@@ -1779,6 +1779,7 @@ class Net(object):
     def _forward_backward(self, db):
         self._activate()
         self.mark_weights_changed()           # (the BatchNorm moving statistics move in every training forward)
+        self._bn_sums.clear()                 # (partials a previous, interrupted backward may have left)
         self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
@@ -1930,6 +1931,7 @@ class Net(object):
         + yolo_custom_loss, no feature_map / ROIAlign / mask head.  db needs images, true_boxes, y_true."""
         self._activate()
         self.mark_weights_changed()
+        self._bn_sums.clear()
         self._await_batch(db)
         cfg = self.cfg
         self.tape = {}
