@@ -87,6 +87,9 @@ def compact_line(res):
     if isinstance(pl, dict) and "ms_random" in pl:
         # the dominant kernel alone, back to back: ms on random / constant operands, package power and shader clock while it runs (cap, nominal 2400 MHz)
         r["power_limit_probe"] = _pick(pl, ("ms_random", "ms_constant", "power_w", "cap_w", "sclk_mhz"))
+        if pl.get("sclk_mhz") and rf.get("frac"):
+            # `frac` is priced against the NOMINAL peak (2400 MHz); this is the same figure against the peak at the clock the package power cap grants
+            r["frac_at_granted_clock"] = rf["frac"] * 2400.0 / max(float(pl["sclk_mhz"]), 1.0)
     if "depthwise" in rf:
         r["depthwise"] = _pick(rf["depthwise"], ("frac", "frac_net", "avg_ms"))
     if "roialign" in rf and "frac" in rf["roialign"]:
