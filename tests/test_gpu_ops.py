@@ -542,7 +542,8 @@ def test_crop_and_resize(B, H, W, C, nb, crop):
     check(dimg, O.crop_and_resize_bwd_image(dout, boxes, bind, img.shape), 1e-4, "crop bwd")
 
 
-@pytest.mark.parametrize("B,H,W,C,R,crop", [(2, 28, 28, 256, 20, 14), (3, 7, 9, 16, 5, 5), (2, 12, 12, 64, 7, 14), (8, 28, 28, 256, 147, 14), (3, 8, 12, 256, 70, 7)])
+@pytest.mark.parametrize("B,H,W,C,R,crop", [(2, 28, 28, 256, 20, 14), (3, 7, 9, 16, 5, 5), (2, 12, 12, 64, 7, 14), (8, 28, 28, 256, 147, 14), (3, 8, 12, 256, 70, 7), (2, 52, 52, 256, 40, 14), (2, 16, 16, 256, 48, 14),
+                                                  (2, 30, 17, 256, 33, 14)])
 def test_roialign_bwd_grouped(B, H, W, C, R, crop):
     """gather formulation == scatter formulation (oracle), incl. degenerate all-zero boxes and boxes
     outside the image; and it is bit-reproducible."""
