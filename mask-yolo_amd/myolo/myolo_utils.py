@@ -144,15 +144,23 @@ def resize_mask(mask, scale):
 
 def load_image_gt(dataset, config, image_id, augment=False, augmentation=None, use_mini_mask=False):
     """-> image, class_ids, bbox [n,(x1,y1,x2,y2)], mask [H,W,n] (myolo_utils.py:274-366): load, resize image and masks to
-    config.IMAGE_SHAPE, drop the instances whose mask came out empty, tight boxes.  Augmentation (imgaug) and mini-masks are image-file
-    I/O options outside the hot path and are refused.  Pinned by tests/golden/ref_load_image_gt.npz (the reference's function executed)."""
-    if augment or augmentation is not None or use_mini_mask:
-        raise NotImplementedError("augmentation / mini-masks are outside the hot path")
+    config.IMAGE_SHAPE, drop the instances whose mask came out empty, tight boxes.  `augment=True` is the reference's deprecated random horizontal flip; imgaug
+    augmentation and mini-masks are image-file I/O options outside the hot path and are refused.  Pinned by tests/golden/ref_load_image_gt.npz (the reference's function executed)."""
+    if augmentation is not None or use_mini_mask:
+        raise NotImplementedError("imgaug augmentation / mini-masks are outside the hot path")
     image = dataset.load_image(image_id)
     mask, class_ids = dataset.load_mask(image_id)
     if list(image.shape[:2]) != list(config.IMAGE_SHAPE[:2]):
         image, scale = resize_image(image, config.IMAGE_SHAPE)
         mask = resize_mask(mask, scale)
+    if augment:
+        # the deprecated random horizontal flip (myolo_utils.py:306-311): ONE draw of the global `random` module per image, as the reference makes it
+        import logging
+        import random
+        logging.warning("'augment' is deprecated. Use 'augmentation' instead.")
+        if random.randint(0, 1):
+            image = np.fliplr(image)
+            mask = np.fliplr(mask)
     keep = np.sum(mask, axis=(0, 1)) > 0
     mask = mask[:, :, keep]
     class_ids = class_ids[keep]

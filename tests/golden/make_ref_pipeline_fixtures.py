@@ -128,6 +128,29 @@ def main():
         out[tag + "_boxes"] = np.concatenate(boxes).astype(np.int32)
         out[tag + "_mask_bits"] = np.concatenate(bits)
         print("load_image_gt[%s]: %d images %dx%d -> 224x224, %d instances" % (tag, n, h, w, sum(counts)))
+    # augment=True (the deprecated random horizontal flip, myolo_utils.py:306-311): one draw of the global `random` module per image, seeded here per image
+    ds = ShapesDataset(1234)
+    ds.load_shapes(24, 224, 224, start_index=2000)
+    ds.prepare()
+    logging.disable(logging.WARNING)                    # (the reference warns "'augment' is deprecated" on every call)
+    imgs, cls, boxes, bits, counts, flips = [], [], [], [], [], []
+    for g in range(24):
+        random.seed(7000 + g)
+        flips.append(random.randint(0, 1))
+        random.seed(7000 + g)
+        image, class_ids, bbox, mask = R["load_image_gt"](ds, rcfg, g, augment=True, augmentation=None, use_mini_mask=False)
+        imgs.append(image); cls.append(class_ids.astype(np.int32)); boxes.append(bbox); counts.append(mask.shape[-1])
+        bits.append(np.packbits(np.ascontiguousarray(mask).reshape(-1)))
+    logging.disable(logging.NOTSET)
+    out["flip_hw_start"] = np.array([224, 224, 2000], np.int64)
+    out["flip_seed0"] = np.array(7000)
+    out["flip_drawn"] = np.array(flips, np.int64)
+    out["flip_images"] = np.stack(imgs)
+    out["flip_counts"] = np.array(counts, np.int64)
+    out["flip_class_ids"] = np.concatenate(cls)
+    out["flip_boxes"] = np.concatenate(boxes).astype(np.int32)
+    out["flip_mask_bits"] = np.concatenate(bits)
+    print("load_image_gt[augment=True]: 24 images, %d flipped" % sum(flips))
     # the wrapper's own arguments, on something that is not piecewise constant: resize() of a random float image and of a ramp
     rng = np.random.default_rng(5)
     a = rng.random((37, 53, 3)) * 255.0

@@ -366,6 +366,40 @@ def test_load_image_gt_matches_reference_output(tag):
     assert off <= 5e-3 * fx[tag + "_images"].size           # flat colours sit exactly on integers: (1-d)*v + d*v truncates either way
 
 
+def test_load_image_gt_random_flip_matches_reference_output():
+    """load_image_gt(augment=True), the deprecated random horizontal flip (myolo_utils.py:306-311): under the same random.seed the product draws what
+    the reference drew and returns its image, class ids, boxes and masks bit for bit (24 images, 12 of them flipped in the fixture)."""
+    import logging
+    import random
+    from myolo.config import ShapesConfig
+    from myolo.shapes import ShapesDataset
+    fx = _load("ref_load_image_gt.npz")
+    h, w, start, counts, bits = _gt_case(fx, "flip")
+    drawn = fx["flip_drawn"]
+    assert 0 < drawn.sum() < len(drawn)
+    ds = ShapesDataset(int(fx["seed"]))
+    ds.load_shapes(len(counts), h, w, start_index=start)
+    ds.prepare()
+    cfg = ShapesConfig()
+    o_bit = o_box = 0
+    logging.disable(logging.WARNING)
+    try:
+        for g in range(len(counts)):
+            random.seed(int(fx["flip_seed0"]) + g)
+            image, class_ids, bbox, mask = mutils.load_image_gt(ds, cfg, g, augment=True)
+            n = int(counts[g])
+            np.testing.assert_array_equal(image, fx["flip_images"][g])
+            np.testing.assert_array_equal(mask, bits[o_bit:o_bit + 224 * 224 * n].reshape(224, 224, n).astype(bool))
+            np.testing.assert_array_equal(bbox, fx["flip_boxes"][o_box:o_box + n])
+            np.testing.assert_array_equal(class_ids, fx["flip_class_ids"][o_box:o_box + n])
+            plain = mutils.load_image_gt(ds, cfg, g)[0]
+            assert np.array_equal(image, plain[:, ::-1] if drawn[g] else plain)
+            o_bit += 224 * 224 * n
+            o_box += n
+    finally:
+        logging.disable(logging.NOTSET)
+
+
 def test_resize_wrappers_match_reference_output():
     """the scikit-image wrapper's arguments (order 1, constant 0 outside, clip, preserve_range, no anti-aliasing) and scipy's order-0 zoom, on
     inputs that are not piecewise constant: float result to 1e-10, the uint8 round trip to 1 count on < 0.1 %, the zoomed masks bit-exact."""
