@@ -605,15 +605,22 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         for (int u = 0; u < NU; ++u) {
             // smallest terms first
 #define X6_TILE(t)                                                                                                 \
+            if (X6_ALL) {                                                                                          \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][2], acc[t][u], 0, 0, 0);           \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][2], bq[u][0], acc[t][u], 0, 0, 0);           \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][1], acc[t][u], 0, 0, 0);           \
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][1], acc[t][u], 0, 0, 0); }         \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][1], acc[t][u], 0, 0, 0);           \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][0], acc[t][u], 0, 0, 0);           \
             acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][0], acc[t][u], 0, 0, 0);
+#ifdef MM_X6_TUNE
+#define X6_ALL (!(p.tune & 256))          /* 256: only three of the six piece products (timing only: what a three-product scheme could cost at most) */
+#else
+#define X6_ALL true
+#endif
             X6_TILE(0)
             X6_TILE(1)
 #undef X6_TILE
+#undef X6_ALL
 #ifdef MM_X6_TUNE
             if (!(p.tune & 2))
 #endif

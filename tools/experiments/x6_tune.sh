@@ -7,6 +7,7 @@
 #    4  no exact split of A (one piece stored three times)                   8  no epilogue stores
 #   16  A always from the tile's chunk 0 (L2 hits instead of HBM traffic)  32  no barrier, no LDS writes in the loop
 #   64  no LDS fragment reads in the loop                                  128  no A loads in the loop
+#  256  only three of the six piece products (round 5: the most a three-product scheme could save)
 #   build here (no GPU needed):  bash tools/experiments/x6_tune.sh build        run:  gpurun -- 'bash tools/experiments/x6_tune.sh run'
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 L=$ROOT/mask-yolo_amd/myolo/_lib
