@@ -140,13 +140,22 @@ extern "C" int myolo_wprep_refresh(void* h, int first, int last, int max_idle, v
     WPrep* r = (WPrep*)h;
     if (last > (int)r->e.size()) last = (int)r->e.size();
     int n = 0;
+    // the bf16x6 weight splits of the range go out in ONE launch (round 5: ~17 launches of a few microseconds each per training step before); every
+    // other kind through its recorded closure.  Same bytes either way; the order between entries does not matter (distinct slots, read-only sources).
+    std::vector<const void*> bs;
+    std::vector<void*> bd;
+    std::vector<long long> bk, bn_, bkn;
     for (int i = first < 0 ? 0 : first; i < last; ++i) {
         WPrepEntry& en = r->e[i];
         if (max_idle > 0 && r->gen - en.last_use > (unsigned long long)max_idle) continue;
-        en.run(r->arena + en.off, (hipStream_t)stream);
+        if (en.kind == WP_X6_SPLIT && !(g_myolo_opt.tune0 & 2097152)) {
+            bs.push_back(en.w); bd.push_back(r->arena + en.off); bk.push_back(en.d0); bn_.push_back(en.d1); bkn.push_back(en.d2);
+        } else
+            en.run(r->arena + en.off, (hipStream_t)stream);
         en.gen = r->gen;
         ++n;
     }
+    if (!bs.empty()) myolo_x6_split_batched((int)bs.size(), bs.data(), bd.data(), bk.data(), bn_.data(), bkn.data(), (hipStream_t)stream);
     if (hipGetLastError() != hipSuccess) { myolo_set_error("wprep_refresh: a launch failed"); return -1; }
     return n;
 }

@@ -87,6 +87,9 @@ enum { WP_TRANSPOSE = 1, WP_X6_SPLIT = 2, WP_WINO63_U = 3, WP_WINO43_U = 4 };
 const void* myolo_wprep_resolve(const void* w, int kind, long long d0, long long d1, long long d2, size_t bytes, void* fallback, hipStream_t s,
                                 const std::function<void(void*, hipStream_t)>& run);
 
+// csrc/wino_mm.hip: several bf16x6 weight splits in one launch (used by myolo_wprep_refresh for runs of WP_X6_SPLIT entries)
+int myolo_x6_split_batched(int n, const void* const* src, void* const* dst, const long long* K, const long long* N, const long long* kn, hipStream_t s);
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 

@@ -788,10 +788,8 @@ int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nr
 // ---- split filters for a plain [K][N]-shaped operand (not a Winograd plane sequence) ----
 // out: the operand order of wino_mm_x6_kernel, [k / 16][n / 32][piece][(k / 8) % 2][n % 32][k % 8] bf16, of B[k][n] = src[n * K + k]
 // (src_kn = 1: B[k][n] = src[k * N + n], the natural [K][N] layout of a Keras 1x1 kernel)
-__global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restrict__ src, __bf16* __restrict__ out, int K, int N, int src_kn = 0)
+__device__ __forceinline__ void x6_split_one(const float* __restrict__ src, __bf16* __restrict__ out, int K, int N, int src_kn, long long idx)
 {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)K * N) return;
     int n, k;
     if (src_kn) { k = (int)(idx / N); n = (int)(idx - (long long)k * N); }
     else { n = (int)(idx / K); k = (int)(idx - (long long)n * K); }
@@ -802,6 +800,49 @@ __global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restric
     const __bf16 p3 = (__bf16)(r1 - (float)p2);
     __bf16* rec = out + ((((long long)(k >> 4) * (N >> 5) + (n >> 5)) * 6 + ((k >> 3) & 1)) * 256) + (n & 31) * 8 + (k & 7);
     rec[0] = p1; rec[512] = p2; rec[1024] = p3;
+}
+__global__ __launch_bounds__(256) void x6_split_nk_kernel(const float* __restrict__ src, __bf16* __restrict__ out, int K, int N, int src_kn = 0)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)K * N) return;
+    x6_split_one(src, out, K, N, src_kn, idx);
+}
+// several weight matrices in ONE launch (the prepared-weights registry re-splits ~17 of them at the start of every training step: one launch instead of 17)
+#define X6_BATCH_MAX 24
+struct X6SplitBatch {
+    const float* src[X6_BATCH_MAX];
+    __bf16* out[X6_BATCH_MAX];
+    int K[X6_BATCH_MAX], N[X6_BATCH_MAX], kn[X6_BATCH_MAX];
+    unsigned blk0[X6_BATCH_MAX + 1];       // first workgroup of every matrix
+    int n;
+};
+__global__ __launch_bounds__(256) void x6_split_batched_kernel(X6SplitBatch b)
+{
+    int i = 0;
+#pragma unroll 1
+    for (int j = 1; j < b.n; ++j)
+        if (blockIdx.x >= b.blk0[j]) i = j;
+    const long long idx = (long long)(blockIdx.x - b.blk0[i]) * 256 + threadIdx.x;
+    if (idx >= (long long)b.K[i] * b.N[i]) return;
+    x6_split_one(b.src[i], b.out[i], b.K[i], b.N[i], b.kn[i], idx);
+}
+/* csrc/mem_kernels.hip (myolo_wprep_refresh): n <= X6_BATCH_MAX splits in one launch; the same bytes as n calls of x6_split_nk_kernel */
+int myolo_x6_split_batched(int n, const void* const* src, void* const* dst, const long long* K, const long long* N, const long long* kn, hipStream_t s)
+{
+    for (int base = 0; base < n; base += X6_BATCH_MAX) {
+        X6SplitBatch b{};
+        b.n = n - base < X6_BATCH_MAX ? n - base : X6_BATCH_MAX;
+        unsigned blocks = 0;
+        for (int i = 0; i < b.n; ++i) {
+            b.src[i] = (const float*)src[base + i]; b.out[i] = (__bf16*)dst[base + i];
+            b.K[i] = (int)K[base + i]; b.N[i] = (int)N[base + i]; b.kn[i] = (int)kn[base + i];
+            b.blk0[i] = blocks;
+            blocks += (unsigned)(((long long)b.K[i] * b.N[i] + 255) / 256);
+        }
+        b.blk0[b.n] = blocks;
+        if (blocks) hipLaunchKernelGGL(x6_split_batched_kernel, dim3(blocks), dim3(256), 0, s, b);
+    }
+    return MYOLO_OK;
 }
 
 // the three-bf16-piece split of a WEIGHT matrix: into `scratch`, or the copy prepared for this step (prepared-weights registry, csrc/myolo_common.h)
