@@ -243,7 +243,7 @@ python tools/pmc_kbench.py dw_bwd --match dw_bwd_data_kernel --opts dw_bwd_legac
 KBENCH_OPTIONS= python tools/pmc_kbench.py roialign_bwd --match crop_bwd --opts tune0=1 --out $OUT/${TAG}_pmc_crop_bwd_round3_order.json > $OUT/${TAG}_pmc_crop_bwd_round3_order.txt 2>&1
 python tools/pmc_kbench.py roialign_fwd --match crop_fwd --out $OUT/${TAG}_pmc_crop_fwd.json > $OUT/${TAG}_pmc_crop_fwd.txt 2>&1
 python tools/pmc_kbench.py roialign_bwd --match crop_bwd --out $OUT/${TAG}_pmc_crop_bwd.json > $OUT/${TAG}_pmc_crop_bwd.txt 2>&1
-python tools/merge_pmc.py $OUT profiles/${TAG}_pmc_trunk.json
+python tools/merge_pmc.py $OUT gpurun_out/${TAG}_pmc_trunk.json   # (copy into profiles/ afterwards: only gpurun_out/ comes back from the GPU box)
 for f in $OUT/*.txt; do echo "== $f"; cat $f; done
 }
 
