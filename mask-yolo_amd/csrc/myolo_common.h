@@ -32,6 +32,8 @@ struct MyoloOptions {
     int wino_no_mixed;    // winograd: F(4,3) for every tile (no F(2,3) on the ragged last tile row / column)
     int x6_no_half_tiles; // bf16x6 plain products: 1 = keep 128 x 256 tiles when they do not fill the chip (default: 128 x 128 tiles then)
     int w63_order;        // wino63 boundary kernels: 1 = the previous workgroup order (all images of channel slice 0, then slice 1, ...)
+    int w63_wgs;          // wino63 boundary kernels: persistent workgroups per CU (0 = default 1)
+    int w63_legacy;       // wino63 boundary kernels: 1 = the round-5 kernel (scalar transforms); the packed form gives the same bits (test reference)
     int pw_x6_min_rows;   // pointwise convs: fewest rows for the bf16x6 kernels (0 = default 4096)
     int deconv_no_x6;     // deconv forward / data gradient: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int dw_wgrad_generic; // depthwise weight gradient: the generic 9-accumulator column reduction instead of the tiled kernel (ablation)

@@ -37,13 +37,16 @@ __host__ __device__ constexpr int w63_grp(int i, int j) { return ((i == 5 || i =
 __host__ __device__ constexpr int w63_qfirst(int g) { return g == 0 ? 0 : g == 1 ? 36 : g == 2 ? 48 : 60; }
 
 // ---- one-dimensional transforms.  CLS = 6: F(6,3) (8 points, patch of 8, 6 outputs); CLS = 4: F(4,3) on S6 with rho folded in ----
-template <int CLS>
-__device__ __forceinline__ void w63_bt(const float d[8], float t[8])
+// T = float, or f2 = two independent columns (rows) at once: the same expression trees element by element (v_pk_* on gfx950)
+typedef float f2 __attribute__((ext_vector_type(2)));
+template <typename T> __device__ __forceinline__ T w63_zero() { return (T)(0.f); }
+template <int CLS, typename T = float>
+__device__ __forceinline__ void w63_bt(const T d[8], T t[8])
 {
     if (CLS == 6) {
-        const float e0 = d[2] + d[6] - 4.25f * d[4], o0 = d[1] + d[5] - 4.25f * d[3];
-        const float e1 = 0.25f * d[2] - 1.25f * d[4] + d[6], o1 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
-        const float e2 = 4.f * d[2] - 5.f * d[4] + d[6], o2 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
+        const T e0 = d[2] + d[6] - 4.25f * d[4], o0 = d[1] + d[5] - 4.25f * d[3];
+        const T e1 = 0.25f * d[2] - 1.25f * d[4] + d[6], o1 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
+        const T e2 = 4.f * d[2] - 5.f * d[4] + d[6], o2 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
         t[0] = (d[6] - d[0]) + 5.25f * (d[2] - d[4]);
         t[1] = e0 + o0;
         t[2] = e0 - o0;
@@ -58,17 +61,17 @@ __device__ __forceinline__ void w63_bt(const float d[8], float t[8])
         t[2] = 0.75f * (4.f * (d[1] - d[2]) - d[3] + d[4]);
         t[3] = 3.75f * (2.f * (d[3] - d[1]) - d[2] + d[4]);
         t[4] = 3.75f * (2.f * (d[1] - d[3]) - d[2] + d[4]);
-        t[5] = 0.f;
-        t[6] = 0.f;
+        t[5] = w63_zero<T>();
+        t[6] = w63_zero<T>();
         t[7] = 4.f * d[1] - 5.f * d[3] + d[5];
     }
 }
-template <int CLS>
-__device__ __forceinline__ void w63_at(const float m[8], float y[6])
+template <int CLS, typename T = float>
+__device__ __forceinline__ void w63_at(const T m[8], T y[6])
 {
-    const float s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    const T s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
     if (CLS == 6) {
-        const float s56 = m[5] + m[6], d56 = m[5] - m[6];
+        const T s56 = m[5] + m[6], d56 = m[5] - m[6];
         y[0] = m[0] + s12 + s34 + s56;
         y[1] = d12 + 2.f * d34 + 0.5f * d56;
         y[2] = s12 + 4.f * s34 + 0.25f * s56;
@@ -80,8 +83,8 @@ __device__ __forceinline__ void w63_at(const float m[8], float y[6])
         y[1] = d12 + 2.f * d34;
         y[2] = s12 + 4.f * s34;
         y[3] = d12 + 8.f * d34 + m[7];
-        y[4] = 0.f;
-        y[5] = 0.f;
+        y[4] = w63_zero<T>();
+        y[5] = w63_zero<T>();
     }
 }
 // G8 (8x3) on a 3-vector
@@ -98,24 +101,24 @@ __device__ __forceinline__ void w63_g(const float g[3], float u[8])
 }
 
 // A (8x6 / 6x4): the adjoint of w63_at -- Q = A dY A^T of the weight gradient
-template <int CLS>
-__device__ __forceinline__ void w63_a(const float d[6], float q[8])
+template <int CLS, typename T = float>
+__device__ __forceinline__ void w63_a(const T d[6], T q[8])
 {
     if (CLS == 6) {
-        const float e = d[0] + d[2] + d[4], o = d[1] + d[3] + d[5];
-        const float e2 = d[0] + 4.f * d[2] + 16.f * d[4], o2 = 2.f * d[1] + 8.f * d[3] + 32.f * d[5];
-        const float eh = d[0] + 0.25f * d[2] + 0.0625f * d[4], oh = 0.5f * d[1] + 0.125f * d[3] + 0.03125f * d[5];
+        const T e = d[0] + d[2] + d[4], o = d[1] + d[3] + d[5];
+        const T e2 = d[0] + 4.f * d[2] + 16.f * d[4], o2 = 2.f * d[1] + 8.f * d[3] + 32.f * d[5];
+        const T eh = d[0] + 0.25f * d[2] + 0.0625f * d[4], oh = 0.5f * d[1] + 0.125f * d[3] + 0.03125f * d[5];
         q[0] = d[0];
         q[1] = e + o;  q[2] = e - o;
         q[3] = e2 + o2; q[4] = e2 - o2;
         q[5] = eh + oh; q[6] = eh - oh;
         q[7] = d[5];
     } else {
-        const float e = d[0] + d[2], o = d[1] + d[3], e2 = d[0] + 4.f * d[2], o2 = 2.f * d[1] + 8.f * d[3];
+        const T e = d[0] + d[2], o = d[1] + d[3], e2 = d[0] + 4.f * d[2], o2 = 2.f * d[1] + 8.f * d[3];
         q[0] = d[0];
         q[1] = e + o;  q[2] = e - o;
         q[3] = e2 + o2; q[4] = e2 - o2;
-        q[5] = 0.f; q[6] = 0.f;
+        q[5] = w63_zero<T>(); q[6] = w63_zero<T>();
         q[7] = d[3];
     }
 }
@@ -179,11 +182,16 @@ struct W63Args {
     int keep_cap;
 };
 
+// per-image control words (flags, slots, box indices, boxes) are written by EARLIER kernels and never by these: read through the constant address
+// space so that a wave-uniform index becomes an s_load -- a vector load here would put an s_waitcnt vmcnt(0) in front of every unit of the persistent
+// kernel, i.e. wait for all of the prefetched rows and all of the previous unit's stores
+__device__ __forceinline__ int w63_cload(const int32_t* p, long long i) { return ((const __attribute__((address_space(4))) int32_t*)p)[i]; }
+__device__ __forceinline__ float w63_cload(const float* p, long long i) { return ((const __attribute__((address_space(4))) float*)p)[i]; }
 // where the flagged output of image img goes: its own row block, the compact one of its slot, or -1 (not kept)
 __device__ __forceinline__ long long w63_keep_dst(const W63Args& a, long long img)
 {
     if (!a.flags) return img;
-    const int f = a.flags[img];
+    const int f = w63_cload(a.flags, img);
     if (a.keep_cap > 0) return (f >= 0 && f < a.keep_cap) ? (long long)f : -1;
     return f != 0 ? img : -1;
 }
@@ -196,7 +204,7 @@ __device__ __forceinline__ float w63_act(float v, int act)
 }
 
 // output transform of one tile (class CY x CX) from its M values + bias/affine/activation -> LDS tile (and y)
-template <int CY, int CX>
+template <int CY, int CX, bool TO_LDS>
 __device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& pl, float* act_lds, int oy, int ox, int lane, long long img, int c,
                                             bool wr, float& s1, float& s2)
 {
@@ -228,7 +236,7 @@ __device__ __forceinline__ void w63_front_m(const W63Args& a, const W63Planes& p
             const float pre = r[j] + b;
             const float v = w63_act(fmaf(pre, sc, sh), a.act);
             const int pix = (oy + i) * W63_HW + ox + j;
-            act_lds[pix * W63_CS + lane] = v;
+            if (TO_LDS) act_lds[pix * W63_CS + lane] = v;
             if (wr) ybase[(long long)pix * a.C] = v;
             if (wrp) pbase[(long long)pix * a.C] = pre;
             s1 += v;
@@ -336,16 +344,17 @@ __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, 
     if (FRONT == W63_FROM_M) {
         const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;           // output origin: 0, 6, 10
         float s1 = 0.f, s2 = 0.f;
-        if (ty == 0) { if (tx == 0) w63_front_m<6, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); else w63_front_m<6, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); }
-        else         { if (tx == 0) w63_front_m<4, 6>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); else w63_front_m<4, 4>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); }
-        if (a.stats) {         // BatchNorm statistics of this image's 196 x 64 values: the nine tiles' partial sums, added in tile order
-            __shared__ float red[2][W63_TILES][W63_CS];
-            red[0][wave][lane] = s1; red[1][wave][lane] = s2;
+        constexpr bool L = BACK != W63_TO_NONE;      // without a back half nobody reads the LDS tile: it is neither filled nor allocated
+        if (ty == 0) { if (tx == 0) w63_front_m<6, 6, L>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); else w63_front_m<6, 4, L>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); }
+        else         { if (tx == 0) w63_front_m<4, 6, L>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); else w63_front_m<4, 4, L>(a, pl, act_lds, oy, ox, lane, img, c, wr, s1, s2); }
+        if (BACK == W63_TO_NONE && a.stats) {   // BatchNorm statistics of this image's 196 x 64 values: the nine tiles' partial sums, added in tile order
+            float* red = act_lds;               // [2][W63_TILES][W63_CS] (w63_lds_bytes)
+            red[wave * W63_CS + lane] = s1; red[(W63_TILES + wave) * W63_CS + lane] = s2;
             __syncthreads();
             if (wave == 0) {
                 double t1 = 0, t2 = 0;
 #pragma unroll
-                for (int k = 0; k < W63_TILES; ++k) { t1 += (double)red[0][k][lane]; t2 += (double)red[1][k][lane]; }
+                for (int k = 0; k < W63_TILES; ++k) { t1 += (double)red[k * W63_CS + lane]; t2 += (double)red[(W63_TILES + k) * W63_CS + lane]; }
                 double* dst = a.stats + img * 2 * a.C;
                 dst[c] = t1;
                 dst[a.C + c] = t2;
@@ -437,12 +446,422 @@ __device__ __forceinline__ void w63_unit_body(const W63Args& a, float* act_lds, 
     if (ty == 0) { if (tx == 0) w63_back_v<6, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<6, 4>(a, pl, act_lds, py0, px0, lane); }
     else         { if (tx == 0) w63_back_v<4, 6>(a, pl, act_lds, py0, px0, lane); else w63_back_v<4, 4>(a, pl, act_lds, py0, px0, lane); }
 }
+// ---- round 3-5 form of the kernel (scalar transforms, one address computation per access): kept behind option "w63_legacy" as the
+// reference of tests/test_gpu_ops.py::test_wino63_boundary_packed_equals_legacy -- the packed form below gives the same bits ----
 template <int FRONT, int BACK>
-__global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
+__global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_legacy_kernel(W63Args a)
 {
     extern __shared__ __attribute__((aligned(16))) float act_lds[];         // [14][14][64]
     // workgroup -> (image, 64-channel slice).  a.order = 1: the slices of one image are consecutive workgroups
     w63_unit_body<FRONT, BACK>(a, act_lds, blockIdx.x);
+}
+
+// =====================================================================================================================================
+// The kernel the step runs (round 6): PERSISTENT workgroups, one per CU, that walk the units (image, 64-channel slice) and have the NEXT
+// unit's planes on their way while the current unit is transformed.
+//
+// What the round-5 kernel did wrong, measured (tools/experiments/census, tools/_ab/trace.py; profiles/r6_notes.md):
+//   * a CU of this part admits workgroups as if every SIMD had to take ceil(waves / 4) of their waves: the nine-wave workgroups ran ONE per
+//     CU at 81..96 VGPRs (the occupancy calculator says two), so each CU alternated between "nine waves wait for their 400 loads" and "nine
+//     waves transform" -- the memory pipe of a CU idle ~40 % of the time; with the transforms removed the same access pattern moves 6 TB/s;
+//   * eight-wave workgroups do run two per CU -- in lockstep (both start when both slots free up, both load, both transform): no gain.
+// So the overlap is made explicit: after a wave's first pass has consumed its M values, it requests the same rows of the workgroup's next
+// unit into the same registers; they arrive during the second pass, the barrier, the input transform and the stores.  The LDS tile is
+// double-buffered (one barrier per unit).  Also new: every 1-D transform runs on TWO columns (first pass) or TWO rows (second pass) at once
+// as f2 values (v_pk_add_f32 / v_pk_fma_f32, half the arithmetic instructions), plane addresses are wave-uniform (SGPR base + lane offset),
+// per-channel constants are loaded once per workgroup (its slice never changes: the grid is a multiple of C / 64), the activation fronts
+// request all of a wave's 22 pixels at once.  Same expression trees per element as the legacy form.
+#ifdef W63_TRACE
+__device__ unsigned long long w63_trace_buf[8192 * 9 * 8];
+#define W63_T(k) do { asm volatile("" ::: "memory"); if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && w63_it >= 8 && w63_it < 12) w63_trace_buf[((blockIdx.x * 4 + (w63_it - 8)) * 9 + (threadIdx.x >> 6)) * 8 + (k)] = clock64(); asm volatile("" ::: "memory"); } while (0)
+#else
+#define W63_T(k)
+#endif
+// Plane addressing of the persistent kernel: ONE buffer resource per plane set (32-bit byte offsets: the set must stay below 4 GiB, w63_launch
+// falls back to the legacy kernel otherwise), wave-uniform offset of (plane, this tile's row, this slice's first channel) in an SGPR, the lane's 4 bytes
+// in the VGPR offset: no per-access address arithmetic on the vector ALU and one scalar register per access instead of two.
+struct W63U {
+    unsigned base[4];        // byte offset of (this tile's row, this slice's first channel) in the first plane of each group
+    unsigned sb;             // NR * C * 4: plane strides are 9, 3, 3, 1 times this
+};
+__device__ __forceinline__ W63U w63p_planes(unsigned NR, unsigned img, int ty, int tx, unsigned C, unsigned c0)
+{
+    W63U p;
+    p.sb = NR * C * 4u;
+    p.base[0] = ((img * 9 + ty * 3 + tx) * C + c0) * 4u;
+    p.base[1] = 36u * 9u * p.sb + ((img * 3 + ty) * C + c0) * 4u;
+    p.base[2] = (36u * 9u + 12u * 3u) * p.sb + ((img * 3 + tx) * C + c0) * 4u;
+    p.base[3] = (36u * 9u + 24u * 3u) * p.sb + (img * C + c0) * 4u;
+    return p;
+}
+__host__ __device__ constexpr unsigned w63_gmult(int g) { return g == 0 ? 9u : g == 3 ? 1u : 3u; }
+#define W63P_OFF(pl, i, j) ((pl).base[w63_grp(i, j)] + (unsigned)(w63_q(i, j) - w63_qfirst(w63_grp(i, j))) * w63_gmult(w63_grp(i, j)) * (pl).sb)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t w63_rsrc(const void* base, unsigned nbytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)nbytes, 0x00020000);
+}
+#ifndef W63_LD_AUX
+#define W63_LD_AUX 0
+#endif
+#ifndef W63_ST_AUX
+#define W63_ST_AUX 0
+#endif
+__device__ __forceinline__ float w63_ld(__amdgpu_buffer_rsrc_t r, int voff, unsigned soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, (int)soff, W63_LD_AUX));
+}
+__device__ __forceinline__ void w63_st(float v, __amdgpu_buffer_rsrc_t r, int voff, unsigned soff)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, (int)soff, W63_ST_AUX);
+}
+// the k-th used point of a direction of class CLS (CLS 6: 0..7; CLS 4: 0, 1, 2, 3, 4, 7) and the number of used points
+template <int CLS> __device__ __forceinline__ constexpr int w63_pt(int k) { return CLS == 6 ? k : (k == 5 ? 7 : k); }
+template <int CLS> __device__ __forceinline__ constexpr int w63_npt() { return CLS == 6 ? 8 : 6; }
+// slot of point p in an array indexed [pair][half] over the used points
+template <int CLS> __device__ __forceinline__ constexpr int w63_slot(int p) { return CLS == 6 ? p : (p == 7 ? 5 : p); }
+
+template <int ACT>
+__device__ __forceinline__ float w63p_act(float v)
+{
+    if (ACT == MYOLO_ACT_RELU) return fmaxf(v, 0.f);
+    if (ACT == MYOLO_ACT_RELU6) return fminf(fmaxf(v, 0.f), 6.f);
+    return v;
+}
+
+
+#define W63_NPW ((W63_HW * W63_HW + W63_TILES - 1) / W63_TILES)      // pixels per wave of an activation front: 22
+
+// request the M values of one tile: pf[(pair of used columns * 8 + row) * 2 + half]
+template <int CY, int CX>
+__device__ __forceinline__ void w63q_issue_m(float (&pf)[64], __amdgpu_buffer_rsrc_t src, const W63U& pl, int lane4)
+{
+#pragma unroll
+    for (int jp = 0; jp < w63_npt<CX>() / 2; ++jp) {
+        const int j0 = w63_pt<CX>(2 * jp), j1 = w63_pt<CX>(2 * jp + 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (!w63_used<CY>(i)) continue;
+            pf[(jp * 8 + i) * 2 + 0] = w63_ld(src, lane4, W63P_OFF(pl, i, j0));
+            pf[(jp * 8 + i) * 2 + 1] = w63_ld(src, lane4, W63P_OFF(pl, i, j1));
+        }
+    }
+}
+// first pass of the output transform: A^T m, two columns at a time
+template <int CY, int CX>
+__device__ __forceinline__ void w63q_col_m(const float (&pf)[64], f2 (&tmp)[6][4])
+{
+#pragma unroll
+    for (int jp = 0; jp < w63_npt<CX>() / 2; ++jp) {
+        f2 m[8], r[6];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (w63_used<CY>(i)) { m[i].x = pf[(jp * 8 + i) * 2 + 0]; m[i].y = pf[(jp * 8 + i) * 2 + 1]; }
+            else m[i] = w63_zero<f2>();
+        }
+        w63_at<CY, f2>(m, r);
+#pragma unroll
+        for (int i = 0; i < CY; ++i) tmp[i][jp] = r[i];
+    }
+}
+struct W63Keep { __amdgpu_buffer_rsrc_t y, p; bool wy, wp; };      // wave-uniform: the slice's y / pre-BatchNorm block of the unit (row stride C), written or not
+// second pass, two rows at a time + bias / affine / activation -> LDS tile (and y, ypre, statistics)
+template <int CY, int CX, int BACK, int ACT>
+__device__ __forceinline__ void w63q_row_m(const f2 (&tmp)[6][4], float b, float sc, float sh, const W63Keep& kp, unsigned C, float* act_lds, int oy, int ox,
+                                           int lane, float& s1, float& s2)
+{
+    const int lane4 = lane * 4;
+    constexpr int MY = CY, MX = CX;
+    const f2 b2 = {b, b}, sc2 = {sc, sc}, sh2 = {sh, sh};
+#pragma unroll
+    for (int ip = 0; ip < MY / 2; ++ip) {
+        f2 m[8], r[6];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (w63_used<CX>(j)) {
+                const int sl = w63_slot<CX>(j);
+                m[j].x = tmp[2 * ip][sl >> 1][sl & 1]; m[j].y = tmp[2 * ip + 1][sl >> 1][sl & 1];
+            } else m[j] = w63_zero<f2>();
+        }
+        w63_at<CX, f2>(m, r);
+        const int pix0 = (oy + 2 * ip) * W63_HW + ox;
+        float vy[6];
+#pragma unroll
+        for (int j = 0; j < MX; ++j) {                // short live ranges: every value leaves as soon as it exists
+            const f2 pre = r[j] + b2;
+            f2 v = __builtin_elementwise_fma(pre, sc2, sh2);
+            v.x = w63p_act<ACT>(v.x); v.y = w63p_act<ACT>(v.y);
+            if (BACK != W63_TO_NONE) {
+                act_lds[(pix0 + j) * W63_CS + lane] = v.x;
+                act_lds[(pix0 + W63_HW + j) * W63_CS + lane] = v.y;
+            }
+            if (kp.wy) { w63_st(v.x, kp.y, lane4, (unsigned)(pix0 + j) * C * 4u); w63_st(v.y, kp.y, lane4, (unsigned)(pix0 + W63_HW + j) * C * 4u); }
+            if (kp.wp) { w63_st(pre.x, kp.p, lane4, (unsigned)(pix0 + j) * C * 4u); w63_st(pre.y, kp.p, lane4, (unsigned)(pix0 + W63_HW + j) * C * 4u); }
+            if (BACK == W63_TO_NONE) { s1 += v.x; s2 = fmaf(v.x, v.x, s2); vy[j] = v.y; }      // statistics in the order of the scalar form: row by row
+        }
+        if (BACK == W63_TO_NONE) {
+#pragma unroll
+            for (int j = 0; j < MX; ++j) { s1 += vy[j]; s2 = fmaf(vy[j], vy[j], s2); }
+        }
+    }
+}
+
+// input transform of one tile (class CY x CX) from the LDS activation tile -> V planes.  edge_y / edge_x: the patch's last row / column lies
+// outside the map (tile row / column 2); its first one does for tile row / column 0 (CLS 6), known at compile time
+template <int CY, int CX>
+__device__ __forceinline__ void w63p_back_v(__amdgpu_buffer_rsrc_t Vn, const W63U& pl, const float* act_lds, int py0, int px0, bool edge_y, bool edge_x, int lane)
+{
+    const int lane4 = lane * 4;
+    constexpr int NY = CY + 2, NX = CX + 2;          // patch size per direction
+    f2 tmp[8][4];                                     // [vertical point][pair of patch columns]
+#pragma unroll
+    for (int jp = 0; jp < NX / 2; ++jp) {
+        f2 d[8], r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            d[i] = w63_zero<f2>();
+            if (i >= NY || (CY == 6 && i == 0)) continue;                     // row -1 of tile row 0
+            const int yy = min(py0 + i, W63_HW - 1);
+            const bool yout = (CY == 4 && i == NY - 1) ? edge_y : false;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int j = 2 * jp + h;
+                if (CX == 6 && j == 0) continue;                              // column -1 of tile column 0
+                const int xx = min(px0 + j, W63_HW - 1);
+                const bool out = yout || ((CX == 4 && j == NX - 1) ? edge_x : false);
+                const float t = act_lds[(yy * W63_HW + xx) * W63_CS + lane];
+                d[i][h] = out ? 0.f : t;
+            }
+        }
+        w63_bt<CY, f2>(d, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i][jp] = r[i];
+    }
+#pragma unroll
+    for (int ipp = 0; ipp < w63_npt<CY>() / 2; ++ipp) {
+        const int i0 = w63_pt<CY>(2 * ipp), i1 = w63_pt<CY>(2 * ipp + 1);
+        f2 d[8], r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < NX) { d[j].x = tmp[i0][j >> 1][j & 1]; d[j].y = tmp[i1][j >> 1][j & 1]; }
+            else d[j] = w63_zero<f2>();
+        }
+        w63_bt<CX, f2>(d, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w63_used<CX>(j)) { w63_st(r[j].x, Vn, lane4, W63P_OFF(pl, i0, j)); w63_st(r[j].y, Vn, lane4, W63P_OFF(pl, i1, j)); }
+    }
+}
+
+// Q = A dY A^T of one tile (class CY x CX) from the LDS tile (holding dY) -> Q planes
+template <int CY, int CX>
+__device__ __forceinline__ void w63p_back_q(__amdgpu_buffer_rsrc_t dst, const W63U& pl, const float* act_lds, int oy, int ox, int lane)
+{
+    const int lane4 = lane * 4;
+    constexpr int MY = CY, MX = CX;
+    f2 tmp[8][3];                                     // [vertical point][pair of tile columns]
+#pragma unroll
+    for (int jp = 0; jp < MX / 2; ++jp) {
+        f2 d[6], r[8];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            if (i < MY) { d[i].x = act_lds[((oy + i) * W63_HW + ox + 2 * jp) * W63_CS + lane]; d[i].y = act_lds[((oy + i) * W63_HW + ox + 2 * jp + 1) * W63_CS + lane]; }
+            else d[i] = w63_zero<f2>();
+        }
+        w63_a<CY, f2>(d, r);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) tmp[i][jp] = r[i];
+    }
+#pragma unroll
+    for (int ipp = 0; ipp < w63_npt<CY>() / 2; ++ipp) {
+        const int i0 = w63_pt<CY>(2 * ipp), i1 = w63_pt<CY>(2 * ipp + 1);
+        f2 d[6], r[8];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            if (j < MX) { d[j].x = tmp[i0][j >> 1][j & 1]; d[j].y = tmp[i1][j >> 1][j & 1]; }
+            else d[j] = w63_zero<f2>();
+        }
+        w63_a<CX, f2>(d, r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (w63_used<CX>(j)) { w63_st(r[j].x, dst, lane4, W63P_OFF(pl, i0, j)); w63_st(r[j].y, dst, lane4, W63P_OFF(pl, i1, j)); }
+    }
+}
+
+
+// the persistent loop of one wave = one tile position (ty, tx) of class CY x CX
+template <int CY, int CX, int FRONT, int BACK, int ACT>
+__device__ __forceinline__ void w63q_loop(const W63Args& a, float* lds, const int ty, const int tx, const int wave, const int lane)
+{
+    const unsigned C = (unsigned)a.C, NR = (unsigned)a.NR;
+    const unsigned ns = C / W63_CS, nunits = NR * ns, stride = gridDim.x;
+    unsigned unit = blockIdx.x;
+    const unsigned slice = unit % ns;                         // the same for every unit of this workgroup: gridDim.x % ns == 0 (w63_launch)
+    const unsigned c0 = slice * W63_CS;
+    const int c = (int)c0 + lane, lane4 = lane * 4;
+    const int oy = ty == 0 ? 0 : 2 + 4 * ty, ox = tx == 0 ? 0 : 2 + 4 * tx;               // output origin: 0, 6, 10
+    const int py0 = ty == 0 ? -1 : 1 + 4 * ty, px0 = tx == 0 ? -1 : 1 + 4 * tx;           // patch origin: -1, 5, 9
+    const bool ey = ty == 2, ex = tx == 2;
+    const int tile = ty * 3 + tx;
+    const unsigned set_bytes = 400u * NR * C * 4u;            // < 4 GiB (w63_launch)
+    const unsigned img_bytes = (unsigned)(W63_HW * W63_HW) * C * 4u;
+    // per-channel constants of the slice
+    const float cb = (FRONT == W63_FROM_M && a.bias) ? a.bias[c] : 0.f;
+    const float sc = a.scale ? a.scale[c] : 1.f, sh = a.scale ? a.shift[c] : 0.f;
+    const float ka = FRONT == W63_FROM_LAZY ? a.ka[c] : 0.f, kb = FRONT == W63_FROM_LAZY ? a.kb[c] : 0.f;
+    const __amdgpu_buffer_rsrc_t rsrc = w63_rsrc(a.src, FRONT == W63_FROM_M ? set_bytes : 0u);      // FROM_M: the M planes
+    const __amdgpu_buffer_rsrc_t rv = w63_rsrc(a.Vn, set_bytes), rq = w63_rsrc(BACK == W63_TO_VQ ? a.Qn : a.Vn, set_bytes);
+    constexpr int LDS_TILE = BACK == W63_TO_NONE ? 2 * W63_TILES * W63_CS : W63_HW * W63_HW * W63_CS;   // floats per buffer
+    float pf[64];                                             // FROM_M: the tile's M values; FROM_ACT / FROM_LAZY: [0, 22) x, [32, 54) compact dy
+    int slot = -1;                                            // FROM_LAZY: compact slot of the image whose values are in pf
+    // the unit's activation rows of this wave: pixel wave + 9 k of image img (clamped: the 22nd of waves 7, 8 re-reads pixel 195, never used)
+#define W63Q_ISSUE_ACT(IMG)                                                                                                          \
+    do {                                                                                                                             \
+        const __amdgpu_buffer_rsrc_t rx = w63_rsrc(a.src + ((long long)(IMG) * W63_HW * W63_HW) * a.C + c0, img_bytes);              \
+        _Pragma("unroll") for (int k = 0; k < W63_NPW; ++k)                                                                          \
+            pf[k] = w63_ld(rx, lane4, (unsigned)min(wave + k * W63_TILES, W63_HW * W63_HW - 1) * C * 4u);                             \
+        if (FRONT == W63_FROM_LAZY) {                                                                                                \
+            slot = w63_cload(a.inv, (IMG));                                                                                          \
+            if (slot >= 0) {                                                                                                         \
+                const __amdgpu_buffer_rsrc_t rg = w63_rsrc(a.dyc + ((long long)slot * W63_HW * W63_HW) * a.C + c0, img_bytes);       \
+                _Pragma("unroll") for (int k = 0; k < W63_NPW; ++k)                                                                  \
+                    pf[32 + k] = w63_ld(rg, lane4, (unsigned)min(wave + k * W63_TILES, W63_HW * W63_HW - 1) * C * 4u);                \
+            }                                                                                                                        \
+        }                                                                                                                            \
+    } while (0)
+    if (unit < nunits) {
+        const unsigned img = unit / ns;
+        if (FRONT == W63_FROM_M) w63q_issue_m<CY, CX>(pf, rsrc, w63p_planes(NR, img, ty, tx, C, c0), lane4);
+        else if (FRONT == W63_FROM_ACT || FRONT == W63_FROM_LAZY) W63Q_ISSUE_ACT(img);
+    }
+    int buf = 0;
+#ifdef W63_TRACE
+    int w63_it = -1;
+#endif
+    for (; unit < nunits; unit += stride, buf ^= 1) {
+#ifdef W63_TRACE
+        ++w63_it;
+#endif
+        W63_T(0);
+        const unsigned img = unit / ns;
+        const unsigned nxt = unit + stride;
+        const bool more = nxt < nunits;
+        const unsigned nimg = nxt / ns;
+        float* act = lds + buf * LDS_TILE;
+        const W63U pl = w63p_planes(NR, img, ty, tx, C, c0);
+        if (FRONT == W63_FROM_M) {
+            W63Keep kp;
+            const long long yd = a.ypre ? (long long)img : w63_keep_dst(a, img);
+            kp.wy = a.y && yd >= 0;
+            kp.y = w63_rsrc(a.y + (yd * W63_HW * W63_HW) * a.C + c0, kp.wy ? img_bytes : 0u);
+            const long long pd = a.ypre ? w63_keep_dst(a, img) : -1;
+            kp.wp = pd >= 0;
+            kp.p = w63_rsrc(a.ypre + (pd * W63_HW * W63_HW) * a.C + c0, kp.wp ? img_bytes : 0u);
+            f2 tmp[6][4];                             // [output row][pair of used columns]
+            w63q_col_m<CY, CX>(pf, tmp);
+            W63_T(1);
+            if (more) w63q_issue_m<CY, CX>(pf, rsrc, w63p_planes(NR, nimg, ty, tx, C, c0), lane4);      // the next unit's rows into the registers just consumed
+            float s1 = 0.f, s2 = 0.f;
+            w63q_row_m<CY, CX, BACK, ACT>(tmp, cb, sc, sh, kp, C, act, oy, ox, lane, s1, s2);
+            if (BACK == W63_TO_NONE && a.stats) {     // BatchNorm statistics of this image's 196 x 64 values: the nine tiles' partial sums, added in tile order
+                act[tile * W63_CS + lane] = s1; act[(W63_TILES + tile) * W63_CS + lane] = s2;
+                __syncthreads();
+                if (wave == 0) {
+                    double t1 = 0, t2 = 0;
+#pragma unroll
+                    for (int k = 0; k < W63_TILES; ++k) { t1 += (double)act[k * W63_CS + lane]; t2 += (double)act[(W63_TILES + k) * W63_CS + lane]; }
+                    double* dst = a.stats + (long long)img * 2 * a.C;
+                    dst[c] = t1;
+                    dst[a.C + c] = t2;
+                }
+            }
+        } else if (FRONT == W63_FROM_CROP) {
+            // lane = (pixel lane >> 4 of a group of four, channel quad lane & 15): every corner read is 16 bytes per lane, 4 x 256 B per wave
+            const float by1 = w63_cload(a.boxes, (long long)img * 4), bx1 = w63_cload(a.boxes, (long long)img * 4 + 1);
+            const float by2 = w63_cload(a.boxes, (long long)img * 4 + 2), bx2 = w63_cload(a.boxes, (long long)img * 4 + 3);
+            const int cq = (lane & 15) * 4;
+            const float* fb = a.src + (long long)w63_cload(a.bind, img) * a.FH * a.FW * a.C + c0 + cq;
+            constexpr int NP = 3;                                                          // pixels (x 4 corners) in flight per lane
+            constexpr int STEP = 4 * W63_TILES;                                            // pixels per pass of the workgroup
+            for (int p0 = wave * 4 + (lane >> 4); p0 < W63_HW * W63_HW; p0 += NP * STEP) {
+                float4 tl[NP], tr[NP], bl[NP], br[NP];
+                float wx[NP], wy[NP];
+                bool ok[NP];
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int pix = min(p0 + k * STEP, W63_HW * W63_HW - 1);
+                    const int py = pix / W63_HW, px = pix - py * W63_HW;
+                    const W63CropAxis ay = w63_crop_axis(by1, by2, a.FH, W63_HW, py), ax = w63_crop_axis(bx1, bx2, a.FW, W63_HW, px);
+                    ok[k] = ay.ok && ax.ok; wx[k] = ax.w; wy[k] = ay.w;
+                    tl[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.lo * a.FW + ax.lo) * a.C);
+                    tr[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.lo * a.FW + ax.hi) * a.C);
+                    bl[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.hi * a.FW + ax.lo) * a.C);
+                    br[k] = *reinterpret_cast<const float4*>(fb + ((long long)ay.hi * a.FW + ax.hi) * a.C);
+                }
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const int pix = p0 + k * STEP;
+                    if (pix >= W63_HW * W63_HW) continue;
+                    float4 o;
+                    float top, bot;
+                    top = tl[k].x + (tr[k].x - tl[k].x) * wx[k]; bot = bl[k].x + (br[k].x - bl[k].x) * wx[k]; o.x = top + (bot - top) * wy[k];
+                    top = tl[k].y + (tr[k].y - tl[k].y) * wx[k]; bot = bl[k].y + (br[k].y - bl[k].y) * wx[k]; o.y = top + (bot - top) * wy[k];
+                    top = tl[k].z + (tr[k].z - tl[k].z) * wx[k]; bot = bl[k].z + (br[k].z - bl[k].z) * wx[k]; o.z = top + (bot - top) * wy[k];
+                    top = tl[k].w + (tr[k].w - tl[k].w) * wx[k]; bot = bl[k].w + (br[k].w - bl[k].w) * wx[k]; o.w = top + (bot - top) * wy[k];
+                    if (!ok[k]) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(&act[pix * W63_CS + cq]) = o;
+                }
+            }
+        } else {
+            // FROM_ACT / FROM_LAZY: a wave owns the pixels wave, wave + 9, ...
+            const long long ydst = w63_keep_dst(a, img);
+            const bool wy = a.y && ydst >= 0;
+            const __amdgpu_buffer_rsrc_t ry = w63_rsrc(a.y + (ydst * W63_HW * W63_HW) * a.C + c0, wy ? img_bytes : 0u);
+            float v[W63_NPW];
+            if (FRONT == W63_FROM_LAZY) {
+#pragma unroll
+                for (int k = 0; k < W63_NPW; ++k) {
+                    const float z = fmaf(pf[k], sc, sh);
+                    const float pass = a.act == MYOLO_ACT_RELU ? (z > 0.f ? 1.f : 0.f) : a.act == MYOLO_ACT_RELU6 ? ((z > 0.f && z < 6.f) ? 1.f : 0.f) : 1.f;
+                    const float g = slot >= 0 ? pf[32 + k] : 0.f;
+                    v[k] = fmaf(sc, g * pass, fmaf(kb, pf[k], ka));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < W63_NPW; ++k) v[k] = w63p_act<ACT>(fmaf(pf[k], sc, sh));
+            }
+            if (more) W63Q_ISSUE_ACT(nimg);
+#pragma unroll
+            for (int k = 0; k < W63_NPW; ++k) {
+                const int pix = wave + k * W63_TILES;
+                if (pix < W63_HW * W63_HW) act[pix * W63_CS + lane] = v[k];
+            }
+            if (wy) {
+#pragma unroll
+                for (int k = 0; k < W63_NPW; ++k) {
+                    const int pix = wave + k * W63_TILES;
+                    if (pix < W63_HW * W63_HW) w63_st(v[k], ry, lane4, (unsigned)pix * C * 4u);
+                }
+            }
+        }
+        W63_T(2);
+        if (BACK == W63_TO_NONE) continue;
+        __syncthreads();                              // the one barrier of a unit: the tile is complete; the other buffer is free again after the NEXT one
+        if (BACK == W63_TO_Q || BACK == W63_TO_VQ) w63p_back_q<CY, CX>(rq, pl, act, oy, ox, lane);
+        W63_T(3);
+        if (BACK == W63_TO_V || BACK == W63_TO_VQ) w63p_back_v<CY, CX>(rv, pl, act, py0, px0, ey, ex, lane);
+        W63_T(4);
+    }
+#undef W63Q_ISSUE_ACT
+}
+
+template <int FRONT, int BACK, int ACT>
+__global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_kernel(W63Args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float act_lds[];         // 2 x [14][14][64]; TO_NONE: 2 x [2][9][64] for the statistics
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ty = wave / 3, tx = wave - ty * 3;
+    if (ty == 0) { if (tx == 0) w63q_loop<6, 6, FRONT, BACK, ACT>(a, act_lds, ty, tx, wave, lane); else w63q_loop<6, 4, FRONT, BACK, ACT>(a, act_lds, ty, tx, wave, lane); }
+    else         { if (tx == 0) w63q_loop<4, 6, FRONT, BACK, ACT>(a, act_lds, ty, tx, wave, lane); else w63q_loop<4, 4, FRONT, BACK, ACT>(a, act_lds, ty, tx, wave, lane); }
 }
 
 // (A persistent form -- a few workgroups per CU walking the units in a loop, the unit body an out-of-line call because the inlined loop made the
@@ -522,19 +941,57 @@ __global__ __launch_bounds__(256) void wino63_w_kernel(const float* __restrict__
 
 static int w63_layout(int K, int N) { return myolo_gemm_nt_batched_x6(K, N) ? 2 : 1; }
 
+static int w63_num_cus()
+{
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) return 256;
+        n = prop.multiProcessorCount;
+    }
+    return n;
+}
+template <int FRONT, int BACK, int ACT>
+static void w63_launch_act(const W63Args& b, unsigned grid, size_t lds, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)wino63_boundary_kernel<FRONT, BACK, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((wino63_boundary_kernel<FRONT, BACK, ACT>), dim3(grid), dim3(W63_TILES * 64), lds, s, b);
+}
 template <int FRONT, int BACK>
 static int w63_launch(const W63Args& a, hipStream_t s)
 {
-    static bool attr_set = false;
-    const size_t lds = (size_t)W63_HW * W63_HW * W63_CS * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wino63_boundary_kernel<FRONT, BACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     W63Args b = a;
     b.order = g_myolo_opt.w63_order ? 0 : 1;
-    const long long grid = a.NR * (a.C / W63_CS);
-    hipLaunchKernelGGL((wino63_boundary_kernel<FRONT, BACK>), dim3((unsigned)grid), dim3(W63_TILES * 64), lds, s, b);
+    const long long units = a.NR * (a.C / W63_CS);
+    if (units <= 0 || units >= (1LL << 31)) return MYOLO_EINVAL;
+    if (g_myolo_opt.w63_legacy) {
+        static bool attr_set = false;
+        const size_t lds = (size_t)W63_HW * W63_HW * W63_CS * sizeof(float);
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)wino63_boundary_legacy_kernel<FRONT, BACK>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((wino63_boundary_legacy_kernel<FRONT, BACK>), dim3((unsigned)units), dim3(W63_TILES * 64), lds, s, b);
+        return MYOLO_OK;
+    }
+    // one persistent workgroup per CU (option "w63_wgs": workgroups per CU, default 1), a multiple of the slices per image so that a workgroup's slice
+    // never changes; two LDS buffers (without a back half nobody reads the tile: only the statistics' partial sums pass through LDS)
+    const int ns = a.C / W63_CS;
+    const int per_cu = g_myolo_opt.w63_wgs > 0 ? g_myolo_opt.w63_wgs : 1;
+    long long grid = (long long)w63_num_cus() * per_cu;
+    grid -= grid % ns;
+    if (grid < ns) grid = ns;
+    if (grid > units) grid = units;                                        // units % ns == 0
+    const size_t lds = 2 * sizeof(float) * (BACK == W63_TO_NONE ? (size_t)2 * W63_TILES * W63_CS : (size_t)W63_HW * W63_HW * W63_CS);
+    // the activation is a compile-time parameter where the kernel applies it element by element (FROM_LAZY reads it as a mask: run time)
+    if (FRONT == W63_FROM_LAZY || FRONT == W63_FROM_CROP || a.act == MYOLO_ACT_NONE) w63_launch_act<FRONT, BACK, MYOLO_ACT_NONE>(b, (unsigned)grid, lds, s);
+    else if (a.act == MYOLO_ACT_RELU) w63_launch_act<FRONT, BACK, MYOLO_ACT_RELU>(b, (unsigned)grid, lds, s);
+    else w63_launch_act<FRONT, BACK, MYOLO_ACT_RELU6>(b, (unsigned)grid, lds, s);
     return MYOLO_OK;
 }
 
@@ -721,6 +1178,9 @@ int myolo_wino63_output_transform_bn_stats(const float* M, const float* bias, fl
     return MYOLO_OK;
 }
 
+#ifdef W63_TRACE
+int myolo_w63_trace_read(void* dst, size_t bytes) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(w63_trace_buf), bytes) == hipSuccess ? 0 : -1; }
+#endif
 static const long long* w63_run_rows(long long NR, long long rows[3]) { rows[0] = 9 * NR; rows[1] = 3 * NR; rows[2] = NR; return rows; }
 
 }  // extern "C"

@@ -977,6 +977,103 @@ def test_winograd_f63_tiling(N, Cin, Cout, x6, request):
         assert torch.equal(yk[::2], y2[::2]) and bool(torch.isnan(yk[1::2]).all()), "activation must be written for flagged images only"
 
 
+@pytest.mark.parametrize("N,C", [(5, 256), (3, 64)])
+def test_wino63_boundary_packed_equals_legacy(N, C):
+    """Round 6's boundary kernel (two columns / rows per v_pk_* instruction, wave-uniform plane addresses, all of a wave's pixels
+    requested at once) against the round-5 kernel kept behind option "w63_legacy": every front x back combination the library
+    instantiates, every activation, the keep / slot / pre-BatchNorm / statistics outputs -- bit for bit, NaN patterns included."""
+    rng = np.random.default_rng(61)
+    st = X.stream()
+    pe = X.wino63_plane_elems(N, C)
+    Mp = dt(rnd(rng, pe))
+    x = dt(rnd(rng, N, 14, 14, C))
+    b, sc, sh = dt(rnd(rng, C)), dt(1 + 0.1 * rnd(rng, C)), dt(rnd(rng, C, scale=0.1))
+    flags = torch.zeros(N, dtype=torch.int32, device=DEV)
+    flags[::2] = 1
+    slots = torch.full((N,), -1, dtype=torch.int32, device=DEV)
+    slots[1], slots[N - 1] = 1, 0
+    cap = 2
+    npos = 2
+    inv = torch.full((N,), -1, dtype=torch.int32, device=DEV)
+    inv[0], inv[N - 2] = 1, 0
+    dyc = dt(rnd(rng, npos, 196, C))
+    ka, kb = dt(rnd(rng, C, scale=0.01)), dt(rnd(rng, C, scale=0.01))
+    B, FH, FW, nb = 2, 28, 28, N
+    feat, boxes = dt(rnd(rng, B, FH, FW, C)), _boxes(rng, nb)
+    boxes[0] = [-0.2, 0.1, 0.7, 1.3]
+    boxes_t, bind = dt(boxes), dt(rng.integers(0, B, nb).astype(np.int32))
+    gamma, beta = dt(1 + 0.1 * rnd(rng, C)), dt(rnd(rng, C, scale=0.1))
+    nan = lambda *s: torch.full(s, float("nan"), device=DEV)       # noqa: E731
+
+    def run():
+        out = {}
+        for act in (0, 1, 2):
+            V, y = nan(pe), nan(N, 14, 14, C)
+            X.call("myolo_wino63_output_input_transform", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(y), X.ptr(flags), X.ptr(V), N, C, act, st)
+            out["M->V act%d" % act] = (V, y)
+            y2 = nan(N, 14, 14, C)
+            X.call("myolo_wino63_output_transform", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(y2), N, C, act, st)
+            out["M->y act%d" % act] = (y2,)
+            V3, y3 = nan(pe), nan(N, 14, 14, C)
+            X.call("myolo_wino63_input_transform", X.ptr(x), X.ptr(sc), X.ptr(sh), act, X.ptr(y3), X.ptr(flags), X.ptr(V3), N, C, st)
+            out["x->V act%d" % act] = (V3, y3)
+            V4, Q4 = nan(pe), nan(pe)
+            X.call("myolo_wino63_lazybn_transforms", X.ptr(x), X.ptr(dyc), X.ptr(inv), X.ptr(sc), X.ptr(sh), X.ptr(ka), X.ptr(kb), act, X.ptr(V4), X.ptr(Q4), N, C, st)
+            out["lazy->VQ act%d" % act] = (V4, Q4)
+        V, yp = nan(pe), nan(N, 14, 14, C)
+        X.call("myolo_wino63_output_input_transform", X.ptr(Mp), None, None, None, None, None, X.ptr(V), N, C, 0, st)
+        out["M->V plain"] = (V,)
+        V = nan(pe)
+        X.call("myolo_wino63_output_input_transform_keep_pre", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(yp), X.ptr(flags), X.ptr(V), N, C, 1, st)
+        out["M->V keep_pre"] = (V, yp)
+        V, ypc = nan(pe), nan(cap, 14, 14, C)
+        X.call("myolo_wino63_output_input_transform_keep_pre_slots", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(ypc), X.ptr(slots), cap, X.ptr(V), N, C, 1, st)
+        out["M->V keep_pre slots"] = (V, ypc)
+        y, yp = nan(N, 14, 14, C), nan(N, 14, 14, C)
+        X.call("myolo_wino63_output_transform_keep_pre", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(y), X.ptr(yp), X.ptr(flags), N, C, 1, st)
+        out["M->y keep_pre"] = (y, yp)
+        y, ypc = nan(N, 14, 14, C), nan(cap, 14, 14, C)
+        X.call("myolo_wino63_output_transform_keep_pre_slots", X.ptr(Mp), X.ptr(b), X.ptr(sc), X.ptr(sh), X.ptr(y), X.ptr(ypc), X.ptr(slots), cap, N, C, 1, st)
+        out["M->y keep_pre slots"] = (y, ypc)
+        V, yc = nan(pe), nan(cap, 14, 14, C)
+        X.call("myolo_wino63_input_transform_slots", X.ptr(x), X.ptr(sc), X.ptr(sh), 1, X.ptr(yc), X.ptr(slots), cap, X.ptr(V), N, C, st)
+        out["x->V slots"] = (V, yc)
+        V = nan(pe)
+        X.call("myolo_wino63_input_transform_roialign", X.ptr(feat), X.ptr(boxes_t), X.ptr(bind), X.ptr(V), B, FH, FW, C, nb, st)
+        out["roialign->V"] = (V,)
+        y = nan(N, 14, 14, C)
+        mean, var, s2, t2 = new(C), new(C), new(C), new(C)
+        mm, mv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        wsb = torch.empty(X.wino63_out_bn_ws_bytes(N, C), dtype=torch.uint8, device=DEV)
+        X.call("myolo_wino63_output_transform_bn_stats", X.ptr(Mp), X.ptr(b), X.ptr(y), N, C, X.ptr(gamma), X.ptr(beta), X.ptr(mean), X.ptr(var), X.ptr(s2), X.ptr(t2),
+               X.ptr(mm), X.ptr(mv), wsb.data_ptr(), wsb.numel(), st)
+        out["M->y + statistics"] = (y, mean, var, s2, t2, mm, mv)
+        if C == 256:
+            dy, dw = dt(rnd(rng2, N, 14, 14, C)), new(3, 3, C, C)
+            wsw = torch.empty(X.wino63_ws_bytes(N, C, C, 2), dtype=torch.uint8, device=DEV)
+            X.call("myolo_conv3x3_wino63_bwd_weight", X.ptr(x), None, X.ptr(dy), X.ptr(dw), N, C, C, wsw.data_ptr(), wsw.numel(), st)   # FROM_ACT -> Q
+            out["act->Q (weight gradient)"] = (dw,)
+            dwl = new(3, 3, C, C)
+            Vs = dt(rnd(rng2, pe))
+            wsl = torch.empty(X.wino63_bwd_weight_ws_bytes(N, C, C), dtype=torch.uint8, device=DEV)
+            X.call("myolo_wino63_bwd_weight_lazybn", X.ptr(Vs), X.ptr(x), X.ptr(dyc), X.ptr(inv), X.ptr(sc), X.ptr(sh), X.ptr(ka), X.ptr(kb), 1, X.ptr(dwl), N, C, C,
+                   wsl.data_ptr(), wsl.numel(), st)                                                                                       # FROM_LAZY -> Q
+            out["lazy->Q (weight gradient)"] = (dwl,)
+        torch.cuda.synchronize()
+        return out
+
+    rng2 = np.random.default_rng(62)
+    new_out = run()
+    rng2 = np.random.default_rng(62)
+    with X.option("w63_legacy", 1):
+        old_out = run()
+    for k in new_out:
+        for i, (a, o) in enumerate(zip(new_out[k], old_out[k])):
+            same = torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(o, nan=12345.0)) and torch.equal(torch.isnan(a), torch.isnan(o))
+            assert same, (k, i, float((torch.nan_to_num(a) - torch.nan_to_num(o)).abs().max()))
+        assert not bool(torch.isnan(new_out[k][0]).any()), k
+
+
 def test_winograd_f63_conv1_pieces():
     """conv1 of the mask head on the F(6,3)/F(4,3) tiling: (a) ROIAlign fused into the input transform == crop_and_resize followed by
     the plain input transform, bit for bit (same sampling expressions, same transform code); (b) the output transform that also
