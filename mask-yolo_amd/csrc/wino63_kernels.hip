@@ -40,30 +40,38 @@ __host__ __device__ constexpr int w63_qfirst(int g) { return g == 0 ? 0 : g == 1
 // T = float, or f2 = two independent columns (rows) at once: the same expression trees element by element (v_pk_* on gfx950)
 typedef float f2 __attribute__((ext_vector_type(2)));
 template <typename T> __device__ __forceinline__ T w63_zero() { return (T)(0.f); }
+// one rounding: a * b + c (v_fma_f32 / v_pk_fma_f32)
+__device__ __forceinline__ float w63_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ f2 w63_fma(float a, f2 b, f2 c) { const f2 av = {a, a}; return __builtin_elementwise_fma(av, b, c); }
+// B^T (8x8 / 6x6 with rho): the only transform with multipliers that are not powers of two (4.25, 1.25, 2.5, 5, 5.25, 0.75, 3.75).  Where an expression
+// sums TWO products the compiler may fuse either one, and which one it picks depends on the code around the call (seen: the scalar and the packed
+// instantiation of `0.25 d2 - 1.25 d4` differed) -- so contraction is off here and every fused multiply-add is written out: the inexact product is the
+// fused one, the power-of-two product (exact) is formed first.  Legacy and packed kernels then agree bit for bit by construction.
 template <int CLS, typename T = float>
 __device__ __forceinline__ void w63_bt(const T d[8], T t[8])
 {
+#pragma clang fp contract(off)
     if (CLS == 6) {
-        const T e0 = d[2] + d[6] - 4.25f * d[4], o0 = d[1] + d[5] - 4.25f * d[3];
-        const T e1 = 0.25f * d[2] - 1.25f * d[4] + d[6], o1 = 0.5f * d[1] - 2.5f * d[3] + 2.f * d[5];
-        const T e2 = 4.f * d[2] - 5.f * d[4] + d[6], o2 = 2.f * d[1] - 2.5f * d[3] + 0.5f * d[5];
-        t[0] = (d[6] - d[0]) + 5.25f * (d[2] - d[4]);
+        const T e0 = w63_fma(-4.25f, d[4], d[2] + d[6]), o0 = w63_fma(-4.25f, d[3], d[1] + d[5]);
+        const T e1 = w63_fma(-1.25f, d[4], 0.25f * d[2]) + d[6], o1 = w63_fma(2.f, d[5], w63_fma(-2.5f, d[3], 0.5f * d[1]));
+        const T e2 = w63_fma(-5.f, d[4], 4.f * d[2]) + d[6], o2 = w63_fma(0.5f, d[5], w63_fma(-2.5f, d[3], 2.f * d[1]));
+        t[0] = w63_fma(5.25f, d[2] - d[4], d[6] - d[0]);
         t[1] = e0 + o0;
         t[2] = e0 - o0;
         t[3] = e1 + o1;
         t[4] = e1 - o1;
         t[5] = e2 + o2;
         t[6] = e2 - o2;
-        t[7] = (d[7] - d[1]) + 5.25f * (d[3] - d[5]);
+        t[7] = w63_fma(5.25f, d[3] - d[5], d[7] - d[1]);
     } else {            // rho .* (B6^T d), patch d[0..5]
-        t[0] = -d[0] + 1.25f * d[2] - 0.25f * d[4];
-        t[1] = 0.75f * (d[3] + d[4] - 4.f * (d[1] + d[2]));
-        t[2] = 0.75f * (4.f * (d[1] - d[2]) - d[3] + d[4]);
-        t[3] = 3.75f * (2.f * (d[3] - d[1]) - d[2] + d[4]);
-        t[4] = 3.75f * (2.f * (d[1] - d[3]) - d[2] + d[4]);
+        t[0] = w63_fma(-0.25f, d[4], w63_fma(1.25f, d[2], -d[0]));
+        t[1] = 0.75f * w63_fma(-4.f, d[1] + d[2], d[3] + d[4]);                 // (products by powers of two are exact: fused or not, the same bits)
+        t[2] = 0.75f * (w63_fma(4.f, d[1] - d[2], -d[3]) + d[4]);
+        t[3] = 3.75f * (w63_fma(2.f, d[3] - d[1], -d[2]) + d[4]);
+        t[4] = 3.75f * (w63_fma(2.f, d[1] - d[3], -d[2]) + d[4]);
         t[5] = w63_zero<T>();
         t[6] = w63_zero<T>();
-        t[7] = 4.f * d[1] - 5.f * d[3] + d[5];
+        t[7] = w63_fma(-5.f, d[3], 4.f * d[1]) + d[5];
     }
 }
 template <int CLS, typename T = float>

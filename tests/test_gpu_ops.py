@@ -1067,11 +1067,15 @@ def test_wino63_boundary_packed_equals_legacy(N, C):
     rng2 = np.random.default_rng(62)
     with X.option("w63_legacy", 1):
         old_out = run()
+    bad = []
     for k in new_out:
         for i, (a, o) in enumerate(zip(new_out[k], old_out[k])):
             same = torch.equal(torch.nan_to_num(a, nan=12345.0), torch.nan_to_num(o, nan=12345.0)) and torch.equal(torch.isnan(a), torch.isnan(o))
-            assert same, (k, i, float((torch.nan_to_num(a) - torch.nan_to_num(o)).abs().max()))
+            if not same:
+                d = (torch.nan_to_num(a) - torch.nan_to_num(o)).abs()
+                bad.append((k, i, float(d.max()), float((d > 0).float().mean()), float(torch.nan_to_num(o).abs().max())))
         assert not bool(torch.isnan(new_out[k][0]).any()), k
+    assert not bad, bad
 
 
 def test_winograd_f63_conv1_pieces():
