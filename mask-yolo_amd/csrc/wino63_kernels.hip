@@ -977,7 +977,11 @@ static int w63_launch(const W63Args& a, hipStream_t s)
     b.order = g_myolo_opt.w63_order ? 0 : 1;
     const long long units = a.NR * (a.C / W63_CS);
     if (units <= 0 || units >= (1LL << 31)) return MYOLO_EINVAL;
-    if (g_myolo_opt.w63_legacy) {
+    // The ROIAlign front gathers from the (cache-resident) feature map in five dependent passes: nothing to prefetch, and what hides its latency is a
+    // SECOND workgroup on the CU -- the one-unit kernel at 80 VGPRs / 50 KB of LDS fits two (0.45 ms against 0.53-0.55 for the persistent form): it stays.
+    // Plane sets of 4 GiB and more (32-bit buffer offsets) also take the one-unit kernel.
+    const bool one_unit = g_myolo_opt.w63_legacy || FRONT == W63_FROM_CROP || (unsigned long long)400 * a.NR * a.C * 4ull >= (1ull << 32);
+    if (one_unit) {
         static bool attr_set = false;
         const size_t lds = (size_t)W63_HW * W63_HW * W63_CS * sizeof(float);
         if (!attr_set) {
