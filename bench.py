@@ -424,7 +424,7 @@ def bench_train(args, rank, world, local):
         assert hasattr(net, name), "unknown engine attribute %s" % name
         setattr(net, name, type(getattr(net, name))(int(val)))
     comm_stream = None if args.comm_own_stream else net._copy_stream        # (see GradReducer: a fresh HIP stream is not free)
-    reducer = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], backend=args.comm, timing=world > 1, stream=comm_stream)
+    reducer = mdist.GradReducer(net.flat_g, net.bucket_ranges, backend=args.comm, timing=world > 1, stream=comm_stream)
     reducer.attach(net)
     ranks_seen = reducer.ranks_seen() if world > 1 else 1
 
@@ -487,6 +487,7 @@ def bench_train(args, rank, world, local):
     conv_ms, conv_n = net.kernel_ms("mask_conv3x3_fwd")
     mul_ms, mul_n = net.kernel_ms("wino_multiply")
     bucket_ms = reducer.bucket_ms() if world > 1 else None
+    release_ms = reducer.release_ms_before_wait() if world > 1 else None
     weights_same = None
     if world > 1:
         # every rank must hold bit-identical weights after the K averaged updates: an integer digest of the flat parameter buffer, MIN == MAX over ranks
@@ -601,18 +602,25 @@ def bench_train(args, rank, world, local):
         # (b) what the three real gradient buckets cost as RCCL collectives on the comm stream while backward runs: a 1-rank
         #     communicator through the C-ABI (launch + stream + kernel cost of the exchange, not the wire), and the step with it
         try:
-            probe = mdist.GradReducer(net.flat_g, [net.bucket_ranges[i] for i in (0, 1, 2)], always=True, backend="capi", timing=True, stream=comm_stream)
+            probe = mdist.GradReducer(net.flat_g, net.bucket_ranges, always=True, backend="capi", timing=True, stream=comm_stream)
             probe.attach(net)
             for i in range(2):
                 net.train_step(dbs[i % nb], args.lr)
             probe.bucket_ms()                                    # drop the warm-up pairs
             probe._ms = [[] for _ in probe._ms]
+            probe._rel_ms = [[] for _ in probe._rel_ms]
             el, _ = timed_steps(net, dbs, args.steps, args.lr, barrier)
+            rel = probe.release_ms_before_wait()
+            bb = [4 * (hi - lo) for lo, hi in net.bucket_ranges]
             extras["comm_overlap_probe_ms"] = {
-                "bucket_allreduce_ms": probe.bucket_ms(), "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
+                "bucket_allreduce_ms": probe.bucket_ms(), "bucket_bytes": bb,
+                "release_ms_before_step_end": rel,
+                "bytes_released_3ms_or_more_before_step_end_frac": (sum(b for b, r in zip(bb, rel) if r >= 3.0) / float(sum(bb))) if rel else None,
                 "ms_per_step_with_probe": 1e3 * el / args.steps,
-                "note": "1-rank RCCL communicator (myolo_comm_* through the C-ABI): the three real buckets all-reduced on the comm stream "
-                        "as backward completes them [backbone, yolo head + feature_map, mask head]; cost of issuing the exchange, not of the wire"}
+                "note": "1-rank RCCL communicator (myolo_comm_* through the C-ABI): the five real buckets all-reduced on the comm stream as backward "
+                        "completes them [backbone, YOLO blocks + conv_23, feature_map, mask conv1 + bn1, rest of the mask head]; cost of issuing the "
+                        "exchange, not of the wire.  release_ms_before_step_end: from the event a bucket's collective waits for to the end of backward "
+                        "(the join in front of Adam) -- the time available to hide that bucket's exchange"}
             probe.close()
         except Exception as e:
             extras["comm_overlap_probe_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -800,8 +808,9 @@ def bench_train(args, rank, world, local):
                                    "RCCL via %s" % ("the C-ABI (myolo_comm_*)" if args.comm == "capi" else "torch.distributed (nccl)")),
                        "rccl_ranks_seen": ranks_seen, "bucket_allreduce_ms": bucket_ms, "weights_identical_across_ranks": weights_same,
                        "bucket_bytes": [4 * (hi - lo) for lo, hi in net.bucket_ranges],
-                       "note": "buckets in flat-buffer order [backbone, yolo head + feature_map, mask head]; launched mask head first, each "
-                               "on the comm stream as soon as backward completes it"}
+                       "release_ms_before_step_end": release_ms,
+                       "note": "buckets in flat-buffer order [backbone, YOLO blocks + conv_23, feature_map, mask conv1 + bn1, rest of the mask head]; each "
+                               "launched on the comm stream as soon as backward completes it (YOLO head first, about half a step before the end)"}
     res.update(extras)
     # the dominant kernel is co-bound: at K = 256 with fp32 in / out its algorithmic bytes at the measured copy rate take as long as its products on the
     # matrix pipe -- both fractions are reported: frac_mfma = flop / peak / time, frac_composite = max(flop / peak, bytes / copy rate) / time

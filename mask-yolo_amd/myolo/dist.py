@@ -5,8 +5,9 @@ backward pass has produced the bucket, so the exchange overlaps the rest of back
 The reference has no distributed code (GPU_COUNT = 0 everywhere, config.py:47); the step
 shards naturally over images: BN batch statistics and the loss
 normalisers stay local to each replica, gradients are averaged (sum all-reduce, then 1/world
-inside the fused Adam kernel).  Buckets are the three contiguous ranges of Net.flat_g in the
-order backward completes them: mask head -> YOLO head + feature_map -> backbone.
+inside the fused Adam kernel).  Buckets are the five contiguous ranges of Net.flat_g (engine.layer_table), each released the moment
+backward has produced it: YOLO blocks + conv_23 (under the mask head's forward, about half a step before the end) -> the mask head behind
+conv1 (when the compact chain's weight gradients retire) -> myolo_mask_conv1 + bn1 -> feature_map -> backbone.
 
 torch.distributed is plumbing here (backend "nccl" is RCCL on ROCm; "gloo" on CPU for tests).
 """
@@ -90,6 +91,10 @@ class GradReducer(object):
             # timing: one (start, end) event pair per collective, kept until bucket_ms() reads them -- nothing synchronises inside a step
             self._pairs = [[] for _ in self.ranges]
             self._ms = [[] for _ in self.ranges]
+            # timing: when was bucket i released, relative to the end of backward (the wait() in front of the optimiser)?
+            self._rel_open = [None for _ in self.ranges]
+            self._rel_pairs = [[] for _ in self.ranges]
+            self._rel_ms = [[] for _ in self.ranges]
         if backend == "capi" and self.active:
             if not self.cuda:
                 raise ValueError("backend 'capi' (RCCL through the C-ABI) needs device tensors")
@@ -132,10 +137,21 @@ class GradReducer(object):
         self._collect()
         return [float(sum(v) / len(v)) if v else 0.0 for v in self._ms]
 
+    def release_ms_before_wait(self):
+        """[mean ms between bucket i's release (the event the collective waits for) and the end of backward (wait())] (timing=True; synchronises):
+        how much of the step is left to hide the exchange behind."""
+        if not (self.timing and self.active):
+            return None
+        self._collect()
+        return [float(sum(v) / len(v)) if v else 0.0 for v in self._rel_ms]
+
     def _collect(self):
         torch.cuda.synchronize(self.flat.device)
         for i, pairs in enumerate(self._pairs):
             self._ms[i] += [a.elapsed_time(b) for a, b in pairs]
+            del pairs[:]
+        for i, pairs in enumerate(self._rel_pairs):
+            self._rel_ms[i] += [a.elapsed_time(b) for a, b in pairs]
             del pairs[:]
 
     def close(self):
@@ -162,8 +178,10 @@ class GradReducer(object):
         lo, hi = self.ranges[i]
         view = self.flat[lo:hi]
         if self.cuda:
-            ready = torch.cuda.Event()
+            ready = torch.cuda.Event(enable_timing=self.timing)
             ready.record(torch.cuda.current_stream())
+            if self.timing:
+                self._rel_open[i] = ready
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(ready)
                 if self.timing:
@@ -188,6 +206,15 @@ class GradReducer(object):
             return
         if self.cuda:
             cur = torch.cuda.current_stream()
+            if self.timing:
+                end = torch.cuda.Event(enable_timing=True)
+                end.record(cur)                   # the end of backward on the compute stream, before it waits for the exchange
+                for i, ready in enumerate(self._rel_open):
+                    if ready is not None:
+                        if len(self._rel_pairs[i]) >= 512:
+                            del self._rel_pairs[i][:256]
+                        self._rel_pairs[i].append((ready, end))
+                    self._rel_open[i] = None
             for ev in self.done:
                 cur.wait_event(ev)
         else:

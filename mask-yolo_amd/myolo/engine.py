@@ -31,9 +31,16 @@ MASK_FILTERS = 256                                                              
 WINO_MIN_ROWS = 8192       # CONV3X3_ALGO='auto': output pixels from which the Winograd form of a 3x3 conv is used (Rice 416 at batch 4: feature_map has 10816)
 
 
+BUCKET_BACKBONE, BUCKET_YOLO, BUCKET_FEATURE_MAP, BUCKET_MASK_CONV1, BUCKET_MASK_REST = 0, 1, 2, 3, 4
+N_BUCKETS = 5
+
+
 def layer_table(cfg):
     """[(layer name, kind, shape, bucket)] -- names are the reference's Keras layer names (the
-    checkpoint schema).  bucket: 0 backbone, 1 yolo head + feature_map, 2 mask head."""
+    checkpoint schema).  bucket = the gradient all-reduce bucket, cut where backward FINISHES a group of layers (the flat
+    buffer is laid out bucket by bucket, so each is one contiguous slice): 0 backbone (complete at the end of the step), 1 YOLO blocks + conv_23
+    (complete when the YOLO head's backward retires, under the mask head's forward), 2 feature_map, 3 myolo_mask_conv1 + bn1 (conv1's dense weight
+    gradient: late), 4 the rest of the mask head (complete when the compact chain's weight gradients retire).  Same flat layout as rounds 1-5."""
     a, C = cfg.ALPHA, cfg.NUM_CLASSES
     t = [("conv1", "conv", (3, 3, 3, int(32 * a)), 0), ("conv1_bn", "bn", int(32 * a), 0)]
     cin, bid = int(32 * a), 1
@@ -46,14 +53,15 @@ def layer_table(cfg):
             c4 = co
         cin = co
         bid += 1
-    t += [("conv_23", "convb", (1, 1, cin, cfg.N_BOX * (5 + C)), 1),
-          ("feature_map", "convb", (3, 3, c4, cfg.TOP_FEATURE_MAP_DEPTH), 1)]
+    t += [("conv_23", "convb", (1, 1, cin, cfg.N_BOX * (5 + C)), BUCKET_YOLO),
+          ("feature_map", "convb", (3, 3, c4, cfg.TOP_FEATURE_MAP_DEPTH), BUCKET_FEATURE_MAP)]
     cm = cfg.TOP_FEATURE_MAP_DEPTH
     for i in range(1, 5):
-        t += [("myolo_mask_conv%d" % i, "convb", (3, 3, cm, MASK_FILTERS), 2), ("myolo_mask_bn%d" % i, "bn", MASK_FILTERS, 2)]
+        bk = BUCKET_MASK_CONV1 if i == 1 else BUCKET_MASK_REST
+        t += [("myolo_mask_conv%d" % i, "convb", (3, 3, cm, MASK_FILTERS), bk), ("myolo_mask_bn%d" % i, "bn", MASK_FILTERS, bk)]
         cm = MASK_FILTERS
-    t += [("myolo_mask_deconv", "deconv", (2, 2, MASK_FILTERS, MASK_FILTERS), 2),
-          ("myolo_mask", "convb", (1, 1, MASK_FILTERS, C), 2)]
+    t += [("myolo_mask_deconv", "deconv", (2, 2, MASK_FILTERS, MASK_FILTERS), BUCKET_MASK_REST),
+          ("myolo_mask", "convb", (1, 1, MASK_FILTERS, C), BUCKET_MASK_REST)]
     return t
 
 
@@ -159,7 +167,7 @@ class Net(object):
         self.pslots, self.sslots = {}, {}
         self.bucket_ranges = []
         off, soff = 0, 0
-        for bucket in (0, 1, 2):
+        for bucket in range(N_BUCKETS):
             b0 = off
             for name, kind, shp, bk in self.table:
                 if bk != bucket:
@@ -203,7 +211,10 @@ class Net(object):
         self._ws_active = self._ws_main
         self._yolo_stream = _shared_stream(self.dev, "yolo_head_bwd")
         self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
-        self.yolo_bwd_early = 0           # 1 = launched right behind the YOLO loss (under the mask head's FORWARD) instead of at the start of its backward
+        # 1 = the YOLO head's backward is launched right behind the YOLO loss, under the mask head's FORWARD (0: at the start of the mask head's backward,
+        # rounds 3-5).  Same step time on one GPU (19.40 against 19.41 ms, round 6), but its 12.9 MB gradient bucket is then complete 9.3 ms before the step
+        # ends instead of 2.9, and the weight-gradient stream is free for the compact chain's weight gradients (their bucket: 6.0 instead of 2.4 ms)
+        self.yolo_bwd_early = 1
         # conv1's weight gradient (MFMA-bound, 2.7 ms, nothing downstream but the optimiser) on a third stream with its own
         # scratch, underneath conv1's data gradient -> ROIAlign backward -> backbone backward (launch- / HBM-bound small kernels)
         self._wgrad_stream = _shared_stream(self.dev, "weight_gradients")
@@ -808,9 +819,30 @@ class Net(object):
         try:
             with torch.cuda.stream(self._yolo_stream):
                 da = self.yolo_head_bwd(dyolo)
+                self._release_yolo_bucket()
         finally:
             self._ws_active = self._ws_main
         self.tape["yolo_bwd"] = da
+
+    def _release_on_wgrad_stream(self, bucket, stream, pending):
+        """hand `bucket` to the all-reduce hook once the current stream AND `stream` (the one its weight gradients were queued on) have produced it:
+        on `stream`, behind an event of the current stream -- the current stream does not wait"""
+        if not self.on_bucket_ready:
+            return
+        if not pending:
+            self.on_bucket_ready(bucket)
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        stream.wait_event(ev)
+        with torch.cuda.stream(stream):
+            self.on_bucket_ready(bucket)
+
+    def _release_yolo_bucket(self):
+        """bucket 1 = YOLO blocks + conv_23: complete when the YOLO head's backward retires -- about half a step before the step ends when that
+        backward runs on its side stream under the mask head (start_yolo_head_bwd).  Its data gradients and BatchNorm / conv_23 gradients are on the
+        current stream, the blocks' weight gradients on the trunk's weight-gradient stream."""
+        self._release_on_wgrad_stream(BUCKET_YOLO, self._twg_stream, self.overlap_trunk_wgrad and self._twg_pending)
 
     def trunk_bwd(self, dF, dyolo):
         C4, c4shape, a14, s14 = self.tape["trunk"]
@@ -818,6 +850,7 @@ class Net(object):
         started = da is not None                # launched earlier on the side stream (start_yolo_head_bwd)
         if not started:
             da = self.yolo_head_bwd(dyolo)
+            self._release_yolo_bucket()
 
         def join():
             if started:
@@ -847,20 +880,15 @@ class Net(object):
             join()
             X.call("myolo_add_inplace", X.ptr(dC4), X.ptr(da), dC4.numel(), X.stream())
         if self.on_bucket_ready:
-            # bucket 1 = YOLO head + feature_map.  Its last pieces are on two streams: the YOLO head's chain (joined into the compute
-            # stream just above) and the weight-gradient stream (feature_map's and the YOLO blocks' weight gradients).  The bucket is
-            # released ON the weight-gradient stream, behind an event of the compute stream -- the compute stream itself does not wait
-            # (round 3 joined the whole weight-gradient stream here, conv1's 2.7 ms weight gradient included, in front of the
-            # backbone backward: +3 ms per step whenever a reducer was attached).
+            # bucket 2 = feature_map: its weight gradient sits on the weight-gradient stream (or was zeroed on this one).  Released ON that
+            # stream, behind an event of the compute stream -- the compute stream itself does not wait (round 3 joined the whole
+            # weight-gradient stream here, conv1's 2.7 ms weight gradient included, in front of the backbone backward: +3 ms per step whenever
+            # a reducer was attached).
             if self.bucket1_on_wgrad_stream and self.overlap_trunk_wgrad and self._twg_pending:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self._twg_stream.wait_event(ev)
-                with torch.cuda.stream(self._twg_stream):
-                    self.on_bucket_ready(1)
+                self._release_on_wgrad_stream(BUCKET_FEATURE_MAP, self._twg_stream, True)
             else:
                 self.join_trunk_wgrad()
-                self.on_bucket_ready(1)
+                self.on_bucket_ready(BUCKET_FEATURE_MAP)
         da = dC4
         if self.backbone_wgrad_on_yolo_stream and self.overlap_trunk_wgrad and self.overlap_yolo_bwd:
             self._twg_override = (self._yolo_stream, self._ws_side)
@@ -877,7 +905,7 @@ class Net(object):
         X.call("myolo_conv3x3s2_c3_bwd_weight", X.ptr(images), X.ptr(dy), X.ptr(self.g["conv1/kernel"]), N, H, W, C0, *self._wsargs(), X.stream())
         self.join_trunk_wgrad()
         if self.on_bucket_ready:
-            self.on_bucket_ready(0)
+            self.on_bucket_ready(BUCKET_BACKBONE)
 
     def _box_image_index(self, B, R):
         """box_ind of crop_and_resize for R boxes per image (cached: no host-synchronising op in the step / under graph capture)."""
@@ -1205,7 +1233,8 @@ class Net(object):
         dF = self._new(n * h * w, cf)
         X.call("myolo_roialign_bwd_grouped", X.ptr(da), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
         if self.on_bucket_ready:
-            self.on_bucket_ready(2)
+            self.on_bucket_ready(BUCKET_MASK_REST)
+            self.on_bucket_ready(BUCKET_MASK_CONV1)
         return dF
 
     def _gather(self, t, idx, n, group_rows):
@@ -1353,12 +1382,12 @@ class Net(object):
         n, h, w, cf = fshape
         compact = "compact" in self.tape          # forward already ran on the positives only
         NP, idx_d, inv_d = self.tape["compact"] if compact else self._positive_index(B, R)
-        lo, hi = self.bucket_ranges[2]
         if NP == 0:                       # no positive ROI: mask loss is the constant 0 (model.py:750-752)
-            self.flat_g[lo:hi].zero_()
+            self.flat_g[self.bucket_ranges[BUCKET_MASK_CONV1][0]:self.bucket_ranges[BUCKET_MASK_REST][1]].zero_()
             dF = torch.zeros(n * h * w, cf, dtype=torch.float32, device=self.dev)
             if self.on_bucket_ready:
-                self.on_bucket_ready(2)
+                self.on_bucket_ready(BUCKET_MASK_REST)
+                self.on_bucket_ready(BUCKET_MASK_CONV1)
             return dF
         q = ps * ps
         kept = self.tape.get("compact_rows", ())          # tensors the forward wrote in compact order (rows of positive k at block k)
@@ -1484,8 +1513,11 @@ class Net(object):
             off_chain(conv_wgrad, (xin, dy) + ((src[1],) if lazy_xin is not None else ()))
             da = self._new(NP * q, MASK_FILTERS)
             self.conv3x3_bwd_data(dy, cn, da, NP, ps, ps, MASK_FILTERS, MASK_FILTERS)
+        # bucket 4 (conv2-4, bn2-4, deconv, myolo_mask) is complete: its data-path gradients on this stream, the weight gradients hanging off the
+        # compact chain on the side stream -- in FRONT of conv1's dense weight gradient, i.e. several milliseconds before the step ends
+        self._release_on_wgrad_stream(BUCKET_MASK_REST, self._wgrad_stream, side_wg and self._wgrad_pending)
         # bn1: batch statistics -> dense dx from the row-sparse upstream gradient
-        released = [False]                      # the mask-head bucket handed to the all-reduce hook on the side stream (fork_wgrad)
+        released = [False]                      # conv1's bucket handed to the all-reduce hook on the side stream (fork_wgrad)
         c1, act, _ = self.tape["myolo_mask_bn1"]
         buf = self.bnbuf["myolo_mask_bn1"]
         M1 = NR * q
@@ -1533,8 +1565,8 @@ class Net(object):
                 self._wgrad_stream.wait_stream(cur)
                 with torch.cuda.stream(self._wgrad_stream):
                     conv1_wgrad(self._ws_wgrad.ptr, self._ws_wgrad.size)
-                    if self.on_bucket_ready:          # every other gradient of the mask-head bucket was complete at the fork
-                        self.on_bucket_ready(2)
+                    if self.on_bucket_ready:          # bn1's gradients (this bucket's other members) were complete at the fork
+                        self.on_bucket_ready(BUCKET_MASK_CONV1)
                 for t in (v1, c1, da, inv_d, kab) + ((Qd,) if merged else ()):
                     t.record_stream(self._wgrad_stream)
                 self._wgrad_pending = True
@@ -1571,7 +1603,7 @@ class Net(object):
         X.call("myolo_roialign_bwd_grouped", X.ptr(dp0), X.ptr(boxes), X.ptr(dF), n, h, w, cf, NR // n, ps, ps, X.stream())
         if self.on_bucket_ready and not released[0]:
             self.join_conv1_wgrad()       # the compacted weight gradients on the side stream, if any
-            self.on_bucket_ready(2)       # (otherwise the bucket was released on the weight gradient's stream, behind that kernel)
+            self.on_bucket_ready(BUCKET_MASK_CONV1)       # (otherwise the bucket was released on the weight gradient's stream, behind that kernel)
         return dF
 
     def join_conv1_wgrad(self):
@@ -1946,10 +1978,10 @@ class Net(object):
         X.call("myolo_yolo_loss_warmup", X.ptr(db["y_true"]), X.ptr(yo), X.ptr(db["true_boxes"]), X.ptr(self.anchors),
                X.ptr(self.class_weights), float(cfg.OBJECT_SCALE), float(cfg.NO_OBJECT_SCALE), float(cfg.COORD_SCALE),
                float(cfg.CLASS_SCALE), w1, warm, X.ptr(yterms), X.ptr(dyolo), B, G, A, C, T, *self._wsargs(), X.stream())
-        lo, hi = self.bucket_ranges[2]
-        self.flat_g[lo:hi].zero_()
+        self.flat_g[self.bucket_ranges[BUCKET_MASK_CONV1][0]:self.bucket_ranges[BUCKET_MASK_REST][1]].zero_()
         if self.on_bucket_ready:
-            self.on_bucket_ready(2)
+            self.on_bucket_ready(BUCKET_MASK_REST)
+            self.on_bucket_ready(BUCKET_MASK_CONV1)
         self.trunk_bwd(None, dyolo)
         return dict(yolo_output=yo.view(B, G, G, A, 5 + C), yolo_terms=yterms, loss_weights=(w1, 0.0))
 

@@ -80,11 +80,14 @@ def test_shard_range_requires_even_split():
 
 
 def test_engine_bucket_ranges_cover_flat_buffer_contiguously():
-    """the three all-reduce buckets tile Net.flat_g exactly (layout computed without touching the GPU)."""
-    from myolo.engine import layer_table
+    """the five all-reduce buckets tile Net.flat_g exactly, in table order, each cut where backward finishes a group of layers: backbone | YOLO blocks +
+    conv_23 | feature_map | myolo_mask_conv1 + bn1 | the rest of the mask head (layout computed without touching the GPU; same offsets as rounds 1-5)."""
+    from myolo.engine import layer_table, N_BUCKETS, BUCKET_BACKBONE, BUCKET_YOLO, BUCKET_FEATURE_MAP, BUCKET_MASK_CONV1, BUCKET_MASK_REST
     from myolo.config import ShapesConfig
     cfg = ShapesConfig()
-    sizes = {0: 0, 1: 0, 2: 0}
+    sizes = {k: 0 for k in range(N_BUCKETS)}
+    names = {k: [] for k in range(N_BUCKETS)}
+    order = []
     for name, kind, shp, bk in layer_table(cfg):
         if kind in ("conv", "convb"):
             n = [int(np.prod(shp))] + ([shp[3]] if kind == "convb" else [])
@@ -95,9 +98,20 @@ def test_engine_bucket_ranges_cover_flat_buffer_contiguously():
         else:
             n = [shp, shp]
         sizes[bk] += sum((k + 3) // 4 * 4 for k in n)
+        names[bk].append(name)
+        order.append(bk)
+    assert order == sorted(order), "buckets must be contiguous runs of the table (the flat buffer is laid out bucket by bucket)"
     total = sum(sizes.values())
     assert 7296031 <= total < 7296031 + 4 * 200                        # SURVEY.md Appendix B count + alignment padding
-    assert sizes[2] > sizes[0]                                          # mask head is the largest bucket but the backbone
+    assert names[BUCKET_BACKBONE][0] == "conv1" and names[BUCKET_BACKBONE][-1] == "conv_pw_6_bn"
+    assert names[BUCKET_YOLO][0] == "conv_dw_7" and names[BUCKET_YOLO][-1] == "conv_23"
+    assert names[BUCKET_FEATURE_MAP] == ["feature_map"]
+    assert names[BUCKET_MASK_CONV1] == ["myolo_mask_conv1", "myolo_mask_bn1"]
+    assert names[BUCKET_MASK_REST][0] == "myolo_mask_conv2" and names[BUCKET_MASK_REST][-1] == "myolo_mask"
+    # mask head 10.5 MB, feature_map 4.7 MB, YOLO head 13.0 MB, backbone 1.0 MB
+    mb = {k: 4 * v / 1e6 for k, v in sizes.items()}
+    assert abs(mb[BUCKET_YOLO] - 13.0) < 0.2 and abs(mb[BUCKET_FEATURE_MAP] - 4.72) < 0.05 and abs(mb[BUCKET_BACKBONE] - 1.02) < 0.05
+    assert abs(mb[BUCKET_MASK_CONV1] + mb[BUCKET_MASK_REST] - 10.5) < 0.1
 
 
 @pytest.mark.parametrize("n,batch,world", [(50, 8, 2), (64, 8, 8), (500, 32, 4), (9, 8, 2), (100, 8, 3)])

@@ -119,7 +119,7 @@ def _worker(rank, world, port, q, freeze, backend="gloo", reducer="torch", posit
             elif not bool((after[~fz] != before[~fz]).any()):
                 frozen_ok = "trainable weights did not move"
         ms = model._reducer.bucket_ms()
-        q.put((rank, err, same, frozen_ok, str(ms) if not (ms is not None and len(ms) == 3 and all(v >= 0 for v in ms)) else "ok"))
+        q.put((rank, err, same, frozen_ok, str(ms) if not (ms is not None and len(ms) == 5 and all(v >= 0 for v in ms)) else "ok"))
         if model._reducer.backend == "capi":
             model._reducer.close()
     finally:
@@ -185,7 +185,40 @@ def test_rccl_through_the_c_abi_one_rank():
         assert torch.equal(g, g0)
         ms = red.bucket_ms()
         assert len(ms) == 3 and all(v > 0 for v in ms)
+        rel = red.release_ms_before_wait()
+        assert len(rel) == 3 and all(v >= 0 for v in rel)
     finally:
+        red.close()
+
+
+def test_engine_releases_buckets_where_backward_finishes_them():
+    """SURVEY 8(e) "each bucket launched when its last dW kernel completes": with a (1-rank, C-ABI) reducer attached, every one of the five buckets is
+    released exactly once per step, the YOLO-head bucket FIRST (its backward runs on a side stream under the mask head) and the backbone LAST, and the
+    YOLO-head and mask-head-rest buckets are released EARLIER (relative to the end of backward) than conv1's and the backbone's."""
+    from myolo.model import MaskYOLO
+    from myolo.dist import GradReducer
+    from myolo import engine as E
+    cfg, P, batches = _case()
+    model = MaskYOLO(mode="training", config=cfg, device="cuda:0")
+    model.load_state_dict(P)
+    red = GradReducer(model.net.flat_g, model.net.bucket_ranges, always=True, backend="capi", timing=True).attach(model.net)
+    order = []
+    inner = model.net.on_bucket_ready
+    model.net.on_bucket_ready = lambda i: (order.append(i), inner(i))[1]
+    try:
+        model.set_trainable(".*")
+        model.compile(1e-3, 0.9)
+        for k in range(3):
+            del order[:]
+            model.train_on_batch(batches[k % len(batches)])
+            assert sorted(order) == list(range(E.N_BUCKETS)), order
+            assert order[0] == E.BUCKET_YOLO and order[-1] == E.BUCKET_BACKBONE, order
+            assert order.index(E.BUCKET_MASK_REST) < order.index(E.BUCKET_MASK_CONV1), order
+        rel = red.release_ms_before_wait()
+        assert len(rel) == E.N_BUCKETS and all(v >= 0 for v in rel)
+        assert rel[E.BUCKET_YOLO] > rel[E.BUCKET_BACKBONE] and rel[E.BUCKET_MASK_REST] >= rel[E.BUCKET_MASK_CONV1] - 0.05, rel
+    finally:
+        model.net.on_bucket_ready = inner
         red.close()
 
 
@@ -213,7 +246,7 @@ def test_engine_step_with_capi_reducer_is_bit_identical_to_no_reducer():
 def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     """`python bench.py --gpus 2` end to end on this one-GPU box: the script re-launches itself under torch.distributed.run, two ranks
     build the engine, exchange gradients every step (gloo instead of RCCL: --share-gpu puts both ranks on cuda:0), take the MAX over
-    ranks of the timed region, and rank 0 prints ONE JSON line on stdout with n_gpus = 2, the comm object (two ranks seen, three
+    ranks of the timed region, and rank 0 prints ONE JSON line on stdout with n_gpus = 2, the comm object (two ranks seen, five
     bucket timings) and weak-scaling semantics (global batch = 2 x per-GPU batch).  What the driver's 8-GPU command runs, minus the wire."""
     import json
     import subprocess
@@ -230,7 +263,7 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["config"]["share_gpu"] is True
-    assert d["comm"]["rccl_ranks_seen"] == 2 and len(d["comm"]["bucket_allreduce_ms"]) == 3 and all(v > 0 for v in d["comm"]["bucket_allreduce_ms"])
+    assert d["comm"]["rccl_ranks_seen"] == 2 and len(d["comm"]["bucket_allreduce_ms"]) == 5 and all(v > 0 for v in d["comm"]["bucket_allreduce_ms"])
     assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert d["dense_mask_backward_ms_per_step"] > 0                               # the variants ran in lockstep on both ranks
     assert len(lines[0]) < 6000 and d["detail"] == "bench_detail.json"            # the compact line; the full object is beside it
@@ -256,6 +289,6 @@ def test_bench_eight_ranks_at_full_config2_size_on_one_gpu():
     assert len(lines) == 1 and len(lines[0]) < 6000, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 256 and d["config"]["parallelism"] == "dp8" and d["config"]["share_gpu"] is True
-    assert d["comm"]["rccl_ranks_seen"] == 8 and len(d["comm"]["bucket_allreduce_ms"]) == 3
+    assert d["comm"]["rccl_ranks_seen"] == 8 and len(d["comm"]["bucket_allreduce_ms"]) == 5
     assert d["comm"]["weights_identical_across_ranks"] is True
     assert "224x224" in d["config"]["workload"] and "batch 32/GPU" in d["config"]["workload"] and np.isfinite(d["config"]["final_loss"])

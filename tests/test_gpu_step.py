@@ -1101,7 +1101,7 @@ if __name__ == "__main__":
 
 
 def test_rccl_reducer_path_single_rank_group():
-    """The data-parallel step on ONE GPU through the real RCCL path: a 1-rank "nccl" process group, the three
+    """The data-parallel step on ONE GPU through the real RCCL path: a 1-rank "nccl" process group, the five
     gradient buckets all-reduced on the side stream as backward completes them, Adam waiting on their events.
     Must reproduce the no-communication step bit for bit (sum over one rank, grad_scale 1)."""
     import os
