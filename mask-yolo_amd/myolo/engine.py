@@ -304,11 +304,13 @@ class Net(object):
         # inference forwards: the weight-only preparations (bf16 packing + BatchNorm folding of the mask head, bf16x6 splits of the pointwise layers,
         # Winograd filter transforms) are made ONCE per weight version and kept -- round 4 re-ran them in every forward (5 packs, ~17 splits, a filter
         # transform: ~0.14 ms of a 3.7 ms Rice-416 batch) although the weights of an inference net are frozen.  `_wver` is bumped by load_state_dict,
-        # every optimizer step and every training forward (moving statistics); code that writes flat_p / flat_s directly calls mark_weights_changed().
-        self.infer_weight_cache = 1       # 0 = prepare inside every forward (round 4)
+        # every optimizer step and every training forward (moving statistics); code that writes flat_p / flat_s through raw pointers calls
+        # mark_weights_changed().  In-place torch writes (net.p[k].copy_(...), an EMA, a broadcast into flat_p) are caught by themselves: the tensors'
+        # autograd version counters are part of the cached state (_weight_state).
+        self._infer_weight_cache = 1      # 0 = prepare inside every forward (round 4); property infer_weight_cache: a change drops the captured graphs
         self._wver = 0
         self._iprep = None                # X.WeightPrep of the inference path (arena owned by it)
-        self._iprep_state = (-1, -1)      # (weight version, registry entries) the arena + packs were last refreshed for
+        self._iprep_state = None          # _weight_state() + registry entries the arena + packs were last refreshed for
         self._iprep_ev = None
         self._bf16_packs = {}             # layer -> (packed bf16 weights, folded bias) of mask_head_fwd_bf16, refreshed with the arena
         self.load_state_dict(init_state_dict(cfg, seed))
@@ -345,8 +347,30 @@ class Net(object):
 
     def mark_weights_changed(self):
         """tell the engine that parameters or moving statistics were written (load_state_dict, the optimizer and the training forward call this
-        themselves): the next inference forward re-makes its cached weight preparations (_infer_prep_sync) before it runs or replays a graph."""
+        themselves): the next inference forward re-makes its cached weight preparations (_infer_prep_sync) before it runs or replays a graph.
+        REQUIRED after any write to flat_p / flat_s / p[...] / s[...] that torch cannot see (a kernel launched on their data_ptr()); writes through
+        torch's own in-place operators are noticed without it."""
         self._wver += 1
+
+    def _weight_state(self):
+        """what the cached weight preparations depend on: the explicit version and the version counters torch bumps on every in-place write to the flat
+        parameter / statistics buffers or to any view of them"""
+        return (self._wver, int(self.flat_p._version), int(self.flat_s._version))
+
+    @property
+    def infer_weight_cache(self):
+        return self._infer_weight_cache
+
+    @infer_weight_cache.setter
+    def infer_weight_cache(self, v):
+        v = int(v)
+        if v != self._infer_weight_cache:
+            # graphs captured under the other setting hold (or lack) the preparation launches and the arena's pointers: drop them
+            if torch.cuda.is_available() and self.dev.type == "cuda":
+                torch.cuda.synchronize(self.dev)
+            self._graphs.clear()
+            self._iprep_state = None
+        self._infer_weight_cache = v
 
     def grads_dict(self):
         self.join_conv1_wgrad()           # conv1's weight gradient may still be running on its side stream
@@ -2041,10 +2065,10 @@ class Net(object):
         if self._iprep is None:
             self._iprep = X.WeightPrep(self.dev, arena_bytes=min(self._wprep_arena_bytes(), 256 << 20))
         ip = self._iprep
-        state = (self._wver, ip.count())
+        state = (self._weight_state(), ip.count())
         cur = torch.cuda.current_stream()
         if state != self._iprep_state and not torch.cuda.is_current_stream_capturing():
-            if state[0] != self._iprep_state[0]:
+            if self._iprep_state is None or state[0] != self._iprep_state[0]:
                 # the weights changed: forwards of other lanes may still be reading the arena / the packs
                 torch.cuda.synchronize(self.dev)
                 ip.invalidate()

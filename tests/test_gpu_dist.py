@@ -264,7 +264,7 @@ def test_bench_multi_rank_path_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["config"]["global_batch"] == 8 and d["config"]["parallelism"] == "dp2" and d["config"]["share_gpu"] is True
     assert d["comm"]["rccl_ranks_seen"] == 2 and len(d["comm"]["bucket_allreduce_ms"]) == 5 and all(v > 0 for v in d["comm"]["bucket_allreduce_ms"])
-    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["value"] > 0 and abs(d["value"] - 8 * 1e3 / d["ms_per_step"]) < 1e-5 * d["value"]      # (both are printed rounded to four decimals)
     assert d["dense_mask_backward_ms_per_step"] > 0                               # the variants ran in lockstep on both ranks
     assert len(lines[0]) < 6000 and d["detail"] == "bench_detail.json"            # the compact line; the full object is beside it
     full = json.load(open(os.path.join(root, "bench_detail.json")))

@@ -784,12 +784,15 @@ def test_inference_weight_preparations_are_cached_per_weight_version(dtype):
     rng = np.random.default_rng(2)
     x = torch.as_tensor(rng.random((2, 128, 128, 3), dtype=np.float32), device=net.dev)
 
+    # the reference: a second net that never caches, kept in step with the first one's weights
+    model_u = MaskYOLO(mode="inference", config=cfg)
+    model_u.load_state_dict(P)
+    net_u = model_u.net
+    net_u.infer_weight_cache = 0
+
     def uncached():
-        net.infer_weight_cache = 0
-        try:
-            return [t.clone() for t in net.predict(x)]
-        finally:
-            net.infer_weight_cache = 1
+        assert torch.equal(net_u.flat_p, net.flat_p) and torch.equal(net_u.flat_s, net.flat_s)
+        return [t.clone() for t in net_u.predict(x)]
     ref = uncached()
     a = [t.clone() for t in net.predict(x)]            # records the sites (misses), packs the bf16 operands
     s1 = net._iprep.stats()
@@ -804,25 +807,43 @@ def test_inference_weight_preparations_are_cached_per_weight_version(dtype):
         ptrs = {k: v[0].data_ptr() for k, v in net._bf16_packs.items()}
     g0 = [t.clone() for t in net.predict_graphed(x)]
     assert all(torch.equal(u, v) for u, v in zip(ref, g0))
-    # three ways the weights change
+    # the ways the weights change: the three the engine is told about, and two it has to notice itself (in-place torch writes to a parameter
+    # view / to the flat statistics buffer WITHOUT mark_weights_changed() -- caught by the tensors' version counters)
     P2 = {k: (v * 1.02).astype(np.float32) for k, v in P.items()}
-    for how in ("load_state_dict", "mark", "adam"):
-        if how == "load_state_dict":
-            model.load_state_dict(P2)
-        elif how == "mark":
-            net.flat_p.mul_(0.99)
-            net.mark_weights_changed()
-        else:
-            net.flat_g.fill_(1e-3)
-            net.adam_step(1e-3)
-        got_g = [t.clone() for t in net.predict_graphed(x)]
+    prev = ref
+    for how in ("load_state_dict", "mark", "adam", "silent view write", "silent statistics write"):
+        for m in (model, model_u):
+            n_ = m.net
+            if how == "load_state_dict":
+                m.load_state_dict(P2)
+            elif how == "mark":
+                n_.flat_p.mul_(0.99)
+                n_.mark_weights_changed()
+            elif how == "adam":
+                n_.flat_g.fill_(1e-3)
+                n_.adam_step(1e-3)
+            elif how == "silent view write":
+                n_.p["myolo_mask_conv2/kernel"].mul_(1.05)
+                n_.p["conv_pw_3/kernel"].add_(0.01)
+            else:
+                n_.s["conv_pw_5_bn/moving_mean"].add_(0.05)
+        got_g = [t.clone() for t in net.predict_graphed(x)]       # REPLAY of the graph captured above
         got_e = [t.clone() for t in net.predict(x)]
         want = uncached()
         assert all(torch.equal(u, v) and torch.equal(u, w) for u, v, w in zip(want, got_g, got_e)), how
-        assert not all(torch.equal(u, v) for u, v in zip(want, ref)), how
+        assert not all(torch.equal(u, v) for u, v in zip(want, prev)), how
+        prev = want
     if dtype == "bf16":
         assert ptrs == {k: v[0].data_ptr() for k, v in net._bf16_packs.items()}       # persistent buffers: the graph reads them
     assert len(net._graphs) == 1
+    # turning the cache off drops the captured graphs (they hold no preparation launch and would read a stale arena); results stay those of the uncached net
+    net.infer_weight_cache = 0
+    assert len(net._graphs) == 0
+    net.p["myolo_mask_conv3/kernel"].mul_(0.97)
+    net_u.p["myolo_mask_conv3/kernel"].mul_(0.97)
+    got = [t.clone() for t in net.predict_graphed(x)]
+    assert all(torch.equal(u, v) for u, v in zip(uncached(), got))
+    net.infer_weight_cache = 1
 
 
 @pytest.mark.parametrize("in_flight", [1, 2, 3])
