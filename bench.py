@@ -1116,9 +1116,19 @@ def main():
                 res["inference_rice416_bf16"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         sys.stdout.flush()
-        line = json.dumps(compact_line(res))
-        assert len(line) < MAX_LINE_BYTES, "bench line grew to %d bytes: move detail to bench_detail.json" % len(line)
-        write_detail(res, args)
+        write_detail(res, args)                       # the full object first: nothing below can lose it
+        obj = compact_line(res)
+        line = json.dumps(obj)
+        # the driver parses ONE line: if it ever outgrows the cap (a long option list, an error string), optional keys go before the result does
+        for path in (("config", "lib_options"), ("config", "net_attrs"), ("comm", "note"), ("cpu_baseline", "sample"), ("comm",), ("roofline", "note")):
+            if len(line) < MAX_LINE_BYTES:
+                break
+            d = obj
+            for k in path[:-1]:
+                d = d.get(k) if isinstance(d, dict) else None
+            if isinstance(d, dict) and path[-1] in d:
+                d[path[-1]] = "(dropped: line over %d bytes; see bench_detail.json)" % MAX_LINE_BYTES
+                line = json.dumps(obj)
         os.write(json_fd, (line + "\n").encode())
     if world > 1:
         dist.barrier()

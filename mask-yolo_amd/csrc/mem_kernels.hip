@@ -1372,6 +1372,7 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
     // MODE 3: per-channel terms of the BatchNorm whose backward sums are formed, and the queue of its pre-BN rows (step r emits output row y0 + r - 2)
     dw_f4p bsc = dw_zero(), bsh = dw_zero(), bmu = dw_zero(), brs = dw_zero();
     float blo = -INFINITY, bhi = INFINITY;
+    bool ball = true;                               // MODE 3: no activation -> dz = out whatever z is (actmask(): also for a non-finite z)
     float4 yq[PF];
     __amdgpu_buffer_rsrc_t rq = ry;
     if (MODE == 3) {
@@ -1379,7 +1380,8 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
         bsc = dw_pk(ld4g(fu.bw.scale + c)); bsh = dw_pk(ld4g(fu.bw.shift + c)); bmu = dw_pk(ld4g(fu.bw.mean + c));
         const float4 vr = ld4g(fu.bw.var + c);
         brs = dw_pk(make_float4(rsqrtf(vr.x + BN_EPS_F), rsqrtf(vr.y + BN_EPS_F), rsqrtf(vr.z + BN_EPS_F), rsqrtf(vr.w + BN_EPS_F)));
-        blo = fu.bw.act == MYOLO_ACT_NONE ? -INFINITY : 0.f;
+        ball = fu.bw.act != MYOLO_ACT_RELU && fu.bw.act != MYOLO_ACT_RELU6;
+        blo = ball ? -INFINITY : 0.f;
         bhi = fu.bw.act == MYOLO_ACT_RELU6 ? 6.f : INFINITY;
         rq = __builtin_amdgcn_make_buffer_rsrc((void*)(fu.bw.x + (long long)n * Ho * Wo * C), 0, Ho * Wo * C * 4, 0x00020000);
     }
@@ -1417,8 +1419,8 @@ __global__ __launch_bounds__(256, 4) void dw_rows_kernel(const float* __restrict
             // dz = out * actmask(x * scale + shift); xhat = (x - mean) * rstd  (OpBnBwd's expressions)
             const dw_f4p z = dw_fma(qv, bsc, bsh);
             dw_f4p dz;
-            dz.lo.x = (z.lo.x > blo && z.lo.x < bhi) ? o.lo.x : 0.f; dz.lo.y = (z.lo.y > blo && z.lo.y < bhi) ? o.lo.y : 0.f;
-            dz.hi.x = (z.hi.x > blo && z.hi.x < bhi) ? o.hi.x : 0.f; dz.hi.y = (z.hi.y > blo && z.hi.y < bhi) ? o.hi.y : 0.f;
+            dz.lo.x = (ball || (z.lo.x > blo && z.lo.x < bhi)) ? o.lo.x : 0.f; dz.lo.y = (ball || (z.lo.y > blo && z.lo.y < bhi)) ? o.lo.y : 0.f;
+            dz.hi.x = (ball || (z.hi.x > blo && z.hi.x < bhi)) ? o.hi.x : 0.f; dz.hi.y = (ball || (z.hi.y > blo && z.hi.y < bhi)) ? o.hi.y : 0.f;
             dw_f4p xh;
             xh.lo = (qv.lo - bmu.lo) * brs.lo; xh.hi = (qv.hi - bmu.hi) * brs.hi;
             s1.lo += dz.lo; s1.hi += dz.hi;

@@ -1299,7 +1299,7 @@ def _check_bn_outputs(y_ref2d, g, b, mm, mv, mean, var, scale, shift, tmm, tmv):
     check(tmv, rmv, 1e-5, "fused moving var")
 
 
-@pytest.mark.parametrize("act", [2, 0])
+@pytest.mark.parametrize("act", [2, 1, 0])
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 16, 16, 32, 1), (3, 14, 14, 512, 1), (2, 8, 8, 1024, 1), (32, 28, 28, 256, 1), (2, 46, 40, 96, 1), (4, 9, 7, 1024, 1),
                                             (2, 112, 112, 32, 1), (2, 16, 16, 32, 2), (2, 46, 40, 64, 2), (1, 30, 58, 160, 2), (3, 112, 112, 64, 2), (2, 56, 56, 128, 2),
                                             (2, 28, 28, 512, 2), (2, 12, 12, 24, 1)])
