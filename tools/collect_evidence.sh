@@ -1,7 +1,7 @@
 #!/bin/bash
 # The evidence set of a round in one gpurun call:   gpurun --timeout 3000 -- 'bash tools/collect_evidence.sh r5'   (-> gpurun_out/evidence_<tag>/, copy into profiles/)
 #   the full default bench line, the step profile (default and 20 forced positives), the kernel micro-benchmarks on cold inputs.
-TAG=${1:-r5}
+TAG=${1:-r6}
 cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/evidence_$TAG
 mkdir -p $OUT
@@ -29,8 +29,13 @@ cp gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_stats.csv gpurun_out/p
   python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
   KBENCH_OPTIONS=tune0=1 python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
   KBENCH_OPTIONS=tune0=4 python tools/kbench.py roialign_bwd --iters 20 --warm 10 2>&1 | grep -v amdgpu
-  echo "--- Winograd kernels (unchanged this round), steady state"
-  for k in wino63_mm wino63_wgrad wino63_boundary; do KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
+  echo "--- Winograd kernels, steady state (boundary: round 6 persistent kernel; then the round-5 kernel, w63_legacy=1)"
+  for k in wino63_mm wino63_wgrad wino63_boundary wino63_lazy; do KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
+  for k in wino63_boundary wino63_lazy; do KBENCH_OPTIONS=wino_x6=1,w63_legacy=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
+  echo "--- what a plain copy of the boundary kernels' plane sets moves (tools/experiments/vecwidth: persistent nine-wave workgroups, 64 strided planes, 4 / 8 / 16 bytes per lane)"
+  hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/vecwidth tools/experiments/vecwidth/vecwidth.hip > /dev/null 2>&1 && /tmp/vecwidth | head -13
+  echo "--- residency census (tools/experiments/census: workgroups of T threads / V VGPRs / L bytes of LDS a CU holds at once; API = hipOccupancyMaxActiveBlocksPerMultiprocessor)"
+  hipcc --offload-arch=gfx950 -O2 -Wno-unused-result -o /tmp/census tools/experiments/census/census.hip > /dev/null 2>&1 && /tmp/census | grep -E "lds  50176|lds   1024"
   echo "--- HBM stream copy"
   python tools/kbench.py copy --iters 5 2>&1 | grep -v amdgpu | head -8
   echo "--- stream / process-group experiment (tools/experiments/pg_stream_cost.py): default = high-priority side streams; MYOLO_STREAM_PRIORITY=0 = rounds 1-3"

@@ -96,7 +96,7 @@ if "GRBM_GUI_ACTIVE" in v:
     m["effective_clock_GHz"] = cyc / ns
     m["mfma_util"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
     m["mfma_busy_cycles_minimum"] = m["algorithmic_flop_fp32"] / 4096 * 64
-for kname, key in (("wino63_boundary_kernel<1, 0>", "input_transform"), ("wino63_boundary_kernel<0, 1>", "output_transform")):
+for kname, key in (("wino63_boundary_kernel<1, 0", "input_transform"), ("wino63_boundary_kernel<0, 1", "output_transform")):
     e = {}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         try:
@@ -199,7 +199,7 @@ res = {"shape": "NR = 4704 ROIs (32 x 147), 14x14, 256 -> 256 channels, F(6,3)/F
 for target, kname, key, alg_bytes, alg_flop in (
         ("wino63_mm", "wino_mm_x6_kernel", "multiply_x6", 2.0 * pe * 4 + 64 * C * C * 6, 2.0 * 400 * NR * C * C),
         ("wino63_wgrad", "wino_tn_x6_kernel", "weight_gradient_x6", 2.0 * pe * 4, 2.0 * 400 * NR * C * C),
-        ("wino63_boundary", "wino63_boundary_kernel<0, 0>", "boundary_M_to_V", 2.0 * pe * 4, 0.0)):
+        ("wino63_boundary", "wino63_boundary_kernel<0, 0", "boundary_M_to_V", 2.0 * pe * 4, 0.0)):
     e = {"kernel": kname, "kbench": target, "algorithmic_bytes": alg_bytes, "algorithmic_flop_fp32": alg_flop}
     for c in ("FETCH_SIZE", "WRITE_SIZE"):
         try:
