@@ -468,7 +468,7 @@ __global__ __launch_bounds__(W63_TILES * 64) void wino63_boundary_legacy_kernel(
 // The kernel the step runs (round 6): PERSISTENT workgroups, one per CU, that walk the units (image, 64-channel slice) and have the NEXT
 // unit's planes on their way while the current unit is transformed.
 //
-// What the round-5 kernel did wrong, measured (tools/experiments/census, tools/_ab/trace.py; profiles/r6_notes.md):
+// What the round-5 kernel did wrong, measured (tools/experiments/census, tools/experiments/w63/trace_*.py; profiles/r6_notes.md):
 //   * a CU of this part admits workgroups as if every SIMD had to take ceil(waves / 4) of their waves: the nine-wave workgroups ran ONE per
 //     CU at 81..96 VGPRs (the occupancy calculator says two), so each CU alternated between "nine waves wait for their 400 loads" and "nine
 //     waves transform" -- the memory pipe of a CU idle ~40 % of the time; with the transforms removed the same access pattern moves 6 TB/s;
