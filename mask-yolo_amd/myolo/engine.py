@@ -1879,7 +1879,10 @@ class Net(object):
                 self._ws_active = self._ws_main
         else:
             yolo_loss()
-        if self.overlap_yolo_bwd and self.yolo_bwd_early:
+        # (a tape_hook rewrites saved tensors between forward and backward -- tests force the oracle's activations there: the YOLO head's backward must
+        # not have read them before the hook runs, so it then starts at the old place)
+        early = bool(self.overlap_yolo_bwd and self.yolo_bwd_early and not self.tape_hook)
+        if early:
             self.start_yolo_head_bwd(dyolo)
         if self.sparse_mask_fwd:
             if not self.sparse_mask_bwd:
@@ -1923,7 +1926,7 @@ class Net(object):
                    *self._wsargs(), X.stream())
         if self.tape_hook:
             self.tape_hook(self)
-        if self.overlap_yolo_bwd and not self.yolo_bwd_early:
+        if self.overlap_yolo_bwd and not early:
             # under the compacted part of the mask head's backward (small launches on the positive ROIs), not under the big
             # forward GEMMs: two streams of small kernels fill the chip together, and the dense kernels keep it to themselves
             self.start_yolo_head_bwd(dyolo)
