@@ -625,7 +625,7 @@ def bench_train(args, rank, world, local):
         except Exception as e:
             extras["comm_overlap_probe_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
         finally:
-            net.on_bucket_ready, net.before_optimizer, net.grad_scale = reducer.bucket_ready, reducer.wait, reducer.grad_scale
+            reducer.attach(net)
         # (c) the DROP-IN surface (model.py:943-1060): MaskYOLO.train() on a ShapesDataset through BatchGenerator + the pinned
         #     prefetch/upload path, and train_shapes_stream() with the inputs produced on the device -- img/s of the public calls, to be
         #     read against `value` (Net.train_step on batches already resident in HBM)

@@ -227,4 +227,5 @@ class GradReducer(object):
         net.on_bucket_ready = self.bucket_ready
         net.before_optimizer = self.wait
         net.grad_scale = self.grad_scale
+        net.exchange_active = bool(self.active)       # the engine schedules the YOLO head's backward early when there is an exchange to hide
         return self

@@ -211,10 +211,14 @@ class Net(object):
         self._ws_active = self._ws_main
         self._yolo_stream = _shared_stream(self.dev, "yolo_head_bwd")
         self.overlap_yolo_bwd = True      # YOLO-head backward on a side stream, under the mask head (training step)
-        # 1 = the YOLO head's backward is launched right behind the YOLO loss, under the mask head's FORWARD (0: at the start of the mask head's backward,
-        # rounds 3-5).  Same step time on one GPU (19.40 against 19.41 ms, round 6), but its 12.9 MB gradient bucket is then complete 9.3 ms before the step
-        # ends instead of 2.9, and the weight-gradient stream is free for the compact chain's weight gradients (their bucket: 6.0 instead of 2.4 ms)
-        self.yolo_bwd_early = 1
+        # When the YOLO head's backward is launched: 1 = right behind the YOLO loss, under the mask head's FORWARD; 0 = at the start of the mask head's
+        # backward (rounds 3-5); -1 (default) = early exactly when a gradient exchange is active (GradReducer.attach sets exchange_active).  Same step
+        # time on one GPU either way (19.40 against 19.41 ms, round 6).  Early, its 12.9 MB gradient bucket is complete 9.3 ms before the step ends
+        # instead of 2.9 and the weight-gradient stream is free for the compact chain's weight gradients (their bucket: 6.0 instead of 2.4 ms) -- that is
+        # what a data-parallel run needs; without an exchange the ~60 small launches only take chip time from the forward's multiplies (the dominant
+        # kernel's launches: 1.36 against 1.19 ms) and give it back in the backward, so the late form stays there.
+        self.yolo_bwd_early = -1
+        self.exchange_active = False      # set by myolo.dist.GradReducer.attach: collectives are really issued (world > 1, or a 1-rank probe)
         # conv1's weight gradient (MFMA-bound, 2.7 ms, nothing downstream but the optimiser) on a third stream with its own
         # scratch, underneath conv1's data gradient -> ROIAlign backward -> backbone backward (launch- / HBM-bound small kernels)
         self._wgrad_stream = _shared_stream(self.dev, "weight_gradients")
@@ -1881,7 +1885,8 @@ class Net(object):
             yolo_loss()
         # (a tape_hook rewrites saved tensors between forward and backward -- tests force the oracle's activations there: the YOLO head's backward must
         # not have read them before the hook runs, so it then starts at the old place)
-        early = bool(self.overlap_yolo_bwd and self.yolo_bwd_early and not self.tape_hook)
+        want_early = self.exchange_active if self.yolo_bwd_early < 0 else bool(self.yolo_bwd_early)
+        early = bool(self.overlap_yolo_bwd and want_early and not self.tape_hook)
         if early:
             self.start_yolo_head_bwd(dyolo)
         if self.sparse_mask_fwd:

@@ -202,6 +202,7 @@ def test_engine_releases_buckets_where_backward_finishes_them():
     model = MaskYOLO(mode="training", config=cfg, device="cuda:0")
     model.load_state_dict(P)
     red = GradReducer(model.net.flat_g, model.net.bucket_ranges, always=True, backend="capi", timing=True).attach(model.net)
+    assert model.net.exchange_active and model.net.yolo_bwd_early == -1      # an active exchange: the YOLO head's backward goes under the mask head's forward
     order = []
     inner = model.net.on_bucket_ready
     model.net.on_bucket_ready = lambda i: (order.append(i), inner(i))[1]
