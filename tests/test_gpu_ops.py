@@ -977,7 +977,7 @@ def test_winograd_f63_tiling(N, Cin, Cout, x6, request):
         assert torch.equal(yk[::2], y2[::2]) and bool(torch.isnan(yk[1::2]).all()), "activation must be written for flagged images only"
 
 
-@pytest.mark.parametrize("N,C", [(5, 256), (3, 64), (333, 256), (700, 64)])      # the last two: several units per persistent workgroup (prefetch across units, both LDS buffers)
+@pytest.mark.parametrize("N,C", [(5, 256), (3, 64), (333, 256), (700, 64), (70, 512), (40, 320)])      # the last two: several units per persistent workgroup (prefetch across units, both LDS buffers)
 def test_wino63_boundary_packed_equals_legacy(N, C):
     """Round 6's boundary kernel (two columns / rows per v_pk_* instruction, wave-uniform plane addresses, all of a wave's pixels
     requested at once) against the round-5 kernel kept behind option "w63_legacy": every front x back combination the library
