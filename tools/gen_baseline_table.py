@@ -30,11 +30,11 @@ new = '''## %(sec)d. Results (round %(rnd)s, measured on 1x MI355X by ONE `pytho
 
 | Object of the line | img/s | ms | what it is |
 |---|---|---|---|
-| **headline** `value` (`config.fp32_products = "%(fp)s"`, `dtype f32`) | **%(val).1f** | **%(ms).2f** (p10 %(p10).2f / p50 %(p50).2f / p90 %(p90).2f) | Shapes 224x224, batch 32, N_BOX=3 (R=147), forward + backward + Adam; round 4: 1596 / 20.05 (best box 1630 / 19.63), round 3: 1487.8 / 21.51, round 2: 1139.2 / 28.09, round 1: 863.4 / 37.06 |
+| **headline** `value` (`config.fp32_products = "%(fp)s"`, `dtype f32`) | **%(val).1f** | **%(ms).2f** (p10 %(p10).2f / p50 %(p50).2f / p90 %(p90).2f) | Shapes 224x224, batch 32, N_BOX=3 (R=147), forward + backward + Adam; round 5: 1620 / 19.75, round 4: 1596 / 20.05 (best box 1630 / 19.63), round 3: 1487.8 / 21.51, round 2: 1139.2 / 28.09, round 1: 863.4 / 37.06 |
 | `train_api.train` = `MaskYOLO.train()` on a 512-image ShapesDataset | %(tav).1f | %(tams).2f | the drop-in call (model.py:943-1060): host BatchGenerator on a prefetch thread, pinned byte staging, lazy losses |
 | `train_api.train_shapes_stream` | %(tsv).1f | %(tsms).2f | inputs produced on the device |
 | `train_api.reference_same_state` | %(rsv).1f | %(rsms).2f | `Net.train_step` on resident batches right after those calls, same weights (%(rsn).2f positives per image; the headline's random-init net: %(hn)s): the like-for-like reference of the public calls |
-| `comm_overlap_probe_ms.ms_per_step_with_probe` | | %(cpms).2f | the same step with the three gradient buckets all-reduced on the copy stream (1-rank RCCL communicator through the C-ABI) |
+| `comm_overlap_probe_ms.ms_per_step_with_probe` | | %(cpms).2f | the same step with the gradient buckets (five from round 6, three before) all-reduced on the copy stream as backward completes them (1-rank RCCL communicator through the C-ABI) |
 | `variants.fp32_products_native` | %(nat_v).1f | %(nat_ms).2f | the same step with every product on `v_mfma_f32_32x32x2_f32` |
 | `variants.dense_mask_backward` | %(dn_v).1f | %(dn_ms).2f | structural zeros of the mask-head backward not exploited |
 | `variants.mask_head_forward_on_positives_only` | %(po_v).1f | %(po_ms).2f | opt-in, DESIGN 4b; never the headline |
