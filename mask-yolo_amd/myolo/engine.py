@@ -1751,8 +1751,21 @@ class Net(object):
         if not self.weight_prep:
             return
         if self._wprep is None:
-            self._wprep = X.WeightPrep(self.dev, arena_bytes=self._wprep_arena_bytes())
+            self._wprep_cap = self._wprep_arena_bytes()
+            self._wprep = X.WeightPrep(self.dev, arena_bytes=self._wprep_cap)
+            self._wprep_calls, self._wprep_misses = 0, None
         wp = self._wprep
+        # an arena that is too small makes its sites re-prepare in place every step, silently.  A site misses once (the step that records
+        # it); misses that still grow between the fourth and the fifth step mean entries that never found room: say so once.
+        self._wprep_calls += 1
+        if self._wprep_calls in (4, 5):
+            st = wp.stats()
+            if self._wprep_calls == 5 and self._wprep_misses is not None and st["misses"] > self._wprep_misses:
+                import warnings
+                warnings.warn("myolo: the prepared-weights arena (%d MiB, %d MiB used, %d entries) is too small: %d preparations per step are re-made in place "
+                              "(correct, slower).  Net._wprep_arena_bytes() sizes it." % (self._wprep_cap >> 20, st["bytes_used"] >> 20, st["entries"],
+                                                                                       st["misses"] - self._wprep_misses))
+            self._wprep_misses = st["misses"]
         self._wprep_ev = None
         n = wp.count()
         if n:
@@ -1772,12 +1785,14 @@ class Net(object):
 
     def _wprep_arena_bytes(self):
         """capacity of a prepared-weights arena for this net (was a fixed 768 MiB): every weight matrix may be kept once as a transpose
-        (4 bytes per value), once as a bf16x6 split (6) and every 3x3 kernel once as 64 transformed planes of six bytes (64 / 9 * 6 per value),
-        + 256-byte alignment per entry.  ~330 MiB at the alpha-1 Shapes net; an entry beyond the capacity is made in place by its site."""
+        (4 bytes per value), once as a bf16x6 split (6) and every 3x3 kernel twice (forward, rotated for the data gradient) as 64 transformed planes of
+        six bytes (64 / 9 * 6 per value), + 256-byte alignment per entry.  ~360 MiB at the alpha-1 Shapes net; an entry beyond the capacity is made in
+        place by its site, and _wprep_begin warns once when that keeps happening."""
         n = 0
         for k, v in self.p.items():
-            if v.dim() == 4 and v.shape[0] == 3 and v.shape[2] > 3:            # 3x3 convs with many input channels: Winograd filter planes
-                n += int(v.numel()) * (64 * 6 // 9 + 10)
+            if v.dim() == 4 and v.shape[0] == 3 and v.shape[2] > 3:            # 3x3 convs with many input channels: Winograd filter planes,
+                n += int(v.numel()) * (2 * (64 * 6 // 9 + 1) + 10)               # once for the forward and once rotated for the data gradient (round 6: the
+                                                                                 # one-set budget overflowed at config 2 -- 207 of 211 MiB, two sites re-made in place)
             elif v.dim() >= 2:
                 n += int(v.numel()) * 10
             n += 512
