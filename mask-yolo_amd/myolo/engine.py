@@ -289,6 +289,7 @@ class Net(object):
         self._bn_fused_bytes = {}
         self.weight_prep = 1              # training step: weight-only re-layouts (transposes, bf16x6 splits, Winograd filter transforms) re-run on a side stream at the step's start instead of inside the chain (X.WeightPrep); 0 = in place (round 3)
         self._wprep = None
+        self._wprep_calls, self._wprep_misses, self._wprep_cap = 0, None, 0      # (_wprep_begin: one warning if the arena turns out too small)
         self.wprep_wait_late = 1          # 0: wait for the trunk's prepared weights right behind conv1 (A/B)
         self._wprep_ntrunk = None         # registry entries recorded before the mask head (their consumers are the trunk's first layers)
         self._wprep_ev = None
@@ -1753,7 +1754,6 @@ class Net(object):
         if self._wprep is None:
             self._wprep_cap = self._wprep_arena_bytes()
             self._wprep = X.WeightPrep(self.dev, arena_bytes=self._wprep_cap)
-            self._wprep_calls, self._wprep_misses = 0, None
         wp = self._wprep
         # an arena that is too small makes its sites re-prepare in place every step, silently.  A site misses once (the step that records
         # it); misses that still grow between the fourth and the fifth step mean entries that never found room: say so once.

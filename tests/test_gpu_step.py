@@ -190,6 +190,13 @@ def test_prepared_weights_with_an_arena_that_is_too_small():
         if prep:
             st = net._wprep.stats()
             assert st["hits"] > 0 and st["misses"] > st["entries"] and st["bytes_used"] <= 3 << 20, st
+            # ... and the engine says so, once, when the misses keep growing after warm-up (it used to be silent)
+            import warnings
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                for step in range(4):
+                    net.train_step(db, 1e-3)
+            assert sum("prepared-weights arena" in str(x.message) for x in w) == 1, [str(x.message) for x in w]
     assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][0], res[1][0])
 
 
