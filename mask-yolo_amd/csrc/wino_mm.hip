@@ -479,9 +479,18 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         const bool has_aff = PW && p.a_scale;
         auto gstage = [&](auto st, bool valid) {
             constexpr int S = decltype(st)::value;
+#ifdef MM_X6_TUNE
+            if (!(p.tune & 2048)) {
+#endif
             qa[S][0] = mm_bufld4(ra, valid ? aoffg : MM_OOB);
             qa[S][1] = mm_bufld4(ra, valid ? aoffg + 16u : MM_OOB);
+#ifdef MM_X6_TUNE
+            }
+#endif
             aoffg += MM_BK * 4u;
+#ifdef MM_X6_TUNE
+            if (p.tune & 8192) return;
+#endif
             if constexpr (PW) {
                 const int kc = (valid && has_aff) ? kch : ah * 8;
                 qsc[S][0] = *reinterpret_cast<const float4*>(csc + kc); qsc[S][1] = *reinterpret_cast<const float4*>(csc + kc + 4);
@@ -505,6 +514,9 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
             constexpr int I = decltype(ic)::value;
             constexpr int cur = I & 1, SA = (I + 1) % 3, SB = I & 1;
             const bool more = c + 1 < nk;
+#ifdef MM_X6_TUNE
+            if (!(p.tune & 16384))
+#endif
 #pragma unroll
             for (int pc = 0; pc < 3; ++pc) fa[1][pc] = *reinterpret_cast<const bf16x8*>(As[cur] + afr + 32 * X6_REC + pc * 32);
             float x[8] = {qa[SA][0].x, qa[SA][0].y, qa[SA][0].z, qa[SA][0].w, qa[SA][1].x, qa[SA][1].y, qa[SA][1].z, qa[SA][1].w};
@@ -522,16 +534,25 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
             bf16x8 fn0, fn1, fn2;
 #pragma unroll
             for (int u = 0; u < NU; ++u) {
-#define X6_TILE(t)                                                                                                     \
+#ifdef MM_X6_TUNE
+#define X6_GO (!(p.tune & 512))
+#else
+#define X6_GO true
+#endif
+#define X6_TILE(t)  if (X6_GO) {                                                                                         \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][2], acc[t][u], 0, 0, 0);       \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][2], qb[SB][u][0], acc[t][u], 0, 0, 0);       \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], qb[SB][u][1], acc[t][u], 0, 0, 0);       \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][1], acc[t][u], 0, 0, 0);       \
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], qb[SB][u][0], acc[t][u], 0, 0, 0);       \
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][0], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], qb[SB][u][0], acc[t][u], 0, 0, 0); }
                 X6_TILE(0)
                 X6_TILE(1)
 #undef X6_TILE
+#undef X6_GO
+#ifdef MM_X6_TUNE
+                if (!(p.tune & 1024))
+#endif
 #pragma unroll
                 for (int pc = 0; pc < 3; ++pc) qb[SB][u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, b2);      // chunk c+2 into the stage chunk c leaves
                 if (u == 0) {
@@ -543,14 +564,25 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
                         p2[e] = x6_top(b0, b1);
                         p3[e] = x6_top(x6_rest(b0), x6_rest(b1));
                     }
+#ifdef MM_X6_TUNE
+                    if (more && !(p.tune & 4096)) {
+#else
                     if (more) {
+#endif
                         *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto) = p1;
                         *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 32) = p2;
                         *reinterpret_cast<u32x4*>(As[cur ^ 1] + asto + 64) = p3;
                     }
                 } else {
+#ifdef MM_X6_TUNE
+                    if (!(p.tune & 4096))
+#endif
                     __syncthreads();
+#ifdef MM_X6_TUNE
+                    if (more && !(p.tune & 16384)) {
+#else
                     if (more) {
+#endif
                         fn0 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr);
                         fn1 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 32);
                         fn2 = *reinterpret_cast<const bf16x8*>(As[cur ^ 1] + afr + 64);
@@ -849,6 +881,9 @@ int myolo_x6_split_batched(int n, const void* const* src, void* const* dst, cons
 static const float* x6_split_weights(const float* w, void* scratch, int K, int N, int src_kn, hipStream_t s)
 {
     const long long total = (long long)K * N;
+#ifdef MM_X6_TUNE
+    if (g_myolo_opt.tune0 & (1 << 20)) return (const float*)scratch;          // timing only: the split left there by an earlier call
+#endif
     return (const float*)myolo_wprep_resolve(w, WP_X6_SPLIT, K, N, src_kn, (size_t)total * 6, scratch, s, [=](void* d, hipStream_t st) {
         hipLaunchKernelGGL(x6_split_nk_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, w, (__bf16*)d, K, N, src_kn);
     });
@@ -1300,6 +1335,9 @@ int myolo_pw_x6_fwd(const float* x, const float* in_scale, const float* in_shift
     MMArgs a{};
     a.A = x; a.C = y; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
     a.a_scale = in_scale; a.a_shift = in_shift; a.a_act = in_act; a.stat = stat;
+#ifdef MM_X6_TUNE
+    a.tune = g_myolo_opt.tune0;
+#endif
     MMRun& R = a.run[0];
     R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
     R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
