@@ -292,28 +292,35 @@ class KernelTimer(object):
         return tot / max(1, steps), n // max(1, steps)
 
 
-def timed_steps(net, dbs, steps, lr, barrier, per_step=None):
+def timed_steps(net, dbs, steps, lr, barrier, per_step=None, host_ms=None):
     """K steps between two barriers (host wall clock = the reported time).  per_step (a list): filled with the K step durations in ms
     from HIP events recorded on the compute stream at the step boundaries (no synchronisation inside the region)."""
     import gc
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if per_step is not None else None
     # the host runs about one step (~20 ms) ahead of the GPU and cannot run further ahead (it reads n_pos every step): a collector pause inside
     # the region comes straight out of that lead, so the cyclic collector is parked for the K steps (reference counting still frees everything)
-    gc.collect()
+    # (a caller that parked it BEFORE its warm-up steps -- bench_train -- keeps the GPU busy right up to the first barrier: a full collection here is
+    # 10-40 ms of idle GPU in front of step 0, which then ran 2-14 ms long in most runs' step_ms)
     gc_was = gc.isenabled()
-    gc.disable()
+    if gc_was:
+        gc.collect()
+        gc.disable()
     try:
         barrier()
         t0 = time.perf_counter()
         out = None
+        th = [t0]
         for i in range(steps):
             if evs:
                 evs[i].record()
             out = net.train_step(dbs[i % len(dbs)], lr)
+            th.append(time.perf_counter())
         if evs:
             evs[steps].record()
         barrier()
         el = time.perf_counter() - t0
+        if host_ms is not None:                  # host wall time per train_step call (issue + the wait for n_pos): a step that is long HERE and on the GPU is a host stall
+            host_ms.extend(1e3 * (th[i + 1] - th[i]) for i in range(steps))
     finally:
         if gc_was:
             gc.enable()
@@ -470,6 +477,10 @@ def bench_train(args, rank, world, local):
         net.proposals_hook = None
         net.seen = 0
         torch.cuda.synchronize()
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect()                                 # host housekeeping in front of the warm-up, not between it and the timed region (see timed_steps)
+    gc.disable()
     for i in range(args.warmup):
         net.train_step(dbs[i % nb], args.lr)
     # ---- the timed region: only the dominant kernel (and the conv op it belongs to) is bracketed with events
@@ -478,7 +489,10 @@ def bench_train(args, rank, world, local):
     net.timings = {}
     step_ms = []
     net.host_wait_s = 0.0
-    elapsed, out = timed_steps(net, dbs, args.steps, args.lr, barrier, per_step=step_ms)
+    host_ms = []
+    elapsed, out = timed_steps(net, dbs, args.steps, args.lr, barrier, per_step=step_ms, host_ms=host_ms)
+    if gc_was:
+        gc.enable()
     npos_wait_ms = 1e3 * net.host_wait_s / max(1, args.steps)
     elapsed = maxr(elapsed)
     loss = float(out["yolo_terms"][0]) + float(out["mask_terms"][0])
@@ -772,6 +786,7 @@ def bench_train(args, rank, world, local):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "step_ms": percentiles(step_ms),
+        "host_step_ms": dict(percentiles(host_ms), source="host wall clock around each train_step call inside the timed region (issue + the wait for n_pos)"),
         "config": {"winograd_tiles": net.wino_tiles, "fp32_products": net.fp32_matmul,
                    "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step (fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
                        args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R, "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS),
@@ -922,6 +937,10 @@ def bench_infer(args):
     # the timed region runs the forward the way MaskYOLO.detect() does (cfg.INFERENCE_HIP_GRAPH): replayed from a captured hipGraph,
     # one graph launch per step on the host instead of ~150 kernel launches
     run = net.predict_graphed if cfg.INFERENCE_HIP_GRAPH else net.predict
+    import gc
+    gc_was = gc.isenabled()
+    gc.collect()                                 # the cyclic collector is parked for the two timed regions below (as in bench_train)
+    gc.disable()
     for _ in range(max(2, args.warmup)):
         run(x)
     torch.cuda.synchronize()
@@ -948,6 +967,8 @@ def bench_infer(args):
             pass
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+    if gc_was:
+        gc.enable()
     # per-kernel timings (HIP events around eager launches) in a second pass, outside the timed region
     net.timed_tags = {"mask_conv3x3_fwd", "roialign_fwd", "mask_deconv_fwd"}
     net.timings = {}
