@@ -310,17 +310,21 @@ def timed_steps(net, dbs, steps, lr, barrier, per_step=None, host_ms=None):
         t0 = time.perf_counter()
         out = None
         th = [t0]
+        diag = []
         for i in range(steps):
             if evs:
                 evs[i].record()
             out = net.train_step(dbs[i % len(dbs)], lr)
             th.append(time.perf_counter())
+            if host_ms is not None:
+                diag.append((int(getattr(net, "_np_seen", -1)), int(torch.cuda.memory_reserved())))
         if evs:
             evs[steps].record()
         barrier()
         el = time.perf_counter() - t0
         if host_ms is not None:                  # host wall time per train_step call (issue + the wait for n_pos): a step that is long HERE and on the GPU is a host stall
             host_ms.extend(1e3 * (th[i + 1] - th[i]) for i in range(steps))
+            timed_steps.last_diag = diag         # (positive ROIs the host read, bytes reserved by the caching allocator) after every step
     finally:
         if gc_was:
             gc.enable()
@@ -787,6 +791,9 @@ def bench_train(args, rank, world, local):
         "dtype": "f32", "data": "synthetic",
         "step_ms": percentiles(step_ms),
         "host_step_ms": dict(percentiles(host_ms), source="host wall clock around each train_step call inside the timed region (issue + the wait for n_pos)"),
+        "step_trace": {"gpu_ms": [round(v, 3) for v in step_ms], "host_ms": [round(v, 3) for v in host_ms],
+                       "n_pos_total": [d[0] for d in getattr(timed_steps, "last_diag", [])],
+                       "allocator_reserved_mb": [d[1] >> 20 for d in getattr(timed_steps, "last_diag", [])]},
         "config": {"winograd_tiles": net.wino_tiles, "fp32_products": net.fp32_matmul,
                    "workload": "Shapes %dx%d, batch %d/GPU, MobileNet alpha %.1f, N_BOX=%d (R=%d ROIs/img), fp32 training step (fwd+bwd+Adam%s), mask head forward on %s ROIs" % (
                        args.size, args.size, args.batch, args.alpha, cfg.N_BOX, R, "+RCCL all-reduce" if world > 1 else "", cfg.TRAIN_MASK_HEAD_ROIS),
