@@ -49,6 +49,7 @@ int myolo_wprep_count(void* h);
 int myolo_wprep_invalidate(void* h);
 int myolo_wprep_refresh(void* h, int first, int last, int max_idle, void* stream);
 int myolo_wprep_stats(void* h, long long* hits, long long* misses, long long* bytes_used);
+int myolo_wprep_overflows(void* h, long long* n);      /* resolve() calls whose new site found no room in the arena (made in place every step, never recorded) */
 
 /* Exact-sparsity helpers for the mask head backward (build_mask_graph model.py:690-708: bn1 is the only
  * batch-statistics layer, so behind it only ROIs with a positive target carry non-zero gradient):

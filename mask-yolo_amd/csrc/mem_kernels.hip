@@ -78,6 +78,7 @@ struct WPrep {
     unsigned long long gen;
     std::vector<WPrepEntry> e;
     long long hits, misses;
+    long long overflows;               // resolve() calls of a NEW site that found no room in the arena (it stays unrecorded and is made in place every step)
 };
 static WPrep* g_wprep = nullptr;       // the active registry (one launch thread)
 
@@ -98,7 +99,8 @@ const void* myolo_wprep_resolve(const void* w, int kind, long long d0, long long
         if (r->used + need <= r->cap) {            // new site: reserve a slot, prepared by the owner's next refresh
             r->e.push_back(WPrepEntry{w, kind, d0, d1, d2, r->used, bytes, 0ull, r->gen, run});
             r->used += need;
-        }
+        } else
+            ++r->overflows;
         ++r->misses;
     }
     run(fallback, s);
@@ -109,7 +111,7 @@ extern "C" int myolo_wprep_create(void* arena, size_t arena_bytes, void** handle
 {
     MYOLO_REQUIRE(handle && arena && ((uintptr_t)arena & 255) == 0, "wprep_create: needs a 256-byte aligned device arena and a handle slot");
     WPrep* r = new WPrep();
-    r->arena = (char*)arena; r->cap = arena_bytes; r->used = 0; r->gen = 1; r->hits = r->misses = 0;
+    r->arena = (char*)arena; r->cap = arena_bytes; r->used = 0; r->gen = 1; r->hits = r->misses = r->overflows = 0;
     *handle = r;
     return MYOLO_OK;
 }
@@ -129,6 +131,12 @@ extern "C" int myolo_wprep_stats(void* h, long long* hits, long long* misses, lo
     if (hits) *hits = r->hits;
     if (misses) *misses = r->misses;
     if (bytes_used) *bytes_used = (long long)r->used;
+    return MYOLO_OK;
+}
+extern "C" int myolo_wprep_overflows(void* h, long long* n)
+{
+    MYOLO_REQUIRE(h && n, "wprep_overflows: null registry or result slot");
+    *n = ((WPrep*)h)->overflows;
     return MYOLO_OK;
 }
 /* re-run the recorded preparations [first, last) into their slots on `stream` and mark them valid for the current weight generation; entries no

@@ -67,6 +67,7 @@ SIGS = {
     "myolo_wino63_output_input_transform_keep_pre_slots": [P, P, P, P, P, P, I, P, I, I, I, P],
     "myolo_wino63_output_transform_keep_pre_slots": [P, P, P, P, P, P, P, I, I, I, I, P],
     "myolo_wprep_stats": [P, P, P, P],
+    "myolo_wprep_overflows": [P, P],
     "myolo_bn_act_bwd_fused": [P, P, P, P, P, P, P, P, P, L, I, I, P, P, Z, P],
     "myolo_wino63_input_transform": [P, P, P, I, P, P, P, I, I, P],
     "myolo_wino63_output_input_transform": [P, P, P, P, P, P, P, I, I, I, P],
@@ -261,7 +262,9 @@ class WeightPrep(object):
     def stats(self):
         a, b, c = ctypes.c_longlong(0), ctypes.c_longlong(0), ctypes.c_longlong(0)
         call("myolo_wprep_stats", self.h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c))
-        return dict(hits=a.value, misses=b.value, bytes_used=c.value, entries=self.count())
+        o = ctypes.c_longlong(0)
+        call("myolo_wprep_overflows", self.h, ctypes.byref(o))
+        return dict(hits=a.value, misses=b.value, bytes_used=c.value, entries=self.count(), overflows=o.value)
 
     def close(self):
         if getattr(self, "h", None):

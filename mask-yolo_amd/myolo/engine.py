@@ -1755,17 +1755,18 @@ class Net(object):
             self._wprep_cap = self._wprep_arena_bytes()
             self._wprep = X.WeightPrep(self.dev, arena_bytes=self._wprep_cap)
         wp = self._wprep
-        # an arena that is too small makes its sites re-prepare in place every step, silently.  A site misses once (the step that records
-        # it); misses that still grow between the fourth and the fifth step mean entries that never found room: say so once.
+        # an arena that is too small makes its sites re-prepare in place every step, silently.  The registry counts the resolve() calls
+        # whose new site found no room (a site that merely appears late -- a shape first seen at step 5 -- misses once and is recorded: no warning);
+        # if that count still grows between the fourth and the fifth step, say so once.
         self._wprep_calls += 1
         if self._wprep_calls in (4, 5):
             st = wp.stats()
-            if self._wprep_calls == 5 and self._wprep_misses is not None and st["misses"] > self._wprep_misses:
+            if self._wprep_calls == 5 and self._wprep_misses is not None and st["overflows"] > self._wprep_misses:
                 import warnings
                 warnings.warn("myolo: the prepared-weights arena (%d MiB, %d MiB used, %d entries) is too small: %d preparations per step are re-made in place "
                               "(correct, slower).  Net._wprep_arena_bytes() sizes it." % (self._wprep_cap >> 20, st["bytes_used"] >> 20, st["entries"],
-                                                                                       st["misses"] - self._wprep_misses))
-            self._wprep_misses = st["misses"]
+                                                                                       st["overflows"] - self._wprep_misses))
+            self._wprep_misses = st["overflows"]
         self._wprep_ev = None
         n = wp.count()
         if n:
