@@ -26,6 +26,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 template <int V> struct IntC { static constexpr int value = V; };
 enum { AM_PLAIN = 0, AM_CONV3 = 1 };
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x2 __attribute__((ext_vector_type(2)));
 enum { EP_PLAIN = 0, EP_DECONV = 1, EP_DECONV_MASK = 2 };
 
 struct Bf16Args {
@@ -39,6 +41,8 @@ struct Bf16Args {
     int act;
     const float* w2;         // EP_DECONV_MASK: 1x1 mask conv kernel [Co][ncls] (fp32)
     float* part;             // EP_DECONV_MASK: partial logits [slab][4*M][ncls]
+    const float* b2;         // EP_DECONV_MASK, FIN kernels: bias of the 1x1 mask conv [ncls]
+    float* out;              //   and the probabilities [4*M][ncls] (no partial logits, no finish launch)
     int ncls;
     int tune;                // BF16_TUNE builds only (tools/experiments/bf16_tune.sh): timing-only ablations, results are wrong
 };
@@ -498,9 +502,20 @@ __device__ __forceinline__ void epi_plain_256(f32x16 (&acc)[4][2], const Bf16Arg
 // epilogue as in its four k tiles; in the long loop the next tap's tiles arrive while the previous tap's epilogue runs, and three of the
 // four fetches of the activation tile come from L2.  In the inference step 0.62 against 0.67 ms (stand-alone at M = 921984: 0.85 against
 // 0.89 ms) once the epilogue stopped spilling (class-count specialisation, pixel indices formed once); bf16_no_loopn=1 is the ablation.
-template <int AMODE, int EPI, bool LOOPN = false>
+// MEP (EP_DECONV_MASK): the 1x1 mask conv on the matrix pipe.  The accumulators are C^T (a lane holds ONE pixel and 16 channels of a 32 x 32
+// block), which is exactly the B-operand layout of v_mfma_f32_32x32x16_bf16 up to a permutation of k -- so max(acc, 0) is rounded to bf16
+// in place (v_cvt_pk_bf16_f32 + v_pk_max_i16: two VALU instructions per pair) and multiplied by W2^T (rows = classes, bf16 like every
+// other weight of this path, the same k permutation applied when its fragments are built) without leaving the registers: 16 short MFMAs
+// per wave and tap against the 128 of the main loop, instead of ~650 VALU instructions and 256 LDS reads.  The deconv output and the
+// 1x1 kernel are rounded to bf16 here (the VALU epilogue kept both in fp32: bf16_mask_valu=1).  Stand-alone at M = 662480 (Rice-416,
+// batch 4): 0.566 -> 0.44 ms with the finish launch; without any epilogue 0.397 (profiles/r6_notes.md section 6).
+// FIN (LOOPN + MEP, Co == 256: a workgroup holds ALL channels of its pixels): the four waves' 64-channel partial logits meet in LDS, in the
+// finish kernel's order (bias, slab 0..3), and the sigmoid is stored by this kernel -- no partial-logit round trip through HBM (4 slabs
+// x 4 M x classes floats written and read back), no finish launch; bit-identical to partials + deconv_mask_finish.
+template <int AMODE, int EPI, bool LOOPN = false, bool MEP = false, bool FIN = false>
 __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
 {
+    static_assert(!FIN || (LOOPN && MEP && EPI == EP_DECONV_MASK), "FIN needs the all-taps loop and the matrix-pipe epilogue");
     __shared__ __attribute__((aligned(16))) unsigned char lds[8 * 128 * W2_ROW > 2 * 2 * T2M * 128 ? 8 * 128 * W2_ROW : 2 * 2 * T2M * 128];
     unsigned char (*buf)[2][T2M * 128] = reinterpret_cast<unsigned char (*)[2][T2M * 128]>(lds);      // [buffer][A|B][row*128 + chunk*16]
 
@@ -530,14 +545,34 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
 
     // EP_DECONV_MASK: {deconv bias, 1x1 mask-conv weights of up to four classes} of the tile's 256 output channels, in LDS before the
     // main loop (the epilogue used to fetch them from global memory element by element, with the accumulators pinning every register)
-    __shared__ float4 etab[EPI == EP_DECONV_MASK ? (LOOPN ? 512 : T2N) : 1];
-    __shared__ float etab3[EPI == EP_DECONV_MASK ? (LOOPN ? 512 : T2N) : 1];
+    __shared__ float4 etab[EPI == EP_DECONV_MASK && !MEP ? (LOOPN ? 512 : T2N) : 1];
+    __shared__ float ebias[EPI == EP_DECONV_MASK && MEP ? (LOOPN ? 512 : T2N) : 1];              // MEP: the deconv bias alone
+    __shared__ float4 ered[FIN ? 2 * 4 * 4 * 32 : 1];                                             // FIN: [wm][wn][t][pixel lane] partial logits of a tap
+    __shared__ float etab3[EPI == EP_DECONV_MASK && !MEP ? (LOOPN ? 512 : T2N) : 1];
+    // MEP: W2^T fragments [group of 16 channels][half][class 0..3][8 bf16]: element i of (group q, half h) is channel
+    // 16 q + 8 (i / 4) + 4 h + i % 4 -- the channel accumulator register 8 pr + i of a lane of that half holds (q = 2 u + pr); one more
+    // entry of zeros at the end for the lanes whose row of W2^T is no class
+    __shared__ __attribute__((aligned(16))) uint16_t w2tab[EPI == EP_DECONV_MASK && MEP ? ((LOOPN ? 512 : T2N) / 2 + 1) * 8 : 8];
     if constexpr (EPI == EP_DECONV_MASK) {
         if (tid < (LOOPN ? p.Co : T2N)) {                        // LOOPN: all Co (<= 512) channels, indexed by channel
             const int co = LOOPN ? tid : n0 % p.Co + tid;
             const float* w2r = p.w2 + (long long)co * p.ncls;
-            etab[tid] = make_float4(p.bias ? p.bias[co] : 0.f, w2r[0], p.ncls > 1 ? w2r[1] : 0.f, p.ncls > 2 ? w2r[2] : 0.f);
-            etab3[tid] = p.ncls > 3 ? w2r[3] : 0.f;
+            if constexpr (MEP) {
+                ebias[tid] = p.bias ? p.bias[co] : 0.f;
+                const int nent = (LOOPN ? p.Co : T2N) / 2;
+                if (tid <= nent) {
+                    const int q = tid >> 3, h = (tid >> 2) & 1, cls = tid & 3;
+                    const int cb = LOOPN ? 0 : n0 % p.Co;
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int ch = cb + q * 16 + 8 * (i >> 2) + 4 * h + (i & 3);
+                        w2tab[tid * 8 + i] = (tid < nent && cls < p.ncls) ? f2bf(p.w2[(long long)ch * p.ncls + cls]) : (uint16_t)0;
+                    }
+                }
+            } else {
+                etab[tid] = make_float4(p.bias ? p.bias[co] : 0.f, w2r[0], p.ncls > 1 ? w2r[1] : 0.f, p.ncls > 2 ? w2r[2] : 0.f);
+                etab3[tid] = p.ncls > 3 ? w2r[3] : 0.f;
+            }
         }
     }
 
@@ -644,7 +679,9 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float b = etab[tb + u * 32 + 8 * g + 4 * half + e].x;
+                        const int bi = tb + u * 32 + 8 * g + 4 * half + e;
+                        float b;
+                        if constexpr (MEP) b = ebias[bi]; else b = etab[bi].x;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc[t][u][4 * g + e] = b;
                     }
@@ -703,8 +740,73 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_256(Bf16Args p)
             }
         }
     };
+    auto mask_epilogue_mfma = [&](int nb) {
+        const int tap2 = nb / p.Co;
+        const int c0w = nb - tap2 * p.Co + wn * 64;                    // first channel of the wave's 64
+        const int q0 = (LOOPN ? c0w : wn * 64) >> 4;
+        bf16x8 wf[2][2];                                               // [u][16-channel half of the block]; rows >= 4 (no class): the zero entry
+        const int zent = (LOOPN ? p.Co : T2N) / 2;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const int ent = l31 < 4 ? ((q0 + 2 * u + pr) * 2 + half) * 4 + l31 : zent;
+                wf[u][pr] = *reinterpret_cast<const bf16x8*>(&w2tab[ent * 8]);
+            }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    u32x4 rr;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {                      // (the bias is in the accumulator since acc_start)
+                        const f32x2 a2 = {acc[t][u][8 * pr + 2 * j], acc[t][u][8 * pr + 2 * j + 1]};
+                        s16x2 b2 = __builtin_bit_cast(s16x2, __builtin_convertvector(a2, bf16x2));
+                        b2 = __builtin_elementwise_max(b2, s16x2{0, 0});         // ReLU on the bf16 bits: negative <=> sign bit <=> negative int16
+                        rr[j] = __builtin_bit_cast(unsigned, b2);
+                    }
+                    const bf16x8 rb8 = __builtin_bit_cast(bf16x8, rr);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[u][pr], rb8, o, 0, 0, 0);
+                }
+            // rows 0..3 of the product = the classes, in registers 0..3 of the lower half
+            if constexpr (FIN) {
+                if (half == 0) ered[((wm * 4 + wn) * 4 + t) * 32 + l31] = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (half == 0 && pixb[t] >= 0) {
+                const long long pix = pixb[t] + (long long)(tap2 >> 1) * 2 * p.W + (tap2 & 1);
+                float* dst = p.part + ((long long)(c0w / 64) * 4 * p.M + pix) * p.ncls;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) if (c < p.ncls) dst[c] = o[c];
+            }
+        }
+        if constexpr (FIN) {
+            __syncthreads();               // (the next tap's partials are written four k-tile barriers from here)
+            const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)                                // wave (wm, wn) finishes pixel group t = wn of its 128 rows
+                if (t == wn_s && half == 0 && pixb[t] >= 0) {
+                    const long long pix = pixb[t] + (long long)(tap2 >> 1) * 2 * p.W + (tap2 & 1);
+                    float4 sl[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) sl[k] = ered[((wm * 4 + k) * 4 + t) * 32 + l31];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < p.ncls) {
+                            float sacc = p.b2[c];
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) sacc += c == 0 ? sl[k].x : c == 1 ? sl[k].y : c == 2 ? sl[k].z : sl[k].w;
+                            p.out[pix * p.ncls + c] = 1.f / (1.f + expf(-sacc));
+                        }
+                }
+        }
+    };
     auto mask_epilogue = [&](int nb) {
-        if (p.ncls <= 2) mask_epilogue_nc(IntC<2>{}, nb);
+        if constexpr (MEP) mask_epilogue_mfma(nb);
+        else if (p.ncls <= 2) mask_epilogue_nc(IntC<2>{}, nb);
         else mask_epilogue_nc(IntC<4>{}, nb);
     };
     bf16x8 fa[2][4], fb[2][2];
@@ -1174,12 +1276,22 @@ int myolo_deconv2x2s2_mask_bf16_fwd(const uint16_t* x, const uint16_t* wt, const
     const long long tiles = cdiv64(M, TBM) * (a.N / TBN);
     const long long tiles256 = cdiv64(M, T2M) * (a.N / T2N);
     const bool no256 = g_myolo_opt.bf16_no256 != 0, force256 = g_myolo_opt.bf16_force256 != 0;
-    if (!no256 && (Cout % T2N) == 0 && Cout <= 512 && !g_myolo_opt.bf16_no_loopn && (tiles256 >= 1536 || force256))
+    const bool valu = g_myolo_opt.bf16_mask_valu != 0;      // 1 = the VALU epilogue on the fp32 deconv output (rounds 3-5; ablation / the tighter numerics)
+    if (!no256 && (Cout % T2N) == 0 && Cout <= 512 && !g_myolo_opt.bf16_no_loopn && (tiles256 >= 1536 || force256)) {
         // one workgroup per 256 rows walks all four taps in one pipelined loop (bf16_no_loopn=1: a workgroup per (row tile, tap); same
         // Cout/64 column slabs in all three kernels)
-        hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, true>), dim3((unsigned)cdiv64(M, T2M)), dim3(512), 0, (hipStream_t)stream, a);
-    else if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256))
-        hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);
+        if (valu) hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, true, false>), dim3((unsigned)cdiv64(M, T2M)), dim3(512), 0, (hipStream_t)stream, a);
+        else if (Cout == T2N && !g_myolo_opt.bf16_mask_nofin) {      // all channels of a pixel in one workgroup: sigmoid stored by the kernel itself
+            a.b2 = b2; a.out = p_out;
+            hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, true, true, true>), dim3((unsigned)cdiv64(M, T2M)), dim3(512), 0, (hipStream_t)stream, a);
+            MYOLO_CHECK_LAUNCH();
+            return MYOLO_OK;
+        }
+        else hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, true, true>), dim3((unsigned)cdiv64(M, T2M)), dim3(512), 0, (hipStream_t)stream, a);
+    } else if (!no256 && (Cout % T2N) == 0 && (tiles256 >= 1536 || force256)) {
+        if (valu) hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, false, false>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((gemm_bf16_256<AM_PLAIN, EP_DECONV_MASK, false, true>), dim3((unsigned)tiles256), dim3(512), 0, (hipStream_t)stream, a);
+    }
     else
         hipLaunchKernelGGL((gemm_bf16_glds<AM_PLAIN, EP_DECONV_MASK>), dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
     myolo_launch_deconv_mask_finish(a.part, b2, p_out, 4 * M, ncls, nslabs, (hipStream_t)stream);

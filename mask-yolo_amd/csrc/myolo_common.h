@@ -19,6 +19,8 @@ struct MyoloOptions {
     int bf16_regstage;    // bf16 gemm: register-staged variant instead of LDS-DMA
     int bf16_no256;       // bf16 gemm: never the 256x256-tile kernel
     int bf16_no_loopn;    // bf16 deconv+mask: a workgroup per (row tile, tap) instead of one per row tile walking all four taps (ablation)
+    int bf16_mask_valu;   // bf16 deconv+mask, 256-row kernels: 1 = the 1x1 mask conv on the VALU from the fp32 deconv output (rounds 3-5) instead of on the matrix pipe from its bf16 rounding
+    int bf16_mask_nofin;  // bf16 deconv+mask, all-taps kernel at 256 channels: 1 = partial logits per 64-channel slab + the finish launch (ablation / test reference)
     int bf16_no_c3;       // bf16 3x3 conv: the nine-fetch implicit GEMM instead of the LDS-resident activation block (ablation)
     int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
     int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS
