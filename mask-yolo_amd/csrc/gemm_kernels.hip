@@ -1924,9 +1924,10 @@ static int deconv2x2s2_mask_fwd_impl(const float* x, const float* w, const float
     MYOLO_REQUIRE(((uintptr_t)x & 15) == 0, "deconv2x2s2_mask_fwd: x must be 16-byte aligned");
     if (myolo_deconv_mask_mm_ok(Cin, Cout)) {          // csrc/wino_mm.hip: 128x256 tiles, b128 fragments; bf16x6 with option "wino_x6"
         float* part = (float*)((char*)ws + wb);
-        const int rc = myolo_deconv_mask_mm(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s, keep_inv, keep_d, keep_cap);
+        int finished = 0;
+        const int rc = myolo_deconv_mask_mm(x, w, bias, w2, part, ws, (long long)N * H * W, H, W, Cin, Cout, ncls, s, keep_inv, keep_d, keep_cap, b2, p_out, &finished);
         if (rc != MYOLO_OK) return rc;
-        myolo_launch_deconv_mask_finish(part, b2, p_out, 4ll * N * H * W, ncls, Cout / 128, s);      // a wave covers 128 channels there
+        if (!finished) myolo_launch_deconv_mask_finish(part, b2, p_out, 4ll * N * H * W, ncls, Cout / 128, s);      // a wave covers 128 channels there
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }

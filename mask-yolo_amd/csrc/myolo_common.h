@@ -21,6 +21,7 @@ struct MyoloOptions {
     int bf16_no_loopn;    // bf16 deconv+mask: a workgroup per (row tile, tap) instead of one per row tile walking all four taps (ablation)
     int bf16_mask_valu;   // bf16 deconv+mask, 256-row kernels: 1 = the 1x1 mask conv on the VALU from the fp32 deconv output (rounds 3-5) instead of on the matrix pipe from its bf16 rounding
     int bf16_mask_nofin;  // bf16 deconv+mask, all-taps kernel at 256 channels: 1 = partial logits per 64-channel slab + the finish launch (ablation / test reference)
+    int deconv_mask_legacy; // fp32 (bf16x6) deconv + mask forward: 1 = the untransposed tile with the per-class butterfly epilogue (rounds 3-5), 2 = the transposed tile with partial logits + the finish launch; 0 = transposed, sigmoid stored by the kernel at 256 channels
     int bf16_no_c3;       // bf16 3x3 conv: the nine-fetch implicit GEMM instead of the LDS-resident activation block (ablation)
     int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
     int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS
@@ -109,7 +110,8 @@ bool myolo_deconv_mask_mm_ok(int Cin, int Cout);
 size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout);
 int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
                          long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s,
-                         const int32_t* keep_inv = nullptr, float* keep_d = nullptr, int keep_cap = 0);
+                         const int32_t* keep_inv = nullptr, float* keep_d = nullptr, int keep_cap = 0,
+                         const float* b2 = nullptr, float* p_out = nullptr, int* finished = nullptr);
 int myolo_gemm_nt_batched_runs(const float* A, const float* Bt, float* C, int nruns, const long long* rows, const long long* a_off,
                                const long long* b_off, const long long* c_off, const int* nq, int K, int N, hipStream_t s);
 // csrc/wino_mm.hip: C[z] = A[z]^T B[z] with six exact bf16 piece products per fp32 product (the Winograd weight gradient under "wino_x6")

@@ -54,6 +54,10 @@ struct MMArgs {
     const int32_t* keep_inv;
     float* keep_d;
     int keep_cap;
+    // MM_EP_DECONV_MASK_T with Co == 256 (a workgroup holds all channels of its pixels): the 1x1 conv's bias and the probabilities [4*M][ncls] --
+    // the two waves' 128-channel slabs meet in LDS and the kernel stores the sigmoid itself (NULL: partial logits to `part` + deconv_mask_finish)
+    const float* b2;
+    float* out;
     // PW (pointwise conv of the trunk in training mode, see gemm_kernels.hip myolo_pwconv1x1_bnstats_fwd): A := act(A * a_scale[k] + a_shift[k])
     // on load; stat: per row-tile partial sums of the output columns [M tiles][2][N] doubles
     const float* a_scale;
@@ -77,7 +81,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mm_rsrc(const float* base, lon
 }
 __device__ __forceinline__ float f4c(const float4& v, int s) { return s == 0 ? v.x : s == 1 ? v.y : s == 2 ? v.z : v.w; }
 
-enum { MM_EP_PLAIN = 0, MM_EP_DECONV_MASK = 1, MM_EP_DECONV = 2 };     // DECONV: 2x2 / s2 transposed-conv scatter of a (tap, co) column tile + bias + activation
+enum { MM_EP_PLAIN = 0, MM_EP_DECONV_MASK = 1, MM_EP_DECONV = 2, MM_EP_DECONV_MASK_T = 3 };   // _T (bf16x6 kernel): the tile formed transposed, see mm_deconv_mask_epilogue_t     // DECONV: 2x2 / s2 transposed-conv scatter of a (tap, co) column tile + bias + activation
 enum { MM_A_PLAIN = 0, MM_A_DECONV = 1 };                               // DECONV: A row m = the four taps of output pixel block m gathered from [N,2H,2W,Cc] (K = 4 Cc)
 
 // Epilogue of the fused deconv + ReLU + 1x1 mask conv (model.py:711-714; csrc/gemm_kernels.hip EP_DECONV_MASK for 4 column tiles per
@@ -161,6 +165,147 @@ __device__ __forceinline__ void mm_deconv_mask_epilogue(const MMArgs& p, const f
             }
             if (dst) dst[c] = outv;
         }
+}
+
+// {bias, w2} of the tile's 256 channels into LDS: called in the kernel's PROLOGUE (its global loads ride on the first operand loads, its LDS
+// writes are published by the prologue's barrier) -- built in the epilogue it cost two barriers and an exposed L2 round trip per tile
+__device__ __forceinline__ void mm_deconv_mask_table(const MMArgs& p, unsigned char* lds, int n0, int tid)
+{
+    float* tab = reinterpret_cast<float*>(lds);
+    const int co = n0 - (n0 / p.Co) * p.Co + tid;
+    const float* w2r = p.w2 + (long long)co * p.ncls;
+    tab[tid] = p.bias[co];
+    *reinterpret_cast<float4*>(tab + 256 + 4 * tid) = make_float4(w2r[0], p.ncls > 1 ? w2r[1] : 0.f, p.ncls > 2 ? w2r[2] : 0.f, p.ncls > 3 ? w2r[3] : 0.f);
+}
+
+// The same epilogue for a tile formed TRANSPOSED (bf16x6 kernel, MM_EP_DECONV_MASK_T: mfma(B, A) instead of mfma(A, B)): a lane then holds ONE
+// pixel (row m0 + wm*64 + t*32 + l31) and 16 channels of each 32 x 32 block (register 4g+e = channel u*32 + 8g + 4*half + e of the wave's 128),
+// so the channel sum of the 1x1 conv is a chain of FMAs in registers and ONE shuffle between the half-waves -- the untransposed form above
+// multiplies per class and runs a 31-shuffle reduce-scatter butterfly per class and row block (~2100 instructions per wave against ~900; the
+// epilogue was 0.24 of the kernel's 2.46 ms).  {bias, w2} of the tile's 256 channels wait in LDS (free after the loop).  With p.out set (Co ==
+// 256) the two waves' slabs are summed in LDS in deconv_mask_finish's order and the sigmoid is stored here: no partial logits, no finish launch.
+__device__ __forceinline__ void mm_deconv_mask_epilogue_t(const MMArgs& p, const f32x16 (&acc)[2][4], unsigned char* lds, long long m0, long long M, int n0,
+                                                          int tid, int wm, int wn, int half, int l31)
+{
+    const float* tab = reinterpret_cast<const float*>(lds);       // bias [256], then w2 [256][4 classes] (mm_deconv_mask_table, filled in the kernel's prologue)
+    float4* red = reinterpret_cast<float4*>(lds + 5120);          // [wm][wn][t][32 pixels] partial logits (p.out only)
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int tap = n0 / p.Co;
+    const int cb0 = n0 - tap * p.Co;
+    // (opaque copies: nothing of the epilogue's index arithmetic may be scheduled above the main loop, which runs at 247 of 256 registers --
+    //  hoisted there, the pixel / keep pointers cost 256 spills)
+    asm volatile("" : "+v"(tid), "+v"(l31));
+    const long long hw = (long long)p.H * p.W;
+    long long pix[2];
+    float* kdp[2] = {nullptr, nullptr};
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const long long row = m0 + wm * 64 + t * 32 + l31;
+        pix[t] = -1;
+        if (row < M) {
+            const long long n_img = row / hw;
+            const int rem = (int)(row - n_img * hw);
+            const int y = rem / p.W, x = rem - y * p.W;
+            const long long inimg = (long long)(2 * y + (tap >> 1)) * 2 * p.W + 2 * x + (tap & 1);
+            pix[t] = n_img * 4 * hw + inimg;
+            if (p.keep_d) {
+                const int sl = p.keep_inv[n_img];
+                if (sl >= 0 && sl < p.keep_cap) kdp[t] = p.keep_d + ((long long)sl * 4 * hw + inimg) * p.Co + cb0 + wn * 128 + 4 * half;
+            }
+        }
+    }
+    // the ReLU'd deconv rows of the images the caller keeps (few tiles hold one: a pass of its own, so that the class sums below stay one
+    // straight line -- with the conditional stores inside it the allocator spilled 256 registers)
+    if (__builtin_amdgcn_ballot_w64(kdp[0] != nullptr || kdp[1] != nullptr) != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(p.bias + cb0 + wn * 128 + u * 32 + 8 * g + 4 * half);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+                    if (kdp[t])
+                        *reinterpret_cast<float4*>(kdp[t] + u * 32 + 8 * g) =
+                            make_float4(fmaxf(acc[t][u][4 * g] + b4.x, 0.f), fmaxf(acc[t][u][4 * g + 1] + b4.y, 0.f),
+                                        fmaxf(acc[t][u][4 * g + 2] + b4.z, 0.f), fmaxf(acc[t][u][4 * g + 3] + b4.w, 0.f));
+            }
+    }
+    // two groups of four channels per scheduling region: their ten 16-byte table reads are issued together and waited for once (one channel
+    // at a time -- a read, a wait, eight FMAs -- the epilogue was slower than the butterfly it replaces: 0.29 against 0.25 ms); the four
+    // class FMAs of a value as two packed ones (v_pk_fma_f32 on {class 0, 1} and {class 2, 3})
+    f32x2 q01[2], q23[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { q01[t] = f32x2{0.f, 0.f}; q23[t] = f32x2{0.f, 0.f}; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            float4 bb[2], ww[2][4];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+                const int cl = wn * 128 + u * 32 + 8 * (2 * gp + gg) + 4 * half;
+                bb[gg] = *reinterpret_cast<const float4*>(tab + cl);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ww[gg][e] = *reinterpret_cast<const float4*>(tab + 256 + 4 * (cl + e));
+            }
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+                for (int ep = 0; ep < 2; ++ep)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        const int r = 4 * (2 * gp + gg) + 2 * ep;
+                        const f32x2 sv = f32x2{acc[t][u][r], acc[t][u][r + 1]} + f32x2{f4c(bb[gg], 2 * ep), f4c(bb[gg], 2 * ep + 1)};     // v_pk_add_f32
+#pragma unroll
+                        for (int k = 0; k < 2; ++k) {
+                            const float a = fmaxf(k ? sv.y : sv.x, 0.f);
+                            const f32x2 aa = {a, a};
+                            const float4 w4 = ww[gg][2 * ep + k];
+                            q01[t] = __builtin_elementwise_fma(aa, f32x2{w4.x, w4.y}, q01[t]);
+                            q23[t] = __builtin_elementwise_fma(aa, f32x2{w4.z, w4.w}, q23[t]);
+                        }
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    float ps[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) { ps[t][0] = q01[t].x; ps[t][1] = q01[t].y; ps[t][2] = q23[t].x; ps[t][3] = q23[t].y; }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ps[t][c] += __shfl_xor(ps[t][c], 32, 64);
+    if (p.out) {
+        if (half == 0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) red[((wm * 2 + wn) * 2 + t) * 32 + l31] = make_float4(ps[t][0], ps[t][1], ps[t][2], ps[t][3]);
+        }
+        __syncthreads();
+        const int wn_s = __builtin_amdgcn_readfirstlane(wn);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)                                // wave (wm, wn) finishes row block t = wn
+            if (t == wn_s && half == 0 && pix[t] >= 0) {
+                const float4 s0 = red[((wm * 2 + 0) * 2 + t) * 32 + l31], s1 = red[((wm * 2 + 1) * 2 + t) * 32 + l31];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (c < p.ncls) {
+                        float sacc = p.b2[c];
+                        sacc += f4c(s0, c);
+                        sacc += f4c(s1, c);
+                        p.out[pix[t] * p.ncls + c] = 1.f / (1.f + expf(-sacc));
+                    }
+            }
+        return;
+    }
+    if (half == 0) {
+        const int slab = (cb0 + wn * 128) >> 7;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (pix[t] < 0) continue;
+            float* dst = p.part + ((long long)slab * 4 * M + pix[t]) * p.ncls;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (c < p.ncls) dst[c] = ps[t][c];
+        }
+    }
 }
 
 template <int EPI>
@@ -320,6 +465,12 @@ __device__ __forceinline__ bf16x8 x6_ldb(__amdgpu_buffer_rsrc_t r, unsigned voff
 }
 
 template <int V> struct IntK { static constexpr int value = V; };
+// SWAP: the product transposed (rows = B's columns): both operands have the same fragment layout (lane & 31 = row / column, lane >> 5 = k half)
+template <bool SWAP> __device__ __forceinline__ f32x16 x6_mfma(bf16x8 a, bf16x8 b, f32x16 c)
+{
+    if constexpr (SWAP) return __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
 __device__ __forceinline__ float mm_act(float v, int act)
 {
@@ -336,6 +487,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     static_assert(NU == 4 || (NU == 2 && EPI == MM_EP_PLAIN && AG == MM_A_PLAIN), "the 128-column tile exists for the plain product only");
     constexpr int BN = 64 * NU;
     __shared__ __attribute__((aligned(16))) unsigned char As[2][MM_BM * X6_REC];
+    __shared__ __attribute__((aligned(16))) unsigned char etab[EPI == MM_EP_DECONV_MASK_T ? 5120 + 4096 : 16];      // {bias, w2} table + the slab exchange
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
@@ -460,6 +612,7 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
         for (int pc = 0; pc < 3; ++pc) bq[u][pc] = x6_ldb(rb, bvo + u * 3072u + pc * 1024u, bso);
     sstore(0);
     if (nk > 1) gload();
+    if constexpr (EPI == MM_EP_DECONV_MASK_T) mm_deconv_mask_table(p, etab, n0, tid);
     __syncthreads();
     bf16x8 fa[2][3];
 #pragma unroll
@@ -638,12 +791,12 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
             // smallest terms first
 #define X6_TILE(t)                                                                                                 \
             if (X6_ALL) {                                                                                          \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][2], acc[t][u], 0, 0, 0);           \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][2], bq[u][0], acc[t][u], 0, 0, 0);           \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][1], acc[t][u], 0, 0, 0); }         \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][1], acc[t][u], 0, 0, 0);           \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][1], bq[u][0], acc[t][u], 0, 0, 0);           \
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][0], bq[u][0], acc[t][u], 0, 0, 0);
+            acc[t][u] = x6_mfma<EPI == MM_EP_DECONV_MASK_T>(fa[t][0], bq[u][2], acc[t][u]);           \
+            acc[t][u] = x6_mfma<EPI == MM_EP_DECONV_MASK_T>(fa[t][2], bq[u][0], acc[t][u]);           \
+            acc[t][u] = x6_mfma<EPI == MM_EP_DECONV_MASK_T>(fa[t][1], bq[u][1], acc[t][u]); }         \
+            acc[t][u] = x6_mfma<EPI == MM_EP_DECONV_MASK_T>(fa[t][0], bq[u][1], acc[t][u]);           \
+            acc[t][u] = x6_mfma<EPI == MM_EP_DECONV_MASK_T>(fa[t][1], bq[u][0], acc[t][u]);           \
+            acc[t][u] = x6_mfma<EPI == MM_EP_DECONV_MASK_T>(fa[t][0], bq[u][0], acc[t][u]);
 #ifdef MM_X6_TUNE
 #define X6_ALL (!(p.tune & 256))          /* 256: only three of the six piece products (timing only: what a three-product scheme could cost at most) */
 #else
@@ -701,7 +854,17 @@ __global__ __launch_bounds__(256, 2) void wino_mm_x6_kernel(MMArgs p)
     }
 
     if constexpr (EPI == MM_EP_DECONV_MASK) {
+#ifdef MM_X6_TUNE
+        if (p.tune & 32768) return;        // timing only: what the epilogue costs
+#endif
         mm_deconv_mask_epilogue(p, acc, m0, M, n0, wm, wn, half, l31);
+        return;
+    }
+    if constexpr (EPI == MM_EP_DECONV_MASK_T) {
+#ifdef MM_X6_TUNE
+        if (p.tune & 32768) return;
+#endif
+        mm_deconv_mask_epilogue_t(p, acc, etab, m0, M, n0, tid, wm, wn, half, l31);
         return;
     }
     if constexpr (PW) {
@@ -897,8 +1060,10 @@ size_t myolo_deconv_mask_mm_split_bytes(int Cin, int Cout) { return align256((si
  * transposed operand [N][K] the fp32 kernel wants), split = scratch of myolo_deconv_mask_mm_split_bytes (bf16x6 only),
  * part = [Cout/128][4*M][ncls] partial logits.  Option "wino_x6": six bf16 piece products per fp32 product. */
 int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, const float* w2, float* part, void* split,
-                         long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s, const int32_t* keep_inv, float* keep_d, int keep_cap)
+                         long long M, int H, int W, int Cin, int Cout, int ncls, hipStream_t s, const int32_t* keep_inv, float* keep_d, int keep_cap,
+                         const float* b2, float* p_out, int* finished)
 {
+    if (finished) *finished = 0;              // 1: the kernel stored the probabilities itself (no deconv_mask_finish launch wanted)
     const int K = Cin, N = 4 * Cout;
     MMArgs a{};
     a.A = x; a.C = nullptr; a.K = K; a.N = N; a.nruns = 1; a.nt = 0;
@@ -908,9 +1073,16 @@ int myolo_deconv_mask_mm(const float* x, const float* w, const float* bias, cons
     R.rows = M; R.a_off = 0; R.b_off = 0; R.c_off = 0; R.nq = 1; R.tile0 = 0;
     R.mtiles = (int)((M + MM_BM - 1) / MM_BM);
     const long long tiles = (long long)R.mtiles * (N / MM_BN);
+    a.tune = g_myolo_opt.tune0;
     if (g_myolo_opt.wino_x6) {
         a.Bt = x6_split_weights(w, split, K, N, 0, s);
-        hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+        if (g_myolo_opt.deconv_mask_legacy == 1)  // rounds 3-5: the untransposed tile with the butterfly epilogue (ablation / test reference)
+            hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+        else {
+            // 2 = the transposed tile, but partial logits + the finish launch (test reference of the in-kernel finish)
+            if (Cout == MM_BN && b2 && p_out && finished && g_myolo_opt.deconv_mask_legacy != 2) { a.b2 = b2; a.out = p_out; *finished = 1; }
+            hipLaunchKernelGGL(wino_mm_x6_kernel<MM_EP_DECONV_MASK_T>, dim3((unsigned)tiles), dim3(256), 0, s, a);
+        }
     } else {
         a.Bt = w;
         hipLaunchKernelGGL(wino_mm_kernel<MM_EP_DECONV_MASK>, dim3((unsigned)tiles), dim3(256), 0, s, a);

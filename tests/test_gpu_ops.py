@@ -322,6 +322,21 @@ def test_deconv_mask_fused(N, H, W, Cin, Cout, C, x6, request):
     X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(p3), N, H, W, Cin, Cout,
            C, wsb.data_ptr(), wsb.numel(), X.stream())
     assert torch.equal(p, p3), "fused deconv+mask is not bit-reproducible"
+    if x6 and Cout % 256 == 0:
+        # round 6: the bf16x6 kernel forms the tile transposed (a lane = one pixel: the 1x1 conv's channel sum stays in registers) and, at 256
+        # channels, sums the two waves' slabs and stores the sigmoid itself.  deconv_mask_legacy = 2: the same tile with partial logits + the
+        # finish launch (same bits); = 1: the untransposed tile with the per-class butterfly of rounds 3-5 (another summation order)
+        outs = {}
+        for mode in (1, 2):
+            with X.option("deconv_mask_legacy", mode):
+                q = new(N, 2 * H, 2 * W, C)
+                X.call("myolo_deconv2x2s2_mask_fwd", X.ptr(dt(x)), X.ptr(dt(w)), X.ptr(dt(b)), X.ptr(dt(w2)), X.ptr(dt(b2)), X.ptr(q), N, H, W, Cin, Cout,
+                       C, wsb.data_ptr(), wsb.numel(), X.stream())
+                torch.cuda.synchronize()
+            outs[mode] = q
+        assert torch.equal(p, outs[2]), "in-kernel finish differs from partial logits + deconv_mask_finish"
+        assert float((p - outs[1]).abs().max()) < 2e-6
+        check(outs[1], ref, 1e-5, "fused deconv+mask, legacy epilogue")
 
 
 @pytest.mark.parametrize("M,C,act", [(32 * 112 * 112, 32, 2), (32 * 14 * 14, 512, 2), (32 * 7 * 7, 1024, 2), (4 * 9 * 9, 96, 1), (37, 8, 0), (5000, 256, 2),
