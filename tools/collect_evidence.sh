@@ -32,6 +32,10 @@ cp gpurun_out/prof_${TAG}_pos20/${TAG}_pos20_bench_kernel_stats.csv gpurun_out/p
   echo "--- Winograd kernels, steady state (boundary: round 6 persistent kernel; then the round-5 kernel, w63_legacy=1)"
   for k in wino63_mm wino63_wgrad wino63_boundary wino63_lazy; do KBENCH_OPTIONS=wino_x6=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
   for k in wino63_boundary wino63_lazy; do KBENCH_OPTIONS=wino_x6=1,w63_legacy=1 python tools/kbench.py $k --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -3; done
+  echo "--- deconv + ReLU + 1x1 mask conv, training (bf16x6): round 6 = transposed tile, packed channel sums, in-kernel finish; then deconv_mask_legacy=2 (partials + finish launch) and =1 (the round-5 butterfly epilogue)"
+  for o in wino_x6=1 wino_x6=1,deconv_mask_legacy=2 wino_x6=1,deconv_mask_legacy=1 wino_x6=1; do KBENCH_OPTIONS=$o python tools/kbench.py deconv_mask_fwd --warm 30 --iters 20 2>&1 | grep -vE "amdgpu.ids|^$" | tail -1 | sed "s/^/$o  /"; done
+  echo "--- the same op of the bf16 inference path at the Rice-416 shape (3380 boxes): round 6 = 1x1 conv on the matrix pipe + in-kernel finish; then bf16_mask_nofin=1 (partials + finish) and bf16_mask_valu=1 (the round-3 VALU epilogue)"
+  for o in tune0=0 bf16_mask_nofin=1 bf16_mask_valu=1 tune0=0; do KBENCH_OPTIONS=$o python tools/kbench.py deconv_mask_bf16_fwd --rois 3380 --warm 30 --iters 20 2>&1 | grep deconv_mask | sed "s/^/$o  /"; done
   echo "--- what a plain copy of the boundary kernels' plane sets moves (tools/experiments/vecwidth: persistent nine-wave workgroups, 64 strided planes, 4 / 8 / 16 bytes per lane)"
   hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o /tmp/vecwidth tools/experiments/vecwidth/vecwidth.hip > /dev/null 2>&1 && /tmp/vecwidth | head -13
   echo "--- residency census (tools/experiments/census: workgroups of T threads / V VGPRs / L bytes of LDS a CU holds at once; API = hipOccupancyMaxActiveBlocksPerMultiprocessor)"
