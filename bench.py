@@ -1037,7 +1037,7 @@ def bench_infer(args):
                         "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK,
                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flop": flop, "algorithmic_bytes": 2.0 * M * 256 * 2 + 9 * 256 * 256 * 2,
                         "launches_timed": conv_n, "avg_launch_ms": conv_ms,
-                        "deconv_mask": {"kernel": "gemm_bf16_256<PLAIN, DECONV_MASK> + deconv_mask_finish (2x2/s2 transposed conv + ReLU + 1x1 mask conv + sigmoid, "
+                        "deconv_mask": {"kernel": "gemm_bf16_256<PLAIN, DECONV_MASK, LOOPN, MEP, FIN> (2x2/s2 transposed conv + ReLU + 1x1 mask conv on the matrix pipe + sigmoid in ONE launch, "
                                                   "the 28x28x256 tensor never written)", "bound": "mfma", "avg_ms": dec_ms,
                                         "algorithmic_flop": 2.0 * M * 256 * 4 * 256,
                                         "achieved": 2.0 * M * 256 * 4 * 256 / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else 0.0, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s"},
