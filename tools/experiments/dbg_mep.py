@@ -1,3 +1,6 @@
+"""Error statistics of the bf16 deconv + mask kernel's matrix-pipe epilogue (round 6, profiles/r6_notes.md section 6) against the float64 oracle with and
+without the bf16 roundings of the deconv output / the 1x1 kernel, for the all-taps kernel and the one-tap-per-workgroup kernel:
+    gpurun -- 'python tools/experiments/dbg_mep.py'      (uses the helpers of tests/test_gpu_bf16.py)"""
 import sys, numpy as np, torch
 sys.path.insert(0, "tests"); sys.path.insert(0, "mask-yolo_amd"); sys.path.insert(0, ".")
 import test_gpu_bf16 as T
