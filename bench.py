@@ -944,6 +944,10 @@ def bench_infer(args):
     bsz = args.batch if args.batch_given else 4
     cfg = make_config(RiceConfig, BATCH_SIZE=bsz, INFERENCE_DTYPE="bf16")
     net = Net(cfg, device=dev, seed=0)
+    for kv in args.net_attr:
+        name, _, val = kv.partition("=")
+        assert hasattr(net, name), "unknown engine attribute %s" % name
+        setattr(net, name, type(getattr(net, name))(int(val)))
     x = torch.rand(bsz, 416, 416, 3, device=dev)
     # the timed region runs the forward the way MaskYOLO.detect() does (cfg.INFERENCE_HIP_GRAPH): replayed from a captured hipGraph,
     # one graph launch per step on the host instead of ~150 kernel launches
@@ -1041,7 +1045,7 @@ def bench_infer(args):
                                                   "the 28x28x256 tensor never written)", "bound": "mfma", "avg_ms": dec_ms,
                                         "algorithmic_flop": 2.0 * M * 256 * 4 * 256,
                                         "achieved": 2.0 * M * 256 * 4 * 256 / (dec_ms * 1e-3) / 1e12 if dec_ms > 0 else 0.0, "peak": BF16_MFMA_PEAK, "unit": "TFLOP/s"},
-                        "roialign": {"kernel": "crop_fwd_bf16_kernel", "bound": "hbm", "avg_ms": roi_ms,
+                        "roialign": {"kernel": "crop_fwd_bf16_walk_kernel (a feature-map column fetched once per output row)", "bound": "hbm", "avg_ms": roi_ms,
                                      "algorithmic_bytes": M * 256 * 2.0 + bsz * 52 * 52 * 256 * 4.0,
                                      "achieved": (M * 256 * 2.0 + bsz * 52 * 52 * 256 * 4.0) / (roi_ms * 1e-3) / 1e9 if roi_ms > 0 else 0.0,
                                      "peak": HBM_PEAK_GBS, "unit": "GB/s"}}}

@@ -218,6 +218,10 @@ int myolo_wino63_bwd_data_lazybn(const float* y_pre, const float* dy_compact, co
  * its pre-BN output, so the normalised activation is never written (NULL: the input is used as it is).  "phases": 3 = both launches
  * (the conv, then the statistics finish); 1 / 2 = only the first / second, for callers that bracket the conv kernel with events.  The "*_bwd_weight_affine_in"
  * gradients re-normalise the same pre-BN tensor on load.  Results equal the unfused sequences up to fp32 summation order. ---- */
+/* inference: act(conv(x) * scale + shift) in one launch: the frozen conv1_bn + ReLU6 folded into the conv's store (scale / shift from
+ * myolo_bn_frozen_coeffs[_batched]); bit-identical to myolo_conv3x3s2_c3_fwd + myolo_bn_apply_act (model.py:45-52, BatchNormalization in inference mode) */
+int myolo_conv3x3s2_c3_affine_act_fwd(const float* x, const float* w, const float* scale, const float* shift, int act, float* y,
+                                      int N, int H, int W, int Cout, void* stream);
 size_t myolo_conv3x3s2_c3_bnstats_ws_bytes(int N, int H, int W, int Cout);
 int myolo_conv3x3s2_c3_bnstats_fwd(const float* x, const float* w, float* y, const float* gamma, const float* beta, float* mean, float* var,
                                    float* scale, float* shift, float* moving_mean, float* moving_var, int N, int H, int W, int Cout, int phases,

@@ -1150,6 +1150,70 @@ __global__ __launch_bounds__(256) void crop_fwd_bf16_kernel(const float* __restr
     }
 }
 
+// The same crops with every feature-map column fetched ONCE per output row.  crop_fwd_bf16_kernel reads four corners per output element:
+// 64 bytes from L1 / L2 for 8 bytes stored -- 2.7 GB through the vector caches for 339 MB written at the Rice-416 shape, and that traffic, not
+// the HBM write, set its 0.126 ms.  The x coordinates of a box are the same for all of its rows and channels, and with boxes narrower than
+// ~2 x the crop (every anchor of the Rice / Shapes configs) neighbouring sample points share columns: lx(px + 1) is lx(px) or rx(px).  Here a
+// thread owns (output row, 8 channels) and walks the crop's columns; the two feature-map columns of a sample (rows ty / by, 2 x 32 bytes each)
+// stay in registers, and a column is loaded only when the walk reaches one it does not hold.  The column indices are wave-uniform (they depend
+// on the box alone), so the reuse tests are scalar branches.  Same expressions per element as crop_fwd_bf16_kernel: the same bits.
+struct CropCol { float4 t0, t1, b0, b1; };           // rows ty / by of one feature-map column, this thread's 8 channels
+__global__ __launch_bounds__(256) void crop_fwd_bf16_walk_kernel(const float* __restrict__ img, const float* __restrict__ boxes,
+                                                                 const int32_t* __restrict__ bind, uint16_t* __restrict__ out,
+                                                                 int H, int W, int C, int ch, int cw)
+{
+    const int b = blockIdx.y;
+    const int co = C >> 3;
+    const int item = blockIdx.x * 256 + threadIdx.x;
+    const bool live = item < ch * co;
+    const int py = live ? item / co : 0;
+    const int c = (live ? item - py * co : 0) * 8;
+    const float4 bx = *reinterpret_cast<const float4*>(boxes + (long long)b * 4);
+    float iny;
+    const bool vy = crop_coord_b(bx.x, bx.z, H, ch, py, iny);
+    const int ty = (int)floorf(iny), by = (int)ceilf(iny);
+    const float wy = iny - (float)ty;
+    const float* base = img + (long long)bind[b] * H * W * C + c;
+    const float* rowt = base + (long long)(vy ? ty : 0) * W * C;       // (a row outside the image is never used: its outputs are zeros)
+    const float* rowb = base + (long long)(vy ? by : 0) * W * C;
+    uint16_t* orow = out + ((long long)b * ch + py) * cw * C + c;
+    CropCol L, R;
+    L.t0 = L.t1 = L.b0 = L.b1 = R.t0 = R.t1 = R.b0 = R.b1 = make_float4(0.f, 0.f, 0.f, 0.f);
+    int il = -1, ir = -1;                               // the columns L / R hold
+    auto fetch = [&](CropCol& d, int x) {
+        const float* pt = rowt + (long long)x * C;
+        const float* pb = rowb + (long long)x * C;
+        d.t0 = *reinterpret_cast<const float4*>(pt); d.t1 = *reinterpret_cast<const float4*>(pt + 4);
+        d.b0 = *reinterpret_cast<const float4*>(pb); d.b1 = *reinterpret_cast<const float4*>(pb + 4);
+    };
+    for (int px = 0; px < cw; ++px) {
+        float inx;
+        const bool vx = crop_coord_b(bx.y, bx.w, W, cw, px, inx);
+        uint4 pk = make_uint4(0u, 0u, 0u, 0u);
+        if (__builtin_amdgcn_readfirstlane((int)vx)) {
+            const int lx = __builtin_amdgcn_readfirstlane((int)floorf(inx)), rx = __builtin_amdgcn_readfirstlane((int)ceilf(inx));
+            const float wx = inx - (float)lx;
+            if (lx != il) { if (lx == ir) L = R; else fetch(L, lx); il = lx; }
+            if (rx != ir) { if (rx == il) R = L; else fetch(R, rx); ir = rx; }
+            const float tl[8] = {L.t0.x, L.t0.y, L.t0.z, L.t0.w, L.t1.x, L.t1.y, L.t1.z, L.t1.w};
+            const float tr[8] = {R.t0.x, R.t0.y, R.t0.z, R.t0.w, R.t1.x, R.t1.y, R.t1.z, R.t1.w};
+            const float bl[8] = {L.b0.x, L.b0.y, L.b0.z, L.b0.w, L.b1.x, L.b1.y, L.b1.z, L.b1.w};
+            const float br[8] = {R.b0.x, R.b0.y, R.b0.z, R.b0.w, R.b1.x, R.b1.y, R.b1.z, R.b1.w};
+            float o[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float top = tl[k] + (tr[k] - tl[k]) * wx, bot = bl[k] + (br[k] - bl[k]) * wx;
+                o[k] = vy ? top + (bot - top) * wy : 0.f;
+            }
+            pk.x = (unsigned)f2bf(o[0]) | ((unsigned)f2bf(o[1]) << 16);
+            pk.y = (unsigned)f2bf(o[2]) | ((unsigned)f2bf(o[3]) << 16);
+            pk.z = (unsigned)f2bf(o[4]) | ((unsigned)f2bf(o[5]) << 16);
+            pk.w = (unsigned)f2bf(o[6]) | ((unsigned)f2bf(o[7]) << 16);
+        }
+        if (live) *reinterpret_cast<uint4*>(orow + (long long)px * C) = pk;
+    }
+}
+
 // final 1x1 conv + bias + sigmoid, bf16 activations in, fp32 probabilities out (one wave per row)
 template <int CC>
 __global__ __launch_bounds__(256) void mask_out_bf16_kernel(const uint16_t* __restrict__ x, const float* __restrict__ w,
@@ -1304,8 +1368,12 @@ int myolo_crop_and_resize_bf16_fwd(const float* image, const float* boxes, const
 {
     MYOLO_REQUIRE(image && boxes && box_ind && out && B > 0 && (C & 3) == 0 && nb >= 0 && nb <= 65535, "crop_and_resize_bf16_fwd: bad arguments");
     if (nb == 0) return MYOLO_OK;
-    hipLaunchKernelGGL(crop_fwd_bf16_kernel, dim3(crop_h, nb), dim3(256), 0, (hipStream_t)stream, image, boxes, box_ind, out, H, W, C,
-                       crop_h, crop_w);
+    if ((C & 7) == 0 && (((uintptr_t)image | (uintptr_t)out) & 15) == 0 && !g_myolo_opt.crop_bf16_legacy)
+        hipLaunchKernelGGL(crop_fwd_bf16_walk_kernel, dim3((unsigned)((crop_h * (C >> 3) + 255) / 256), nb), dim3(256), 0, (hipStream_t)stream, image, boxes,
+                           box_ind, out, H, W, C, crop_h, crop_w);
+    else
+        hipLaunchKernelGGL(crop_fwd_bf16_kernel, dim3(crop_h, nb), dim3(256), 0, (hipStream_t)stream, image, boxes, box_ind, out, H, W, C,
+                           crop_h, crop_w);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
 }

@@ -1442,7 +1442,8 @@ __global__ __launch_bounds__(256) void pw_bwd_data_thin_kernel(const float* __re
 template <int NU, int NJ>
 __global__ __launch_bounds__(256) void pw_fwd_thin_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                           double* __restrict__ stat, long long M, const float* __restrict__ a_scale,
-                                                          const float* __restrict__ a_shift, int a_act)
+                                                          const float* __restrict__ a_shift, int a_act, const float* __restrict__ o_scale = nullptr,
+                                                          const float* __restrict__ o_shift = nullptr, int o_act = MYOLO_ACT_NONE)
 {
     constexpr int K = 8 * NJ, N = 32 * NU, LDW = K + 4;
     extern __shared__ __align__(16) float pwt_lds[];             // [N][K + 4] floats, afterwards [4][2][N] doubles
@@ -1458,6 +1459,10 @@ __global__ __launch_bounds__(256) void pw_fwd_thin_kernel(const float* __restric
         sh[j] = a_scale ? *reinterpret_cast<const float4*>(a_shift + 8 * j + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const int act = a_scale ? a_act : MYOLO_ACT_NONE;
+    // inference (o_scale): the frozen BatchNorm + activation behind the conv on the way out (splitk_epilogue's / bn_apply_kernel's expressions); no statistics then
+    float osc[NU], osh[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { osc[u] = o_scale ? o_scale[32 * u + l31] : 1.f; osh[u] = o_scale ? o_shift[32 * u + l31] : 0.f; }
     __syncthreads();
     const long long nblk = (M + 31) / 32;
     const long long wave0 = (long long)blockIdx.x * 4 + wave, nwave = (long long)gridDim.x * 4;
@@ -1501,7 +1506,8 @@ __global__ __launch_bounds__(256) void pw_fwd_thin_kernel(const float* __restric
             if (full || orow < M) {
 #pragma unroll
                 for (int u = 0; u < NU; ++u) {
-                    const float t = acc[u][r];
+                    float t = acc[u][r];
+                    if (o_scale) t = gemm_act(fmaf(t, osc[u], osh[u]), o_act);
                     y[orow * N + 32 * u + l31] = t;
                     s1[u] += t; s2[u] = fmaf(t, t, s2[u]);
                 }
@@ -1541,12 +1547,13 @@ static int pw_fwd_thin_wgs(long long M)
 }
 
 static void pw_fwd_thin_launch(const float* x, const float* in_scale, const float* in_shift, int in_act, const float* w, float* y, double* stat,
-                               long long M, int Cin, int Cout, hipStream_t s)
+                               long long M, int Cin, int Cout, hipStream_t s, const float* o_scale = nullptr, const float* o_shift = nullptr,
+                               int o_act = MYOLO_ACT_NONE)
 {
     const unsigned wgs = (unsigned)pw_fwd_thin_wgs(M);
     size_t lds = (size_t)Cout * (Cin + 4) * sizeof(float);
     if (lds < (size_t)8 * Cout * sizeof(double)) lds = (size_t)8 * Cout * sizeof(double);
-#define PWT(NU_, NJ_) hipLaunchKernelGGL((pw_fwd_thin_kernel<NU_, NJ_>), dim3(wgs), dim3(256), lds, s, x, w, y, stat, M, in_scale, in_shift, in_act)
+#define PWT(NU_, NJ_) hipLaunchKernelGGL((pw_fwd_thin_kernel<NU_, NJ_>), dim3(wgs), dim3(256), lds, s, x, w, y, stat, M, in_scale, in_shift, in_act, o_scale, o_shift, o_act)
     if (Cin == 32 && Cout == 64) PWT(2, 4);
     else if (Cin == 32) PWT(4, 4);
     else if (Cout == 64) PWT(2, 8);
@@ -1575,6 +1582,13 @@ int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
+    if (!bias && pw_fwd_thin_ok(M, Cin, Cout) && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && !g_myolo_opt.gemm_generic) {
+        // the thin layers (conv_pw_1 / 2) on the register-fed kernel of the training forward, without statistics: the same bits as
+        // myolo_pwconv1x1_bnstats_fwd's y, and what myolo_pwconv1x1_affine_act_fwd applies its affine to
+        pw_fwd_thin_launch(x, nullptr, nullptr, MYOLO_ACT_NONE, w, y, nullptr, M, Cin, Cout, (hipStream_t)stream);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     // ws (optional): split-K partials for the 14x14 / 7x7 layers, whose few output tiles and long K loop (a serial chain of
     // load -> LDS -> MFMA steps) would leave most of the chip idle
     // (measured, tools/pw_layers.py: 7x7 layers 83 -> 52 us and 77 -> 30 us; the 14x14 layers' 196 tiles are better left alone)
@@ -1594,6 +1608,12 @@ int myolo_pwconv1x1_affine_act_fwd(const float* x, const float* w, const float* 
     a.A = x; a.B = w; a.C = y; a.M = M; a.N = Cout; a.K = Cin;
     a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = act;
     a.scale = scale; a.shift = shift;
+    if (pw_fwd_thin_ok(M, Cin, Cout) && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && !g_myolo_opt.gemm_generic) {
+        // conv_pw_1 / 2 at inference sizes: 33.9 / 19.9 us on gemm_nn_fast (Rice-416, batch 4); the affine + activation on the accumulators
+        pw_fwd_thin_launch(x, nullptr, nullptr, MYOLO_ACT_NONE, w, y, nullptr, M, Cin, Cout, (hipStream_t)stream, scale, shift, act);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     launch_nn<AM_PLAIN, EP_PLAIN>(a, (hipStream_t)stream, ws, ws_bytes, 128);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;

@@ -39,7 +39,7 @@ static int* option_slot(const char* name)
         {"no_nt", &MyoloOptions::no_nt}, {"gemm_generic", &MyoloOptions::gemm_generic}, {"no_splitk", &MyoloOptions::no_splitk},
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn}, {"bf16_mask_valu", &MyoloOptions::bf16_mask_valu}, {"deconv_mask_legacy", &MyoloOptions::deconv_mask_legacy}, {"bf16_mask_nofin", &MyoloOptions::bf16_mask_nofin},
-        {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds},
+        {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds}, {"crop_bf16_legacy", &MyoloOptions::crop_bf16_legacy},
         {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_bwd_legacy", &MyoloOptions::dw_bwd_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"tn_wgs", &MyoloOptions::tn_wgs}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"w63_legacy", &MyoloOptions::w63_legacy}, {"w63_wgs", &MyoloOptions::w63_wgs}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
@@ -951,7 +951,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 #define C1F_STEPS 2
 #define C1F_SMAX 8
 __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
-                                                             int H, int W, int Co, int cq_shift, int chunks, double* __restrict__ stat)
+                                                             int H, int W, int Co, int cq_shift, int chunks, double* __restrict__ stat,
+                                                             const float* __restrict__ osc = nullptr, const float* __restrict__ osh = nullptr, int oact = MYOLO_ACT_NONE)
 {
     extern __shared__ __attribute__((aligned(16))) float c1f_lds[];     // [5][4 + 3 W]
     __shared__ float4 red[256];
@@ -962,6 +963,8 @@ __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __rest
     float4 wr[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) wr[k] = ld4g(w + k * Co + c4);
+    // inference (osc): the frozen BatchNorm + activation behind the conv on the way out -- bn_apply_kernel's expressions; no statistics then
+    const float4 osc4 = osc ? ld4g(osc + c4) : f4zero(), osh4 = osc ? ld4g(osh + c4) : f4zero();
     if (tid < 20) c1f_lds[(tid >> 2) * rowf + (tid & 3)] = 0.f;
     const int nsteps = (Ho + 1) / 2;
     const int st0 = ch * C1F_STEPS, st1 = st0 + C1F_STEPS < nsteps ? st0 + C1F_STEPS : nsteps;
@@ -1007,6 +1010,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __rest
                     acc.x = fmaf(a, wv.x, acc.x); acc.y = fmaf(a, wv.y, acc.y);
                     acc.z = fmaf(a, wv.z, acc.z); acc.w = fmaf(a, wv.w, acc.w);
                 }
+            if (osc)
+                acc = make_float4(actf(fmaf(acc.x, osc4.x, osh4.x), oact), actf(fmaf(acc.y, osc4.y, osh4.y), oact), actf(fmaf(acc.z, osc4.z, osh4.z), oact),
+                                  actf(fmaf(acc.w, osc4.w, osh4.w), oact));
             st4g(y + (((long long)n * Ho + oy) * Wo + ox) * Co + c4, acc);
             s1.x += acc.x; s1.y += acc.y; s1.z += acc.z; s1.w += acc.w;
             s2 = f4fma(acc, acc, s2);
@@ -1040,13 +1046,14 @@ static bool conv1_fwd_rows_ok(int H, int W, int Cout)
     return (H & 1) == 0 && (W & 3) == 0 && 5 * 3 * W / 4 <= C1F_SMAX * 256 && cq >= 1 && cq <= 64 && (cq & (cq - 1)) == 0 && !(g_myolo_opt.tune0 & 16384);
 }
 static int conv1_fwd_rows_chunks(int H) { return ((H / 2 + 1) / 2 + C1F_STEPS - 1) / C1F_STEPS; }
-static void conv1_fwd_rows_launch(const float* x, const float* w, float* y, int N, int H, int W, int Cout, double* stat, hipStream_t s)
+static void conv1_fwd_rows_launch(const float* x, const float* w, float* y, int N, int H, int W, int Cout, double* stat, hipStream_t s,
+                                  const float* osc = nullptr, const float* osh = nullptr, int oact = MYOLO_ACT_NONE)
 {
     const int chunks = conv1_fwd_rows_chunks(H);
     int sh = 0;
     while ((1 << sh) < Cout / 4) ++sh;
     hipLaunchKernelGGL(conv1_fwd_rows_kernel, dim3((unsigned)(N * chunks)), dim3(256), (size_t)5 * (4 + 3 * W) * sizeof(float), s, x, w, y, H, W, Cout, sh, chunks,
-                       stat);
+                       stat, osc, osh, oact);
 }
 
 // dw[k][co] = sum_pixels patch[k] * dy[co]; rows = output pixels, "channels" = Co, 27 accumulators
@@ -3120,6 +3127,22 @@ int myolo_conv3x3s2_c3_fwd(const float* x, const float* w, float* y, int N, int 
                            x, w, y, N, H, W, Cout, (double*)nullptr);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
+}
+
+/* inference: act(conv(x) * scale + shift) -- conv_block (model.py:42-52) with its BatchNormalization in inference mode folded into the conv's
+ * store (scale / shift from myolo_bn_frozen_coeffs[_batched]); bit-identical to myolo_conv3x3s2_c3_fwd + myolo_bn_apply_act */
+int myolo_conv3x3s2_c3_affine_act_fwd(const float* x, const float* w, const float* scale, const float* shift, int act, float* y, int N, int H, int W,
+                                      int Cout, void* stream)
+{
+    MYOLO_REQUIRE(x && w && y && scale && shift && N > 0 && (H & 1) == 0 && (W & 1) == 0 && (Cout & 3) == 0, "conv3x3s2_c3_affine_act_fwd: bad arguments");
+    if (conv1_fwd_rows_ok(H, W, Cout) && (long long)N * conv1_fwd_rows_chunks(H) < (1ll << 31)) {
+        conv1_fwd_rows_launch(x, w, y, N, H, W, Cout, nullptr, (hipStream_t)stream, scale, shift, act);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
+    const int rc = myolo_conv3x3s2_c3_fwd(x, w, y, N, H, W, Cout, stream);          // shapes the row kernel does not take: the two launches (in place)
+    if (rc != MYOLO_OK) return rc;
+    return myolo_bn_apply_act(y, scale, shift, y, (int64_t)N * (H / 2) * (W / 2), Cout, act, stream);
 }
 
 /* conv_block of the backbone in training mode (model.py:42-52): the conv and the batch statistics of its output (what myolo_bn_stats

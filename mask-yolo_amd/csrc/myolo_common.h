@@ -24,6 +24,7 @@ struct MyoloOptions {
     int deconv_mask_legacy; // fp32 (bf16x6) deconv + mask forward: 1 = the untransposed tile with the per-class butterfly epilogue (rounds 3-5), 2 = the transposed tile with partial logits + the finish launch; 0 = transposed, sigmoid stored by the kernel at 256 channels
     int bf16_no_c3;       // bf16 3x3 conv: the nine-fetch implicit GEMM instead of the LDS-resident activation block (ablation)
     int bf16_force256;    // bf16 gemm: always the 256x256-tile kernel
+    int crop_bf16_legacy; // bf16 ROIAlign forward: 1 = four corner loads per output element (rounds 2-5) instead of the column walk; the same bits (test reference)
     int crop_bwd_nolds;   // ROIAlign backward: per-box terms recomputed per thread instead of staged in LDS
     int tune0;            // scratch integer for kernel-tuning experiments (0 = off); never set by the product
     int dw_min_wg;        // depthwise forward (row-sliding kernel): workgroups wanted before rows stop being split into chunks (0 = default 1024)

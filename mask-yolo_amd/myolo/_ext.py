@@ -20,6 +20,7 @@ P, I, L, F, Z = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float, c
 # name -> argtypes (all return int).  Order/meaning: include/myolo_hip.h
 SIGS = {
     "myolo_conv3x3s2_c3_fwd": [P, P, P, I, I, I, I, P],
+    "myolo_conv3x3s2_c3_affine_act_fwd": [P, P, P, P, I, P, I, I, I, I, P],
     "myolo_conv3x3s2_c3_bwd_weight": [P, P, P, I, I, I, I, P, Z, P],
     "myolo_dwconv3x3_fwd": [P, P, P, I, I, I, I, I, P],
     "myolo_dwconv3x3_affine_act_fwd": [P, P, P, P, I, P, I, I, I, I, I, P],

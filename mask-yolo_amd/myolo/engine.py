@@ -205,6 +205,9 @@ class Net(object):
         self._graphs = {}                 # predict_graphed: (input shape, modes, lane) -> (hipGraph, static input, static outputs)
         self._lanes = {}                  # predict_stream: lane -> its stream / scratch / coefficient buffers
         self._cap_stream = None           # graph capture never happens with the default stream current (see _capture_predict)
+        self._fm_stream = None            # inference: feature_map's conv beside the YOLO head (trunk_fwd)
+        self.infer_fork_feature_map = True    # only forwards that run alone: with several batches in flight (predict_stream) the forked graphs cost 9 % (1150 -> 1055 img/s at Rice-416), alone they return 0.5 %
+        self._fork_now = None             # the effective value while predict_graphed captures / runs a forward for a given number of lanes
         # a captured graph bakes in pointers to the scratch buffer: growing it (a bigger launch on the same Net) drops the graphs
         self._ws_main = Workspace(self.dev, on_realloc=lambda: self._drop_graphs(0))
         self._ws_side = Workspace(self.dev)    # scratch of the YOLO-head backward running on the side stream
@@ -578,7 +581,7 @@ class Net(object):
         if self._fz_table is None:
             rows, off = [], 0
             self._fz_slot = {}
-            for name in sorted(k[:-len("/gamma")] for k in self.pslots if k.endswith("_bn/gamma") and (k.startswith("conv_dw_") or k.startswith("conv_pw_"))):
+            for name in sorted(k[:-len("/gamma")] for k in self.pslots if k.endswith("_bn/gamma") and (k.startswith("conv_dw_") or k.startswith("conv_pw_") or k.startswith("conv1_bn/"))):
                 C = int(self.p[name + "/gamma"].numel())
                 rows.append([self.pslots[name + "/gamma"][0], self.pslots[name + "/beta"][0], self.sslots[name + "/moving_mean"][0],
                              self.sslots[name + "/moving_variance"][0], off, C])
@@ -778,6 +781,11 @@ class Net(object):
                    N, H, W, C0, 3, *self._wsargs(), X.stream())
             self.tape["conv1_bn"] = (y, ACT_RELU6, True)
             a = ("lazy", y, "conv1_bn")
+        elif not train and self.fold_frozen_bn and C0 % 4 == 0:
+            # inference: conv1_bn (frozen) + ReLU6 in the conv's store, like every depthwise / pointwise layer behind it
+            sc, sh = self._frozen_affine("conv1_bn")
+            X.call("myolo_conv3x3s2_c3_affine_act_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), sc, sh, ACT_RELU6, X.ptr(y), N, H, W, C0, X.stream())
+            a = y
         else:
             X.call("myolo_conv3x3s2_c3_fwd", X.ptr(images), X.ptr(self.p["conv1/kernel"]), X.ptr(y), N, H, W, C0, X.stream())
             a = self.bn_act_fwd("conv1_bn", y, ACT_RELU6, train)
@@ -803,8 +811,19 @@ class Net(object):
         n, h, w, c = c4shape
         Cf = cfg.TOP_FEATURE_MAP_DEPTH
         Fm = self._new(n * h * w, Cf)
-        # (running this conv on a side stream underneath the YOLO head's forward blocks was measured in round 3: 21.55 vs 21.55 / 21.67 ms, nothing)
-        self.conv3x3_fwd(C4, "feature_map", Fm, n, h, w, c, Cf)
+        # (running this conv on a side stream underneath the YOLO head's forward blocks was measured in round 3 for the TRAINING step: 21.55 vs
+        # 21.55 / 21.67 ms, nothing -- at batch 32 both branches fill the chip.  An inference forward at batch 4 is a chain of ~45 small launches:
+        # there the conv's three kernels run beside the YOLO head's sixteen, infer_fork_feature_map.)
+        fork = (not train) and (self.infer_fork_feature_map if self._fork_now is None else self._fork_now) and self._wino_ok(n, h, w, c, Cf)
+        if fork:
+            cur = torch.cuda.current_stream()
+            if self._fm_stream is None:
+                self._fm_stream = _shared_stream(self.dev, "infer_feature_map")
+            self._fm_stream.wait_stream(cur)          # (inside a capture this pulls the side stream into the graph: the fork is a graph edge)
+            with torch.cuda.stream(self._fm_stream):  # the planes it allocates live and die in this stream's pool; Fm and C4 belong to `cur`
+                self.conv3x3_fwd(C4, "feature_map", Fm, n, h, w, c, Cf)
+        else:
+            self.conv3x3_fwd(C4, "feature_map", Fm, n, h, w, c, Cf)
         for f, s in YOLO_BLOCKS:
             a, shape = self.dw_block_fwd(bid, a, shape, s, train)
             bid += 1
@@ -815,6 +834,8 @@ class Net(object):
         X.call("myolo_pwconv1x1_fwd", X.ptr(a), X.ptr(self.p["conv_23/kernel"]), X.ptr(self.p["conv_23/bias"]), X.ptr(yo),
                n2 * h2 * w2, c2, D, *self._wsargs(), X.stream())
         self.tape["trunk"] = (C4, c4shape, a, shape)
+        if fork:
+            cur.wait_stream(self._fm_stream)         # Fm is complete for whatever the caller does next (detections, ROIAlign)
         if train:
             self._wprep_mark_trunk()
             self._wprep_wait(1)           # everything else that was prepared (before any stream forks off this one)
@@ -2195,16 +2216,18 @@ class Net(object):
         for k in [k for k in self._graphs if k[-1] == lane]:
             del self._graphs[k]
 
-    def predict_graphed(self, images, lane=0):
+    def predict_graphed(self, images, lane=0, solo=True):
         """predict() replayed from a captured hipGraph (one per input shape and lane): the ~150 launches of an inference forward
         cost one graph launch on the host.  Same kernels, same buffers for the weights (updates are seen), static input / output
         buffers: the returned tensors are overwritten by the next call with the same shape on the same lane.  lane > 0: a second
         (third ...) graph with its own scratch and static buffers, so that forwards of different lanes may run concurrently on
         different streams (predict_stream)."""
-        key = (tuple(images.shape), self.cfg.INFERENCE_DTYPE, self.conv3x3_algo, self.fp32_matmul, self.wino_tiles, lane)
+        fork = bool(self.infer_fork_feature_map and solo)       # solo = no other lane's forward runs beside this one (predict_stream says so)
+        key = (tuple(images.shape), self.cfg.INFERENCE_DTYPE, self.conv3x3_algo, self.fp32_matmul, self.wino_tiles, fork, lane)
         ent = self._graphs.get(key)
         if ent is None or ent[0] is None:
             saved = None
+            self._fork_now = fork
             if lane > 0:
                 st = self._lane_state(lane)
                 saved = (self._ws_main, self._ws_active, self.bnbuf, self._fz_coeffs)
@@ -2217,6 +2240,7 @@ class Net(object):
                 if ent[0] is None:
                     return self.predict(images)
             finally:
+                self._fork_now = None
                 if saved is not None:
                     self._ws_main, self._ws_active, self.bnbuf, self._fz_coeffs = saved
         graph, static_in, outs = ent
@@ -2284,7 +2308,7 @@ class Net(object):
             s.wait_stream(cur)
             images.record_stream(s)
             with torch.cuda.stream(s):
-                outs = tuple(t.clone() for t in self.predict_graphed(images, lane=i % in_flight))
+                outs = tuple(t.clone() for t in self.predict_graphed(images, lane=i % in_flight, solo=in_flight == 1))
                 ev = torch.cuda.Event()
                 ev.record(s)
             pending.append((ev, outs))

@@ -217,6 +217,33 @@ def test_crop_and_resize_bf16_is_rounded_fp32_kernel(B, H, W, C, nb, crop):
     assert (d <= BF16_STEP * np.abs(o32.cpu().numpy()) + 1e-6).all()
 
 
+@pytest.mark.parametrize("B,H,W,C,nb,crop", [(2, 52, 52, 256, 300, 14), (3, 7, 9, 16, 40, 5), (1, 5, 6, 8, 12, 1)])
+def test_crop_and_resize_bf16_column_walk_equals_corner_loads(B, H, W, C, nb, crop):
+    """the column-walking kernel (a feature-map column fetched once per output row) against the four-corner-loads one it replaces
+    (crop_bf16_legacy=1): the same bits -- narrow boxes (columns shared by several samples), boxes wider than the crop (no reuse),
+    boxes partly / wholly outside the image (zeros), degenerate and flipped boxes, integer sample positions (lx == rx)"""
+    rng = np.random.default_rng(11)
+    img = rnd(rng, B, H, W, C)
+    boxes = _boxes(rng, nb)
+    boxes[0] = [0.0, 0.0, 1.0, 1.0]                       # the whole map: sample points on integer positions when crop - 1 divides size - 1
+    boxes[1] = [0.3, 0.4, 0.3, 0.4]                       # a point
+    boxes[2] = [0.7, 0.8, 0.2, 0.1]                       # flipped
+    boxes[3] = [-0.5, -0.2, 0.4, 0.5]                     # partly outside
+    boxes[4] = [1.2, 1.3, 1.8, 1.9]                       # wholly outside
+    boxes[5] = [0.41, 0.40, 0.47, 0.44]                   # narrower than one feature pixel at small maps
+    boxes[6] = [0.0, 0.0, 2.0, 3.0]                       # much wider than the map
+    bind = rng.integers(0, B, nb).astype(np.int32)
+    a = (X.ptr(dt(img)), X.ptr(dt(boxes)), X.ptr(dt(bind)))
+    o_new = torch.full((nb, crop, crop, C), 7.0, dtype=torch.bfloat16, device=DEV)
+    o_old = torch.full((nb, crop, crop, C), 9.0, dtype=torch.bfloat16, device=DEV)
+    X.call("myolo_crop_and_resize_bf16_fwd", *a, X.ptr(o_new), B, H, W, C, nb, crop, crop, X.stream())
+    with X.option("crop_bf16_legacy", 1):
+        X.call("myolo_crop_and_resize_bf16_fwd", *a, X.ptr(o_old), B, H, W, C, nb, crop, crop, X.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o_new.view(torch.int16), o_old.view(torch.int16))
+    check_bf16(from_bf16(o_new), O.crop_and_resize(img, boxes, bind, (crop, crop)), "crop bf16 (column walk) vs oracle")
+
+
 @pytest.mark.parametrize("C", [1, 2, 4])
 def test_mask_head_out_bf16(C):
     rng = np.random.default_rng(9)

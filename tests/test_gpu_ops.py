@@ -1246,7 +1246,8 @@ def _frozen_bn(rng, C):
 
 @pytest.mark.parametrize("M,Cin,Cout,act", [(4 * 26 * 26, 128, 256, 2),     # the MFMA fast path
                                             (2 * 7 * 7, 512, 1024, 2),      # few tiles, long K: split-K with the affine in its epilogue
-                                            (300, 24, 40, 1), (77, 32, 64, 0)])   # the generic kernel's shapes; ReLU; no activation
+                                            (300, 24, 40, 1), (77, 32, 64, 0),    # the generic kernel's shapes; ReLU; no activation
+                                            (4 * 104 * 104 + 5, 64, 64, 2), (16384, 32, 64, 1)])   # conv_pw_2 / conv_pw_1 shapes: the register-fed thin kernel (ragged last block)
 def test_pwconv1x1_affine_act_fwd_equals_conv_then_frozen_bn(M, Cin, Cout, act):
     """inference fold (model.py:68-76 with BatchNormalization in inference mode): the pointwise conv with the frozen BatchNorm's affine and
     the activation in its epilogue == myolo_pwconv1x1_fwd, then myolo_bn_apply_act, bit for bit; the coefficients come from the batched
@@ -1276,6 +1277,24 @@ def test_pwconv1x1_affine_act_fwd_equals_conv_then_frozen_bn(M, Cin, Cout, act):
     ref = ref * (g / np.sqrt(v_ + 1e-3)) + (b_ - m_ * g / np.sqrt(v_ + 1e-3))
     ref = np.clip(ref, 0, 6) if act == 2 else (np.maximum(ref, 0) if act == 1 else ref)
     assert np.abs(y2.cpu().numpy() - ref).max() < 2e-4
+
+
+@pytest.mark.parametrize("N,H,W,Cout,act", [(2, 416, 416, 32, 2), (3, 64, 48, 16, 1), (1, 30, 26, 32, 2)])      # the row kernel (W % 4 == 0) twice, the generic one
+def test_conv1_affine_act_fwd_equals_conv_then_frozen_bn(N, H, W, Cout, act):
+    """conv_block in inference mode (model.py:42-52): myolo_conv3x3s2_c3_affine_act_fwd == myolo_conv3x3s2_c3_fwd + myolo_bn_apply_act, bit for bit"""
+    rng = np.random.default_rng(10)
+    x, w = dt(rnd(rng, N, H, W, 3)), dt(rnd(rng, 3, 3, 3, Cout, scale=0.3))
+    gamma, beta, mm, mv = _frozen_bn(rng, Cout)
+    Ho, Wo = H // 2, W // 2
+    st = X.stream()
+    y0, y1, y2, sc, sh = new(N, Ho, Wo, Cout), new(N, Ho, Wo, Cout), new(N, Ho, Wo, Cout), new(Cout), new(Cout)
+    X.call("myolo_conv3x3s2_c3_fwd", X.ptr(x), X.ptr(w), X.ptr(y0), N, H, W, Cout, st)
+    X.call("myolo_bn_frozen_coeffs", X.ptr(gamma), X.ptr(beta), X.ptr(mm), X.ptr(mv), X.ptr(sc), X.ptr(sh), Cout, st)
+    X.call("myolo_bn_apply_act", X.ptr(y0), X.ptr(sc), X.ptr(sh), X.ptr(y1), N * Ho * Wo, Cout, act, st)
+    X.call("myolo_conv3x3s2_c3_affine_act_fwd", X.ptr(x), X.ptr(w), X.ptr(sc), X.ptr(sh), act, X.ptr(y2), N, H, W, Cout, st)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    assert float(y1.abs().max()) > 0
 
 
 @pytest.mark.parametrize("N,H,W,C,stride", [(2, 52, 52, 128, 1), (2, 52, 52, 128, 2), (3, 13, 13, 512, 1), (1, 6, 10, 8, 2), (1, 3, 5, 4, 1)])
