@@ -1530,6 +1530,156 @@ __global__ __launch_bounds__(256) void pw_fwd_thin_kernel(const float* __restric
         stat[(long long)blockIdx.x * 2 * N + e] = (red[0 * 2 * N + e] + red[1 * 2 * N + e]) + (red[2 * 2 * N + e] + red[3 * 2 * N + e]);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pointwise layers with FEW rows and a long K (the 7x7 layers of the training step, M = 1568; every layer of the YOLO head of an inference
+// forward, M = 676 / 2704 at Rice-416 batch 4): y [M][N] = act((act_in(x * a_scale + a_shift) [M][K] * w [K][N] + bias) * scale + shift).
+// gemm_nn_fast ran them as split-K launches of 128 x 128 tiles -- raw partials to HBM, a second launch (splitk_epilogue) to sum them, and
+// 352 workgroups on 256 CUs: 28 + 9 us for 1.4 GFLOP (M = 2704, 512 -> 512) where the fp32 matrix pipe needs 9.
+// Here a workgroup owns 32 T rows x 128 columns and its four waves split K among themselves: a wave multiplies the whole tile over a quarter
+// of K straight from registers (no LDS in the loop, no barrier), the four partial tiles meet in LDS once, are summed in wave order
+// (deterministic) and leave through the epilogue as 16-byte stores.  One launch, no partials in HBM, <= 256-384 workgroups of equal work.
+// Operand layout without a transposition: lane (l31, half) loads 16 bytes of its ROW of x per step (k = 8 j + 4 half + e, e = 0..3, the
+// thin kernels' order: the reduction index may be walked in any order as long as both operands agree) and, for each e, 16 bytes of w's row
+// k: columns n0 + 4 l31 .. + 3.  Component c of that float4 is the B operand of column block c, i.e. block c holds the columns
+// n0 + 4 l + c -- a permutation of the tile's columns that the epilogue undoes for free (a lane ends up with four CONSECUTIVE columns).
+// fp32 operands on the fp32 matrix pipe: the arithmetic of gemm_nn_fast, another summation order.
+template <int T>
+__global__ __launch_bounds__(256) void pw_smallm_kernel(GemmArgs p)
+{
+    __shared__ __attribute__((aligned(16))) float part[4 * 4 * T * 16 * 64];       // [wave][column block][t][r][lane]: 64 T KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, half = lane >> 5;
+    const int ntn = p.N >> 7;
+    const int tn = (int)(blockIdx.x % (unsigned)ntn);                              // the column tiles of one row tile are neighbours: x stays in L2
+    const long long m0 = (long long)(blockIdx.x / (unsigned)ntn) * (32 * T);
+    const int n0 = tn << 7;
+    const int kq = p.K >> 2, k0 = wave * kq + 4 * half, nj = kq >> 3;
+    const float* ap[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const long long row = m0 + 32 * t + l31;
+        ap[t] = p.A + (row < p.M ? row : p.M - 1) * p.lda + k0;                    // (rows past the end repeat the last one; never stored)
+    }
+    const float* bp = p.B + (long long)k0 * p.ldb + n0 + 4 * l31;
+    const bool aff = p.a_scale != nullptr;
+    const float* scp = aff ? p.a_scale + k0 : p.A;                                 // (never dereferenced beyond valid floats when unused: same offsets as x's row)
+    const float* shp = aff ? p.a_shift + k0 : p.A;
+    const int a_act = aff ? p.a_act : MYOLO_ACT_NONE;
+
+    f32x16 acc[T][4];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][c][r] = 0.f;
+
+    // three register stages: step j's operands are requested two steps ahead (a step is 16 T MFMAs = 1024 T cycles, an L2 hit ~2000)
+    struct Stage { float4 a[T], b[4], sc, sh; };
+    Stage s0, s1, s2;
+    auto load = [&](Stage& st, int j) {
+        const int jj = j < nj ? j : nj - 1;                                        // past the end: the last step again (no load inside a branch)
+#pragma unroll
+        for (int t = 0; t < T; ++t) st.a[t] = ld4(ap[t] + 8 * jj);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st.b[e] = ld4(bp + (long long)(8 * jj + e) * p.ldb);
+        st.sc = ld4(scp + 8 * jj); st.sh = ld4(shp + 8 * jj);
+    };
+    auto step = [&](const Stage& st) {
+        float av[T][4];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            av[t][0] = st.a[t].x; av[t][1] = st.a[t].y; av[t][2] = st.a[t].z; av[t][3] = st.a[t].w;
+        }
+        if (aff) {
+            const float sc[4] = {st.sc.x, st.sc.y, st.sc.z, st.sc.w}, sh[4] = {st.sh.x, st.sh.y, st.sh.z, st.sh.w};
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) av[t][e] = gemm_act(fmaf(av[t][e], sc[e], sh[e]), a_act);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float bv[4] = {st.b[e].x, st.b[e].y, st.b[e].z, st.b[e].w};
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t][e], bv[c], acc[t][c], 0, 0, 0);
+        }
+    };
+    load(s0, 0); load(s1, 1); load(s2, 2);
+    for (int j = 0; j < nj; j += 3) {
+        step(s0); load(s0, j + 3);
+        if (j + 1 < nj) step(s1);
+        load(s1, j + 4);
+        if (j + 2 < nj) step(s2);
+        load(s2, j + 5);
+    }
+
+    // the four waves' partial tiles meet in LDS ...
+    float* mine = part + wave * (4 * T * 1024);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[((c * T + t) * 16 + r) * 64 + lane] = acc[t][c][r];
+    __syncthreads();
+    // ... and wave w finishes the rows r = 4 w .. 4 w + 3 of every 32-row block: the partials summed in wave order, then splitk_epilogue's expressions
+    float bs[4] = {0.f, 0.f, 0.f, 0.f}, cs[4], ct[4];
+    const int col = n0 + 4 * l31;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p.bias) bs[e] = p.bias[col + e];
+        col_affine(p, col + e, cs[e], ct[e]);
+    }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+            const int r = 4 * wave + rr;
+            float v[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < 4; ++wv) sacc += part[wv * (4 * T * 1024) + ((c * T + t) * 16 + r) * 64 + lane];
+                v[c] = sacc;
+            }
+            const long long row = m0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (row < p.M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (p.bias) v[e] += bs[e];
+                    if (p.scale) v[e] = fmaf(v[e], cs[e], ct[e]);
+                    v[e] = gemm_act(v[e], p.act);
+                }
+                *reinterpret_cast<float4*>(p.C + row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+}
+
+// 32 T = rows of a workgroup's tile for this shape, 0 = not this kernel (too many rows: the big-tile kernels fill the chip; short K: nothing to split)
+static int pw_smallm_T(long long M, int K, int N)
+{
+    if (g_myolo_opt.pw_no_smallm || (N & 127) != 0 || (K & 31) != 0 || K < 256 || M <= 0) return 0;
+    const long long w1 = cdiv64(M, 32) * (N >> 7), w2 = cdiv64(M, 64) * (N >> 7);
+    if (g_myolo_opt.tune0 & 3) return w2 <= 384 ? (g_myolo_opt.tune0 & 3) : 0;      // experiment: force T
+    if (w1 <= 256) return 1;
+    return w2 <= 384 ? 2 : 0;
+}
+static bool pw_smallm_ok(const GemmArgs& a)
+{
+    return pw_smallm_T(a.M, a.K, a.N) != 0 && (((uintptr_t)a.A | (uintptr_t)a.B | (uintptr_t)a.C) & 15) == 0 && (a.lda & 3) == 0 && (a.ldb & 3) == 0 &&
+           (a.ldc & 3) == 0 && !g_myolo_opt.gemm_generic;
+}
+static void pw_smallm_launch(const GemmArgs& a, hipStream_t s)
+{
+    const int T = pw_smallm_T(a.M, a.K, a.N);
+    const unsigned wgs = (unsigned)(cdiv64(a.M, 32 * T) * (a.N >> 7));
+    if (T == 1) hipLaunchKernelGGL(pw_smallm_kernel<1>, dim3(wgs), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(pw_smallm_kernel<2>, dim3(wgs), dim3(256), 0, s, a);
+}
+
 static bool pw_fwd_thin_ok(long long M, int Cin, int Cout)
 {
     // 128 output channels (conv_pw_3, 100 352 rows = one row block per wave): 43 us here against 36 us on gemm_nn_fast -- the 32 KB of w^T every
@@ -1589,6 +1739,11 @@ int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
+    if (pw_smallm_ok(a)) {                  // few rows, long K: one launch, the waves of a workgroup split K (pw_smallm_kernel)
+        pw_smallm_launch(a, (hipStream_t)stream);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     // ws (optional): split-K partials for the 14x14 / 7x7 layers, whose few output tiles and long K loop (a serial chain of
     // load -> LDS -> MFMA steps) would leave most of the chip idle
     // (measured, tools/pw_layers.py: 7x7 layers 83 -> 52 us and 77 -> 30 us; the 14x14 layers' 196 tiles are better left alone)
@@ -1611,6 +1766,11 @@ int myolo_pwconv1x1_affine_act_fwd(const float* x, const float* w, const float* 
     if (pw_fwd_thin_ok(M, Cin, Cout) && (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0 && !g_myolo_opt.gemm_generic) {
         // conv_pw_1 / 2 at inference sizes: 33.9 / 19.9 us on gemm_nn_fast (Rice-416, batch 4); the affine + activation on the accumulators
         pw_fwd_thin_launch(x, nullptr, nullptr, MYOLO_ACT_NONE, w, y, nullptr, M, Cin, Cout, (hipStream_t)stream, scale, shift, act);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
+    if (pw_smallm_ok(a)) {                  // the YOLO head of an inference forward (M = 676 / 2704 at Rice-416 batch 4): no split-K pair of launches
+        pw_smallm_launch(a, (hipStream_t)stream);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
@@ -1647,6 +1807,11 @@ int myolo_pwconv1x1_bwd_data(const float* dy, const float* w, float* dx,
     a.A = dy; a.B = wt; a.C = dx; a.M = M; a.N = Cin; a.K = Cout;
     a.lda = Cout; a.ldb = Cin; a.ldc = Cin;
     const size_t wbytes = align256((size_t)Cin * Cout * sizeof(float));
+    if (pw_smallm_ok(a)) {                  // the 7x7 layers' data gradients (M = 1568)
+        pw_smallm_launch(a, s);
+        MYOLO_CHECK_LAUNCH();
+        return MYOLO_OK;
+    }
     launch_nn<AM_PLAIN, EP_PLAIN>(a, s, (char*)ws + wbytes, ws_bytes > wbytes ? ws_bytes - wbytes : 0);
     MYOLO_CHECK_LAUNCH();
     return MYOLO_OK;
@@ -1785,6 +1950,14 @@ int myolo_pwconv1x1_bnstats_fwd(const float* x, const float* in_scale, const flo
         if (phases & 2) myolo_bn_stats_from_partials(part, tot, wgs, Cout, (double)M, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, s);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
+    }
+    if (pw_smallm_ok(a)) {
+        // the 7x7 layers (M = 1568): the small-M kernel with the producing BatchNorm on its loads, then a statistics pass over y (a few MB) as
+        // behind the split-K pair it replaces
+        if (phases & 1) pw_smallm_launch(a, s);
+        MYOLO_CHECK_LAUNCH();
+        if (!(phases & 2)) return MYOLO_OK;
+        return myolo_bn_stats_launch(y, gamma, beta, mean, var, scale, shift, moving_mean, moving_var, M, Cout, ws, ws_bytes, s);
     }
     a.stat = g_myolo_opt.no_trunk_fusion ? nullptr : part;
     // the split-K scratch shares ws with the partials: when the launcher picks split-K it drops a.stat (nothing is written there)

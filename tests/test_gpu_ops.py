@@ -1279,6 +1279,50 @@ def test_pwconv1x1_affine_act_fwd_equals_conv_then_frozen_bn(M, Cin, Cout, act):
     assert np.abs(y2.cpu().numpy() - ref).max() < 2e-4
 
 
+@pytest.mark.parametrize("M,Cin,Cout", [(4 * 26 * 26, 512, 512), (4 * 13 * 13, 512, 1024), (4 * 13 * 13, 1024, 1024), (1568, 1024, 1024), (1568, 512, 1024),
+                                        (2705, 256, 128), (33, 288, 256), (5, 256, 128), (16384, 256, 128)])
+def test_pwconv1x1_small_m_kernel(M, Cin, Cout):
+    """pw_smallm_kernel (few rows, K >= 256, N % 128 == 0: a workgroup's four waves split K, partial tiles summed in LDS, one launch) through the
+    four entry points that reach it -- plain / bias forward, the inference fold (bias-free, per-column affine + ReLU6), the training forward with the
+    producing BatchNorm on its loads, the data gradient -- against float64, and against the split-K pair of launches it replaces (pw_no_smallm=1:
+    same fp32 products, another summation order)"""
+    rng = np.random.default_rng(31)
+    x, w = rnd(rng, M, Cin), rnd(rng, Cin, Cout, scale=0.1)
+    b = rnd(rng, Cout)
+    sc, sh = 1 + rnd(rng, Cout, scale=0.2), rnd(rng, Cout, scale=0.5)
+    isc, ish = 1 + rnd(rng, Cin, scale=0.3), rnd(rng, Cin, scale=0.5) + 1.0
+    dy = rnd(rng, M, Cout)
+    st = X.stream()
+    xd, wd, bd, scd, shd, iscd, ishd, dyd = (dt(t) for t in (x, w, b, sc, sh, isc, ish, dy))
+    g, be = dt(1 + rnd(rng, Cout, scale=0.2)), dt(rnd(rng, Cout, scale=0.3))
+    wsb = torch.empty(max(X.pw_bnstats_ws_bytes(M, Cin, Cout), 64 << 20), dtype=torch.uint8, device=DEV)
+
+    def run():
+        y0, y1, y2, y3, dx = new(M, Cout), new(M, Cout), new(M, Cout), new(M, Cout), new(M, Cin)
+        X.call("myolo_pwconv1x1_fwd", X.ptr(xd), X.ptr(wd), None, X.ptr(y0), M, Cin, Cout, wsb.data_ptr(), wsb.numel(), st)
+        X.call("myolo_pwconv1x1_fwd", X.ptr(xd), X.ptr(wd), X.ptr(bd), X.ptr(y1), M, Cin, Cout, wsb.data_ptr(), wsb.numel(), st)
+        X.call("myolo_pwconv1x1_affine_act_fwd", X.ptr(xd), X.ptr(wd), X.ptr(scd), X.ptr(shd), 2, X.ptr(y2), M, Cin, Cout, wsb.data_ptr(), wsb.numel(), st)
+        mean, var, scale, shift, tmm, tmv = new(Cout), new(Cout), new(Cout), new(Cout), dt(np.zeros(Cout, np.float32)), dt(np.ones(Cout, np.float32))
+        X.call("myolo_pwconv1x1_bnstats_fwd", X.ptr(xd), X.ptr(iscd), X.ptr(ishd), 2, X.ptr(wd), X.ptr(y3), X.ptr(g), X.ptr(be), X.ptr(mean), X.ptr(var),
+               X.ptr(scale), X.ptr(shift), X.ptr(tmm), X.ptr(tmv), M, Cin, Cout, 3, wsb.data_ptr(), wsb.numel(), st)
+        X.call("myolo_pwconv1x1_bwd_data", X.ptr(dyd), X.ptr(wd), X.ptr(dx), M, Cin, Cout, wsb.data_ptr(), wsb.numel(), st)
+        torch.cuda.synchronize()
+        return [t.cpu().numpy() for t in (y0, y1, y2, y3, dx, mean, var)]
+
+    new_ = run()
+    with X.option("pw_no_smallm", 1):
+        old_ = run()
+    x64, w64 = x.astype(np.float64), w.astype(np.float64)
+    r0 = x64 @ w64
+    r3 = np.clip(x64 * isc + ish, 0, 6) @ w64
+    refs = [r0, r0 + b, np.clip(r0 * sc + sh, 0, 6), r3, dy.astype(np.float64) @ w64.T, r3.mean(0), r3.var(0)]
+    for name, got, was, ref in zip(("fwd", "fwd + bias", "affine + relu6 fwd", "bnstats fwd", "dx", "batch mean", "batch variance"), new_, old_, refs):
+        scale_ = np.abs(ref).max() + 1e-6
+        assert np.abs(got - ref).max() <= 2e-5 * scale_ + 1e-6, (name, np.abs(got - ref).max(), scale_)
+        assert np.abs(got - was).max() <= 2e-5 * scale_ + 1e-6, (name, "against the split-K pair")
+    assert np.array_equal(new_[0] + 0, run()[0])            # run to run: the same bits
+
+
 @pytest.mark.parametrize("N,H,W,Cout,act", [(2, 416, 416, 32, 2), (3, 64, 48, 16, 1), (1, 30, 26, 32, 2)])      # the row kernel (W % 4 == 0) twice, the generic one
 def test_conv1_affine_act_fwd_equals_conv_then_frozen_bn(N, H, W, Cout, act):
     """conv_block in inference mode (model.py:42-52): myolo_conv3x3s2_c3_affine_act_fwd == myolo_conv3x3s2_c3_fwd + myolo_bn_apply_act, bit for bit"""
