@@ -1663,8 +1663,7 @@ static int pw_smallm_T(long long M, int K, int N)
 {
     if (g_myolo_opt.pw_no_smallm || (N & 127) != 0 || (K & 31) != 0 || K < 256 || M <= 0) return 0;
     const long long w1 = cdiv64(M, 32) * (N >> 7), w2 = cdiv64(M, 64) * (N >> 7);
-    if (g_myolo_opt.tune0 & 3) return w2 <= 384 ? (g_myolo_opt.tune0 & 3) : 0;      // experiment: force T
-    if (w1 <= 256) return 1;
+    if (w1 <= 256) return 1;                // (measured both ways per shape, tools/experiments/pw_smallm.py: 32-row tiles win exactly when they fit one round)
     return w2 <= 384 ? 2 : 0;
 }
 static bool pw_smallm_ok(const GemmArgs& a)

@@ -42,8 +42,4 @@ for name, M, K, N in shapes:
                     res.append((off, time_us(fn)))
         new = [t for o, t in res if o == 0]
         old = [t for o, t in res if o == 1]
-        forced = []
-        for T in (1, 2):
-            with X.option("tune0", T):
-                forced.append(time_us(fn))
-        print("%-22s M=%5d K=%4d N=%4d %-15s small-M %6.1f / %6.1f us (T=1 %6.1f, T=2 %6.1f)   split-K pair %6.1f / %6.1f us" % (name, M, K, N, cn, new[0], new[1], forced[0], forced[1], old[0], old[1]), flush=True)
+        print("%-22s M=%5d K=%4d N=%4d %-15s small-M %6.1f / %6.1f us   split-K pair %6.1f / %6.1f us" % (name, M, K, N, cn, new[0], new[1], old[0], old[1]), flush=True)
