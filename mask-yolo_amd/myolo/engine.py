@@ -206,7 +206,7 @@ class Net(object):
         self._lanes = {}                  # predict_stream: lane -> its stream / scratch / coefficient buffers
         self._cap_stream = None           # graph capture never happens with the default stream current (see _capture_predict)
         self._fm_stream = None            # inference: feature_map's conv beside the YOLO head (trunk_fwd)
-        self.infer_fork_feature_map = True    # only forwards that run alone: with several batches in flight (predict_stream) the forked graphs cost 9 % (1150 -> 1055 img/s at Rice-416), alone they return 0.5 %
+        self.infer_fork_feature_map = False   # opt-in, and then only forwards that run alone: measured +0.0-0.5 % alone, -9 % with several batches in flight (forked graphs, 1150 -> 1055 img/s at Rice-416); and the extra stream it brings into a process moved the lanes' hardware-queue mapping in the full bench run (three lanes 1152 -> 1086)
         self._fork_now = None             # the effective value while predict_graphed captures / runs a forward for a given number of lanes
         # a captured graph bakes in pointers to the scratch buffer: growing it (a bigger launch on the same Net) drops the graphs
         self._ws_main = Workspace(self.dev, on_realloc=lambda: self._drop_graphs(0))

@@ -1,5 +1,5 @@
 """One inference batch in flight (Rice-416, bf16 mask head, batch 4; Net.predict_graphed): feature_map's conv beside the YOLO head
-(Net.infer_fork_feature_map, the default) against the serial order, alternating on one box; and, under rocprofv3 --kernel-trace, the
+(Net.infer_fork_feature_map, opt-in) against the serial order, alternating on one box; and, under rocprofv3 --kernel-trace, the
 kernel sequence of one replay of each form.
   gpurun -- 'python tools/experiments/infer_fork.py'                                  -> ms per forward, alternating
   gpurun -- 'bash tools/experiments/infer_fork.sh'                                    -> + gpurun_out/infer_fork/sequence_{fork,serial}.txt
