@@ -7,7 +7,7 @@ import torch
 from myolo import _ext as X
 
 dev = "cuda:0"
-shapes = [("infer 26x26 pw8-12", 2704, 512, 512), ("infer 13x13 pw13", 676, 512, 1024), ("infer 13x13 pw14", 676, 1024, 1024),
+shapes = [("train 14x14 pw7-12", 6272, 512, 512), ("infer 26x26 pw8-12", 2704, 512, 512), ("infer 13x13 pw13", 676, 512, 1024), ("infer 13x13 pw14", 676, 1024, 1024),
           ("train 7x7 pw13", 1568, 512, 1024), ("train 7x7 pw14", 1568, 1024, 1024)]
 ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
 st = torch.cuda.current_stream().cuda_stream
