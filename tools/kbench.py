@@ -210,6 +210,30 @@ def main():
         ms = timeit(fn, a.iters)
         flop = 2.0 * M * C * 4 * C
         print("deconv_fwd M=%d: %.3f ms  %.1f TFLOP/s" % (M, ms, flop / ms / 1e9))
+    elif a.which == "roialign_bf16_fwd":
+        # the inference ROIAlign at the Rice-416 shape: batch 4, 52 x 52 x 256 feature map, --rois boxes (3380 = 4 x 845) of the five Rice anchors' sizes, bf16 out
+        B, H = 4, 52
+        NRb = a.rois if a.rois != 32 * 147 else 3380
+        feat = rn(B, H, H, C)
+        anch = torch.tensor([2.09, 2.48, 2.59, 3.01, 3.60, 3.64, 5.25, 4.56, 6.21, 6.25], device=dev).view(5, 2) / 13.0
+        wh = anch[torch.arange(NRb, device=dev) % 5] * (0.8 + 0.4 * torch.rand(NRb, 2, device=dev, generator=g))
+        ctr = torch.rand(NRb, 2, device=dev, generator=g)
+        boxes = torch.cat([ctr - wh / 2, ctr + wh / 2], 1).contiguous()
+        bind = (torch.arange(NRb, device=dev, dtype=torch.int32) % B).contiguous()
+        out = torch.empty(NRb * ps * ps, C, dtype=torch.bfloat16, device=dev)
+        nbytes = NRb * ps * ps * C * 2 + B * H * H * C * 4
+        fn = lambda: X.call("myolo_crop_and_resize_bf16_fwd", X.ptr(feat), X.ptr(boxes), X.ptr(bind), X.ptr(out), B, H, H, C, NRb, ps, ps, st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        print("roialign_bf16_fwd (%d boxes): %.4f ms  %.0f GB/s (%.1f%% of 8000) on %.1f MB" % (NRb, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80, nbytes / 1e6))
+    elif a.which == "pw_smallm":
+        # a pointwise layer of the inference YOLO head (26 x 26 x 4 rows, 512 -> 512) with the frozen BatchNorm + ReLU6 fold: pw_smallm_kernel (pw_no_smallm=1: the split-K pair)
+        Mr, K, N = 4 * 26 * 26, 512, a.cout if a.cout != 256 else 512
+        x, w, y = rn(Mr, K), rn(K, N) * 0.05, torch.empty(Mr, N, device=dev)
+        sc, sh = torch.rand(N, device=dev, generator=g) + 0.5, rn(N)
+        fn = lambda: X.call("myolo_pwconv1x1_affine_act_fwd", X.ptr(x), X.ptr(w), X.ptr(sc), X.ptr(sh), 2, X.ptr(y), Mr, K, N, ws.data_ptr(), ws.numel(), st)   # noqa: E731
+        ms = timeit(fn, a.iters)
+        nbytes = 4.0 * (Mr * K + K * N + Mr * N)
+        print("pw_smallm M=%d %d->%d: %.4f ms  %.1f TF/s (%.1f%% of 157.3 fp32 MFMA)  %.0f GB/s on %.1f MB" % (Mr, K, N, ms, 2.0 * Mr * K * N / ms / 1e9, 2.0 * Mr * K * N / ms / 1e9 / 1.573, nbytes / ms / 1e6, nbytes / 1e6))
     elif a.which.startswith("roialign"):
         B, H = 32, 28
         R = NR // B
