@@ -1346,13 +1346,16 @@ size_t myolo_workspace_bytes(int64_t rows, int cin, int cout)
 // Neither MFMA kernel takes an N that is not a multiple of 4, and the generic one walks K = 1024 serially in a few workgroups (138 us for
 // 676 x 1024 x 35).  Here a workgroup owns four rows, a lane is an output column, each of the four waves takes a quarter of K and the
 // partial sums meet in LDS: x is read once (16-byte broadcast loads), w once per workgroup from L2.
-__global__ __launch_bounds__(256) void pw_skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
-                                                            float* __restrict__ y, long long M, int K, int N)
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void pw_skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float* __restrict__ y, long long M, int K, int N)
 {
-    __shared__ float red[4][4][64];
+    // NW waves split K (NW = 16 from K = 512 up: the loop is a chain of load latencies -- 64 steps per wave at K = 1024 with four waves took 32 us for
+    // 0.05 GFLOP, on the critical path between the trunk and the YOLO loss / decode; sixteen waves walk 16 steps each)
+    __shared__ float red[NW][4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long r0 = (long long)blockIdx.x * 4;
-    const int kq = K >> 2, k0 = wave * kq;
+    const int kq = K / NW, k0 = wave * kq;
     const int col = lane < N ? lane : 0;
     const float* xr[4];
 #pragma unroll
@@ -1374,10 +1377,15 @@ __global__ __launch_bounds__(256) void pw_skinny_fwd_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
-    // wave r finishes row r
+    // wave r finishes row r: the NW partial sums in pairs of neighbours, then in wave order
     const long long row = r0 + wave;
-    if (row < M && lane < N) {
-        float v = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+    if (wave < 4 && row < M && lane < N) {
+        float v = 0.f;
+        if (NW == 4) v = (red[0][wave][lane] + red[1][wave][lane]) + (red[2][wave][lane] + red[3][wave][lane]);
+        else {
+#pragma unroll
+            for (int q = 0; q < NW; q += 2) v += red[q][wave][lane] + red[q + 1][wave][lane];
+        }
         if (bias) v += bias[lane];
         y[row * N + lane] = v;
     }
@@ -1537,7 +1545,7 @@ __global__ __launch_bounds__(256) void pw_fwd_thin_kernel(const float* __restric
 // 352 workgroups on 256 CUs: 28 + 9 us for 1.4 GFLOP (M = 2704, 512 -> 512) where the fp32 matrix pipe needs 9.
 // Here a workgroup owns 32 T rows x 128 columns and its four waves split K among themselves: a wave multiplies the whole tile over a quarter
 // of K straight from registers (no LDS in the loop, no barrier), the four partial tiles meet in LDS once, are summed in wave order
-// (deterministic) and leave through the epilogue as 16-byte stores.  One launch, no partials in HBM, <= 256-384 workgroups of equal work.
+// (deterministic) and leave through the epilogue as 16-byte stores.  One launch, no partials in HBM, at most 256 workgroups of equal work (one round).
 // Operand layout without a transposition: lane (l31, half) loads 16 bytes of its ROW of x per step (k = 8 j + 4 half + e, e = 0..3, the
 // thin kernels' order: the reduction index may be walked in any order as long as both operands agree) and, for each e, 16 bytes of w's row
 // k: columns n0 + 4 l31 .. + 3.  Component c of that float4 is the B operand of column block c, i.e. block c holds the columns
@@ -1664,7 +1672,7 @@ static int pw_smallm_T(long long M, int K, int N)
     if (g_myolo_opt.pw_no_smallm || (N & 127) != 0 || (K & 31) != 0 || K < 256 || M <= 0) return 0;
     const long long w1 = cdiv64(M, 32) * (N >> 7), w2 = cdiv64(M, 64) * (N >> 7);
     if (w1 <= 256) return 1;                // (measured both ways per shape, tools/experiments/pw_smallm.py: 32-row tiles win exactly when they fit one round)
-    return w2 <= 384 ? 2 : 0;
+    return w2 <= 256 ? 2 : 0;               // (257-384 tiles of 64 rows = two rounds: conv_pw_5 of an inference forward, 10816 x 256 -> 256, ran 36.6 us here against 30.1 on gemm_nn_fast)
 }
 static bool pw_smallm_ok(const GemmArgs& a)
 {
@@ -1727,7 +1735,10 @@ int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = M; a.N = Cout; a.K = Cin;
     a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = MYOLO_ACT_NONE;
     if (Cout <= 64 && (Cout & 3) != 0 && (Cin & 15) == 0 && ((uintptr_t)x & 15) == 0 && !g_myolo_opt.gemm_generic) {
-        hipLaunchKernelGGL(pw_skinny_fwd_kernel, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (long long)M, Cin, Cout);
+        if (Cin >= 512 && (Cin & 63) == 0)
+            hipLaunchKernelGGL(pw_skinny_fwd_kernel<16>, dim3((unsigned)cdiv64(M, 4)), dim3(1024), 0, (hipStream_t)stream, x, w, bias, y, (long long)M, Cin, Cout);
+        else
+            hipLaunchKernelGGL(pw_skinny_fwd_kernel<4>, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (long long)M, Cin, Cout);
         MYOLO_CHECK_LAUNCH();
         return MYOLO_OK;
     }
