@@ -948,11 +948,12 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // [4 floats of left padding][3 W floats], so the nine values of one kernel row of a pixel are nine consecutive floats.  A thread keeps the 27
 // filter values of its four channels in registers (its channel quad never changes: 256 % (Co / 4) == 0) and walks the 2 Wo pixels of the pair.
 // Same order of the 27 products per output as conv1_fwd_kernel (the padded taps add 0 * w): bit-identical y.
-#define C1F_STEPS 2
+#define C1F_STEPS 2                      // with statistics (training): the rows of partials and their scratch are sized for this; without, the launcher may pass 1
 #define C1F_SMAX 8
 __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w, float* __restrict__ y,
                                                              int H, int W, int Co, int cq_shift, int chunks, double* __restrict__ stat,
-                                                             const float* __restrict__ osc = nullptr, const float* __restrict__ osh = nullptr, int oact = MYOLO_ACT_NONE)
+                                                             const float* __restrict__ osc = nullptr, const float* __restrict__ osh = nullptr, int oact = MYOLO_ACT_NONE,
+                                                             int steps = C1F_STEPS)
 {
     extern __shared__ __attribute__((aligned(16))) float c1f_lds[];     // [5][4 + 3 W]
     __shared__ float4 red[256];
@@ -967,7 +968,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_rows_kernel(const float* __rest
     const float4 osc4 = osc ? ld4g(osc + c4) : f4zero(), osh4 = osc ? ld4g(osh + c4) : f4zero();
     if (tid < 20) c1f_lds[(tid >> 2) * rowf + (tid & 3)] = 0.f;
     const int nsteps = (Ho + 1) / 2;
-    const int st0 = ch * C1F_STEPS, st1 = st0 + C1F_STEPS < nsteps ? st0 + C1F_STEPS : nsteps;
+    const int st0 = ch * steps, st1 = st0 + steps < nsteps ? st0 + steps : nsteps;
     const float* xi = x + (long long)n * H * row3;
     float4 sv[C1F_SMAX];
     int soff[C1F_SMAX], srow[C1F_SMAX];
@@ -1045,15 +1046,18 @@ static bool conv1_fwd_rows_ok(int H, int W, int Cout)
     const int cq = Cout / 4;
     return (H & 1) == 0 && (W & 3) == 0 && 5 * 3 * W / 4 <= C1F_SMAX * 256 && cq >= 1 && cq <= 64 && (cq & (cq - 1)) == 0 && !(g_myolo_opt.tune0 & 16384);
 }
-static int conv1_fwd_rows_chunks(int H) { return ((H / 2 + 1) / 2 + C1F_STEPS - 1) / C1F_STEPS; }
+static int conv1_fwd_rows_chunks(int H, int steps = C1F_STEPS) { return ((H / 2 + 1) / 2 + steps - 1) / steps; }
 static void conv1_fwd_rows_launch(const float* x, const float* w, float* y, int N, int H, int W, int Cout, double* stat, hipStream_t s,
                                   const float* osc = nullptr, const float* osh = nullptr, int oact = MYOLO_ACT_NONE)
 {
-    const int chunks = conv1_fwd_rows_chunks(H);
+    // one pair of rows per workgroup when two would leave the chip under-filled and nobody counts the rows of partials (an inference batch of four
+    // 416 x 416 images: 208 workgroups -> 416, 17.3 -> 13.5 us; the training batch keeps two: 30.0 us either way, tools/experiments/conv1_steps.py)
+    const int steps = (!stat && (long long)N * conv1_fwd_rows_chunks(H) < 512) ? 1 : C1F_STEPS;
+    const int chunks = conv1_fwd_rows_chunks(H, steps);
     int sh = 0;
     while ((1 << sh) < Cout / 4) ++sh;
     hipLaunchKernelGGL(conv1_fwd_rows_kernel, dim3((unsigned)(N * chunks)), dim3(256), (size_t)5 * (4 + 3 * W) * sizeof(float), s, x, w, y, H, W, Cout, sh, chunks,
-                       stat, osc, osh, oact);
+                       stat, osc, osh, oact, steps);
 }
 
 // dw[k][co] = sum_pixels patch[k] * dy[co]; rows = output pixels, "channels" = Co, 27 accumulators
