@@ -55,7 +55,8 @@ size_t      myolo_workspace_bytes(int64_t rows, int cin, int cout);
  * untransposed tile with the per-class butterfly epilogue of rounds 3-5, 2 = the transposed tile with partial logits + the finish launch -- same bits as 0),
  * "bf16_mask_nofin" (myolo_deconv2x2s2_mask_bf16_fwd: partial logits + the finish launch; same bits), "crop_bf16_legacy" (myolo_crop_and_resize_bf16_fwd: four corner
  * loads per output element instead of the column walk; same bits), "pw_no_smallm" (pointwise convs with few rows and K >= 256: the split-K pair of launches of
- * rounds 2-5 instead of the one-launch small-M kernel; another fp32 summation order).  Unknown name -> MYOLO_EINVAL.  Every switch selects between
+ * rounds 2-5 instead of the one-launch small-M kernel; another fp32 summation order), "pw_skinny_nw4" (conv_23: four waves per workgroup also from K = 512 up; another
+ * fp32 summation order).  Unknown name -> MYOLO_EINVAL.  Every switch selects between
  * kernels with the same contract.  One switch changes NUMERICS within the bf16 inference path: "bf16_mask_valu" = 1 keeps the deconv output and the 1x1 mask kernel of
  * myolo_deconv2x2s2_mask_bf16_fwd in fp32 (rounds 3-5, VALU epilogue); the default rounds both to bf16 like every other activation / weight of that path and runs the
  * 1x1 conv on the matrix pipe (256-row kernels, i.e. >= 1536 row tiles of 256 channels; smaller problems keep the fp32 form).

@@ -1735,7 +1735,7 @@ int myolo_pwconv1x1_fwd(const float* x, const float* w, const float* bias, float
     a.A = x; a.B = w; a.C = y; a.bias = bias; a.M = M; a.N = Cout; a.K = Cin;
     a.lda = Cin; a.ldb = Cout; a.ldc = Cout; a.act = MYOLO_ACT_NONE;
     if (Cout <= 64 && (Cout & 3) != 0 && (Cin & 15) == 0 && ((uintptr_t)x & 15) == 0 && !g_myolo_opt.gemm_generic) {
-        if (Cin >= 512 && (Cin & 63) == 0)
+        if (Cin >= 512 && (Cin & 63) == 0 && !g_myolo_opt.pw_skinny_nw4)
             hipLaunchKernelGGL(pw_skinny_fwd_kernel<16>, dim3((unsigned)cdiv64(M, 4)), dim3(1024), 0, (hipStream_t)stream, x, w, bias, y, (long long)M, Cin, Cout);
         else
             hipLaunchKernelGGL(pw_skinny_fwd_kernel<4>, dim3((unsigned)cdiv64(M, 4)), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, (long long)M, Cin, Cout);

@@ -40,7 +40,7 @@ static int* option_slot(const char* name)
         {"gemm_w256", &MyoloOptions::gemm_w256}, {"wino_nt", &MyoloOptions::wino_nt}, {"wino_w256", &MyoloOptions::wino_w256},
         {"bf16_regstage", &MyoloOptions::bf16_regstage}, {"bf16_no256", &MyoloOptions::bf16_no256}, {"bf16_no_c3", &MyoloOptions::bf16_no_c3}, {"bf16_no_loopn", &MyoloOptions::bf16_no_loopn}, {"bf16_mask_valu", &MyoloOptions::bf16_mask_valu}, {"deconv_mask_legacy", &MyoloOptions::deconv_mask_legacy}, {"bf16_mask_nofin", &MyoloOptions::bf16_mask_nofin},
         {"bf16_force256", &MyoloOptions::bf16_force256}, {"crop_bwd_nolds", &MyoloOptions::crop_bwd_nolds}, {"crop_bf16_legacy", &MyoloOptions::crop_bf16_legacy},
-        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_bwd_legacy", &MyoloOptions::dw_bwd_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"tn_wgs", &MyoloOptions::tn_wgs}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"pw_no_smallm", &MyoloOptions::pw_no_smallm}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"w63_legacy", &MyoloOptions::w63_legacy}, {"w63_wgs", &MyoloOptions::w63_wgs}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
+        {"tune0", &MyoloOptions::tune0}, {"dw_rows1", &MyoloOptions::dw_rows1}, {"dw_legacy", &MyoloOptions::dw_legacy}, {"dw_bwd_legacy", &MyoloOptions::dw_bwd_legacy}, {"dw_min_wg", &MyoloOptions::dw_min_wg}, {"wino_no_mixed", &MyoloOptions::wino_no_mixed}, {"no_trunk_fusion", &MyoloOptions::no_trunk_fusion}, {"tn_no_x6", &MyoloOptions::tn_no_x6}, {"tn_wgs", &MyoloOptions::tn_wgs}, {"pw_no_x6", &MyoloOptions::pw_no_x6}, {"pw_no_smallm", &MyoloOptions::pw_no_smallm}, {"pw_skinny_nw4", &MyoloOptions::pw_skinny_nw4}, {"dw_wgrad_generic", &MyoloOptions::dw_wgrad_generic}, {"deconv_no_x6", &MyoloOptions::deconv_no_x6}, {"pw_x6_min_rows", &MyoloOptions::pw_x6_min_rows}, {"w63_order", &MyoloOptions::w63_order}, {"w63_legacy", &MyoloOptions::w63_legacy}, {"w63_wgs", &MyoloOptions::w63_wgs}, {"x6_no_half_tiles", &MyoloOptions::x6_no_half_tiles}, {"wino_no_bt", &MyoloOptions::wino_no_bt}, {"wino_x6", &MyoloOptions::wino_x6}, {"bn_fused_tf_variance", &MyoloOptions::bn_fused_tf_variance},
     };
     if (!name) return nullptr;
     for (const auto& e : tab)

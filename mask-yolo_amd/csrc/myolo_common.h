@@ -41,6 +41,7 @@ struct MyoloOptions {
     int pw_x6_min_rows;   // pointwise convs: fewest rows for the bf16x6 kernels (0 = default 4096)
     int deconv_no_x6;     // deconv forward / data gradient: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int dw_wgrad_generic; // depthwise weight gradient: the generic 9-accumulator column reduction instead of the tiled kernel (ablation)
+    int pw_skinny_nw4;    // conv_23 (pw_skinny_fwd_kernel): four waves per workgroup also from K = 512 up (rounds 2-5; ablation -- another summation order)
     int pw_no_smallm;     // pointwise convs with few rows and K >= 256: the split-K pair of gemm_nn_fast launches instead of pw_smallm_kernel (ablation)
     int pw_no_x6;         // pointwise convs with >= 256 channels: the fp32-MFMA kernels even when "wino_x6" is on (ablation)
     int tn_no_x6;         // winograd weight gradient: gemm_tn_fast (fp32 MFMA) even when "wino_x6" is on (ablation of wino_tn_x6_kernel)

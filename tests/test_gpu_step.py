@@ -366,7 +366,12 @@ def test_sparse_mask_backward_equals_dense():
     ROIs one such flip switches a whole gradient term on or off (measured: up to 1.5e-2 of a tensor's maximum for ONE flip).  Which
     element sits that close to zero is rounding luck of the kernels in front, so the tight bound is asserted on the first of a few seeded
     cases in which NO decision flipped (round 4: seed 0 had one flip after the depthwise kernels changed their statistics' summation
-    order; with the round-3 kernels the same case has none and agrees to 3e-5)."""
+    order; with the round-3 kernels the same case has none and agrees to 3e-5).
+    Round 6: one decision is NOT visible to _relu_flips -- conv2's input relu(bn1(conv1)) is formed inside the Winograd layer-boundary kernel
+    by the dense path (never stored) and by gather + bn_apply for the positives by the sparse one; after conv_23 / the 7x7 pointwise layers
+    changed their summation order, seed 1 had no tracked flip and 3.9e-3 on myolo_mask_conv2/kernel (tools/experiments/dbg_sparse_dense.py:
+    with either new kernel switched off other seeds flip instead, and every case without a flip agrees to 1e-5).  A case that misses the tight
+    bound with no tracked flip is therefore held to the one-flip bound and the search goes on."""
     seen = []
     for seed in (0, 1, 2, 3, 4):
         cfg, P, batch, ref = make_case(ShapesConfig, 128, 0.5, 4, seed=seed)
@@ -389,8 +394,8 @@ def test_sparse_mask_backward_equals_dense():
             worst = max(worst, rel(grads[1][k], d))
         seen.append((seed, flips, worst))
         assert len(pos) > 0
-        assert worst < 1e-4 + 3e-2 * flips, seen
-        if flips == 0:
+        assert worst < 1e-4 + 3e-2 * (flips if worst < 1e-4 else max(flips, 1)), seen
+        if flips == 0 and worst < 1e-4:
             return
     raise AssertionError("no seeded case without a ReLU flip between the two forwards: %r" % (seen,))
 
