@@ -886,6 +886,31 @@ def test_predict_stream_matches_predict(in_flight, dtype):
     assert len(net._graphs) == in_flight
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_inference_fork_of_feature_map_gives_the_same_bits(dtype):
+    """Net.infer_fork_feature_map (opt-in): feature_map's conv on a side stream beside the YOLO head -- eagerly and as a fork / join inside the
+    captured graph -- gives exactly the serial forward's outputs; forwards with several lanes in flight keep the serial graphs (the graph key
+    carries the effective flag, so switching it re-captures instead of replaying the other form)."""
+    cfg = make_config(ShapesConfig, IMAGE_SHAPE=[128, 128, 3], ALPHA=0.5, BATCH_SIZE=2, INFERENCE_DTYPE=dtype, CONV3X3_ALGO="winograd")   # (the fork exists for the Winograd form, which 'auto' takes from Rice-416 sizes up)
+    P = np_model.init_params(cfg, seed=3, bias_scale=0.05)
+    model = MaskYOLO(mode="inference", config=cfg)
+    model.load_state_dict(P)
+    net = model.net
+    rng = np.random.default_rng(12)
+    xs = [torch.as_tensor(rng.random((2, 128, 128, 3), dtype=np.float32), device=net.dev) for _ in range(3)]
+    assert net.infer_fork_feature_map is False
+    want = [[t.clone() for t in net.predict(x)] for x in xs]
+    net.infer_fork_feature_map = True
+    for x, w in zip(xs, want):
+        assert all(torch.equal(a, b) for a, b in zip(net.predict(x), w)), "eager forward with the fork differs"
+        assert all(torch.equal(a, b) for a, b in zip(net.predict_graphed(x), w)), "graph replay with the fork differs"
+    assert net._fm_stream is not None and any(k[-2] is True for k in net._graphs)
+    got = [[t.clone() for t in outs] for outs in net.predict_stream(iter(xs), in_flight=2)]
+    assert all(torch.equal(a, b) for g, w in zip(got, want) for a, b in zip(g, w))
+    assert sum(1 for k in net._graphs if k[-2] is False) == 2           # the two lanes' serial graphs beside lane 0's forked one
+    torch.cuda.synchronize()
+
+
 def test_side_streams_are_shared_by_every_net_of_the_process():
     """engine._shared_stream: the side streams exist once per device (a later Net's fresh streams could land on the compute stream's hardware
     queue, profiles/r3_notes.md "hardware queues"), and two Nets used alternately still produce what each produces alone."""
